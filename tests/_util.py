@@ -1,0 +1,82 @@
+"""Shared helpers for the test-suite (fixture loading, namespaces)."""
+import ast
+import glob
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_files(prefix):
+    return sorted(glob.glob(os.path.join(GOLDEN, prefix + "_*.npz")),
+                  key=lambda p: int(os.path.basename(p)[len(prefix) + 1:-4]))
+
+
+def load_golden(path):
+    """-> (top-level dict of tensors/scalars, nested dicts for 'sd/', 'grad/')."""
+    if not os.path.isabs(path):
+        path = os.path.join(GOLDEN, path)
+    z = np.load(path, allow_pickle=False)
+    top, nested = {}, {}
+    for k in z.files:
+        v = z[k]
+        val = torch.from_numpy(v.copy()) if v.dtype.kind in "fiu" and v.ndim > 0 else (
+            v.item() if v.ndim == 0 else v)
+        if "/" in k:
+            head, rest = k.split("/", 1)
+            nested.setdefault(head, {})[rest] = val
+        else:
+            top[k] = val
+    top.update(nested)
+    return top
+
+
+def literal(s):
+    return dict(ast.literal_eval(str(s)))
+
+
+# Defaults of the reference's opt.py for the flags the hot-path models read
+# (opt.py:88-198,350-354,415-428); tests override per fixture.
+OPT_DEFAULTS = dict(
+    num_layers=3, mlp_layers=2, hidden_channels=128, block="res+", conv="gen", gcn_aggr="max", norm="layer",
+    num_tasks=2, t=1.0, p=1.0, learn_t=False, learn_p=False, msg_norm=False, learn_msg_scale=False,
+    conv_encode_edge=False, graph_pooling="mean", node_embedding=False, node_num=5606, node_embedding_dim=32,
+    num_layer_head=1, use_age=False, head_dropout=False, use_edge_attr=False, pathway_readout="maxpool",
+    gnn_encoder="linear", pca_only=False, no_inter_drop=False, no_inter_norm=False, head_init=False,
+    all_init=True, pre_readout_drop=False, pre_concat_age=False, global_edge="onehot", init_emb=False,
+    feature_drop=False, dropout=0.5, mul_attr=False, pathway_global_node=False, pathway_num=146,
+    use_column=None, pathway_edge_num=8,
+    # MultilevelGNN
+    resgnn=False, pca_match_mask=False, final_channels=1, final_head=1, used_omics="012", pca_compare=False,
+    pca_prelinear=False, learnable_pca=False, pca_loss=False, pca_loss_coef=1.0, pca_indep_loss=False,
+    pca_init_type=None, pca_dim=2, pca_pool_dim=2, mutual_info_mask=False, mutual_info_threshold=None,
+    pathway_pool_dim=4, freeze_pca_weight=False, value_att_mask=False, node_select_threshold=1,
+    mutual_neighbors=3, freeze_node_embedding=False, head_dim=64, gnn_name="gat", dense_gnn=False,
+    weighted_edge=False, gnn_act="leakyrelu", reorder_pathway=False, reorder_type="pca", gnn_last_norm=False,
+    gnn_mlp_norm="none", merge_mode="mult", add_coef1=0.5, add_coef2=0.5, repeat_mask=False, repeat_cyclic=2,
+    repeat_norm=False, conv_channel_list=[32, 64], conv_kernel_list=[1, 1], embedding_init_type="xavier",
+    emb_val=0.01, input_drop=None, input_emb_drop=None, gnn_dropout=0.0, device_num=1, edge_type="grnboost2",
+    reduction_method="linear_projection", diff_pooling_location="pathway", diff_pooling_layer=2,
+    diff_pooling_hidden_dim=32, diff_pooling_output_dim=64, after_pooling_layer=1, pooling_type="correlation",
+    freeze_mutual_select_init=False, random_state=12345, remain_all_tf=False, device=0,
+)
+
+
+def make_args(**over):
+    d = dict(OPT_DEFAULTS)
+    d.update(over)
+    return SimpleNamespace(**d)
+
+
+def assert_close(a, b, tol=1e-4, what=""):
+    """|a-b| <= tol * max(1, |b|_inf): absolute for O(1) values, relative for large ones."""
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    if a.numel() == 0:
+        return
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, "%s: max|diff|=%.3e > %.1e*%.3g" % (what, err, tol, scale)

@@ -1,0 +1,125 @@
+/*
+ * mlgnn.h -- C ABI of libmlgnn.so: the MI355X (gfx950) hot path of the multilevel-GNN
+ * forward/backward pass.
+ *
+ * Boundary contract:
+ *   - every entry point is extern "C", takes raw DEVICE pointers + sizes and the caller's
+ *     HIP stream (a hipStream_t passed as void*), returns int:
+ *         0  ok,   >0  a hipError_t from the launch,   <0  argument error (MLGNN_E_*);
+ *   - no allocation, no global state, no host synchronisation, never throws or exits;
+ *     scratch memory is a caller-provided workspace (size from the *_workspace_bytes call);
+ *   - all tensors are contiguous row-major; float tensors are fp32; indices are int32.
+ *
+ * Graph layout ("CSR by destination"): rowptr[N+1], col[E] = source node of every edge,
+ * edges of one destination kept in their original (COO) order; eid[E] = original COO
+ * position of the edge.  The transposed layout ("CSR by source") carries col_t[E] =
+ * destination node, pos_t[E] = position of that edge in the by-destination order.
+ *
+ * Each entry point names the reference interface it stands in for
+ * (paths relative to the reference tree).
+ */
+#ifndef MLGNN_H
+#define MLGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLGNN_ABI_VERSION 1
+
+/* argument errors */
+#define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
+#define MLGNN_E_SHAPE     (-2)  /* negative / inconsistent size                 */
+#define MLGNN_E_MODE      (-3)  /* unknown or unsupported mode / aggregator     */
+#define MLGNN_E_DTYPE     (-4)  /* dtype not supported by this build            */
+#define MLGNN_E_WORKSPACE (-5)  /* workspace too small                          */
+#define MLGNN_E_ALIGN     (-6)  /* pointer not aligned for the vector width     */
+
+/* message: what one edge (j -> i) contributes before the reduction */
+#define MLGNN_MSG_IDENTITY 0  /* x_j                                                            */
+#define MLGNN_MSG_WEIGHTED 1  /* x_j * w_e            SAGEConv.message, torch_vertex.py:279-281  */
+#define MLGNN_MSG_GEN      2  /* relu(x_j + e_e)+eps  GENConv.message,  torch_vertex.py:94-101   */
+
+/* edge term e_e of MLGNN_MSG_GEN */
+#define MLGNN_EDGE_NONE  0    /* e_e = 0                                                         */
+#define MLGNN_EDGE_RANK1 1    /* e_e[c] = a_e*u[c] + v[c]: scalar raw attribute through the two  *
+                               * stacked Linear encoders deepergcn.py:90,213 + torch_vertex.py:68,77 */
+#define MLGNN_EDGE_FULL  2    /* e_e = efull[eid_e, :]: materialised [E,d] embedding             */
+
+/* aggregator: GenMessagePassing.aggregate, torch_message.py:44-85 */
+#define MLGNN_AGGR_SUM     0  /* 'add'  (PyG SumAggregation)                                     */
+#define MLGNN_AGGR_MEAN    1  /* 'mean' sum / clamp(count,1)                                     */
+#define MLGNN_AGGR_MAX     2  /* 'max'  first maximal edge wins, empty row -> 0                  */
+#define MLGNN_AGGR_SOFTMAX 3  /* sum_e m_e * softmax_e(t*m_e)   (:49-57)                         */
+#define MLGNN_AGGR_POWER   4  /* clamp(mean(clamp(m,1e-7,10)^p),1e-7,10)^(1/p)   (:68-74)        */
+
+#define MLGNN_DTYPE_F32 0
+
+int mlgnn_version(void);
+
+/* Number of float elements of workspace mlgnn_csr_aggregate_bwd needs for [.,d] channels. */
+int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d);
+
+/*
+ * Fused message + aggregation over the incoming edges of every node.
+ * Replaces: MessagePassing.propagate -> message -> aggregate as called from
+ *   GENConv.forward  models/gcn_lib/sparse/torch_vertex.py:81-82 (+ :94-101, torch_message.py:44-85)
+ *   SAGEConv.forward models/gcn_lib/sparse/torch_vertex.py:277-286 (aggregate-then-transform)
+ *
+ *   x       [N,d]   node features (rows gathered by col)
+ *   rowptr  [N+1], col [E]                 CSR by destination
+ *   ew      [E]     per-edge scalar in CSR order: weight (MSG_WEIGHTED) or raw attribute a_e
+ *                   (EDGE_RANK1); NULL otherwise
+ *   eu, ev  [d]     rank-1 edge term (EDGE_RANK1)
+ *   efull   [E0,d], eid [E]               materialised edge embedding + COO position (EDGE_FULL)
+ *   out     [N,d]
+ *   aux     [N,d]   SOFTMAX: log2-sum-exp of t*m per (node,channel); POWER: mean(clamp(m)^p)
+ *                   before the outer clamp; may be NULL when no backward is wanted
+ *   aux2    [N,d]   optional second moment for the learnable temperature / exponent:
+ *                   SOFTMAX: sum_e w_e m_e^2 ; POWER: mean(clamp(m)^p * ln clamp(m)); NULL to skip
+ *   argmax  [N,d]   MAX: by-destination edge position of the winner, -1 for an empty row
+ *   t, p            softmax temperature / power exponent; when t_dev / p_dev is non-NULL the value is
+ *                   read from that device address instead (learnable parameters: no host sync)
+ */
+int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t* col,
+                            const float* ew, const float* eu, const float* ev,
+                            const void* efull, const int32_t* eid,
+                            void* out, float* aux, float* aux2, int32_t* argmax,
+                            int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                            int aggr, float t, float p, const float* t_dev, const float* p_dev,
+                            float eps, void* stream);
+
+/*
+ * Backward of the above with respect to x (and the edge term), atomic-free, on the
+ * transposed graph: one wavefront per SOURCE node walks its outgoing edges.
+ *
+ *   grad_out [N,d]  cotangent of out.  POWER: the caller passes
+ *                   q = grad_out * mu^(1/p-1) * [1e-7<=mu<=10] / clamp(deg,1)  instead.
+ *   x, out, aux, argmax: as produced / consumed by the forward
+ *   rowptr_t [N+1], col_t [E] (destination), pos_t [E] (by-destination position)
+ *   rowptr   [N+1]  by-destination row pointer (in-degree for MEAN)
+ *   ew_t [E], eid_t [E]: ew / eid permuted to by-source order
+ *   grad_x   [N,d]
+ *   grad_efull [E0,d]  EDGE_FULL: d loss / d efull, written at eid (every row written once)
+ *   grad_uv  [2,d]     EDGE_RANK1: d loss / d eu, d loss / d ev
+ *   learn_t  non-zero: SOFTMAX weights carry gradient (torch_message.py:51-52)
+ *   workspace: mlgnn_csr_aggregate_bwd_workspace_floats(N,d) floats (EDGE_RANK1 only)
+ */
+int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out, const float* aux,
+                            const int32_t* argmax,
+                            const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
+                            const int32_t* rowptr,
+                            const float* ew_t, const float* eu, const float* ev,
+                            const void* efull, const int32_t* eid_t,
+                            void* grad_x, void* grad_efull, float* grad_uv,
+                            float* workspace, int64_t workspace_floats,
+                            int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                            int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev,
+                            float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLGNN_H */

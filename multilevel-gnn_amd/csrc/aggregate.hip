@@ -1,0 +1,551 @@
+// CSR gather-reduce kernels: fused message + neighbour aggregation (forward, by-destination CSR)
+// and its backward (by-source CSR).  One wavefront owns one node row; the 64 lanes are split
+// into G = 64/LPR groups of LPR lanes, each group streaming whole neighbour rows with 16-byte
+// loads (VEC = 4 floats per lane), so one wave-instruction fetches G coalesced rows.  Groups are
+// combined with wavefront shuffles at the end of the row -- no atomics, no LDS in the forward.
+//
+// Reference semantics (paths relative to the reference tree):
+//   message    relu(x_j + e_ij) + eps              models/gcn_lib/sparse/torch_vertex.py:94-101
+//              x_j * w_ij                          models/gcn_lib/sparse/torch_vertex.py:279-281
+//   aggregate  add / mean / max / softmax / power  models/gcn_lib/sparse/torch_message.py:44-85
+//
+// HBM-bound (0.25-1 FLOP/byte): algorithmic bytes per launch are E*d*4 (neighbour rows)
+// + E*4 (col) + (N+1)*4 (rowptr) + E*4 (edge scalar) [+ E*d*4 full edge embedding] + N*d*4 (out).
+#include "common.h"
+#include "mlgnn.h"
+
+namespace mlgnn {
+
+constexpr int kUnroll = 4;                 // neighbour rows in flight per lane group and batch
+constexpr float kPowLo = 1e-7f, kPowHi = 1e1f;   // torch_message.py:69
+
+enum Mode { M_IDENTITY = 0, M_WEIGHTED = 1, M_GEN_NONE = 2, M_GEN_RANK1 = 3, M_GEN_FULL = 4 };
+enum Aggr { A_SUM = 0, A_MAX = 2, A_SOFTMAX = 3, A_POWER = 4 };   // MEAN = SUM + epilogue flag
+
+struct FwdArgs {
+  const float* x; const int* rowptr; const int* col;
+  const float* ew; const float* eu; const float* ev; const float* efull; const int* eid;
+  float* out; float* aux; float* aux2; int* argmax;
+  const float* t_dev; const float* p_dev;
+  int N; int d; int lpr_log2; int mean;
+  float t; float p; float eps;
+};
+
+// t / p either immediate or read from device memory (learnable parameters: no host sync)
+struct Scalars { float t, t_log2e, p; };
+__device__ __forceinline__ Scalars read_scalars(const float* t_dev, const float* p_dev, float t, float p) {
+  Scalars s;
+  s.t = t_dev ? t_dev[0] : t;
+  s.p = p_dev ? p_dev[0] : p;
+  s.t_log2e = s.t * kLog2e;
+  return s;
+}
+
+template <int MODE>
+__device__ __forceinline__ constexpr bool is_gen() { return MODE >= M_GEN_NONE; }
+
+// message value for one channel; z is returned for the backward's relu mask
+template <int MODE>
+__device__ __forceinline__ float message(float xj, float w_or_a, float u, float v, float ef, float eps,
+                                         float& z) {
+  if constexpr (MODE == M_IDENTITY) { z = xj; return xj; }
+  else if constexpr (MODE == M_WEIGHTED) { z = xj; return xj * w_or_a; }
+  else {
+    if constexpr (MODE == M_GEN_RANK1) z = xj + fmaf(w_or_a, u, v);
+    else if constexpr (MODE == M_GEN_FULL) z = xj + ef;
+    else z = xj;
+    return fmaxf(z, 0.0f) + eps;
+  }
+}
+
+template <int VEC, int MODE, int AGGR>
+__global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << a.lpr_log2;
+  const int groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2;
+  const int cl = lane & (lpr - 1);
+  const RowWalk walk = make_row_walk(a.N);
+  const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
+
+  for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
+    const int c0 = cbase + cl * VEC;
+    const bool cact = c0 < a.d;
+    float eu[VEC], ev[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; }
+    if (MODE == M_GEN_RANK1 && cact) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
+
+    for (int r = walk.first; r < walk.r_end; r += walk.stride) {
+      const int beg = a.rowptr[r];
+      const int end = a.rowptr[r + 1];
+      const int deg = end - beg;
+
+      // accumulators: SUM/POWER use acc; MAX uses acc (best) + bpos; SOFTMAX uses mx, acc (S), w1, w2
+      float acc[VEC], mx[VEC], w1[VEC], w2[VEC];
+      int bpos[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        acc[i] = (AGGR == A_MAX) ? -INFINITY : 0.f;
+        mx[i] = -INFINITY; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1;
+      }
+
+      for (int base = beg; base < end; base += kWave) {
+        const int cnt = min(kWave, end - base);
+        int my_col = 0, my_eid = 0;
+        float my_ew = 0.f;
+        if (lane < cnt) {
+          my_col = a.col[base + lane];
+          if (MODE == M_WEIGHTED || MODE == M_GEN_RANK1) my_ew = a.ew[base + lane];
+          if (MODE == M_GEN_FULL) my_eid = a.eid[base + lane];
+        }
+        for (int k = 0; k < cnt; k += groups * kUnroll) {
+          float xv[kUnroll][VEC], ef[kUnroll][VEC], wa[kUnroll];
+          bool valid[kUnroll];
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            const int idx = k + u * groups + sub;
+            valid[u] = (idx < cnt) && cact;
+            const int j = __shfl(my_col, idx & (kWave - 1));
+            wa[u] = __shfl(my_ew, idx & (kWave - 1));
+            const int e0 = __shfl(my_eid, idx & (kWave - 1));
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { xv[u][i] = 0.f; ef[u][i] = 0.f; }
+            if (valid[u]) {
+              load_vec<VEC>(xv[u], a.x + (size_t)j * a.d + c0);
+              if (MODE == M_GEN_FULL) load_vec<VEC>(ef[u], a.efull + (size_t)e0 * a.d + c0);
+            }
+          }
+          float m[kUnroll][VEC];
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              float z;
+              m[u][i] = message<MODE>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i], a.eps, z);
+            }
+
+          if constexpr (AGGR == A_SUM) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[i] += valid[u] ? m[u][i] : 0.f;
+          } else if constexpr (AGGR == A_MAX) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+              const int pos = base + k + u * groups + sub;
+#pragma unroll
+              for (int i = 0; i < VEC; ++i)
+                if (valid[u] && m[u][i] > acc[i]) { acc[i] = m[u][i]; bpos[i] = pos; }
+            }
+          } else if constexpr (AGGR == A_SOFTMAX) {
+            // online softmax, one rescale per batch of kUnroll neighbours; units: log2
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              float zmax = mx[i];
+#pragma unroll
+              for (int u = 0; u < kUnroll; ++u)
+                zmax = valid[u] ? fmaxf(zmax, sc.t_log2e * m[u][i]) : zmax;
+              if (zmax > -INFINITY) {
+                const float rs = fast_exp2(mx[i] - zmax);     // 0 on the first batch (mx = -inf)
+                float s = acc[i] * rs, s1 = w1[i] * rs, s2 = w2[i] * rs;
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                  const float pe = valid[u] ? fast_exp2(sc.t_log2e * m[u][i] - zmax) : 0.f;
+                  s += pe;
+                  s1 = fmaf(pe, m[u][i], s1);
+                  s2 = fmaf(pe * m[u][i], m[u][i], s2);
+                }
+                acc[i] = s; w1[i] = s1; w2[i] = s2; mx[i] = zmax;
+              }
+            }
+          } else {  // A_POWER
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) {
+                const float mc = fminf(fmaxf(m[u][i], kPowLo), kPowHi);
+                const float l2 = fast_log2(mc);
+                const float pw = fast_exp2(sc.p * l2);
+                acc[i] += valid[u] ? pw : 0.f;
+                w2[i] += valid[u] ? pw * l2 * kLn2 : 0.f;
+              }
+          }
+        }
+      }
+
+      // ---- combine the lane groups (xor-shuffle over the group bits) ----
+      for (int off = lpr; off < kWave; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          if constexpr (AGGR == A_SUM) {
+            acc[i] += __shfl_xor(acc[i], off);
+          } else if constexpr (AGGR == A_POWER) {
+            acc[i] += __shfl_xor(acc[i], off);
+            w2[i] += __shfl_xor(w2[i], off);
+          } else if constexpr (AGGR == A_MAX) {
+            const float ov = __shfl_xor(acc[i], off);
+            const int op = __shfl_xor(bpos[i], off);
+            // larger value wins; on a tie the earlier edge (torch_scatter CPU keeps the first)
+            const bool take = (op >= 0) && (bpos[i] < 0 || ov > acc[i] || (ov == acc[i] && op < bpos[i]));
+            if (take) { acc[i] = ov; bpos[i] = op; }
+          } else {  // SOFTMAX
+            const float om = __shfl_xor(mx[i], off);
+            const float os = __shfl_xor(acc[i], off);
+            const float o1 = __shfl_xor(w1[i], off);
+            const float o2 = __shfl_xor(w2[i], off);
+            const float nm = fmaxf(mx[i], om);
+            if (nm > -INFINITY) {
+              const float sa = fast_exp2(mx[i] - nm), sb = fast_exp2(om - nm);
+              acc[i] = acc[i] * sa + os * sb;
+              w1[i] = w1[i] * sa + o1 * sb;
+              w2[i] = w2[i] * sa + o2 * sb;
+              mx[i] = nm;
+            }
+          }
+        }
+      }
+
+      // ---- epilogue: group 0 writes the row ----
+      if (sub == 0 && cact) {
+        float o[VEC], ax[VEC], ax2[VEC];
+        int am[VEC];
+        const float inv = 1.0f / (float)max(deg, 1);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          ax[i] = 0.f; ax2[i] = 0.f; am[i] = -1;
+          if constexpr (AGGR == A_SUM) {
+            o[i] = a.mean ? acc[i] * inv : acc[i];
+          } else if constexpr (AGGR == A_MAX) {
+            o[i] = (bpos[i] >= 0) ? acc[i] : 0.f;
+            am[i] = bpos[i];
+          } else if constexpr (AGGR == A_SOFTMAX) {
+            if (deg > 0) {
+              const float rs = 1.0f / acc[i];
+              o[i] = w1[i] * rs;
+              ax[i] = mx[i] + fast_log2(acc[i]);
+              ax2[i] = w2[i] * rs;
+            } else { o[i] = 0.f; }
+          } else {  // POWER
+            const float mu = acc[i] * inv;
+            const float muc = fminf(fmaxf(mu, kPowLo), kPowHi);
+            o[i] = fast_exp2(fast_log2(muc) / sc.p);
+            ax[i] = mu;
+            ax2[i] = w2[i] * inv;
+          }
+        }
+        const size_t off = (size_t)r * a.d + c0;
+        store_vec<VEC>(a.out + off, o);
+        if (AGGR == A_MAX && a.argmax) store_vec<VEC>(a.argmax + off, am);
+        if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_vec<VEC>(a.aux + off, ax);
+        if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux2) store_vec<VEC>(a.aux2 + off, ax2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: one wave per SOURCE node j, walking its outgoing edges (j -> i)
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+  const float* go; const float* x; const float* out; const float* aux; const int* argmax;
+  const int* rowptr_t; const int* col_t; const int* pos_t; const int* rowptr;
+  const float* ew_t; const float* eu; const float* ev; const float* efull; const int* eid_t;
+  float* gx; float* ge; float* ws;
+  const float* t_dev; const float* p_dev;
+  int N; int d; int lpr_log2; int mean; int learn_t;
+  float t; float p; float eps;
+};
+
+template <int VEC, int MODE, int AGGR>
+__global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
+  __shared__ float red[kWavesPerBlock][2][kWave * VEC];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int lpr = 1 << a.lpr_log2;
+  const int groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2;
+  const int cl = lane & (lpr - 1);
+  const RowWalk walk = make_row_walk(a.N);
+  const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
+
+  for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
+    const int c0 = cbase + cl * VEC;
+    const bool cact = c0 < a.d;
+    float eu[VEC], ev[VEC], gu[VEC], gv[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; gu[i] = 0.f; gv[i] = 0.f; }
+    if (MODE == M_GEN_RANK1 && cact) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
+
+    for (int r = walk.first; r < walk.r_end; r += walk.stride) {
+      const int beg = a.rowptr_t[r];
+      const int end = a.rowptr_t[r + 1];
+      float xj[VEC], gx[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { xj[i] = 0.f; gx[i] = 0.f; }
+      if (is_gen<MODE>() && cact && end > beg) load_vec<VEC>(xj, a.x + (size_t)r * a.d + c0);
+
+      for (int base = beg; base < end; base += kWave) {
+        const int cnt = min(kWave, end - base);
+        int my_dst = 0, my_pos = 0, my_eid = 0;
+        float my_ew = 0.f, my_inv = 1.f;
+        if (lane < cnt) {
+          my_dst = a.col_t[base + lane];
+          if (AGGR == A_MAX) my_pos = a.pos_t[base + lane];
+          if (MODE == M_WEIGHTED || MODE == M_GEN_RANK1) my_ew = a.ew_t[base + lane];
+          if (MODE == M_GEN_FULL) my_eid = a.eid_t[base + lane];
+          if (AGGR == A_SUM && a.mean)
+            my_inv = 1.0f / (float)max(a.rowptr[my_dst + 1] - a.rowptr[my_dst], 1);
+        }
+        for (int k = 0; k < cnt; k += groups * kUnroll) {
+          float ga[kUnroll][VEC], gb[kUnroll][VEC], gc[kUnroll][VEC], ef[kUnroll][VEC];
+          int ai[kUnroll][VEC];
+          float wa[kUnroll], inv[kUnroll];
+          int pos[kUnroll], e0[kUnroll];
+          bool valid[kUnroll];
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            const int idx = k + u * groups + sub;
+            valid[u] = (idx < cnt) && cact;
+            const int src_lane = idx & (kWave - 1);
+            const int i_dst = __shfl(my_dst, src_lane);
+            wa[u] = __shfl(my_ew, src_lane);
+            inv[u] = __shfl(my_inv, src_lane);
+            pos[u] = __shfl(my_pos, src_lane);
+            e0[u] = __shfl(my_eid, src_lane);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { ga[u][i] = 0.f; gb[u][i] = 0.f; gc[u][i] = 0.f; ef[u][i] = 0.f; ai[u][i] = -2; }
+            if (valid[u]) {
+              const size_t off = (size_t)i_dst * a.d + c0;
+              load_vec<VEC>(ga[u], a.go + off);
+              if (AGGR == A_SOFTMAX) load_vec<VEC>(gb[u], a.aux + off);
+              if (AGGR == A_SOFTMAX && a.learn_t) load_vec<VEC>(gc[u], a.out + off);
+              if (AGGR == A_MAX) load_vec<VEC>(ai[u], a.argmax + off);
+              if (MODE == M_GEN_FULL) load_vec<VEC>(ef[u], a.efull + (size_t)e0[u] * a.d + c0);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            float dz[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              float z;
+              const float m = message<MODE>(xj[i], wa[u], eu[i], ev[i], ef[u][i], a.eps, z);
+              float coef;
+              if constexpr (AGGR == A_SUM) {
+                coef = ga[u][i] * inv[u];
+              } else if constexpr (AGGR == A_MAX) {
+                coef = (ai[u][i] == pos[u]) ? ga[u][i] : 0.f;
+              } else if constexpr (AGGR == A_SOFTMAX) {
+                const float w = fast_exp2(sc.t_log2e * m - gb[u][i]);
+                coef = ga[u][i] * w;
+                if (a.learn_t) coef *= fmaf(sc.t, m - gc[u][i], 1.0f);
+              } else {  // POWER: ga carries q (see mlgnn.h)
+                const float mc = fminf(fmaxf(m, kPowLo), kPowHi);
+                const bool inr = (m >= kPowLo) && (m <= kPowHi);
+                coef = inr ? ga[u][i] * fast_exp2((sc.p - 1.0f) * fast_log2(mc)) : 0.f;
+              }
+              if constexpr (MODE == M_WEIGHTED) coef *= wa[u];
+              if constexpr (is_gen<MODE>()) coef = (z > 0.f) ? coef : 0.f;
+              dz[i] = valid[u] ? coef : 0.f;
+              gx[i] += dz[i];
+              if constexpr (MODE == M_GEN_RANK1) { gu[i] = fmaf(wa[u], dz[i], gu[i]); gv[i] += dz[i]; }
+            }
+            if (MODE == M_GEN_FULL && valid[u]) store_vec<VEC>(a.ge + (size_t)e0[u] * a.d + c0, dz);
+          }
+        }
+      }
+      for (int off = lpr; off < kWave; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gx[i] += __shfl_xor(gx[i], off);
+      if (sub == 0 && cact) store_vec<VEC>(a.gx + (size_t)r * a.d + c0, gx);
+    }
+
+    if constexpr (MODE == M_GEN_RANK1) {
+      // per-workgroup partial of d loss/d u, d loss/d v  ->  ws[block][2][d]; summed by a second launch
+      for (int off = lpr; off < kWave; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { gu[i] += __shfl_xor(gu[i], off); gv[i] += __shfl_xor(gv[i], off); }
+      __syncthreads();
+      if (sub == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { red[wave][0][cl * VEC + i] = gu[i]; red[wave][1][cl * VEC + i] = gv[i]; }
+      }
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 2 * lpr * VEC; idx += kBlock) {
+        const int which = idx / (lpr * VEC), c = idx % (lpr * VEC);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) s += red[w][which][c];
+        if (cbase + c < a.d) a.ws[((size_t)blockIdx.x * 2 + which) * a.d + cbase + c] = s;
+      }
+    }
+  }
+}
+
+// ws[nblk][cols] -> out[cols], fixed summation order (bitwise reproducible)
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ ws,
+                                                                  float* __restrict__ out, int nblk, int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * cols + c];
+  out[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+static int pick_mode(int msg, int edge_mode) {
+  if (msg == MLGNN_MSG_IDENTITY) return M_IDENTITY;
+  if (msg == MLGNN_MSG_WEIGHTED) return M_WEIGHTED;
+  if (msg == MLGNN_MSG_GEN) {
+    if (edge_mode == MLGNN_EDGE_NONE) return M_GEN_NONE;
+    if (edge_mode == MLGNN_EDGE_RANK1) return M_GEN_RANK1;
+    if (edge_mode == MLGNN_EDGE_FULL) return M_GEN_FULL;
+  }
+  return -1;
+}
+
+static int pick_aggr(int aggr) {
+  switch (aggr) {
+    case MLGNN_AGGR_SUM: case MLGNN_AGGR_MEAN: return A_SUM;
+    case MLGNN_AGGR_MAX: return A_MAX;
+    case MLGNN_AGGR_SOFTMAX: return A_SOFTMAX;
+    case MLGNN_AGGR_POWER: return A_POWER;
+  }
+  return -1;
+}
+
+static bool is_gen_mode(int mode) { return mode >= M_GEN_NONE; }
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define MLGNN_DISPATCH_AGGR(KERNEL, VEC, MODE, aggr_id, ...)                                   \
+  switch (aggr_id) {                                                                            \
+    case A_SUM: hipLaunchKernelGGL((KERNEL<VEC, MODE, A_SUM>), __VA_ARGS__); break;             \
+    case A_MAX: hipLaunchKernelGGL((KERNEL<VEC, MODE, A_MAX>), __VA_ARGS__); break;             \
+    case A_SOFTMAX: hipLaunchKernelGGL((KERNEL<VEC, MODE, A_SOFTMAX>), __VA_ARGS__); break;     \
+    default: hipLaunchKernelGGL((KERNEL<VEC, MODE, A_POWER>), __VA_ARGS__); break;              \
+  }
+
+#define MLGNN_DISPATCH_MODE(KERNEL, VEC, mode_id, aggr_id, ...)                                 \
+  switch (mode_id) {                                                                            \
+    case M_IDENTITY: hipLaunchKernelGGL((KERNEL<VEC, M_IDENTITY, A_SUM>), __VA_ARGS__); break;  \
+    case M_WEIGHTED: hipLaunchKernelGGL((KERNEL<VEC, M_WEIGHTED, A_SUM>), __VA_ARGS__); break;  \
+    case M_GEN_NONE: MLGNN_DISPATCH_AGGR(KERNEL, VEC, M_GEN_NONE, aggr_id, __VA_ARGS__) break;  \
+    case M_GEN_RANK1: MLGNN_DISPATCH_AGGR(KERNEL, VEC, M_GEN_RANK1, aggr_id, __VA_ARGS__) break;\
+    default: MLGNN_DISPATCH_AGGR(KERNEL, VEC, M_GEN_FULL, aggr_id, __VA_ARGS__) break;          \
+  }
+
+}  // namespace mlgnn
+
+using namespace mlgnn;
+
+extern "C" int mlgnn_version(void) { return MLGNN_ABI_VERSION; }
+
+extern "C" int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d) {
+  if (N < 0 || d < 0) return MLGNN_E_SHAPE;
+  return (int64_t)grid_for_rows(N) * 2 * d;
+}
+
+extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t* col,
+                                       const float* ew, const float* eu, const float* ev,
+                                       const void* efull, const int32_t* eid,
+                                       void* out, float* aux, float* aux2, int32_t* argmax,
+                                       int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                                       int aggr, float t, float p, const float* t_dev, const float* p_dev, float eps, void* stream) {
+  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
+  const int mode = pick_mode(msg, edge_mode);
+  const int ag = pick_aggr(aggr);
+  if (mode < 0 || ag < 0) return MLGNN_E_MODE;
+  if (!is_gen_mode(mode) && ag != A_SUM) return MLGNN_E_MODE;
+  if (N == 0) return 0;
+  if (!x || !rowptr || !col || !out) return MLGNN_E_NULL;
+  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew) return MLGNN_E_NULL;
+  if (mode == M_GEN_RANK1 && (!eu || !ev)) return MLGNN_E_NULL;
+  if (mode == M_GEN_FULL && (!efull || !eid)) return MLGNN_E_NULL;
+  if (ag == A_POWER && !p_dev && !(p != 0.0f)) return MLGNN_E_MODE;
+
+  FwdArgs a;
+  a.x = (const float*)x; a.rowptr = rowptr; a.col = col; a.ew = ew; a.eu = eu; a.ev = ev;
+  a.efull = (const float*)efull; a.eid = eid; a.out = (float*)out; a.aux = aux; a.aux2 = aux2;
+  a.argmax = argmax; a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN);
+  a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev;
+
+  const bool vec4 = (d % 4 == 0) && aligned16(x) && aligned16(out) && (!efull || aligned16(efull)) &&
+                    (!aux || aligned16(aux)) && (!aux2 || aligned16(aux2)) && (!argmax || aligned16(argmax)) &&
+                    (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  const dim3 grid(grid_for_rows(N)), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec4) {
+    a.lpr_log2 = lanes_per_row_log2(d, 4);
+    MLGNN_DISPATCH_MODE(csr_aggregate_fwd_kernel, 4, mode, ag, grid, block, 0, s, a)
+  } else {
+    a.lpr_log2 = lanes_per_row_log2(d, 1);
+    MLGNN_DISPATCH_MODE(csr_aggregate_fwd_kernel, 1, mode, ag, grid, block, 0, s, a)
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out, const float* aux,
+                                       const int32_t* argmax,
+                                       const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
+                                       const int32_t* rowptr,
+                                       const float* ew_t, const float* eu, const float* ev,
+                                       const void* efull, const int32_t* eid_t,
+                                       void* grad_x, void* grad_efull, float* grad_uv,
+                                       float* workspace, int64_t workspace_floats,
+                                       int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                                       int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev, float eps,
+                                       void* stream) {
+  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
+  const int mode = pick_mode(msg, edge_mode);
+  const int ag = pick_aggr(aggr);
+  if (mode < 0 || ag < 0) return MLGNN_E_MODE;
+  if (!is_gen_mode(mode) && ag != A_SUM) return MLGNN_E_MODE;
+  if (N == 0) return 0;
+  if (!grad_out || !rowptr_t || !col_t || !grad_x) return MLGNN_E_NULL;
+  if (is_gen_mode(mode) && !x) return MLGNN_E_NULL;
+  if (aggr == MLGNN_AGGR_MEAN && !rowptr) return MLGNN_E_NULL;
+  if (ag == A_MAX && (!argmax || !pos_t)) return MLGNN_E_NULL;
+  if (ag == A_SOFTMAX && (!aux || (learn_t && !out))) return MLGNN_E_NULL;
+  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew_t) return MLGNN_E_NULL;
+  if (mode == M_GEN_RANK1 && (!eu || !ev || !grad_uv || !workspace)) return MLGNN_E_NULL;
+  if (mode == M_GEN_FULL && (!efull || !eid_t || !grad_efull)) return MLGNN_E_NULL;
+  const int nblk = grid_for_rows(N);
+  if (mode == M_GEN_RANK1 && workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
+
+  BwdArgs a;
+  a.go = (const float*)grad_out; a.x = (const float*)x; a.out = (const float*)out; a.aux = aux;
+  a.argmax = argmax; a.rowptr_t = rowptr_t; a.col_t = col_t; a.pos_t = pos_t; a.rowptr = rowptr;
+  a.ew_t = ew_t; a.eu = eu; a.ev = ev; a.efull = (const float*)efull; a.eid_t = eid_t;
+  a.gx = (float*)grad_x; a.ge = (float*)grad_efull; a.ws = workspace;
+  a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN); a.learn_t = learn_t;
+  a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev;
+
+  const bool vec4 = (d % 4 == 0) && aligned16(grad_out) && aligned16(grad_x) && (!x || aligned16(x)) &&
+                    (!out || aligned16(out)) && (!aux || aligned16(aux)) && (!argmax || aligned16(argmax)) &&
+                    (!efull || aligned16(efull)) && (!grad_efull || aligned16(grad_efull)) &&
+                    (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  const dim3 grid(nblk), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec4) {
+    a.lpr_log2 = lanes_per_row_log2(d, 4);
+    MLGNN_DISPATCH_MODE(csr_aggregate_bwd_kernel, 4, mode, ag, grid, block, 0, s, a)
+  } else {
+    a.lpr_log2 = lanes_per_row_log2(d, 1);
+    MLGNN_DISPATCH_MODE(csr_aggregate_bwd_kernel, 1, mode, ag, grid, block, 0, s, a)
+  }
+  int err = (int)hipGetLastError();
+  if (err) return err;
+  if (mode == M_GEN_RANK1) {
+    const int cols = 2 * (int)d;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       workspace, grad_uv, nblk, cols);
+    err = (int)hipGetLastError();
+  }
+  return err;
+}

@@ -1,0 +1,101 @@
+// Shared device helpers for the gfx950 kernels of libmlgnn.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mlgnn {
+
+constexpr int kWave = 64;          // CDNA wavefront width
+constexpr int kBlock = 256;        // 4 waves per workgroup, one per SIMD
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with its own L2
+constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 resident workgroups
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(float (&r)[VEC], const float* __restrict__ p) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = p[i];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(int (&r)[VEC], const int* __restrict__ p) {
+  if constexpr (VEC == 4) {
+    const int4 t = *reinterpret_cast<const int4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = p[i];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = r[i];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(int* __restrict__ p, const int (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<int4*>(p) = make_int4(r[0], r[1], r[2], r[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = r[i];
+  }
+}
+
+// exp2 / log2 on the transcendental unit (v_exp_f32 / v_log_f32, ~1 ulp)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// Rows [r0, r1) one XCD walks, and this wave's position in that walk.  Workgroups are dealt
+// round-robin over the 8 XCDs (observed, not guaranteed: it only affects speed), so block b
+// belongs to group b % 8; each group sweeps one contiguous eighth of the rows with all of its
+// waves side by side, which keeps the gathered neighbour rows of a graph in that XCD's L2.
+struct RowWalk {
+  int r_begin, r_end, first, stride;
+};
+
+__device__ __forceinline__ RowWalk make_row_walk(int n_rows) {
+  const int xcd = blockIdx.x % kXcds;
+  const int slot = blockIdx.x / kXcds;
+  const int blocks_per_xcd = gridDim.x / kXcds;          // grid is a multiple of 8
+  const int rows_per_xcd = (n_rows + kXcds - 1) / kXcds;
+  RowWalk w;
+  w.r_begin = xcd * rows_per_xcd;
+  w.r_end = min(n_rows, w.r_begin + rows_per_xcd);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+  w.first = w.r_begin + slot * kWavesPerBlock + wave;
+  w.stride = blocks_per_xcd * kWavesPerBlock;
+  return w;
+}
+
+inline int grid_for_rows(int64_t n_rows) {
+  int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  blocks = (blocks + kXcds - 1) / kXcds * kXcds;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  if (blocks < kXcds) blocks = kXcds;
+  return (int)blocks;
+}
+
+// lanes-per-row (power of two) for d channels at VEC floats per lane, capped at one wave
+inline int lanes_per_row_log2(int64_t d, int vec) {
+  int64_t need = (d + vec - 1) / vec;
+  int l = 0;
+  while ((1 << l) < need && l < 6) ++l;
+  return l;
+}
+
+}  // namespace mlgnn

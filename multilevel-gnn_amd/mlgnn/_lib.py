@@ -1,0 +1,57 @@
+"""ctypes binding of the C ABI in include/mlgnn.h.  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmlgnn.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_I64 = _c.c_int64
+_INT = _c.c_int
+_F = _c.c_float
+
+# name -> (restype, argtypes); mirrors include/mlgnn.h one to one (tests check the export list)
+SIGNATURES = {
+    "mlgnn_version": (_INT, []),
+    "mlgnn_csr_aggregate_bwd_workspace_floats": (_I64, [_I64, _I64]),
+    "mlgnn_csr_aggregate_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                       _I64, _I64, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _P]),
+    "mlgnn_csr_aggregate_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                       _P, _P, _P, _P, _I64,
+                                       _I64, _I64, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _P]),
+}
+
+ERRORS = {-1: "MLGNN_E_NULL", -2: "MLGNN_E_SHAPE", -3: "MLGNN_E_MODE", -4: "MLGNN_E_DTYPE",
+          -5: "MLGNN_E_WORKSPACE", -6: "MLGNN_E_ALIGN"}
+
+
+class MlgnnError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB):
+        raise ImportError(
+            "libmlgnn.so is not built (%s). Build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB)
+    lib = ctypes.CDLL(LIB)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the export is missing
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(code, what):
+    if code == 0:
+        return
+    if code < 0:
+        raise MlgnnError("%s: argument error %s" % (what, ERRORS.get(code, code)))
+    raise MlgnnError("%s: HIP error %d" % (what, code))
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,73 @@
+"""Graph topology container: CSR by destination + CSR by source (int32, device resident).
+
+The reference keeps graphs as COO ``edge_index [2, E]`` int64 and lets every layer re-derive its
+gather/scatter from it (``MessagePassing.propagate``).  Here the topology is sorted once per batch;
+all layers (and forward + backward) share it.
+"""
+import torch
+
+
+class CSRGraph:
+    """``edge_index[0] = src = j``, ``edge_index[1] = dst = i`` (PyG flow source->target).
+
+    by destination:  rowptr [N+1], col [E] = src, eid [E] = COO position   (stable: COO order kept)
+    by source:       rowptr_t [N+1], col_t [E] = dst, pos_t [E] = position in the by-destination
+                     order, eid_t [E] = COO position
+    """
+
+    def __init__(self, edge_index, num_nodes):
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E]")
+        N = int(num_nodes)
+        E = int(edge_index.shape[1])
+        if N >= 2 ** 31 or E >= 2 ** 31:
+            raise ValueError("int32 index range exceeded")
+        dev = edge_index.device
+        src, dst = edge_index[0].long(), edge_index[1].long()
+        order = torch.sort(dst, stable=True).indices
+        col = src[order]
+        order_t = torch.sort(col, stable=True).indices
+        self.num_nodes, self.num_edges, self.device = N, E, dev
+        self.rowptr = self._ptr(dst, N)
+        self.col = col.to(torch.int32)
+        self.eid = order.to(torch.int32)
+        self.rowptr_t = self._ptr(src, N)
+        self.col_t = dst[order][order_t].to(torch.int32)
+        self.pos_t = order_t.to(torch.int32)
+        self.eid_t = order[order_t].to(torch.int32)
+        self._deg = None
+        self._scalar_cache = {}
+
+    @staticmethod
+    def _ptr(index, N):
+        counts = torch.bincount(index, minlength=N)
+        ptr = torch.zeros(N + 1, dtype=torch.int64, device=index.device)
+        torch.cumsum(counts, 0, out=ptr[1:])
+        return ptr.to(torch.int32)
+
+    @property
+    def in_degree(self):
+        """float [N]: number of incoming edges (PyG ``degree(index, N)``)."""
+        if self._deg is None:
+            self._deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
+        return self._deg
+
+    def edge_scalar(self, a):
+        """Per-edge scalar [E] (COO order) -> (by-destination order, by-source order); cached per tensor."""
+        key = (a.data_ptr(), a._version, a.numel())
+        hit = self._scalar_cache.get(key)
+        if hit is None:
+            flat = a.reshape(-1).to(torch.float32)
+            by_dst = flat[self.eid.long()].contiguous()
+            hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
+            self._scalar_cache = {key: hit}
+        return hit
+
+
+def as_graph(edge_index, num_nodes):
+    """Accept a prebuilt :class:`CSRGraph` (e.g. attached by the collate step) or a COO tensor."""
+    if isinstance(edge_index, CSRGraph):
+        if edge_index.num_nodes != num_nodes:
+            raise ValueError("graph has %d nodes, features have %d" % (edge_index.num_nodes, num_nodes))
+        return edge_index
+    return CSRGraph(edge_index, num_nodes)

@@ -1,0 +1,194 @@
+"""torch.autograd bindings of the CSR aggregation kernels (C ABI: include/mlgnn.h).
+
+PyTorch owns memory and the autograd graph; every numeric step of the aggregation itself runs in
+libmlgnn.so.  All functions require CUDA(HIP) fp32 tensors and raise otherwise -- no CPU path.
+"""
+import torch
+
+from . import _lib
+from .graph import CSRGraph
+
+MSG_IDENTITY, MSG_WEIGHTED, MSG_GEN = 0, 1, 2
+EDGE_NONE, EDGE_RANK1, EDGE_FULL = 0, 1, 2
+AGGR_SUM, AGGR_MEAN, AGGR_MAX, AGGR_SOFTMAX, AGGR_POWER = 0, 1, 2, 3, 4
+DTYPE_F32 = 0
+POW_LO, POW_HI = 1e-7, 1e1        # torch_message.py:69
+
+# reference aggregator names (torch_message.py:14,27,45-82) -> kernel aggregator
+AGGR_IDS = {"add": AGGR_SUM, "sum": AGGR_SUM, "mean": AGGR_MEAN, "max": AGGR_MAX,
+            "softmax": AGGR_SOFTMAX, "softmax_sg": AGGR_SOFTMAX, "softmax_sum": AGGR_SOFTMAX,
+            "power": AGGR_POWER, "power_sum": AGGR_POWER}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_f32(t, what):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: libmlgnn has no CPU path" % what)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
+class RankOneEdge:
+    """Edge embedding kept in factored form: ``e_ij = a_ij * weight + bias``.
+
+    ``a`` is the raw scalar edge attribute ``[E]`` in COO order; ``weight``/``bias`` are ``[H]``.
+    This is what ``DeeperGCN.edge_encoder = Linear(1, H)`` (deepergcn.py:90,213) produces, and it
+    stays rank one through ``GENConv.edge_encoder = Linear(H, d)`` (torch_vertex.py:68,77), so the
+    ``[E, d]`` embedding and its 2*E*d*d FLOP GEMM never have to exist.
+    """
+
+    def __init__(self, a, weight, bias):
+        self.a = a.reshape(-1)
+        self.weight = weight
+        self.bias = bias
+
+    def through_linear(self, W, b):
+        """Compose with ``Linear``: ``W (a w + c) + b = a (W w) + (W c + b)``."""
+        return RankOneEdge(self.a, torch.mv(W, self.weight), torch.mv(W, self.bias) + (0 if b is None else b))
+
+    def dense(self):
+        return self.a[:, None] * self.weight[None, :] + self.bias[None, :]
+
+
+class _GenAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t, p, eps, learn_t, learn_p):
+        x = _dev_f32(x, "x")
+        N, d = x.shape
+        if graph.num_nodes != N:
+            raise ValueError("graph/feature size mismatch")
+        edge_mode = EDGE_RANK1 if eu is not None else (EDGE_FULL if efull is not None else EDGE_NONE)
+        eu, ev, efull = _dev_f32(eu, "eu"), _dev_f32(ev, "ev"), _dev_f32(efull, "efull")
+        if efull is not None and tuple(efull.shape) != (graph.num_edges, d):
+            raise ValueError("edge embedding must be [E, d]")
+        if eu is not None and (eu.numel() != d or ev.numel() != d):
+            raise ValueError("rank-1 edge vectors must be [d]")
+        out = torch.empty_like(x)
+        want_bwd = any(ctx.needs_input_grad)
+        aux = torch.empty_like(x) if (aggr_id in (AGGR_SOFTMAX, AGGR_POWER) and want_bwd) else None
+        aux2 = torch.empty_like(x) if ((aggr_id == AGGR_SOFTMAX and learn_t) or
+                                       (aggr_id == AGGR_POWER and learn_p)) else None
+        argmax = torch.empty((N, d), dtype=torch.int32, device=x.device) if aggr_id == AGGR_MAX else None
+        ew = ew_pair[0] if ew_pair is not None else None
+        t_dev = t_par if (learn_t and t_par is not None) else None
+        p_dev = p_par if (learn_p and p_par is not None) else None
+        rc = _lib.lib.mlgnn_csr_aggregate_fwd(
+            x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), _lib.ptr(eu), _lib.ptr(ev),
+            _lib.ptr(efull), graph.eid.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),
+            _lib.ptr(argmax), N, d, DTYPE_F32, MSG_GEN, edge_mode, aggr_id, float(t), float(p),
+            _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), _stream())
+        _lib.check(rc, "mlgnn_csr_aggregate_fwd")
+        ctx.graph, ctx.ew_pair = graph, ew_pair
+        ctx.cfg = (aggr_id, edge_mode, float(t), float(p), float(eps), bool(learn_t), bool(learn_p))
+        ctx.save_for_backward(x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev = ctx.saved_tensors
+        aggr_id, edge_mode, t, p, eps, learn_t, learn_p = ctx.cfg
+        g = ctx.graph
+        N, d = x.shape
+        go = _dev_f32(go, "grad_out")
+        grad_t = grad_p = None
+        go_k = go
+        if aggr_id == AGGR_POWER:
+            pv = p_dev if p_dev is not None else p
+            muc = aux.clamp(POW_LO, POW_HI)
+            inr = ((aux >= POW_LO) & (aux <= POW_HI)).to(go.dtype)
+            go_k = (go * torch.pow(muc, 1.0 / pv - 1.0) * inr / g.in_degree.clamp(min=1)[:, None]).contiguous()
+            if learn_p:
+                grad_p = (go * out * (-torch.log(muc) / (pv * pv) + inr * aux2 / (pv * muc))).sum().reshape(1)
+        if aggr_id == AGGR_SOFTMAX and learn_t:
+            grad_t = (go * (aux2 - out * out)).sum().reshape(1)
+        gx = torch.empty_like(x)
+        ge = torch.empty_like(efull) if edge_mode == EDGE_FULL else None
+        guv = ws = None
+        ws_n = 0
+        if edge_mode == EDGE_RANK1:
+            ws_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_workspace_floats(N, d))
+            ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
+            guv = torch.empty((2, d), dtype=torch.float32, device=x.device)
+        ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
+        rc = _lib.lib.mlgnn_csr_aggregate_bwd(
+            go_k.data_ptr(), x.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(argmax),
+            g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(), g.rowptr.data_ptr(),
+            _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), g.eid_t.data_ptr(),
+            gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
+            N, d, DTYPE_F32, MSG_GEN, edge_mode, aggr_id, int(learn_t), t, p,
+            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, _stream())
+        _lib.check(rc, "mlgnn_csr_aggregate_bwd")
+        geu = guv[0] if guv is not None else None
+        gev = guv[1] if guv is not None else None
+        return gx, geu, gev, ge, grad_t, grad_p, None, None, None, None, None, None, None, None
+
+
+def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, learn_t=False, learn_p=False):
+    """``aggregate(relu(x_j + e_ij) + eps)`` over incoming edges -- GENConv.message + aggregate
+    (torch_vertex.py:94-101, torch_message.py:44-85) in one kernel.
+
+    ``edge``: ``None`` | :class:`RankOneEdge` (already composed to width d) | ``[E, d]`` tensor (COO order).
+    ``t``/``p``: float, or the 1-element parameter when ``learn_t``/``learn_p``.
+    ``*_sum`` variants return the un-scaled value; the caller applies ``deg ** sigmoid(y)``.
+    """
+    if not isinstance(graph, CSRGraph):
+        raise TypeError("graph must be a CSRGraph")
+    aggr_id = AGGR_IDS[aggr]
+    eu = ev = efull = ew_pair = None
+    if isinstance(edge, RankOneEdge):
+        eu, ev = edge.weight, edge.bias
+        ew_pair = graph.edge_scalar(edge.a)
+    elif edge is not None:
+        efull = edge
+    t_par = t if torch.is_tensor(t) else None
+    p_par = p if torch.is_tensor(p) else None
+    t_val = 1.0 if t_par is not None else t
+    p_val = 1.0 if p_par is not None else p
+    return _GenAggregate.apply(x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t_val, p_val, eps,
+                               bool(learn_t) and t_par is not None, bool(learn_p) and p_par is not None)
+
+
+class _WeightedAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, graph, ew_pair, mean):
+        x = _dev_f32(x, "x")
+        N, d = x.shape
+        out = torch.empty_like(x)
+        msg = MSG_WEIGHTED if ew_pair is not None else MSG_IDENTITY
+        aggr_id = AGGR_MEAN if mean else AGGR_SUM
+        ew = ew_pair[0] if ew_pair is not None else None
+        rc = _lib.lib.mlgnn_csr_aggregate_fwd(
+            x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), None, None, None, None,
+            out.data_ptr(), None, None, None, N, d, DTYPE_F32, msg, EDGE_NONE, aggr_id, 1.0, 1.0, None, None,
+            0.0, _stream())
+        _lib.check(rc, "mlgnn_csr_aggregate_fwd")
+        ctx.graph, ctx.ew_pair, ctx.cfg = graph, ew_pair, (msg, aggr_id, N, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        g = ctx.graph
+        msg, aggr_id, N, d = ctx.cfg
+        go = _dev_f32(go, "grad_out")
+        gx = torch.empty_like(go)
+        ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
+        rc = _lib.lib.mlgnn_csr_aggregate_bwd(
+            go.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
+            g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, gx.data_ptr(), None, None, None, 0,
+            N, d, DTYPE_F32, msg, EDGE_NONE, aggr_id, 0, 1.0, 1.0, None, None, 0.0, _stream())
+        _lib.check(rc, "mlgnn_csr_aggregate_bwd")
+        return gx, None, None, None
+
+
+def weighted_mean_aggregate(x, graph, weight=None, mean=True):
+    """``mean_{e: dst(e)=i} w_e x_src(e)`` (count = number of edges, not sum of weights): the SAGE
+    neighbourhood reduction applied BEFORE ``lin_r`` (torch_vertex.py:279-286 by linearity).
+    ``weight``: ``[E]`` / ``[E,1]`` in COO order or ``None``.  No gradient flows to ``weight``."""
+    ew_pair = graph.edge_scalar(weight) if weight is not None else None
+    return _WeightedAggregate.apply(x, graph, ew_pair, bool(mean))

@@ -462,10 +462,10 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   if (mode < 0 || ag < 0) return MLGNN_E_MODE;
   if (!is_gen_mode(mode) && ag != A_SUM) return MLGNN_E_MODE;
   if (N == 0) return 0;
-  if (!x || !rowptr || !col || !out) return MLGNN_E_NULL;
-  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew) return MLGNN_E_NULL;
+  if (!x || !rowptr || !out) return MLGNN_E_NULL;   // col may be NULL iff the graph has no edge
+  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew && col) return MLGNN_E_NULL;
   if (mode == M_GEN_RANK1 && (!eu || !ev)) return MLGNN_E_NULL;
-  if (mode == M_GEN_FULL && (!efull || !eid)) return MLGNN_E_NULL;
+  if (mode == M_GEN_FULL && col && (!efull || !eid)) return MLGNN_E_NULL;
   if (ag == A_POWER && !p_dev && !(p != 0.0f)) return MLGNN_E_MODE;
 
   FwdArgs a;
@@ -507,14 +507,14 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   if (mode < 0 || ag < 0) return MLGNN_E_MODE;
   if (!is_gen_mode(mode) && ag != A_SUM) return MLGNN_E_MODE;
   if (N == 0) return 0;
-  if (!grad_out || !rowptr_t || !col_t || !grad_x) return MLGNN_E_NULL;
+  if (!grad_out || !rowptr_t || !grad_x) return MLGNN_E_NULL;   // col_t may be NULL iff E == 0
   if (is_gen_mode(mode) && !x) return MLGNN_E_NULL;
   if (aggr == MLGNN_AGGR_MEAN && !rowptr) return MLGNN_E_NULL;
-  if (ag == A_MAX && (!argmax || !pos_t)) return MLGNN_E_NULL;
+  if (ag == A_MAX && !argmax) return MLGNN_E_NULL;
   if (ag == A_SOFTMAX && (!aux || (learn_t && !out))) return MLGNN_E_NULL;
-  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew_t) return MLGNN_E_NULL;
+  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew_t && col_t) return MLGNN_E_NULL;
   if (mode == M_GEN_RANK1 && (!eu || !ev || !grad_uv || !workspace)) return MLGNN_E_NULL;
-  if (mode == M_GEN_FULL && (!efull || !eid_t || !grad_efull)) return MLGNN_E_NULL;
+  if (mode == M_GEN_FULL && col_t && (!efull || !eid_t || !grad_efull)) return MLGNN_E_NULL;
   const int nblk = grid_for_rows(N);
   if (mode == M_GEN_RANK1 && workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
 

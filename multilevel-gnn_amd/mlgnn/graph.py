@@ -71,3 +71,32 @@ def as_graph(edge_index, num_nodes):
             raise ValueError("graph has %d nodes, features have %d" % (edge_index.num_nodes, num_nodes))
         return edge_index
     return CSRGraph(edge_index, num_nodes)
+
+
+_SAGE_CACHE = []          # [(edge_index, edge_attr, N, ei_version, ea_version, graph, weight)]
+
+
+def sage_graph(edge_index, edge_attr, num_nodes):
+    """Topology + weights SAGEConv propagates over (torch_vertex.py:272-273): existing self loops
+    dropped, one self loop of weight 1.0 appended per node.  The layers of one forward pass hand in
+    the very same tensors, so the last result is kept (identity + version checked; the cache holds
+    the tensors, so their storage cannot be recycled under it)."""
+    if isinstance(edge_index, CSRGraph):
+        raise TypeError("SAGEConv rewrites self loops: pass the COO edge_index")
+    ea_v = None if edge_attr is None else edge_attr._version
+    for ent in _SAGE_CACHE:
+        if ent[0] is edge_index and ent[1] is edge_attr and ent[2] == num_nodes and \
+                ent[3] == edge_index._version and ent[4] == ea_v:
+            return ent[5], ent[6]
+    keep = edge_index[0] != edge_index[1]
+    loops = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device)
+    ei = torch.cat([edge_index[:, keep], loops.unsqueeze(0).expand(2, -1)], dim=1)
+    weight = None
+    if edge_attr is not None:
+        ea = edge_attr.reshape(edge_attr.shape[0], -1)
+        if ea.shape[1] != 1:
+            raise ValueError("SAGE edge weights must be scalar per edge")
+        weight = torch.cat([ea[keep, 0].to(torch.float32), torch.ones(num_nodes, device=ea.device)])
+    graph = CSRGraph(ei, num_nodes)
+    _SAGE_CACHE[:] = [(edge_index, edge_attr, num_nodes, edge_index._version, ea_v, graph, weight)]
+    return graph, weight

@@ -1,0 +1,16 @@
+"""Model registry with the reference's surface: ``from models import get_model`` (reference
+``models/__init__.py:11-24``).  Only the model families on the accelerated hot path are registered
+(SURVEY.md section 8a); the AE/VAE pre-training variants, PathCNN and the stale DeeperGCN copies
+are out of scope for this library."""
+from .deepergcn import DeeperGCN
+from .multilevel_gnn import MultilevelGNN
+from .diff_pooling import DiffPool, DiffPoolLayer, SAGEConvolutions  # noqa: F401
+
+MODELS = {
+    'deepergcn': DeeperGCN,
+    'multilevel_gnn': MultilevelGNN,
+}
+
+
+def get_model(model_name):
+    return MODELS[model_name]

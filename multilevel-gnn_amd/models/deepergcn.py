@@ -1,0 +1,215 @@
+"""DeeperGCN on the HIP CSR kernels (interface of the reference's ``models/deepergcn.py``:
+class ``DeeperGCN`` :17, ``forward`` :185-323, ``print_params`` :325).
+
+Same constructor ``(args)``, same ``forward(batch) -> softmax probabilities [B, num_tasks]``, same
+``state_dict`` keys.  Differences in HOW: the graph is sorted to CSR once per batch and shared by
+all layers; a scalar raw edge attribute is carried as a rank-one term through both Linear edge
+encoders (no ``[E, d]`` embedding, no per-layer edge GEMM); the per-graph Python loops with
+device->host syncs of the pathway-global-node branch (:221,:290) are index arithmetic on device.
+"""
+import logging
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mlgnn import CSRGraph, RankOneEdge
+from mlgnn.pool import global_pool
+from .gcn_lib.sparse.torch_vertex import GENConv
+from .gcn_lib.sparse.torch_nn import norm_layer
+
+
+class DeeperGCN(torch.nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.num_layers = args.num_layers
+        self.dropout = args.dropout
+        self.block = args.block
+        self.mul_attr = args.mul_attr
+        hidden_channels = args.hidden_channels
+        self.hidden_channels = hidden_channels
+        self.learn_t = args.learn_t
+        self.learn_p = args.learn_p
+        self.msg_norm = args.msg_norm
+        if self.block not in ('res+', 'res', 'plain'):
+            if self.block == 'dense':
+                raise NotImplementedError('To be implemented')
+            raise Exception('Unknown block Type')
+        if args.conv != 'gen':
+            raise Exception('Unknown Conv Type')
+        if args.gnn_encoder != 'linear':
+            raise NotImplementedError("gnn_encoder=%r is outside the accelerated path" % (args.gnn_encoder,))
+        if args.pathway_global_node and args.pathway_readout not in (None, 'maxpool'):
+            raise NotImplementedError("pathway_readout=%r is outside the accelerated path" % (args.pathway_readout,))
+
+        self.pca_only = args.pca_only
+        self.gnn_encoder = args.gnn_encoder
+        self.no_inter_drop = args.no_inter_drop
+        self.no_inter_norm = args.no_inter_norm
+        self.feature_drop_flag = args.feature_drop
+
+        self.gcns = torch.nn.ModuleList()
+        self.norms = torch.nn.ModuleList()
+        for _ in range(self.num_layers):
+            self.gcns.append(GENConv(hidden_channels, hidden_channels, aggr=args.gcn_aggr, t=args.t,
+                                     learn_t=self.learn_t, p=args.p, learn_p=self.learn_p,
+                                     gnn_encoder=self.gnn_encoder, msg_norm=self.msg_norm,
+                                     learn_msg_scale=args.learn_msg_scale, encode_edge=args.conv_encode_edge,
+                                     edge_feat_dim=hidden_channels, norm=args.norm, mlp_layers=args.mlp_layers,
+                                     pca_only=self.pca_only))
+            self.norms.append(norm_layer(args.norm, hidden_channels))
+
+        self.node_embedding = args.node_embedding
+        if self.node_embedding:
+            self.node_embedding_encoder = torch.nn.Embedding(args.node_num, args.node_embedding_dim)
+        input_dim = 3 + (args.node_embedding_dim if self.node_embedding else 0) + (2 if self.mul_attr else 0)
+        self.node_features_encoder = torch.nn.Linear(input_dim, hidden_channels)
+        self.edge_encoder = torch.nn.Linear(7 if args.use_column is None else 1, hidden_channels)
+
+        self.global_edge = args.global_edge
+        if args.global_edge == "onehot":
+            self.edge_encoder = torch.nn.Embedding(args.pathway_edge_num, hidden_channels)
+
+        self.use_edge_attr = args.use_edge_attr
+        self.pathway_global_node = args.pathway_global_node
+        if self.pathway_global_node:
+            self.pathway_num = args.pathway_num
+            self.pathway_features_encoder = torch.nn.Linear(6, hidden_channels)
+
+        self.num_layer_head = args.num_layer_head
+        self.pathway_readout = args.pathway_readout
+        self.pre_concat_age = args.pre_concat_age
+        self.feature_drop = nn.Dropout(0.25)
+        if self.pathway_global_node and self.pathway_readout == 'maxpool':
+            readout_in = (self.pathway_num // 4) * hidden_channels + (1 if args.pre_concat_age else 0)
+            mods = [nn.Linear(readout_in, hidden_channels), nn.ReLU()]
+            if not args.pre_readout_drop:
+                mods.append(nn.Dropout(0.5))
+            self.readout_func = nn.Sequential(*mods)
+
+        if args.graph_pooling not in ("sum", "mean", "max"):
+            raise Exception('Unknown Pool Type')
+        self.graph_pooling = args.graph_pooling
+
+        self.graph_pred_linear = torch.nn.Sequential()
+        self.use_age = args.use_age
+        head_embedding = (hidden_channels + 1) if args.use_age and not args.pre_concat_age else hidden_channels
+        for i in range(args.num_layer_head - 1):
+            self.graph_pred_linear.add_module(str(2 * i), torch.nn.Linear(head_embedding, head_embedding))
+            self.graph_pred_linear.add_module(str(2 * i + 1), torch.nn.ReLU())
+            if args.head_dropout:
+                self.graph_pred_linear.add_module("drop{}".format(str(i)), torch.nn.Dropout(self.dropout))
+        self.graph_pred_linear.add_module(str(2 * args.num_layer_head), torch.nn.Linear(head_embedding, args.num_tasks))
+
+        if args.all_init:
+            self.init_weight()
+        elif args.head_init:
+            for m in self.graph_pred_linear.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.xavier_uniform_(m.weight.data)
+                    torch.nn.init.constant_(m.bias.data, 0.0)
+
+    # ------------------------------------------------------------------ helpers
+    def _edge_term(self, edge_attr):
+        """Model-level edge embedding (deepergcn.py:212-215), kept factored when it is rank one."""
+        if not self.use_edge_attr:
+            return None
+        if self.global_edge == "onehot":
+            return self.edge_encoder(edge_attr.to(torch.long))               # [E, 1, H]
+        if edge_attr.dim() == 2 and edge_attr.shape[1] == 1:
+            return RankOneEdge(edge_attr[:, 0], self.edge_encoder.weight[:, 0], self.edge_encoder.bias)
+        return self.edge_encoder(edge_attr)
+
+    def _pathway_rows(self, node_size):
+        """Row indices of the last ``pathway_num`` nodes of every graph, [B * pathway_num]."""
+        ends = torch.cumsum(node_size.to(torch.long), dim=0)
+        offs = torch.arange(-self.pathway_num, 0, device=ends.device)
+        return (ends[:, None] + offs[None, :]).reshape(-1)
+
+    def _drop(self, h):
+        return F.dropout(h, p=self.dropout, training=self.training)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_batch):
+        x = input_batch.x
+        if self.pca_only:
+            raise NotImplementedError("pca_only is outside the accelerated path")
+        graph = getattr(input_batch, "csr", None)
+        if graph is None:
+            graph = CSRGraph(input_batch.edge_index, x.shape[0])
+        batch = input_batch.batch
+        age = input_batch.age
+
+        if self.node_embedding:
+            emb = self.node_embedding_encoder(x[:, -1].to(torch.long))
+            h = self.node_features_encoder(torch.cat([x[:, :-1], emb], dim=-1))
+        else:
+            h = self.node_features_encoder(x)
+        edge_emb = self._edge_term(input_batch.edge_attr)
+
+        rows = None
+        if self.pathway_global_node:
+            pemb = self.pathway_features_encoder(input_batch.pathway_node_attr)
+            rows = self._pathway_rows(input_batch.node_size)
+            h = h.index_copy(0, rows, pemb.reshape(-1, pemb.shape[-1]))
+
+        L = self.num_layers
+        if self.block == 'res+':
+            h = self.gcns[0](h, graph, edge_emb)
+            for layer in range(1, L):
+                h1 = h if self.no_inter_norm else self.norms[layer - 1](h)
+                h2 = F.relu(h1)
+                if not self.no_inter_drop:
+                    h2 = self._drop(h2)
+                h = self.gcns[layer](h2, graph, edge_emb) + h
+            h = self.norms[L - 1](h)
+            if not self.no_inter_drop:
+                h = self._drop(h)
+        elif self.block == 'res':
+            h = self._drop(F.relu(self.norms[0](self.gcns[0](h, graph, edge_emb))))
+            for layer in range(1, L):
+                h = F.relu(self.norms[layer](self.gcns[layer](h, graph, edge_emb))) + h
+                h = self._drop(h)
+        else:  # plain
+            h = self._drop(F.relu(self.norms[0](self.gcns[0](h, graph, edge_emb))))
+            for layer in range(1, L):
+                h1 = self.gcns[layer](h, graph, edge_emb)
+                h2 = h1 if self.no_inter_norm else self.norms[layer](h1)
+                h = F.relu(h2) if layer != L - 1 else h2
+                if not self.no_inter_drop:
+                    h = self._drop(h)
+
+        n_graphs = int(age.shape[0]) if age is not None else None
+        if self.pathway_global_node:
+            prow = h.index_select(0, rows)
+            if self.pathway_readout is None:
+                h_graph = global_pool(prow, batch.index_select(0, rows), self.graph_pooling, n_graphs)
+            else:  # maxpool
+                prow = prow.reshape(-1, self.pathway_num, h.shape[-1])
+                if self.feature_drop_flag:
+                    prow = self.feature_drop(prow)
+                h_graph = torch.flatten(F.max_pool1d(prow.transpose(1, 2), 4), start_dim=1)
+                if self.pre_concat_age:
+                    h_graph = torch.cat([h_graph, age[:, None]], dim=-1)
+                h_graph = self.readout_func(h_graph)
+        else:
+            h_graph = global_pool(h, batch, self.graph_pooling, n_graphs)
+
+        if self.use_age and not self.pre_concat_age:
+            h_graph = torch.cat([h_graph, age[:, None]], dim=-1)
+        return F.softmax(self.graph_pred_linear(h_graph), dim=-1)
+
+    def print_params(self, epoch=None, final=False):
+        for flag, attr, tag in ((self.learn_t, 't', 't'), (self.learn_p, 'p', 'p')):
+            if flag:
+                vals = [getattr(g, attr).item() for g in self.gcns]
+                print('Final {} {}'.format(tag, vals)) if final else logging.info('Epoch {}, {} {}'.format(epoch, tag, vals))
+        if self.msg_norm:
+            ss = [g.msg_norm.msg_scale.item() for g in self.gcns]
+            print('Final s {}'.format(ss)) if final else logging.info('Epoch {}, s {}'.format(epoch, ss))
+
+    def init_weight(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.xavier_uniform_(m.weight.data)
+                torch.nn.init.constant_(m.bias.data, 0.0)

@@ -1,0 +1,60 @@
+"""Dense building blocks of the graph convolutions (interface of the reference's
+``models/gcn_lib/sparse/torch_nn.py``: ``act_layer`` :9-24, ``norm_layer`` :27-38, ``MLP`` :54-75).
+
+These are the dense epilogues of every conv (GEMM + norm + activation); they run on
+rocBLAS/hipBLASLt and MIOpen through torch.  The OGB ``AtomEncoder``/``BondEncoder`` tables of
+the reference are molecule-dataset leftovers outside the hot path and are not provided.
+"""
+from torch import nn
+
+_ACTS = {
+    "relu": lambda inplace, slope, n: nn.ReLU(inplace),
+    "leakyrelu": lambda inplace, slope, n: nn.LeakyReLU(slope, inplace),
+    "prelu": lambda inplace, slope, n: nn.PReLU(num_parameters=n, init=slope),
+    "elu": lambda inplace, slope, n: nn.ELU(),
+    "tanh": lambda inplace, slope, n: nn.Tanh(),
+}
+
+_NORMS = {
+    "batch": lambda nc: nn.BatchNorm1d(nc, affine=True),
+    "layer": lambda nc: nn.LayerNorm(nc, elementwise_affine=True),
+    "instance": lambda nc: nn.InstanceNorm1d(nc, affine=False),
+}
+
+
+def act_layer(act_type, inplace=False, neg_slope=0.2, n_prelu=1):
+    try:
+        return _ACTS[act_type.lower()](inplace, neg_slope, n_prelu)
+    except KeyError:
+        raise NotImplementedError("activation layer [%s] is not found" % act_type)
+
+
+def norm_layer(norm_type, nc):
+    try:
+        return _NORMS[norm_type.lower()](nc)
+    except KeyError:
+        raise NotImplementedError("normalization layer [%s] is not found" % norm_type)
+
+
+def _enabled(name):
+    return name is not None and isinstance(name, str) and name.lower() != "none"
+
+
+class MLP(nn.Sequential):
+    """``Linear -> [norm] -> [act] -> [Dropout2d]`` per hop; the last hop is a bare Linear when
+    ``last_lin``.  Child indices (and so ``state_dict`` keys) follow the reference's layout."""
+
+    def __init__(self, channels, act="relu", norm=None, bias=True, drop=0., last_lin=False):
+        layers = []
+        hops = len(channels) - 1
+        for h in range(hops):
+            layers.append(nn.Linear(channels[h], channels[h + 1], bias))
+            if last_lin and h == hops - 1:
+                break
+            if _enabled(norm):
+                layers.append(norm_layer(norm, channels[h + 1]))
+            if _enabled(act):
+                layers.append(act_layer(act))
+            if drop > 0:
+                layers.append(nn.Dropout2d(drop))
+        super().__init__(*layers)

@@ -1,0 +1,144 @@
+"""Sparse graph convolutions on the HIP CSR kernels (interface of the reference's
+``models/gcn_lib/sparse/torch_vertex.py``: ``GENConv`` :12-104, ``SAGEConv`` :226-294,
+``RSAGEConv`` :297-304, ``GraphConv`` :338-363).
+
+Only the conv types reachable from the shipped configs are provided (``gen``, ``sage``, ``rsage``);
+the PyG-wrapper types (edge/mr/gat/gcn/gin) raise ``NotImplementedError``.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from mlgnn import RankOneEdge, as_graph, weighted_mean_aggregate
+from mlgnn.graph import sage_graph
+from .torch_message import GenMessagePassing, MsgNorm
+from .torch_nn import MLP
+
+
+class GENConv(GenMessagePassing):
+    """GENeralized graph convolution: ``MLP(x + [MsgNorm] aggregate(relu(x_j + e_ij) + eps))``."""
+
+    def __init__(self, in_dim, emb_dim, aggr='softmax', t=1.0, learn_t=False, p=1.0, learn_p=False,
+                 y=0.0, learn_y=False, gnn_encoder='linear', msg_norm=False, learn_msg_scale=True,
+                 encode_edge=False, bond_encoder=False, edge_feat_dim=None, norm='batch', mlp_layers=2,
+                 eps=1e-7, pca_only=False):
+        super().__init__(aggr=aggr, t=t, learn_t=learn_t, p=p, learn_p=learn_p, y=y, learn_y=learn_y)
+        if gnn_encoder != 'linear':
+            raise NotImplementedError("gnn_encoder=%r is outside the accelerated path" % (gnn_encoder,))
+        if bond_encoder:
+            raise NotImplementedError("OGB bond encoder is outside the accelerated path")
+        self.gnn_encoder = gnn_encoder
+        self.feature_encoder = MLP([in_dim] + [in_dim * 2] * (mlp_layers - 1) + [emb_dim], norm=norm, last_lin=True)
+        self.eps = eps
+        self.encode_edge = encode_edge
+        self.bond_encoder = bond_encoder
+        self.msg_norm = MsgNorm(learn_msg_scale=learn_msg_scale) if msg_norm else None
+        if encode_edge:
+            self.edge_encoder = nn.Linear(edge_feat_dim, in_dim)
+        self.pca_only = pca_only
+
+    def forward(self, x, edge_index, edge_attr=None):
+        """``edge_index``: COO ``[2, E]`` or a prebuilt :class:`mlgnn.CSRGraph`.
+        ``edge_attr``: ``[E, d_e]`` tensor, or a :class:`mlgnn.RankOneEdge` (scalar raw attribute
+        kept factored through the Linear encoders: no ``[E, d]`` tensor, no edge GEMM)."""
+        if self.pca_only:
+            return self.feature_encoder(x)
+        graph = as_graph(edge_index, x.shape[0])
+        if isinstance(edge_attr, RankOneEdge):
+            edge = edge_attr.through_linear(self.edge_encoder.weight, self.edge_encoder.bias) \
+                if self.encode_edge else edge_attr
+        elif edge_attr is not None:
+            edge = self.edge_encoder(edge_attr) if self.encode_edge else edge_attr
+            edge = edge.flatten(1)
+        else:
+            edge = None
+        flat = x.flatten(1)
+        m = self.reduce_messages(flat, graph, edge, self.eps)
+        if self.msg_norm is not None:
+            m = self.msg_norm(x, m)
+        return self.feature_encoder(x + m.reshape(x.shape))
+
+
+class Linear(nn.Module):
+    """Bias-optional affine map that is deliberately NOT an ``nn.Linear`` subclass, like the PyG
+    ``Linear`` the reference's SAGE base class creates: the models' xavier ``init_weight`` sweeps
+    (multilevel_gnn.py:294-299) skip it, so it keeps kaiming-uniform(a=sqrt 5) initial values."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(in_channels)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+class SAGEConv(nn.Module):
+    """Weighted-mean GraphSAGE: ``nn(cat(x, mean_j((x_j * w_ij [- x_i]) W_r^T)))``.
+
+    The reference multiplies every EDGE by ``W_r`` before the mean (torch_vertex.py:279-286);
+    the mean is linear, so the kernel reduces ``x_j * w_ij`` first and ``W_r`` is applied to ``N``
+    rows instead of ``E + N``.  ``lin_l`` exists only for ``state_dict`` compatibility (the
+    reference never uses it either)."""
+
+    def __init__(self, in_channels, out_channels, nn, norm=True, bias=True, relative=False, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.relative = relative
+        self.lin_l = Linear(in_channels, out_channels, bias=bias)
+        self.lin_r = Linear(in_channels, out_channels, bias=False)
+        self.nn = nn
+        self.normalize = norm
+        if bias:
+            self.bias = torch.nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.bias = None
+
+    def forward(self, x, edge_index, size=None, edge_attr=None):
+        if size is not None:
+            raise NotImplementedError("bipartite propagation is outside the accelerated path")
+        x = x.unsqueeze(-1) if x.dim() == 1 else x
+        graph, weight = sage_graph(edge_index, edge_attr, x.shape[0])
+        agg = weighted_mean_aggregate(x, graph, weight, mean=True)
+        if self.relative:
+            agg = agg - x                    # every node has its self loop: mean_j(x_i) = x_i
+        aggr_out = F.linear(agg, self.lin_r.weight)
+        if self.bias is not None:
+            aggr_out = aggr_out + self.bias
+        out = self.nn(torch.cat((x, aggr_out), dim=1))
+        if self.normalize:
+            out = F.normalize(out, p=2, dim=-1)
+        return out
+
+
+class RSAGEConv(SAGEConv):
+    def __init__(self, in_channels, out_channels, act='relu', norm=False, mlp_norm=None, bias=True,
+                 relative=False, drop=0.0):
+        nn_ = MLP([out_channels + in_channels, out_channels], act, mlp_norm, bias, drop=drop)
+        super().__init__(in_channels, out_channels, nn_, norm, False, relative)
+
+
+class GraphConv(nn.Module):
+    """Static graph convolution dispatcher (torch_vertex.py:338-363)."""
+
+    def __init__(self, in_channels, out_channels, conv='edge', act='relu', norm=None, bias=True, heads=8,
+                 mlp_norm=None, drop=0.0):
+        super().__init__()
+        kind = conv.lower()
+        if kind == 'sage':
+            self.gconv = RSAGEConv(in_channels, out_channels, act, norm, mlp_norm, bias, False, drop)
+        elif kind == 'rsage':
+            self.gconv = RSAGEConv(in_channels, out_channels, act, norm, mlp_norm, bias, True, drop)
+        elif kind in ('edge', 'mr', 'gat', 'gcn', 'gin'):
+            raise NotImplementedError('conv {} needs PyG layers outside the accelerated path'.format(conv))
+        else:
+            raise NotImplementedError('conv {} is not implemented'.format(conv))
+
+    def forward(self, x, edge_index, edge_attr=None):
+        return self.gconv(x, edge_index, edge_attr=edge_attr)

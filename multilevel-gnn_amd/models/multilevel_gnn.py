@@ -1,0 +1,263 @@
+"""MultilevelGNN on the HIP kernels (interface of the reference's ``models/multilevel_gnn.py``:
+class ``MultilevelGNN`` :14, ``forward`` :132-292, ``get_feature_loss`` :329, setters :301-311,
+:350-351, :383-384, ``generate_mutual_mask`` :353).
+
+Level 0: per-node embedding scale -> GraphConv('sage'|'rsage') stack on the CSR kernels -> value
+mask; level 1: gene -> pathway learnable-projection pooling; level 2: 1x1 conv head.  Same
+constructor, ``forward(batch) -> (pred [B,2], pca_feature [B,C,146,3k])`` and ``state_dict`` keys.
+The reference's ``except: pdb.set_trace()`` traps around the layer calls are NOT reproduced:
+errors propagate as exceptions.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from mlgnn.project import segment_project
+from .gcn_lib.sparse.torch_vertex import GraphConv
+
+N_PATHWAYS = 146          # hard-coded in the reference's forward (:239) and head sizing (:121)
+N_OMICS = 3
+
+
+class MultilevelGNN(nn.Module):
+
+    def __init__(self, args, pca_params=None, pathway_indexs=None):
+        super().__init__()
+        for flag in ("pca_compare", "pca_prelinear"):
+            if getattr(args, flag):
+                raise NotImplementedError("%s is outside the accelerated path" % flag)
+        if args.reduction_method != "linear_projection":
+            raise NotImplementedError("reduction_method=%r (CPU SVD branch) is outside the accelerated path"
+                                      % (args.reduction_method,))
+        self.args = args
+        self.pca_loss = args.pca_loss
+        self.pca_indep_loss = args.pca_indep_loss
+        self.pca_dim = args.pca_dim
+        self.pathway_pool_dim = args.pathway_pool_dim
+        self.pca_pool_dim = args.pca_pool_dim
+        self.pathway_indexs = None
+        self.reorder_idxs = None
+        self.mutual_info_mask = args.mutual_info_mask
+        self.mutual_info_threshold = args.mutual_info_threshold
+        self.pca_loss_coef = args.pca_loss_coef
+        self.node_select_threshold = args.node_select_threshold
+        self.mutual_neighbors = args.mutual_neighbors
+        self.node_num = 5135
+        self.mutual_info_mask_cache = {}
+        self.head_dim = args.head_dim
+        self.epoch = None
+        self.step = None
+        self.used_omics = args.used_omics
+
+        self.input_drop = nn.Dropout(p=args.input_drop) if args.input_drop is not None else None
+        self.input_emb_drop = nn.Dropout(p=args.input_emb_drop) if args.input_emb_drop is not None else None
+
+        if args.node_embedding:
+            self.node_embedding = nn.Parameter(torch.rand([self.node_num * N_OMICS, args.node_embedding_dim]),
+                                               requires_grad=not args.freeze_node_embedding)
+            kind = args.embedding_init_type
+            if kind == "xavier":
+                nn.init.xavier_uniform_(self.node_embedding)
+            elif kind == "ones":
+                nn.init.constant_(self.node_embedding, 1)
+            elif kind == "constant":
+                nn.init.constant_(self.node_embedding, args.emb_val)
+            elif kind == "uniform":
+                nn.init.uniform_(self.node_embedding)
+            self.node_embedding_dim = args.node_embedding_dim
+        else:
+            self.node_embedding = None
+            self.node_embedding_dim = 1
+
+        conv_kw = dict(act=args.gnn_act, conv=args.gnn_name, mlp_norm=args.gnn_mlp_norm, drop=args.gnn_dropout)
+        blocks = [GraphConv(self.node_embedding_dim, args.hidden_channels, **conv_kw)]
+        for _ in range(args.num_layers - 2):
+            blocks.append(GraphConv(args.hidden_channels, args.hidden_channels, **conv_kw))
+        blocks.append(GraphConv(args.hidden_channels, args.final_channels, heads=args.final_head,
+                                norm=args.gnn_last_norm, **conv_kw))
+        self.gnn_model = nn.ModuleList(blocks)
+
+        self.learnable_pca_params = nn.Parameter(torch.rand([25015, self.pca_dim]),
+                                                 requires_grad=(not args.freeze_pca_weight))
+        if pca_params is None:
+            if args.pca_init_type is None:
+                nn.init.xavier_uniform_(self.learnable_pca_params.data)
+            elif args.pca_init_type == "orthogonal":
+                nn.init.orthogonal_(self.learnable_pca_params.data)
+        else:
+            self.learnable_pca_params.data = pca_params
+
+        # the reference mutates args here too (:93-96); kept so that downstream sizing matches
+        if args.edge_type == 'merge':
+            args.final_channels *= 2
+        if args.dense_gnn:
+            args.final_channels = (args.num_layers - 1) * args.hidden_channels + args.final_channels
+
+        convs, cin = [], args.final_channels
+        for cout, kern in zip(args.conv_channel_list, args.conv_kernel_list):
+            convs += [nn.Conv2d(cin, cout, kern, padding=kern // 2), nn.ReLU()]
+            cin = cout
+        self.conv_model = nn.ModuleList(convs)
+
+        self.pooling = nn.MaxPool2d((self.pathway_pool_dim, self.pca_pool_dim))
+        self.drop1 = nn.Dropout(0.25 if args.feature_drop else 0)
+        head_in = args.conv_channel_list[-1] * (N_PATHWAYS // self.pathway_pool_dim) * \
+            ((len(self.used_omics) * self.pca_dim) // self.pca_pool_dim) + (1 if args.use_age else 0)
+        self.head = nn.Sequential(nn.Linear(head_in, self.head_dim), nn.ReLU(), nn.Dropout(0.5),
+                                  nn.Linear(self.head_dim, 2), nn.Softmax(dim=1))
+        self.init_weight()
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_batch, x=None, gene_pca_match=None, raw_indice=None, age=None, require_grad=True):
+        args = self.args
+        with torch.enable_grad() if require_grad else torch.no_grad():
+            if x is None:
+                x = input_batch.x
+                gene_pca_match = input_batch.gene_pca_match
+                raw_indice = input_batch.raw_indice
+                age = input_batch.age
+            mask_x = x
+            x = x.reshape(-1, 1)
+            nodes_per_graph = self.node_num * N_OMICS
+            if self.input_drop is not None:
+                x = self.input_drop(x)
+            if args.node_embedding:
+                x = (x.reshape(-1, nodes_per_graph, 1) * self.node_embedding).reshape(-1, self.node_embedding.shape[-1])
+            if self.input_emb_drop is not None:
+                x = self.input_emb_drop(x)
+
+            if isinstance(input_batch.edge_index, list):
+                raise NotImplementedError("multi-topology edge lists are outside the accelerated path")
+            n_edges = input_batch.edge_index.shape[-1] // args.device_num      # no-op at device_num=1 (:157-165)
+            edge_index = input_batch.edge_index[:, :n_edges].to(x.device)
+            edge_attr = input_batch.edge_attr[:n_edges].to(x.device) if args.weighted_edge else None
+            # NOTE: the reference slices edge_attr on dim 1 (:164), a no-op for [E,1] attributes at
+            # device_num=1; the row slice above is the evident intent and identical there.
+
+            feats = []
+            last = len(self.gnn_model) - 1
+            for i, layer in enumerate(self.gnn_model):
+                if args.dense_gnn:
+                    x = layer(x, edge_index, edge_attr)
+                    feats.append(x)
+                elif args.resgnn:
+                    x = layer(x, edge_index, edge_attr) + x
+                else:
+                    x = layer(x, edge_index, edge_attr)
+                if i != last and args.repeat_mask and (i + 1) % args.repeat_cyclic == 0:
+                    if args.repeat_norm:
+                        x = x / (x ** 2).sum(1).sqrt()[:, None]
+                    x = x * mask_x.reshape(-1, 1)
+            if args.dense_gnn:
+                x = torch.cat(feats, dim=-1)
+            if args.value_att_mask:
+                if args.merge_mode == 'mult':
+                    x = x * mask_x.reshape(-1, 1)
+                elif args.merge_mode in ('add', 'cat'):
+                    x = args.add_coef1 * x + args.add_coef2 * mask_x.reshape(-1, 1)
+
+            if args.final_channels != 1 or self.mutual_info_mask:
+                weights = self.learnable_pca_params * self.info_mask
+            else:
+                weights = self.learnable_pca_params
+            x = segment_project(x, gene_pca_match.to(x.device), raw_indice.to(x.device), weights, nodes_per_graph,
+                                N_PATHWAYS * N_OMICS, match_mask=args.pca_match_mask)
+            x = x.reshape(x.shape[0], x.shape[1], N_PATHWAYS, self.pca_dim * N_OMICS)
+            if args.reorder_pathway and self.reorder_idxs is not None:
+                x = x[:, :, self.reorder_idxs, :]
+
+        pca_feature = x
+        for layer in self.conv_model:
+            x = layer(x)
+        if len(self.used_omics) != N_OMICS:
+            cols = [c for o in self.used_omics for c in range(int(o) * self.pca_dim, (int(o) + 1) * self.pca_dim)]
+            x = x[:, :, :, cols]
+        x = self.pooling(x)
+        x = self.drop1(x)
+        x = torch.flatten(x, start_dim=1)
+        if args.use_age:
+            x = torch.cat([x, age[:, None]], dim=-1)
+        return self.head(x), pca_feature
+
+    # ------------------------------------------------------------------ parameter surface
+    def init_weight(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.xavier_uniform_(m.weight.data)
+
+    def set_pca_params(self, pca_params, mutual_info_mask):
+        """Re-creates the projection parameter (call before building the optimizer), :301-308."""
+        mask = torch.as_tensor(mutual_info_mask).reshape(-1)
+        idxs = torch.nonzero(mask > 0).reshape(-1)
+        self.learnable_pca_params = nn.Parameter(torch.zeros([mask.numel(), self.pca_dim]),
+                                                 requires_grad=(not self.args.freeze_pca_weight))
+        self.learnable_pca_params.data[idxs] = pca_params[:, :self.pca_dim].to(torch.float32).to(
+            self.learnable_pca_params.data.device)
+
+    def set_pathway_indexs(self, pathway_indexs):
+        self.pathway_indexs = pathway_indexs
+
+    def set_info_mask(self, info_mask):
+        self.info_mask = nn.Parameter(data=info_mask, requires_grad=False)
+
+    def set_reorder_idxs(self, reorder_idx):
+        self.reorder_idxs = torch.tensor(reorder_idx)
+
+    def get_feature_loss(self, pca_feature):
+        """``pca_loss``: -coef * log(mean(std over batch)); ``pca_indep_loss``: mean |cos| between
+        projection columns per pathway, evaluated on detached weights (value only, no gradient),
+        accumulated once per outer index exactly as the reference does (:336-346)."""
+        loss = 0
+        if self.pca_loss:
+            flat = pca_feature.reshape(pca_feature.shape[0], -1)
+            loss = loss - self.pca_loss_coef * torch.log(torch.mean(torch.std(flat, dim=0)))
+        if self.pca_indep_loss:
+            w = (self.learnable_pca_params * self.info_mask).detach()
+            seg = self.pathway_indexs.to(w.device)
+            n_seg = int(seg.max()) + 1
+
+            def seg_sum(v):
+                return torch.zeros(n_seg, dtype=w.dtype, device=w.device).index_add_(0, seg, v)
+
+            indep, count = 0, 0
+            for i in range(self.pca_dim - 1):
+                for j in range(i + 1, self.pca_dim):
+                    count += 1
+                    dot = seg_sum(w[:, i] * w[:, j])
+                    length = torch.sqrt(seg_sum(w[:, i] ** 2) * seg_sum(w[:, j] ** 2))
+                indep = indep + torch.mean(torch.abs(dot / (length + 1e-7)))
+            loss = loss + indep / count
+        return loss
+
+    def generate_mutual_mask(self, x, y, mutual_classif=True, fold=0, tf_token=None):
+        """CPU preprocessing (sklearn mutual information), same contract as the reference (:353-381)."""
+        from sklearn.feature_selection import mutual_info_classif, mutual_info_regression
+        x, y = torch.tensor(x), torch.tensor(y)
+        random_state = self.args.random_state if self.args.freeze_mutual_select_init else None
+        fn = mutual_info_classif if mutual_classif else mutual_info_regression
+        mutual_info = fn(x, y, n_neighbors=self.mutual_neighbors, random_state=random_state)
+        if fold in self.mutual_info_mask_cache:
+            res = self.mutual_info_mask_cache[fold]
+        else:
+            thr = (self.node_select_threshold * np.mean(mutual_info) if self.mutual_info_threshold is None
+                   else self.mutual_info_threshold)
+            mi = torch.tensor(mutual_info)
+            res = [torch.where(mi < thr, torch.zeros(mi.shape), torch.ones(mi.shape))[:, None], mutual_info]
+            self.mutual_info_mask_cache[fold] = res
+        if tf_token is not None and self.args.remain_all_tf:
+            merged = self.mutual_info_mask_cache[fold][0].to(torch.int) | torch.tensor(tf_token)[:, None]
+            self.mutual_info_mask_cache[fold][0] = merged
+            res[0] = merged
+        return res
+
+    def load_representation(self, representation_path):
+        self.node_embedding.data = torch.from_numpy(np.load(representation_path)).to(torch.float)
+
+    def load_autoencoder_pretrain(self, ckpt_path):
+        checkpoint = torch.load(ckpt_path, map_location="cuda:" + str(self.args.device))
+        sd = checkpoint['model_state_dict']
+        self.learnable_pca_params = nn.Parameter(torch.zeros(sd['learnable_pca_params'].shape),
+                                                 requires_grad=(not self.args.freeze_pca_weight))
+        self.set_info_mask(sd['info_mask'])
+        names = [n for n, _ in self.named_parameters()]
+        self.load_state_dict({k: v for k, v in sd.items() if k in names}, strict=False)

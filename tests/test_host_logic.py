@@ -1,0 +1,94 @@
+"""Host-side logic that needs no GPU: CSR construction, self-loop rewrite, state_dict surface."""
+from types import SimpleNamespace
+
+import torch
+
+from _util import golden_files, literal, load_golden, make_args
+from oracle import primitives as P
+
+
+def test_csr_graph_layout():
+    from mlgnn import CSRGraph
+    #            e0 e1 e2 e3 e4
+    src = torch.tensor([2, 0, 2, 1, 0])
+    dst = torch.tensor([1, 1, 0, 1, 2])
+    g = CSRGraph(torch.stack([src, dst]), 4)
+    assert g.rowptr.tolist() == [0, 1, 4, 5, 5]
+    assert g.col.tolist() == [2, 2, 0, 1, 0]            # row 1 keeps COO order e0, e1, e3
+    assert g.eid.tolist() == [2, 0, 1, 3, 4]
+    assert g.rowptr_t.tolist() == [0, 2, 3, 5, 5]
+    assert g.col_t.tolist() == [1, 2, 1, 0, 1]
+    assert g.pos_t.tolist() == [2, 4, 3, 0, 1]
+    assert g.eid_t.tolist() == [1, 4, 3, 2, 0]
+    assert g.in_degree.tolist() == [1.0, 3.0, 1.0, 0.0]
+    a = torch.tensor([10., 11., 12., 13., 14.])
+    by_dst, by_src = g.edge_scalar(a)
+    assert by_dst.tolist() == [12., 10., 11., 13., 14.]
+    assert by_src.tolist() == [11., 14., 13., 12., 10.]
+    # every (src, dst) pair survives both orderings
+    pairs = sorted(zip(src.tolist(), dst.tolist()))
+    rows = torch.repeat_interleave(torch.arange(4), (g.rowptr[1:] - g.rowptr[:-1]).long())
+    assert sorted(zip(g.col.tolist(), rows.tolist())) == pairs
+    rows_t = torch.repeat_interleave(torch.arange(4), (g.rowptr_t[1:] - g.rowptr_t[:-1]).long())
+    assert sorted(zip(rows_t.tolist(), g.col_t.tolist())) == pairs
+
+
+def test_sage_graph_matches_self_loop_rewrite():
+    from mlgnn.graph import sage_graph
+    ei = torch.tensor([[0, 1, 2, 2, 1], [1, 1, 0, 2, 0]])
+    ea = torch.tensor([[.1], [.2], [.3], [.4], [-.5]])
+    g, w = sage_graph(ei, ea, 3)
+    g2, w2 = sage_graph(ei, ea, 3)
+    assert g2 is g                                              # same tensors -> cached
+    ei_ref, ea_ref = P.add_self_loops(*P.remove_self_loops(ei, ea), 1.0, 3)
+    assert g.num_edges == ei_ref.shape[1] == 6
+    by_dst, _ = g.edge_scalar(w)
+    order = torch.sort(ei_ref[1], stable=True).indices
+    assert g.col.tolist() == ei_ref[0][order].tolist()
+    assert torch.allclose(by_dst, ea_ref[order, 0])
+
+
+DEEPER_BASE = dict(num_layers=3, hidden_channels=32, dropout=0.0, conv_encode_edge=True, use_edge_attr=True,
+                   use_column="w", global_edge="none", graph_pooling="mean", norm="layer", mlp_layers=2,
+                   block="res+", pathway_global_node=False, node_embedding=False, use_age=False,
+                   num_layer_head=1, pathway_num=8, pathway_readout=None)
+
+
+def test_state_dict_keys_match_reference():
+    """Reference checkpoints must load with strict=True (keys and shapes from the golden fixtures)."""
+    from models import DiffPool, get_model
+    for p in golden_files("deepergcn"):
+        f = load_golden(p)
+        m = get_model("deepergcn")(make_args(**dict(DEEPER_BASE, **literal(f["over"]))))
+        m.load_state_dict(f["sd"], strict=True)
+    for p in golden_files("diffpool"):
+        f = load_golden(p)
+        Bp, C, hid, outc, nl, apl = [int(v) for v in f["cfg"]]
+        dp = DiffPool(C, None, 146, nl, hid, outc, SimpleNamespace(pooling_type="correlation", after_pooling_layer=apl))
+        dp.load_state_dict({k: torch.as_tensor(v) for k, v in f["sd"].items()}, strict=True)
+    for p in golden_files("multilevel"):
+        f = load_golden(p)
+        m = get_model("multilevel_gnn")(make_args(**literal(f["over"])))
+        assert m.node_embedding.shape[0] == 5135 * 3 and m.learnable_pca_params.shape[0] == 25015
+        m.node_embedding = torch.nn.Parameter(f["sd"]["node_embedding"].clone())
+        m.set_pca_params(torch.zeros(int((f["sd"]["info_mask"] > 0).sum()), m.pca_dim), f["sd"]["info_mask"][:, 0])
+        m.set_info_mask(f["sd"]["info_mask"].clone())
+        m.load_state_dict(f["sd"], strict=True)
+
+
+def test_gbm_parameter_count():
+    """config/gbm.yaml shape: 2 858 279 parameters incl. the frozen info_mask."""
+    from models import get_model
+    a = make_args(model="multilevel_gnn", num_layers=2, hidden_channels=64, final_channels=32, final_head=4,
+                  node_embedding=True, node_embedding_dim=64, gnn_name="sage", head_dim=256, use_age=True,
+                  weighted_edge=True, value_att_mask=True, pca_match_mask=True, mutual_info_mask=True,
+                  learnable_pca=True, pca_indep_loss=True, feature_drop=True)
+    m = get_model("multilevel_gnn")(a)
+    m.set_info_mask(torch.ones(25015, 1))          # a frozen nn.Parameter, counted by the reference too
+    assert sum(p.numel() for p in m.parameters()) == 2858279
+    keys = set(m.state_dict())
+    assert {"node_embedding", "learnable_pca_params", "gnn_model.0.gconv.lin_l.weight", "gnn_model.1.gconv.lin_r.weight",
+            "gnn_model.0.gconv.nn.0.weight", "gnn_model.0.gconv.nn.0.bias", "conv_model.0.weight", "conv_model.2.bias",
+            "head.0.weight", "head.3.bias"} <= keys
+    assert tuple(m.state_dict()["head.0.weight"].shape) == (256, 6913)
+    assert tuple(m.state_dict()["gnn_model.1.gconv.nn.0.weight"].shape) == (32, 96)

@@ -1,0 +1,149 @@
+"""Drop-in modules (HIP path) vs golden vectors produced by the reference's own classes, and vs
+the CPU oracle.  Tolerance 1e-4 fp32 (north_star), |diff| <= 1e-4 * max(1, |ref|_inf)."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from _util import assert_close, golden_files, literal, load_golden, make_args
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def _to_dev(ns):
+    return SimpleNamespace(**{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in vars(ns).items()})
+
+
+def _check_param_grads(module, gold, prefix="sd.", tol=TOL):
+    seen = 0
+    for name, p in module.named_parameters():
+        key = prefix + name
+        if key not in gold:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert_close(g, gold[key], tol, "grad " + name)
+        seen += 1
+    assert seen > 0
+
+
+@pytest.mark.parametrize("path", golden_files("genconv"))
+def test_genconv_vs_reference(path):
+    from models.gcn_lib.sparse.torch_vertex import GENConv
+    f = load_golden(path)
+    cfg = literal(f["cfg"])
+    d, full = cfg.pop("d"), cfg.pop("full")
+    conv = GENConv(d, d, encode_edge=True, edge_feat_dim=(d if full else 1), mlp_layers=2, **cfg)
+    conv.load_state_dict(f["sd"], strict=True)
+    conv.to(DEV).train()
+    x = f["x"].to(DEV).requires_grad_(True)
+    ea = f["edge_attr"].to(DEV).requires_grad_(True)
+    out = conv(x, f["edge_index"].to(DEV), ea)
+    assert_close(out, f["out"], TOL, "genconv out")
+    (out * f["cot"].to(DEV)).sum().backward()
+    assert_close(x.grad, f["grad"]["x"], TOL, "grad x")
+    assert_close(ea.grad, f["grad"]["edge_attr"], TOL, "grad edge_attr")
+    _check_param_grads(conv, f["grad"])
+
+
+@pytest.mark.parametrize("path", golden_files("genconv"))
+def test_genconv_rank_one_edge_path(path):
+    """Scalar edge attribute carried factored (no [E,d] tensor): same numbers as the dense path."""
+    from mlgnn import RankOneEdge
+    from models.gcn_lib.sparse.torch_vertex import GENConv
+    f = load_golden(path)
+    cfg = literal(f["cfg"])
+    d, full = cfg.pop("d"), cfg.pop("full")
+    if full:
+        pytest.skip("fixture with a full-width edge input")
+    conv = GENConv(d, d, encode_edge=True, edge_feat_dim=1, mlp_layers=2, **cfg)
+    conv.load_state_dict(f["sd"], strict=True)
+    conv.to(DEV).train()
+    x = f["x"].to(DEV).requires_grad_(True)
+    # Linear(1 -> d) on a scalar a: a * W[:,0] + b  ==  RankOneEdge(a, 1, 0) through the encoder
+    one = torch.ones(1, device=DEV)
+    zero = torch.zeros(1, device=DEV)
+    out = conv(x, f["edge_index"].to(DEV), RankOneEdge(f["edge_attr"][:, 0].to(DEV), one, zero))
+    assert_close(out, f["out"], TOL, "genconv out (rank-1)")
+    (out * f["cot"].to(DEV)).sum().backward()
+    assert_close(x.grad, f["grad"]["x"], TOL, "grad x")
+    _check_param_grads(conv, f["grad"])
+
+
+@pytest.mark.parametrize("path", golden_files("sage"))
+def test_sage_vs_reference(path):
+    from models.gcn_lib.sparse.torch_vertex import GraphConv
+    f = load_golden(path)
+    cout, cin = f["sd"]["gconv.lin_r.weight"].shape
+    conv = GraphConv(cin, cout, conv=str(f["kind"]), act="leakyrelu", mlp_norm="none")
+    conv.load_state_dict(f["sd"], strict=True)
+    conv.to(DEV)
+    x = f["x"].to(DEV).requires_grad_(True)
+    out = conv(x, f["edge_index"].to(DEV), f["edge_attr"].to(DEV))
+    assert_close(out, f["out"], TOL, "sage out")
+    (out * f["cot"].to(DEV)).sum().backward()
+    assert_close(x.grad, f["grad"]["x"], TOL, "grad x")
+    _check_param_grads(conv, f["grad"])
+
+
+DEEPER_BASE = dict(num_layers=3, hidden_channels=32, dropout=0.0, conv_encode_edge=True, use_edge_attr=True,
+                   use_column="w", global_edge="none", graph_pooling="mean", norm="layer", mlp_layers=2,
+                   block="res+", pathway_global_node=False, node_embedding=False, use_age=False,
+                   num_layer_head=1, pathway_num=8, pathway_readout=None)
+
+
+@pytest.mark.parametrize("path", golden_files("deepergcn"))
+def test_deepergcn_vs_reference(path):
+    from models import get_model
+    f = load_golden(path)
+    model = get_model("deepergcn")(make_args(**dict(DEEPER_BASE, **literal(f["over"]))))
+    model.load_state_dict(f["sd"], strict=True)
+    model.to(DEV).train()
+    batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "batch", "age",
+                                                          "pathway_node_attr", "node_size")}))
+    out = model(batch)
+    assert_close(out, f["out"], TOL, "deepergcn out")
+    (out * f["cot"].to(DEV)).sum().backward()
+    _check_param_grads(model, f["grad"])
+
+
+@pytest.mark.parametrize("path", golden_files("multilevel"))
+def test_multilevel_vs_reference(path):
+    from models import get_model
+    f = load_golden(path)
+    model = get_model("multilevel_gnn")(make_args(**literal(f["over"])))
+    model.node_num = int(f["node_num"])
+    model.node_embedding = torch.nn.Parameter(f["sd"]["node_embedding"].clone())
+    model.set_pca_params(torch.zeros(int((f["sd"]["info_mask"] > 0).sum()), model.pca_dim), f["sd"]["info_mask"][:, 0])
+    model.set_info_mask(f["sd"]["info_mask"].clone())
+    model.load_state_dict(f["sd"], strict=True)
+    model.set_pathway_indexs(f["pathway_indexs"].to(DEV))
+    model.to(DEV).eval()
+    batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "gene_pca_match",
+                                                          "raw_indice", "age")}))
+    pred, feat = model(batch)
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
+    assert_close(pred, f["pred"], TOL, "pred")
+    fl = model.get_feature_loss(feat)
+    assert_close(fl, f["feature_loss"], TOL, "feature loss")
+    ((pred * f["cot"].to(DEV)).sum() + fl).backward()
+    _check_param_grads(model, f["grad"])
+
+
+@pytest.mark.parametrize("path", golden_files("diffpool"))
+def test_diffpool_vs_reference(path):
+    from models import DiffPool
+    f = load_golden(path)
+    Bp, C, hid, outc, nl, apl = [int(v) for v in f["cfg"]]
+    dp = DiffPool(C, None, 146, nl, hid, outc, SimpleNamespace(pooling_type="correlation", after_pooling_layer=apl))
+    dp.load_state_dict({k: torch.as_tensor(v) for k, v in f["sd"].items()}, strict=True)
+    dp.to(DEV).eval()
+    x = f["x"].to(DEV).requires_grad_(True)
+    out, link, ent = dp(x, f["adj"].to(DEV))
+    assert_close(out, f["out"], TOL, "diffpool out")
+    assert_close(link, f["link"], TOL, "link")
+    assert_close(ent, f["ent"], TOL, "ent")
+    ((out * f["cot"].to(DEV)).sum() + 0.7 * link + 0.3 * ent).backward()
+    assert_close(x.grad, f["grad"]["x"], TOL, "grad x")
+    _check_param_grads(dp, f["grad"])

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: graphs/s of one full training step (CSR build + forward + backward +
+gradient all-reduce + Adam) of the 3-level GNN on synthetic Erdos-Renyi graphs of TCGA shape
+(BASELINE.json configs[1]: N=10 000 nodes, E=160 000 edges, d=128 per graph, 3 GENConv layers
++ projection pooling + 2-level DiffPool, fp32, 64 graphs per GPU).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; graphs are sharded by rank (weak scaling: 64 graphs per GPU); the only
+collective is ONE RCCL all-reduce of the flat gradient bucket per step.  Rank 0 prints one JSON
+line.  ``roofline`` is the live HIP-event timing of the CSR aggregation kernels over the timed
+region; ``cpu_baseline`` is the CPU oracle (reference-semantics op sequence) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "multilevel-gnn_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graphs-per-gpu", type=int, default=64)
+    ap.add_argument("--nodes", type=int, default=10000)
+    ap.add_argument("--edges", type=int, default=160000)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--members", type=int, default=25000)
+    ap.add_argument("--aggr", default="softmax")
+    ap.add_argument("--pool-batches", type=int, default=2, help="distinct pre-generated batches cycled")
+    ap.add_argument("--cpu-baseline-graphs", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, model_sd):
+    """Oracle fwd+bwd on a bounded sample of the SAME workload, host cores of this box."""
+    from types import SimpleNamespace
+    from mlgnn import workload as W
+    from oracle import workload as OW
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    nb = args.cpu_baseline_graphs
+    match, seg = W.membership(args.nodes, args.members)
+    batch = W.collate(list(range(nb)), args.nodes, args.edges, match, seg, "cpu")
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and k != "pathway_adj")
+          for k, v in model_sd.items()}
+    params = [v for v in sd.values() if v.requires_grad]
+
+    def step():
+        loss = OW.training_loss(sd, batch, aggr=args.aggr)
+        torch.autograd.grad(loss, params, allow_unused=True)
+
+    step()                                   # warm-up (allocator, thread pool)
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or n >= 5:
+            break
+    return {"value": nb * n / el, "unit": "graphs/s", "cores": threads, "kind": "port",
+            "sample": "%d graphs x %d timed fwd+bwd iterations of the same synthetic workload "
+                      "(oracle: materialised [E,d] gather -> elementwise -> scatter, no optimizer step)" % (nb, n)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mlgnn import ops
+    from mlgnn import workload as W
+    from mlgnn.dist import FlatGradBucket, broadcast_parameters
+
+    torch.manual_seed(1234)
+    model = W.ThreeLevelGNN(hidden=args.hidden, num_layers=3, aggr=args.aggr, n_members=args.members).to(dev)
+    broadcast_parameters(model)
+    bucket = FlatGradBucket(model)
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    except (RuntimeError, TypeError):
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    B = args.graphs_per_gpu
+    match, seg = W.membership(args.nodes, args.members)
+    pool = []
+    for k in range(args.pool_batches):
+        ids = [k * world * B + rank * B + i for i in range(B)]          # graph_id = step*global + rank*B + i
+        pool.append(W.collate(ids, args.nodes, args.edges, match, seg, dev))
+    torch.cuda.synchronize()
+
+    def step(i):
+        batch = pool[i % len(pool)]
+        batch.csr = None                       # the CSR build is part of the step
+        bucket.zero()
+        loss = W.training_loss(model, batch)
+        loss.backward()
+        bucket.all_reduce_mean()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    ops.KERNEL_TIMER = timer
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    final_loss = float(loss)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        graphs = args.steps * B * world
+        out = {
+            "metric": "graphs/sec fwd+bwd, 3-level GNN on 10k-node d=128 synthetic; HBM GB/s %peak",
+            "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: ER graphs N=%d E=%d x%d per GPU, d=%d, 3 GENConv(%s, res+, LayerNorm) + "
+                                   "projection pooling G=%d k=2 + DiffPool 146->37->10, fp32; step = CSR build + fwd + "
+                                   "bwd + grad all-reduce + Adam" % (args.nodes, args.edges, B, args.hidden, args.aggr,
+                                                                      args.members),
+                       "graphs_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "final_loss": final_loss},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            kernels = {}
+            for name, d in summ.items():
+                gbs = d["bytes"] / (d["avg_ms"] * 1e-3) / 1e9
+                kernels[name] = {"launches": d["launches"], "avg_ms": d["avg_ms"], "algorithmic_bytes": d["bytes"],
+                                 "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
+            # dominant = the hand-written kernel with the largest total time in the timed region
+            dom = max(summ, key=lambda n: summ[n]["total_ms"])
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom.split("/")[0])
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"],
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac"],
+                               "traffic": traffic, "avg_launch_ms": kernels[dom]["avg_ms"],
+                               "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"]}
+            out["kernels"] = kernels
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, model.state_dict())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, graphs sharded by
+rank, ONE RCCL all-reduce per step over a single flat fp32 gradient buffer.
+
+The reference has no distributed code at all; this is the exchange step
+BASELINE.json's north_star adds.  Parameter sets are 1-37 MB (section 5): on the xGMI mesh that
+is latency-dominated, so the gradients live contiguously in one bucket (``p.grad`` are views into
+it -- autograd accumulates in place, no flatten/unflatten copies) and a single ``all_reduce``
+moves them.  Works with the ``nccl`` (= RCCL) backend on GPUs and ``gloo`` on CPU (tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket:
+    def __init__(self, module, process_group=None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        self.group = process_group
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        """Use instead of ``optimizer.zero_grad()`` (which would drop the views)."""
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        """Sum over ranks, divide by world size: mean of per-rank mean losses = global mean for
+        equal per-rank batch sizes."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.group)
+        if world == 1:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.div_(world)
+
+    def check_views(self):
+        """True while every ``p.grad`` still aliases the bucket."""
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                return False
+            off += p.numel()
+        return True
+
+
+def broadcast_parameters(module, src=0, process_group=None):
+    """Rank ``src``'s initial weights everywhere (one flat broadcast)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b.dtype.is_floating_point]
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.broadcast(flat, src=src, group=process_group)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()

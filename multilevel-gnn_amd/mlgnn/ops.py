@@ -24,6 +24,62 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """HIP-event stopwatch around individual C-ABI launches (events are recorded on the stream the
+    kernel is launched on -- torch's current stream).  ``bench.py`` installs one to report the
+    roofline fraction of the aggregation kernels from live measurements."""
+
+    def __init__(self):
+        self.records = []           # (name, start_event, end_event, algorithmic_bytes)
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, name, start, nbytes):
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.records.append((name, start, end, nbytes))
+
+    def summary(self):
+        """-> {name: dict(launches, avg_ms, bytes)}; call after torch.cuda.synchronize()."""
+        out = {}
+        for name, s, e, nbytes in self.records:
+            d = out.setdefault(name, dict(launches=0, total_ms=0.0, bytes=nbytes))
+            d["launches"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["launches"]
+        return out
+
+
+KERNEL_TIMER = None
+_AGGR_NAMES = {AGGR_SUM: "sum", AGGR_MEAN: "mean", AGGR_MAX: "max", AGGR_SOFTMAX: "softmax", AGGR_POWER: "power"}
+_EDGE_NAMES = {EDGE_NONE: "noedge", EDGE_RANK1: "rank1", EDGE_FULL: "full"}
+
+
+def algorithmic_bytes(N, E, d, aggr_id, edge_mode, backward=False, learn_t=False, weighted=False, gen=True):
+    """Edge-gather byte count of one launch, no cache credit."""
+    s = 4
+    rows = E * d * s                                  # one gathered row per edge
+    idx = E * 4 + (N + 1) * 4                         # col + rowptr
+    scalar = E * 4 if (edge_mode == EDGE_RANK1 or weighted) else 0
+    full = (E * d * s + E * 4) if edge_mode == EDGE_FULL else 0
+    if not backward:
+        extra = N * d * 4 if aggr_id == AGGR_MAX else 0          # argmax write
+        return rows + idx + scalar + full + N * d * s + extra
+    gathers = rows                                                   # grad_out rows
+    if aggr_id == AGGR_SOFTMAX:
+        gathers += rows * (2 if learn_t else 1)                       # lse (+ out) rows for the recompute
+    if aggr_id == AGGR_MAX:
+        gathers += rows + E * 4                                       # argmax rows + pos_t
+    if edge_mode == EDGE_FULL:
+        full += E * d * s                                             # grad_efull write
+    own = (N * d * s if gen else 0) + N * d * s                       # x_j read + grad_x write
+    return gathers + idx + scalar + full + own
+
+
 def _dev_f32(t, what):
     if t is None:
         return None
@@ -78,12 +134,17 @@ class _GenAggregate(torch.autograd.Function):
         ew = ew_pair[0] if ew_pair is not None else None
         t_dev = t_par if (learn_t and t_par is not None) else None
         p_dev = p_par if (learn_p and p_par is not None) else None
+        timer = KERNEL_TIMER
+        t0 = timer.start() if timer is not None else None
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), _lib.ptr(eu), _lib.ptr(ev),
             _lib.ptr(efull), graph.eid.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),
             _lib.ptr(argmax), N, d, DTYPE_F32, MSG_GEN, edge_mode, aggr_id, float(t), float(p),
             _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
+        if timer is not None:
+            timer.stop("csr_aggregate_fwd/%s/%s" % (_AGGR_NAMES[aggr_id], _EDGE_NAMES[edge_mode]), t0,
+                       algorithmic_bytes(N, graph.num_edges, d, aggr_id, edge_mode))
         ctx.graph, ctx.ew_pair = graph, ew_pair
         ctx.cfg = (aggr_id, edge_mode, float(t), float(p), float(eps), bool(learn_t), bool(learn_p))
         ctx.save_for_backward(x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev)
@@ -116,6 +177,8 @@ class _GenAggregate(torch.autograd.Function):
             ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
             guv = torch.empty((2, d), dtype=torch.float32, device=x.device)
         ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
+        timer = KERNEL_TIMER
+        t0 = timer.start() if timer is not None else None
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go_k.data_ptr(), x.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(argmax),
             g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(), g.rowptr.data_ptr(),
@@ -124,6 +187,9 @@ class _GenAggregate(torch.autograd.Function):
             N, d, DTYPE_F32, MSG_GEN, edge_mode, aggr_id, int(learn_t), t, p,
             _lib.ptr(t_dev), _lib.ptr(p_dev), eps, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
+        if timer is not None:
+            timer.stop("csr_aggregate_bwd/%s/%s" % (_AGGR_NAMES[aggr_id], _EDGE_NAMES[edge_mode]), t0,
+                       algorithmic_bytes(N, g.num_edges, d, aggr_id, edge_mode, backward=True, learn_t=learn_t))
         geu = guv[0] if guv is not None else None
         gev = guv[1] if guv is not None else None
         return gx, geu, gev, ge, grad_t, grad_p, None, None, None, None, None, None, None, None

@@ -23,8 +23,10 @@ def load_golden(path):
     top, nested = {}, {}
     for k in z.files:
         v = z[k]
-        val = torch.from_numpy(v.copy()) if v.dtype.kind in "fiu" and v.ndim > 0 else (
-            v.item() if v.ndim == 0 else v)
+        if v.dtype.kind in "fiub":
+            val = torch.from_numpy(v.copy()) if v.ndim > 0 else torch.tensor(v.item())
+        else:
+            val = v.item() if v.ndim == 0 else v
         if "/" in k:
             head, rest = k.split("/", 1)
             nested.setdefault(head, {})[rest] = val

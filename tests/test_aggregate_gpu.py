@@ -144,7 +144,10 @@ def test_reference_aggregators_fixture():
                             learn_p=bool(kw.get("learn_p")))[:N]
         assert_close(out, c["out"], TOL, "fixture %s fwd" % aggr)
         (out * c["cot"].to(dev)).sum().backward()
-        assert_close(x.grad[N:], c["grad/inputs"], TOL, "fixture %s grad inputs" % aggr)
+        # messages sitting exactly on the relu floor (x = 0) get no gradient through relu: an
+        # artefact of feeding the fixture's messages through node features, not of the aggregator
+        live = (inputs > 1e-7).to(torch.float32)
+        assert_close(x.grad[N:].cpu() * live, c["grad/inputs"] * live, TOL, "fixture %s grad inputs" % aggr)
         if kw.get("learn_t") and aggr == "softmax":
             assert_close(tt.grad, c["grad/t"], TOL, "fixture grad t")
         if kw.get("learn_p"):

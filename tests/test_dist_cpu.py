@@ -1,0 +1,87 @@
+"""Data-parallel gradient exchange on CPU: world_size-2 gloo processes vs one process."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+
+
+def _data():
+    g = torch.Generator().manual_seed(1)
+    return torch.randn(8, 6, generator=g), torch.randn(8, 2, generator=g)
+
+
+def _worker(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "multilevel-gnn_amd"))
+    from mlgnn.dist import FlatGradBucket, broadcast_parameters
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # different initial weights per rank ...
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    with torch.no_grad():
+        if rank == 0:
+            for p, q0 in zip(model.parameters(), _model().parameters()):
+                p.copy_(q0)
+    broadcast_parameters(model)                         # ... until rank 0's are broadcast
+    bucket = FlatGradBucket(model)
+    x, y = _data()
+    shard = slice(rank * 4, rank * 4 + 4)
+    for _ in range(2):                                  # second round: views survive zero()
+        bucket.zero()
+        torch.nn.functional.mse_loss(model(x[shard]), y[shard]).backward()
+        assert bucket.check_views()
+        bucket.all_reduce_mean()
+    q.put((rank, bucket.flat.clone(), torch.cat([p.detach().reshape(-1) for p in model.parameters()])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _model()
+    x, y = _data()
+    torch.nn.functional.mse_loss(model(x), y).backward()          # global batch of 8 = mean of two shard means
+    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    ref_w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    for rank, flat, weights in got:
+        assert torch.allclose(flat, ref, atol=1e-6), rank
+        assert torch.equal(weights, ref_w), rank
+
+
+def test_bucket_without_process_group_is_a_noop():
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    from mlgnn.dist import FlatGradBucket
+    model = _model()
+    b = FlatGradBucket(model)
+    x, y = _data()
+    torch.nn.functional.mse_loss(model(x), y).backward()
+    before = b.flat.clone()
+    b.all_reduce_mean()
+    assert torch.equal(before, b.flat) and b.check_views() and float(before.abs().sum()) > 0

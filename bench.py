@@ -53,7 +53,8 @@ def cpu_baseline(args, model_sd):
     from types import SimpleNamespace
     from mlgnn import workload as W
     from oracle import workload as OW
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-core share; more torch threads than that only thrash
+    threads = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
     nb = args.cpu_baseline_graphs
     match, seg = W.membership(args.nodes, args.members)
@@ -141,7 +142,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER = None
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -383,14 +383,28 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
   }
 }
 
-// ws[nblk][cols] -> out[cols], fixed summation order (bitwise reproducible)
-__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ ws,
-                                                                  float* __restrict__ out, int nblk, int cols) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// ws[nblk][cols] -> out[cols] in a fixed summation order (bitwise reproducible).  One workgroup of
+// 1024 threads owns 32 columns: 32 row slices x 32 columns, each thread sums every 32nd row with
+// independent (pipelined) loads, then the 32 slices are folded through LDS in slice order.
+constexpr int kRedCols = 32, kRedSlices = 32;
+__global__ __launch_bounds__(kRedCols * kRedSlices) void reduce_partials_kernel(const float* __restrict__ ws,
+                                                                                 float* __restrict__ out,
+                                                                                 int nblk, int cols) {
+  __shared__ float part[kRedSlices][kRedCols + 1];
+  const int cl = threadIdx.x % kRedCols;
+  const int slice = threadIdx.x / kRedCols;
+  const int c = blockIdx.x * kRedCols + cl;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * cols + c];
-  out[c] = s;
+  if (c < cols)
+    for (int b = slice; b < nblk; b += kRedSlices) s += ws[(size_t)b * cols + c];
+  part[slice][cl] = s;
+  __syncthreads();
+  if (slice == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < kRedSlices; ++k) t += part[k][cl];
+    out[c] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -543,8 +557,8 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   if (err) return err;
   if (mode == M_GEN_RANK1) {
     const int cols = 2 * (int)d;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                       workspace, grad_uv, nblk, cols);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + kRedCols - 1) / kRedCols), dim3(kRedCols * kRedSlices),
+                       0, s, workspace, grad_uv, nblk, cols);
     err = (int)hipGetLastError();
   }
   return err;

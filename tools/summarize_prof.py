@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (``--kernel-trace --stats`` CSVs, optional ``--pmc`` CSVs) into the
+small files kept under ``profiles/``.
+
+  python tools/summarize_prof.py --stats gpurun_out/prof/**/_kernel_stats.csv --tag r01 \
+         [--pmc-fetch <counter_collection.csv>] [--pmc-write <counter_collection.csv>]
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    if not hits:
+        raise SystemExit("no file matches %s" % pattern)
+    return hits[-1]
+
+
+def pmc_per_kernel(path, counter):
+    """-> {kernel short name: mean counter value per dispatch} for mlgnn kernels."""
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        name = r["Kernel_Name"]
+        if "mlgnn::" not in name:
+            continue
+        acc[name.split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stats", required=True)
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--cmd", default="")
+    ap.add_argument("--pmc-fetch")
+    ap.add_argument("--pmc-write")
+    ap.add_argument("--top", type=int, default=30)
+    a = ap.parse_args()
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    rows = list(csv.DictReader(open(find(a.stats))))
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    out = os.path.join(ROOT, "profiles", "%s_kernel_stats.md" % a.tag)
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats summary (%s)\n\n" % a.tag)
+        if a.cmd:
+            f.write("Command: `%s`\n\n" % a.cmd)
+        f.write("Total kernel time: %.2f ms over %d distinct kernels.\n\n" % (total / 1e6, len(rows)))
+        f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+        for r in rows[:a.top]:
+            f.write("| `%s` | %s | %.2f | %.1f | %.1f | %.1f | %.1f |\n" % (
+                r["Name"][:110].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["Percentage"])))
+        f.write("\n## hand-written kernels (libmlgnn.so)\n\n| kernel | calls | avg us |\n|---|---|---|\n")
+        for r in rows:
+            if "mlgnn::" in r["Name"]:
+                f.write("| `%s` | %s | %.1f |\n" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e3))
+    print("wrote", out)
+    if a.pmc_fetch and a.pmc_write:
+        fetch, nf = pmc_per_kernel(find(a.pmc_fetch), "FETCH_SIZE")
+        write, _ = pmc_per_kernel(find(a.pmc_write), "WRITE_SIZE")
+        traffic, detail = {}, {}
+        for k in fetch:
+            # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+            # exactly half of a wide (16 B/lane) coalesced read stream -> doubled; WRITE_SIZE is exact.
+            hbm = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
+            short = k.split("mlgnn::")[1].split("<")[0].replace("_kernel", "")
+            detail[k] = {"dispatches": nf[k], "FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write.get(k, 0.0),
+                         "hbm_bytes_per_launch": hbm}
+            traffic[short] = max(traffic.get(short, 0.0), hbm)
+        json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+        json.dump(detail, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % a.tag), "w"), indent=1)
+        print("wrote profiles/traffic.json", traffic)
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@
 //
 // HBM-bound (0.25-1 FLOP/byte): algorithmic bytes per launch are E*d*4 (neighbour rows)
 // + E*4 (col) + (N+1)*4 (rowptr) + E*4 (edge scalar) [+ E*d*4 full edge embedding] + N*d*4 (out).
+#include <stdlib.h>
 #include "common.h"
 #include "mlgnn.h"
 
@@ -433,6 +434,15 @@ static int pick_aggr(int aggr) {
 
 static bool is_gen_mode(int mode) { return mode >= M_GEN_NONE; }
 
+// development knob (not part of the ABI): override the lanes-per-row split to explore the
+// channel-chunk / L2-footprint trade-off
+static int lpr_override(int dflt) {
+  const char* e = getenv("MLGNN_LPR_LOG2");
+  if (!e) return dflt;
+  const int v = atoi(e);
+  return (v >= 0 && v <= 6 && v <= dflt) ? v : dflt;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #define MLGNN_DISPATCH_AGGR(KERNEL, VEC, MODE, aggr_id, ...)                                   \
@@ -494,7 +504,7 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   const dim3 grid(grid_for_rows(N)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   if (vec4) {
-    a.lpr_log2 = lanes_per_row_log2(d, 4);
+    a.lpr_log2 = lpr_override(lanes_per_row_log2(d, 4));
     MLGNN_DISPATCH_MODE(csr_aggregate_fwd_kernel, 4, mode, ag, grid, block, 0, s, a)
   } else {
     a.lpr_log2 = lanes_per_row_log2(d, 1);
@@ -547,7 +557,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   const dim3 grid(nblk), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   if (vec4) {
-    a.lpr_log2 = lanes_per_row_log2(d, 4);
+    a.lpr_log2 = lpr_override(lanes_per_row_log2(d, 4));
     MLGNN_DISPATCH_MODE(csr_aggregate_bwd_kernel, 4, mode, ag, grid, block, 0, s, a)
   } else {
     a.lpr_log2 = lanes_per_row_log2(d, 1);

@@ -119,6 +119,37 @@ int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out
                             int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev,
                             float eps, void* stream);
 
+/*
+ * Gene -> pathway learnable-projection pooling.
+ * Replaces: models/multilevel_gnn.py:212-239 (advanced-index gather, repeat, mul, permute,
+ * Tensor.scatter_reduce('sum')):
+ *   out[b,c,s,k] = sum_{g: raw_indice[b,g]=s} x[b*NN + match[b,g], c] * [match>=0] * w[g,k]
+ *
+ * Members are addressed by their flat index f = b*G + g (M = B*G of them):
+ *   seg_ptr [n_segments+1], seg_mem [M]   members grouped by (batch, segment), n_segments = B*S
+ *   mem_row [M]   x row of the member (b*NN + match) or -1 when absent
+ *   mem_seg [M]   (batch, segment) id of the member
+ *   node_ptr [n_rows+1], node_mem [.]     present members grouped by x row
+ *   x [n_rows, C], w [G, K] (K <= 4), out_t / gout_t [n_segments, K, C] (channel-contiguous)
+ */
+int mlgnn_segment_project_fwd(const void* x, const float* w, const int32_t* seg_ptr,
+                              const int32_t* seg_mem, const int32_t* mem_row, void* out_t,
+                              int64_t n_segments, int64_t C, int64_t G, int64_t K, int dtype,
+                              void* stream);
+
+/*
+ * Backward of the above.  grad_x [n_rows, C] (NULL to skip) and gw_partial [M, K] (NULL to skip):
+ * gw_partial[f,k] = <x[mem_row[f],:], gout_t[mem_seg[f],k,:]>; the caller sums it over the batch
+ * index to obtain d loss / d w [G,K].
+ */
+int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
+                              const int32_t* seg_ptr, const int32_t* seg_mem,
+                              const int32_t* mem_row, const int32_t* mem_seg,
+                              const int32_t* node_ptr, const int32_t* node_mem,
+                              void* grad_x, float* gw_partial,
+                              int64_t n_segments, int64_t n_rows, int64_t C, int64_t G, int64_t K,
+                              int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

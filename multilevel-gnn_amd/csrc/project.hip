@@ -1,0 +1,288 @@
+// Gene -> pathway learnable-projection pooling (reference: models/multilevel_gnn.py:212-239).
+//
+//   out[b, c, s, k] = sum_{g : raw_indice[b,g] = s}  x[b*NN + match[b,g], c] * [match >= 0] * W[g, k]
+//
+// The reference gathers [B,G,C], repeats it k times, permutes and reduces with an atomic
+// scatter_reduce (>= 3 materialisations of [B,G,C,k]).  Here members are grouped by segment (forward,
+// weight gradient) or by node (input gradient) on the host once per membership table, and every
+// kernel is the same atomic-free row-per-wavefront gather-reduce as the CSR aggregation:
+// lanes hold channels (16-byte loads), lane groups take members round-robin, shuffles merge groups.
+//
+// Layouts: x [R, C] (R = B*NN node rows), member tables int32 over flat members f = b*G + g,
+// out_t / gout_t [B*S, K, C] (channel-contiguous; the host permutes the 30 MB result to [B,C,S,K]).
+// HBM-bound: algorithmic bytes = M*C*4 (gathered rows) + M*(4+4+4K) (tables) + B*S*K*C*4.
+#include "common.h"
+#include "mlgnn.h"
+
+namespace mlgnn {
+
+constexpr int kPUnroll = 4;
+
+struct ProjArgs {
+  const float* x; const float* w; const float* gout_t;
+  const int* ptr; const int* mem; const int* mem_row; const int* mem_seg;
+  float* out; float* gw_partial;
+  int rows; int C; int G; int lpr_log2;
+};
+
+// ---- forward: one wave per (batch, segment); out_t[seg, k, :] = sum_m x[row(m), :] * W[g(m), k]
+template <int VEC, int K>
+__global__ __launch_bounds__(kBlock) void segment_project_fwd_kernel(const ProjArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << a.lpr_log2;
+  const int groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2;
+  const int cl = lane & (lpr - 1);
+  const RowWalk walk = make_row_walk(a.rows);
+  for (int cbase = 0; cbase < a.C; cbase += lpr * VEC) {
+    const int c0 = cbase + cl * VEC;
+    const bool cact = c0 < a.C;
+    for (int r = walk.first; r < walk.r_end; r += walk.stride) {
+      const int beg = a.ptr[r], end = a.ptr[r + 1];
+      float acc[K][VEC];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+      for (int base = beg; base < end; base += kWave) {
+        const int cnt = min(kWave, end - base);
+        int my_row = -1;
+        float my_w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) my_w[k] = 0.f;
+        if (lane < cnt) {
+          const int f = a.mem[base + lane];
+          my_row = a.mem_row[f];
+          const int g = f % a.G;
+#pragma unroll
+          for (int k = 0; k < K; ++k) my_w[k] = a.w[(size_t)g * K + k];
+        }
+        for (int kk = 0; kk < cnt; kk += groups * kPUnroll) {
+          float xv[kPUnroll][VEC], wk[kPUnroll][K];
+#pragma unroll
+          for (int u = 0; u < kPUnroll; ++u) {
+            const int idx = kk + u * groups + sub;
+            const int src = idx & (kWave - 1);
+            const int row = __shfl(my_row, src);
+#pragma unroll
+            for (int k = 0; k < K; ++k) wk[u][k] = __shfl(my_w[k], src);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) xv[u][i] = 0.f;
+            if (idx < cnt && cact && row >= 0) load_vec<VEC>(xv[u], a.x + (size_t)row * a.C + c0);
+          }
+#pragma unroll
+          for (int u = 0; u < kPUnroll; ++u)
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[k][i] = fmaf(xv[u][i], wk[u][k], acc[k][i]);
+        }
+      }
+      for (int off = lpr; off < kWave; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[k][i] += __shfl_xor(acc[k][i], off);
+      if (sub == 0 && cact) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) store_vec<VEC>(a.out + ((size_t)r * K + k) * a.C + c0, acc[k]);
+      }
+    }
+  }
+}
+
+// ---- input gradient: one wave per node row; gx[row, :] = sum_{m -> row} sum_k gout_t[seg(m), k, :] * W[g(m), k]
+template <int VEC, int K>
+__global__ __launch_bounds__(kBlock) void segment_project_bwd_x_kernel(const ProjArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << a.lpr_log2;
+  const int groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2;
+  const int cl = lane & (lpr - 1);
+  const RowWalk walk = make_row_walk(a.rows);
+  for (int cbase = 0; cbase < a.C; cbase += lpr * VEC) {
+    const int c0 = cbase + cl * VEC;
+    const bool cact = c0 < a.C;
+    for (int r = walk.first; r < walk.r_end; r += walk.stride) {
+      const int beg = a.ptr[r], end = a.ptr[r + 1];
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      for (int base = beg; base < end; base += kWave) {
+        const int cnt = min(kWave, end - base);
+        int my_seg = 0;
+        float my_w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) my_w[k] = 0.f;
+        if (lane < cnt) {
+          const int f = a.mem[base + lane];
+          my_seg = a.mem_seg[f];
+          const int g = f % a.G;
+#pragma unroll
+          for (int k = 0; k < K; ++k) my_w[k] = a.w[(size_t)g * K + k];
+        }
+        for (int kk = 0; kk < cnt; kk += groups) {
+          const int idx = kk + sub;
+          const int src = idx & (kWave - 1);
+          const int seg = __shfl(my_seg, src);
+          float wk[K];
+#pragma unroll
+          for (int k = 0; k < K; ++k) wk[k] = __shfl(my_w[k], src);
+          if (idx < cnt && cact) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              float gv[VEC];
+              load_vec<VEC>(gv, a.gout_t + ((size_t)seg * K + k) * a.C + c0);
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[i] = fmaf(gv[i], wk[k], acc[i]);
+            }
+          }
+        }
+      }
+      for (int off = lpr; off < kWave; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+      if (sub == 0 && cact) store_vec<VEC>(a.out + (size_t)r * a.C + c0, acc);
+    }
+  }
+}
+
+// ---- weight gradient: one wave per (batch, segment); gw_partial[f, k] = <x[row(f), :], gout_t[seg, k, :]>
+// (summed over the batch index by the caller).  Requires C <= 64*VEC (one channel chunk per wave).
+template <int VEC, int K>
+__global__ __launch_bounds__(kBlock) void segment_project_bwd_w_kernel(const ProjArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << a.lpr_log2;
+  const int groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2;
+  const int cl = lane & (lpr - 1);
+  const RowWalk walk = make_row_walk(a.rows);
+  const int c0 = cl * VEC;
+  const bool cact = c0 < a.C;
+  for (int r = walk.first; r < walk.r_end; r += walk.stride) {
+    const int beg = a.ptr[r], end = a.ptr[r + 1];
+    float gk[K][VEC];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) gk[k][i] = 0.f;
+      if (cact && end > beg) load_vec<VEC>(gk[k], a.gout_t + ((size_t)r * K + k) * a.C + c0);
+    }
+    for (int base = beg; base < end; base += kWave) {
+      const int cnt = min(kWave, end - base);
+      int my_row = -1, my_f = 0;
+      if (lane < cnt) { my_f = a.mem[base + lane]; my_row = a.mem_row[my_f]; }
+      for (int kk = 0; kk < cnt; kk += groups) {
+        const int idx = kk + sub;
+        const int src = idx & (kWave - 1);
+        const int row = __shfl(my_row, src);
+        const int f = __shfl(my_f, src);
+        float xv[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) xv[i] = 0.f;
+        const bool ok = idx < cnt;
+        if (ok && cact && row >= 0) load_vec<VEC>(xv, a.x + (size_t)row * a.C + c0);
+        float dot[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) s = fmaf(xv[i], gk[k][i], s);
+          for (int off = 1; off < lpr; off <<= 1) s += __shfl_xor(s, off);   // within the lane group
+          dot[k] = s;
+        }
+        if (ok && cl == 0) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) a.gw_partial[(size_t)f * K + k] = dot[k];
+        }
+      }
+    }
+  }
+}
+
+#define MLGNN_PROJ_LAUNCH(KERNEL, VEC, Kc, ...)                                              \
+  switch (Kc) {                                                                              \
+    case 1: hipLaunchKernelGGL((KERNEL<VEC, 1>), __VA_ARGS__); break;                        \
+    case 2: hipLaunchKernelGGL((KERNEL<VEC, 2>), __VA_ARGS__); break;                        \
+    case 3: hipLaunchKernelGGL((KERNEL<VEC, 3>), __VA_ARGS__); break;                        \
+    default: hipLaunchKernelGGL((KERNEL<VEC, 4>), __VA_ARGS__); break;                       \
+  }
+
+static bool p16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace mlgnn
+
+using namespace mlgnn;
+
+extern "C" int mlgnn_segment_project_fwd(const void* x, const float* w, const int32_t* seg_ptr,
+                                         const int32_t* seg_mem, const int32_t* mem_row, void* out_t,
+                                         int64_t n_segments, int64_t C, int64_t G, int64_t K, int dtype,
+                                         void* stream) {
+  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (n_segments < 0 || C <= 0 || G <= 0 || K < 1 || K > 4 || n_segments > INT32_MAX) return MLGNN_E_SHAPE;
+  if (n_segments == 0) return 0;
+  if (!x || !w || !seg_ptr || !mem_row || !out_t) return MLGNN_E_NULL;
+  ProjArgs a{};
+  a.x = (const float*)x; a.w = w; a.ptr = seg_ptr; a.mem = seg_mem; a.mem_row = mem_row;
+  a.out = (float*)out_t; a.rows = (int)n_segments; a.C = (int)C; a.G = (int)G;
+  const dim3 grid(grid_for_rows(n_segments)), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  if (C % 4 == 0 && p16(x) && p16(out_t)) {
+    a.lpr_log2 = lanes_per_row_log2(C, 4);
+    MLGNN_PROJ_LAUNCH(segment_project_fwd_kernel, 4, (int)K, grid, block, 0, s, a)
+  } else {
+    a.lpr_log2 = lanes_per_row_log2(C, 1);
+    MLGNN_PROJ_LAUNCH(segment_project_fwd_kernel, 1, (int)K, grid, block, 0, s, a)
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
+                                         const int32_t* seg_ptr, const int32_t* seg_mem,
+                                         const int32_t* mem_row, const int32_t* mem_seg,
+                                         const int32_t* node_ptr, const int32_t* node_mem,
+                                         void* grad_x, float* gw_partial,
+                                         int64_t n_segments, int64_t n_rows, int64_t C, int64_t G, int64_t K,
+                                         int dtype, void* stream) {
+  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (n_segments < 0 || n_rows < 0 || C <= 0 || G <= 0 || K < 1 || K > 4 || n_rows > INT32_MAX ||
+      n_segments > INT32_MAX) return MLGNN_E_SHAPE;
+  if (!gout_t || !w) return MLGNN_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 block(kBlock);
+  const bool vec4 = (C % 4 == 0) && p16(gout_t) && (!x || p16(x)) && (!grad_x || p16(grad_x));
+  if (grad_x && n_rows > 0) {
+    if (!node_ptr || !mem_seg) return MLGNN_E_NULL;
+    ProjArgs a{};
+    a.gout_t = (const float*)gout_t; a.w = w; a.ptr = node_ptr; a.mem = node_mem; a.mem_seg = mem_seg;
+    a.out = (float*)grad_x; a.rows = (int)n_rows; a.C = (int)C; a.G = (int)G;
+    const dim3 grid(grid_for_rows(n_rows));
+    if (vec4) {
+      a.lpr_log2 = lanes_per_row_log2(C, 4);
+      MLGNN_PROJ_LAUNCH(segment_project_bwd_x_kernel, 4, (int)K, grid, block, 0, s, a)
+    } else {
+      a.lpr_log2 = lanes_per_row_log2(C, 1);
+      MLGNN_PROJ_LAUNCH(segment_project_bwd_x_kernel, 1, (int)K, grid, block, 0, s, a)
+    }
+    const int err = (int)hipGetLastError();
+    if (err) return err;
+  }
+  if (gw_partial && n_segments > 0) {
+    if (!x || !seg_ptr || !mem_row) return MLGNN_E_NULL;
+    if (C > (vec4 ? 256 : 64)) return MLGNN_E_SHAPE;      // one channel chunk per wave
+    ProjArgs a{};
+    a.gout_t = (const float*)gout_t; a.x = (const float*)x; a.ptr = seg_ptr; a.mem = seg_mem;
+    a.mem_row = mem_row; a.gw_partial = gw_partial; a.rows = (int)n_segments; a.C = (int)C; a.G = (int)G;
+    const dim3 grid(grid_for_rows(n_segments));
+    if (vec4) {
+      a.lpr_log2 = lanes_per_row_log2(C, 4);
+      MLGNN_PROJ_LAUNCH(segment_project_bwd_w_kernel, 4, (int)K, grid, block, 0, s, a)
+    } else {
+      a.lpr_log2 = lanes_per_row_log2(C, 1);
+      MLGNN_PROJ_LAUNCH(segment_project_bwd_w_kernel, 1, (int)K, grid, block, 0, s, a)
+    }
+    const int err = (int)hipGetLastError();
+    if (err) return err;
+  }
+  return 0;
+}

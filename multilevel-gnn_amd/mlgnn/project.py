@@ -1,32 +1,109 @@
 """Gene -> pathway learnable-projection pooling (reference ``models/multilevel_gnn.py:212-239``).
 
-``out[b, c, s, k] = sum_{g : raw_indice[b,g] = s} x[b, match[b,g], c] * [match >= 0] * P[g,k] * mask[g]``
+``out[b, c, s, k] = sum_{g : raw_indice[b,g] = s} x[b*NN + match[b,g], c] * [match >= 0] * W[g,k]``
 
 The reference materialises ``[B, G, C, k]`` three times (gather, repeat, permute) and reduces it
-with an atomic ``scatter_reduce``.  Here the gather is reduced per projection column without the
-``k``-fold blow-up.
+with an atomic ``scatter_reduce``.  Here the membership table is grouped by segment and by node
+once (:class:`Membership`), and three atomic-free gather-reduce kernels do forward, input gradient
+and weight gradient (``csrc/project.hip``).
 """
 import torch
+
+from . import _lib
+from .ops import DTYPE_F32, _dev_f32, _stream
+
+
+class Membership:
+    """Index tables of one ``(gene_pca_match, raw_indice)`` pair (int32, device resident)."""
+
+    def __init__(self, gene_pca_match, raw_indice, nodes_per_graph, n_segments, n_rows, match_mask=True):
+        B, G = gene_pca_match.shape
+        dev = gene_pca_match.device
+        self.B, self.G, self.S, self.R = B, G, int(n_segments), int(n_rows)
+        offs = torch.arange(B, device=dev)[:, None]
+        row = gene_pca_match.long() + offs * nodes_per_graph
+        if match_mask:
+            row = torch.where(gene_pca_match >= 0, row, torch.full_like(row, -1))
+        else:
+            row = torch.remainder(row, n_rows)              # negative index wraps like the reference's x[idx]
+        seg = (raw_indice.long() + offs * n_segments).reshape(-1)
+        row = row.reshape(-1)
+        order = torch.sort(seg, stable=True).indices
+        self.seg_mem = order.to(torch.int32)
+        self.seg_ptr = self._ptr(seg, B * self.S)
+        self.mem_seg = seg.to(torch.int32)
+        self.mem_row = row.to(torch.int32)
+        present = torch.nonzero(row >= 0).reshape(-1)
+        order_n = torch.sort(row[present], stable=True).indices
+        self.node_mem = present[order_n].to(torch.int32)
+        self.node_ptr = self._ptr(row[present], self.R)
+
+    @staticmethod
+    def _ptr(index, n):
+        ptr = torch.zeros(n + 1, dtype=torch.int64, device=index.device)
+        torch.cumsum(torch.bincount(index, minlength=n), 0, out=ptr[1:])
+        return ptr.to(torch.int32)
+
+
+_MEMBERSHIP_CACHE = []
+
+
+def membership_tables(gene_pca_match, raw_indice, nodes_per_graph, n_segments, n_rows, match_mask=True):
+    """The table is a per-fold constant in the reference's data; batches hand in the same tensors
+    again and again, so the last few results are kept (tensor identity + version)."""
+    key = (nodes_per_graph, n_segments, n_rows, bool(match_mask), gene_pca_match._version, raw_indice._version)
+    for ent in _MEMBERSHIP_CACHE:
+        if ent[0] is gene_pca_match and ent[1] is raw_indice and ent[2] == key:
+            return ent[3]
+    m = Membership(gene_pca_match, raw_indice, nodes_per_graph, n_segments, n_rows, match_mask)
+    _MEMBERSHIP_CACHE.insert(0, (gene_pca_match, raw_indice, key, m))
+    del _MEMBERSHIP_CACHE[4:]
+    return m
+
+
+class _SegmentProject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, tables):
+        x, w = _dev_f32(x, "x"), _dev_f32(w, "weights")
+        R, C = x.shape
+        G, K = w.shape
+        if G != tables.G or R != tables.R:
+            raise ValueError("membership table does not match the inputs")
+        out_t = torch.empty((tables.B * tables.S, K, C), dtype=torch.float32, device=x.device)
+        rc = _lib.lib.mlgnn_segment_project_fwd(
+            x.data_ptr(), w.data_ptr(), tables.seg_ptr.data_ptr(), _lib.ptr(tables.seg_mem),
+            tables.mem_row.data_ptr(), out_t.data_ptr(), tables.B * tables.S, C, G, K, DTYPE_F32, _stream())
+        _lib.check(rc, "mlgnn_segment_project_fwd")
+        ctx.tables = tables
+        ctx.save_for_backward(x, w)
+        return out_t
+
+    @staticmethod
+    def backward(ctx, gout_t):
+        x, w = ctx.saved_tensors
+        t = ctx.tables
+        R, C = x.shape
+        G, K = w.shape
+        gout_t = _dev_f32(gout_t, "grad_out")
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gwp = torch.empty((t.B * G, K), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        rc = _lib.lib.mlgnn_segment_project_bwd(
+            gout_t.data_ptr(), x.data_ptr(), w.data_ptr(), t.seg_ptr.data_ptr(), _lib.ptr(t.seg_mem),
+            t.mem_row.data_ptr(), t.mem_seg.data_ptr(), t.node_ptr.data_ptr(), _lib.ptr(t.node_mem),
+            _lib.ptr(gx), _lib.ptr(gwp), t.B * t.S, R, C, G, K, DTYPE_F32, _stream())
+        _lib.check(rc, "mlgnn_segment_project_bwd")
+        gw = gwp.reshape(t.B, G, K).sum(0) if gwp is not None else None
+        return gx, gw, None
 
 
 def segment_project(x_nodes, gene_pca_match, raw_indice, weights, nodes_per_graph, n_segments,
                     match_mask=True):
     """``x_nodes [B*NN, C]`` -> ``[B, C, n_segments, k]``; ``weights [G, k]`` already carries the
-    info mask.  A negative ``match`` wraps exactly as the reference's advanced indexing does when
-    ``match_mask`` is off."""
-    B, G = gene_pca_match.shape
-    C = x_nodes.shape[1]
-    k = weights.shape[1]
-    total = x_nodes.shape[0]
-    offs = torch.arange(B, device=x_nodes.device)[:, None] * nodes_per_graph
-    idx = torch.remainder(gene_pca_match + offs, total).reshape(-1)
-    xg = x_nodes.index_select(0, idx).reshape(B, G, C)
-    if match_mask:
-        xg = xg * (gene_pca_match >= 0).to(xg.dtype)[:, :, None]
-    seg = (raw_indice.to(torch.long) + torch.arange(B, device=x_nodes.device)[:, None] * n_segments).reshape(-1)
-    cols = []
-    for j in range(k):
-        contrib = (xg * weights[:, j][None, :, None]).reshape(B * G, C)
-        cols.append(x_nodes.new_zeros((B * n_segments, C)).index_add_(0, seg, contrib))
-    out = torch.stack(cols, dim=-1).reshape(B, n_segments, C, k)
-    return out.permute(0, 2, 1, 3)
+    info mask.  ``match_mask=False`` wraps a negative ``match`` exactly as the reference's advanced
+    indexing does."""
+    B = gene_pca_match.shape[0]
+    tables = membership_tables(gene_pca_match, raw_indice, nodes_per_graph, n_segments, x_nodes.shape[0],
+                               match_mask)
+    out_t = _SegmentProject.apply(x_nodes, weights, tables)          # [B*S, k, C]
+    k, C = out_t.shape[1], out_t.shape[2]
+    return out_t.reshape(B, n_segments, k, C).permute(0, 3, 1, 2)    # [B, C, S, k]

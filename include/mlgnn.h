@@ -150,6 +150,24 @@ int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
                               int64_t n_segments, int64_t n_rows, int64_t C, int64_t G, int64_t K,
                               int dtype, void* stream);
 
+/*
+ * Fused LayerNorm (+ ReLU) over [rows, d] fp32, d <= 256 and d % 4 == 0.
+ * Replaces: norm_layer('layer') followed by act_layer('relu') as chained by MLP
+ * (models/gcn_lib/sparse/torch_nn.py:27-38,54-75) and by the res+ block (models/deepergcn.py:236-241).
+ *   out = relu?( (x - mean) * rstd * gamma + beta ),  rstd = 1/sqrt(var_biased + eps)
+ * mean / rstd [rows] are saved for the backward, which recomputes the ReLU mask from x.
+ * grad_gamma_beta [2,d]; workspace: mlgnn_layernorm_bwd_workspace_floats(rows, d) floats.
+ */
+int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d);
+int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
+                            float* mean, float* rstd, int64_t rows, int64_t d, float eps,
+                            int relu, int dtype, void* stream);
+int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* gamma,
+                            const float* beta, const float* mean, const float* rstd,
+                            void* grad_x, float* grad_gamma_beta, float* workspace,
+                            int64_t workspace_floats, int64_t rows, int64_t d, int relu,
+                            int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -408,6 +408,11 @@ __global__ __launch_bounds__(kRedCols * kRedSlices) void reduce_partials_kernel(
   }
 }
 
+void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + kRedCols - 1) / kRedCols), dim3(kRedCols * kRedSlices),
+                     0, stream, ws, out, nblk, cols);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
@@ -567,8 +572,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   if (err) return err;
   if (mode == M_GEN_RANK1) {
     const int cols = 2 * (int)d;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + kRedCols - 1) / kRedCols), dim3(kRedCols * kRedSlices),
-                       0, s, workspace, grad_uv, nblk, cols);
+    launch_reduce_partials(workspace, grad_uv, nblk, cols, s);
     err = (int)hipGetLastError();
   }
   return err;

@@ -1,0 +1,196 @@
+// Fused LayerNorm (+ ReLU) forward / backward over [rows, d] fp32, d <= 256, d % 4 == 0.
+//
+// Reference: norm_layer('layer') + act_layer('relu') as chained by MLP
+// (models/gcn_lib/sparse/torch_nn.py:27-38,54-75) and by the res+ block
+// (models/deepergcn.py:236-241: norms[l-1](h) -> relu).  ATen runs LayerNorm and ReLU as separate
+// passes forward and three kernels backward; here one pass each way.
+//
+// Lane layout as in the aggregation kernels: LPR = next_pow2(d/4) lanes hold one row (float4 per
+// lane), a wave works on 64/LPR rows at once, row statistics are xor-shuffle reductions inside
+// the lane group.  HBM-bound: forward 2*rows*d*4 bytes, backward 3*rows*d*4 bytes (+ 8 B/row stats).
+#include "common.h"
+#include "mlgnn.h"
+
+namespace mlgnn {
+
+template <int LPR_LOG2>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = 1; off < (1 << LPR_LOG2); off <<= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+struct LnArgs {
+  const float* x; const float* go; const float* gamma; const float* beta;
+  float* out; float* mean; float* rstd; float* gx; float* ws;
+  int rows; int d; float eps; int relu;
+};
+
+template <int LPR_LOG2>
+__global__ __launch_bounds__(kBlock) void layernorm_act_fwd_kernel(const LnArgs a) {
+  constexpr int LPR = 1 << LPR_LOG2, GROUPS = kWave / LPR;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * 4;
+  const bool cact = c0 < a.d;
+  const int wave_global = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int n_waves = gridDim.x * kWavesPerBlock;
+  float g[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  if (cact) { load_vec<4>(g, a.gamma + c0); load_vec<4>(b, a.beta + c0); }
+  const float inv_d = 1.0f / (float)a.d;
+  for (int r0 = wave_global * GROUPS; r0 < a.rows; r0 += n_waves * GROUPS) {
+    const int r = r0 + sub;
+    const bool ok = (r < a.rows) && cact;
+    float v[4] = {0, 0, 0, 0};
+    if (ok) load_vec<4>(v, a.x + (size_t)r * a.d + c0);
+    const float mu = group_sum<LPR_LOG2>(v[0] + v[1] + v[2] + v[3]) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float c = cact ? v[i] - mu : 0.f; q = fmaf(c, c, q); }
+    const float rs = rsqrtf(group_sum<LPR_LOG2>(q) * inv_d + a.eps);
+    if (ok) {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float y = fmaf((v[i] - mu) * rs, g[i], b[i]);
+        o[i] = a.relu ? fmaxf(y, 0.f) : y;
+      }
+      store_vec<4>(a.out + (size_t)r * a.d + c0, o);
+      if (cl == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
+    }
+  }
+}
+
+template <int LPR_LOG2>
+__global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs a) {
+  constexpr int LPR = 1 << LPR_LOG2, GROUPS = kWave / LPR;
+  __shared__ float red[kWavesPerBlock][2][kWave * 4];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * 4;
+  const bool cact = c0 < a.d;
+  const int wave_global = blockIdx.x * kWavesPerBlock + wave;
+  const int n_waves = gridDim.x * kWavesPerBlock;
+  float g[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+  if (cact) { load_vec<4>(g, a.gamma + c0); load_vec<4>(b, a.beta + c0); }
+  const float inv_d = 1.0f / (float)a.d;
+  for (int r0 = wave_global * GROUPS; r0 < a.rows; r0 += n_waves * GROUPS) {
+    const int r = r0 + sub;
+    const bool ok = (r < a.rows) && cact;
+    float v[4] = {0, 0, 0, 0}, go[4] = {0, 0, 0, 0};
+    float mu = 0.f, rs = 0.f;
+    if (ok) {
+      load_vec<4>(v, a.x + (size_t)r * a.d + c0);
+      load_vec<4>(go, a.go + (size_t)r * a.d + c0);
+      mu = a.mean[r]; rs = a.rstd[r];
+    }
+    float xh[4], gg[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xh[i] = (v[i] - mu) * rs;
+      const float y = fmaf(xh[i], g[i], b[i]);
+      const float gy = (a.relu && !(y > 0.f)) ? 0.f : go[i];
+      dg[i] = fmaf(gy, xh[i], dg[i]);
+      db[i] += gy;
+      gg[i] = gy * g[i];
+      s1 += gg[i];
+      s2 = fmaf(gg[i], xh[i], s2);
+    }
+    s1 = group_sum<LPR_LOG2>(s1) * inv_d;
+    s2 = group_sum<LPR_LOG2>(s2) * inv_d;
+    if (ok) {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = rs * (gg[i] - s1 - xh[i] * s2);
+      store_vec<4>(a.gx + (size_t)r * a.d + c0, o);
+    }
+  }
+  // d gamma / d beta: lane groups -> waves -> one [2,d] partial per workgroup
+#pragma unroll
+  for (int off = LPR; off < kWave; off <<= 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dg[i] += __shfl_xor(dg[i], off); db[i] += __shfl_xor(db[i], off); }
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[wave][0][c0 + i] = dg[i]; red[wave][1][c0 + i] = db[i]; }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * a.d; idx += kBlock) {
+    const int which = idx / a.d, c = idx % a.d;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) s += red[w][which][c];
+    a.ws[((size_t)blockIdx.x * 2 + which) * a.d + c] = s;
+  }
+}
+
+static int ln_grid(int64_t rows, int lpr_log2) {
+  const int groups = kWave >> lpr_log2;
+  int64_t blocks = (rows + (int64_t)groups * kWavesPerBlock - 1) / ((int64_t)groups * kWavesPerBlock);
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+static bool ln_ok(int64_t d) { return d > 0 && d <= 256 && d % 4 == 0; }
+static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define MLGNN_LN_LAUNCH(KERNEL, lpr, ...)                                         \
+  switch (lpr) {                                                                  \
+    case 0: hipLaunchKernelGGL((KERNEL<0>), __VA_ARGS__); break;                  \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break;                  \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__); break;                  \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), __VA_ARGS__); break;                  \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__); break;                  \
+    case 5: hipLaunchKernelGGL((KERNEL<5>), __VA_ARGS__); break;                  \
+    default: hipLaunchKernelGGL((KERNEL<6>), __VA_ARGS__); break;                 \
+  }
+
+}  // namespace mlgnn
+
+using namespace mlgnn;
+
+extern "C" int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d) {
+  if (rows < 0 || !ln_ok(d)) return MLGNN_E_SHAPE;
+  return (int64_t)ln_grid(rows, lanes_per_row_log2(d, 4)) * 2 * d;
+}
+
+extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
+                                       float* mean, float* rstd, int64_t rows, int64_t d, float eps,
+                                       int relu, int dtype, void* stream) {
+  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (rows < 0 || rows > INT32_MAX || !ln_ok(d)) return MLGNN_E_SHAPE;
+  if (rows == 0) return 0;
+  if (!x || !gamma || !beta || !out || !mean || !rstd) return MLGNN_E_NULL;
+  if (!a16(x) || !a16(out) || !a16(gamma) || !a16(beta)) return MLGNN_E_ALIGN;
+  LnArgs a{};
+  a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.out = (float*)out; a.mean = mean; a.rstd = rstd;
+  a.rows = (int)rows; a.d = (int)d; a.eps = eps; a.relu = relu;
+  const int lpr = lanes_per_row_log2(d, 4);
+  MLGNN_LN_LAUNCH(layernorm_act_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), dim3(kBlock), 0, (hipStream_t)stream, a)
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* gamma,
+                                       const float* beta, const float* mean, const float* rstd,
+                                       void* grad_x, float* grad_gamma_beta, float* workspace,
+                                       int64_t workspace_floats, int64_t rows, int64_t d, int relu,
+                                       int dtype, void* stream) {
+  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (rows < 0 || rows > INT32_MAX || !ln_ok(d)) return MLGNN_E_SHAPE;
+  if (!grad_gamma_beta || !workspace) return MLGNN_E_NULL;
+  const int lpr = lanes_per_row_log2(d, 4);
+  const int nblk = ln_grid(rows, lpr);
+  if (workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
+  if (rows > 0 && (!grad_out || !x || !gamma || !beta || !mean || !rstd || !grad_x)) return MLGNN_E_NULL;
+  if (!a16(x) || !a16(grad_out) || !a16(grad_x) || !a16(gamma) || !a16(beta)) return MLGNN_E_ALIGN;
+  LnArgs a{};
+  a.x = (const float*)x; a.go = (const float*)grad_out; a.gamma = gamma; a.beta = beta;
+  a.mean = (float*)mean; a.rstd = (float*)rstd; a.gx = (float*)grad_x; a.ws = workspace;
+  a.rows = (int)rows; a.d = (int)d; a.relu = relu;
+  hipStream_t s = (hipStream_t)stream;
+  MLGNN_LN_LAUNCH(layernorm_act_bwd_kernel, lpr, dim3(nblk), dim3(kBlock), 0, s, a)
+  int err = (int)hipGetLastError();
+  if (err) return err;
+  launch_reduce_partials(workspace, grad_gamma_beta, nblk, 2 * (int)d, s);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,54 @@
+"""Fused LayerNorm (+ ReLU) (reference: ``norm_layer('layer')`` + ``act_layer('relu')`` chained by
+``MLP`` -- ``models/gcn_lib/sparse/torch_nn.py:27-38,54-75`` -- and by the res+ block,
+``models/deepergcn.py:236-241``).  One HIP pass forward, one backward (``csrc/norm.hip``)."""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .ops import DTYPE_F32, _stream
+
+
+def fused_supported(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 0 < x.shape[1] <= 256 and x.shape[1] % 4 == 0
+
+
+class _LayerNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu):
+        x = x.contiguous()
+        rows, d = x.shape
+        out = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        weight, bias = weight.contiguous(), bias.contiguous()
+        rc = _lib.lib.mlgnn_layernorm_act_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                              mean.data_ptr(), rstd.data_ptr(), rows, d, float(eps), int(relu),
+                                              DTYPE_F32, _stream())
+        _lib.check(rc, "mlgnn_layernorm_act_fwd")
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        rows, d = x.shape
+        go = go.contiguous()
+        gx = torch.empty_like(x)
+        ggb = torch.empty((2, d), dtype=torch.float32, device=x.device)
+        n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d))
+        ws = torch.empty(n, dtype=torch.float32, device=x.device)
+        rc = _lib.lib.mlgnn_layernorm_act_bwd(go.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                              mean.data_ptr(), rstd.data_ptr(), gx.data_ptr(), ggb.data_ptr(),
+                                              ws.data_ptr(), n, rows, d, int(ctx.relu), DTYPE_F32, _stream())
+        _lib.check(rc, "mlgnn_layernorm_act_bwd")
+        return gx, ggb[0], ggb[1], None, None
+
+
+def layer_norm_act(x, weight, bias, eps=1e-5, relu=False):
+    """``relu?(LayerNorm(x))`` over the last dimension of a 2-D tensor.  Shapes the fused kernel
+    does not cover (d > 256 or d % 4 != 0) take ATen's LayerNorm on the same device."""
+    if weight is not None and bias is not None and fused_supported(x):
+        return _LayerNormAct.apply(x, weight, bias, eps, relu)
+    y = F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+    return F.relu(y) if relu else y

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .graph import CSRGraph
+from .norm import layer_norm_act
 from .ops import RankOneEdge
 from .project import segment_project
 
@@ -112,8 +113,10 @@ class ThreeLevelGNN(nn.Module):
         # res+ block (deepergcn.py:232-247), dropout 0
         h = self.gcns[0](h, graph, edge)
         for l in range(1, self.num_layers):
-            h = self.gcns[l](F.relu(self.norms[l - 1](h)), graph, edge) + h
-        h = self.norms[self.num_layers - 1](h)
+            n = self.norms[l - 1]
+            h = self.gcns[l](layer_norm_act(h, n.weight, n.bias, n.eps, relu=True), graph, edge) + h
+        n = self.norms[self.num_layers - 1]
+        h = layer_norm_act(h, n.weight, n.bias, n.eps)
         # level 1: gene -> pathway projection pooling (multilevel_gnn.py:212-242)
         B = batch.gene_pca_match.shape[0]
         p = segment_project(h, batch.gene_pca_match, batch.raw_indice, self.learnable_pca_params,

@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from mlgnn import CSRGraph, RankOneEdge
+from mlgnn.norm import layer_norm_act
 from mlgnn.pool import global_pool
 from .gcn_lib.sparse.torch_vertex import GENConv
 from .gcn_lib.sparse.torch_nn import norm_layer
@@ -129,6 +130,14 @@ class DeeperGCN(torch.nn.Module):
     def _drop(self, h):
         return F.dropout(h, p=self.dropout, training=self.training)
 
+    def _norm(self, layer, h, relu=False):
+        """``norms[layer](h)`` (+ ReLU): one fused HIP pass for LayerNorm, the module otherwise."""
+        m = self.norms[layer]
+        if isinstance(m, nn.LayerNorm):
+            return layer_norm_act(h, m.weight, m.bias, m.eps, relu)
+        h = m(h)
+        return F.relu(h) if relu else h
+
     # ------------------------------------------------------------------ forward
     def forward(self, input_batch):
         x = input_batch.x
@@ -157,25 +166,24 @@ class DeeperGCN(torch.nn.Module):
         if self.block == 'res+':
             h = self.gcns[0](h, graph, edge_emb)
             for layer in range(1, L):
-                h1 = h if self.no_inter_norm else self.norms[layer - 1](h)
-                h2 = F.relu(h1)
+                h2 = F.relu(h) if self.no_inter_norm else self._norm(layer - 1, h, relu=True)
                 if not self.no_inter_drop:
                     h2 = self._drop(h2)
                 h = self.gcns[layer](h2, graph, edge_emb) + h
-            h = self.norms[L - 1](h)
+            h = self._norm(L - 1, h)
             if not self.no_inter_drop:
                 h = self._drop(h)
         elif self.block == 'res':
-            h = self._drop(F.relu(self.norms[0](self.gcns[0](h, graph, edge_emb))))
+            h = self._drop(self._norm(0, self.gcns[0](h, graph, edge_emb), relu=True))
             for layer in range(1, L):
-                h = F.relu(self.norms[layer](self.gcns[layer](h, graph, edge_emb))) + h
+                h = self._norm(layer, self.gcns[layer](h, graph, edge_emb), relu=True) + h
                 h = self._drop(h)
         else:  # plain
-            h = self._drop(F.relu(self.norms[0](self.gcns[0](h, graph, edge_emb))))
+            h = self._drop(self._norm(0, self.gcns[0](h, graph, edge_emb), relu=True))
             for layer in range(1, L):
                 h1 = self.gcns[layer](h, graph, edge_emb)
-                h2 = h1 if self.no_inter_norm else self.norms[layer](h1)
-                h = F.relu(h2) if layer != L - 1 else h2
+                relu = layer != L - 1
+                h = (F.relu(h1) if relu else h1) if self.no_inter_norm else self._norm(layer, h1, relu=relu)
                 if not self.no_inter_drop:
                     h = self._drop(h)
 

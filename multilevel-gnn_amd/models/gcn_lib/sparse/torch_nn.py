@@ -7,6 +7,8 @@ the reference are molecule-dataset leftovers outside the hot path and are not pr
 """
 from torch import nn
 
+from mlgnn.norm import layer_norm_act
+
 _ACTS = {
     "relu": lambda inplace, slope, n: nn.ReLU(inplace),
     "leakyrelu": lambda inplace, slope, n: nn.LeakyReLU(slope, inplace),
@@ -58,3 +60,19 @@ class MLP(nn.Sequential):
             if drop > 0:
                 layers.append(nn.Dropout2d(drop))
         super().__init__(*layers)
+
+    def forward(self, x):
+        """Same children, same order; a ``LayerNorm`` directly followed by ``ReLU`` runs as ONE
+        fused HIP pass (``mlgnn.norm.layer_norm_act``) instead of two ATen passes."""
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.LayerNorm) and m.elementwise_affine and x.dim() == 2:
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = layer_norm_act(x, m.weight, m.bias, m.eps, relu)
+                i += 2 if relu else 1
+            else:
+                x = m(x)
+                i += 1
+        return x

@@ -168,6 +168,19 @@ int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* ga
                             int64_t workspace_floats, int64_t rows, int64_t d, int relu,
                             int dtype, void* stream);
 
+/*
+ * Weight + bias gradient of y = x W^T + b over a tall activation matrix (N >> M, K):
+ *   grad_w_b[0 : M*K]     = grad_out^T x   ([M,K] row-major, the layout of nn.Linear.weight)
+ *   grad_w_b[M*K : M*K+M] = column sums of grad_out
+ * Replaces: the autograd of nn.Linear inside MLP (models/gcn_lib/sparse/torch_nn.py:54-75).
+ * grad_out [N,M], x [N,K] fp32; ceil(M/32)*ceil(K/32) <= 32 tiles, otherwise MLGNN_E_SHAPE
+ * (the caller then uses a library GEMM).  workspace: mlgnn_linear_wgrad_workspace_floats floats.
+ */
+int64_t mlgnn_linear_wgrad_workspace_floats(int64_t N, int64_t M, int64_t K);
+int mlgnn_linear_wgrad(const void* grad_out, const void* x, float* grad_w_b, float* workspace,
+                       int64_t workspace_floats, int64_t N, int64_t M, int64_t K, int dtype,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,50 @@
 import torch
 import torch.nn.functional as F
 
+from . import _lib
+
 DIFFPOOL_EPS = 1e-15
+WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bottleneck
+
+
+class _TallLinear(torch.autograd.Function):
+    """``y = x W^T + b`` for a tall ``x [N, K]``: forward and ``dX`` are library GEMMs, the
+    weight/bias gradient (reduction over the N node rows) is the split-row fp32-MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight = ctx.saved_tensors
+        go = go.contiguous()
+        N, K = x.shape
+        M = weight.shape[0]
+        gx = go.matmul(weight) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K))
+            ws = torch.empty(n, dtype=torch.float32, device=x.device)
+            out = torch.empty(M * K + M, dtype=torch.float32, device=x.device)
+            rc = _lib.lib.mlgnn_linear_wgrad(go.data_ptr(), x.data_ptr(), out.data_ptr(), ws.data_ptr(), n,
+                                             N, M, K, 0, torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "mlgnn_linear_wgrad")
+            gw = out[:M * K].view(M, K)
+            gb = out[M * K:] if ctx.has_bias else None
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """``nn.Linear`` forward with the tall-matrix weight-gradient kernel behind it when it applies
+    (2-D fp32 CUDA input, >= 8192 rows, <= 32 output tiles of 32x32); ``F.linear`` otherwise."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS
+            and x.is_contiguous() and torch.is_grad_enabled()
+            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], weight.shape[0], weight.shape[1]) > 0):
+        return _TallLinear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
 
 
 def dense_sage(x, adj, w_rel, w_root, b_root, normalize=True):

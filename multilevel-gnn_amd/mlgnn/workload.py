@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .dense import linear
 from .graph import CSRGraph
 from .norm import layer_norm_act
 from .ops import RankOneEdge
@@ -108,7 +109,7 @@ class ThreeLevelGNN(nn.Module):
         graph = getattr(batch, "csr", None)
         if graph is None:
             graph = CSRGraph(batch.edge_index, N)
-        h = self.node_features_encoder(batch.x)
+        h = linear(batch.x, self.node_features_encoder.weight, self.node_features_encoder.bias)
         edge = RankOneEdge(batch.edge_attr[:, 0], self.edge_encoder.weight[:, 0], self.edge_encoder.bias)
         # res+ block (deepergcn.py:232-247), dropout 0
         h = self.gcns[0](h, graph, edge)

@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from mlgnn import CSRGraph, RankOneEdge
+from mlgnn.dense import linear
 from mlgnn.norm import layer_norm_act
 from mlgnn.pool import global_pool
 from .gcn_lib.sparse.torch_vertex import GENConv
@@ -151,9 +152,10 @@ class DeeperGCN(torch.nn.Module):
 
         if self.node_embedding:
             emb = self.node_embedding_encoder(x[:, -1].to(torch.long))
-            h = self.node_features_encoder(torch.cat([x[:, :-1], emb], dim=-1))
+            h = linear(torch.cat([x[:, :-1], emb], dim=-1), self.node_features_encoder.weight,
+                       self.node_features_encoder.bias)
         else:
-            h = self.node_features_encoder(x)
+            h = linear(x, self.node_features_encoder.weight, self.node_features_encoder.bias)
         edge_emb = self._edge_term(input_batch.edge_attr)
 
         rows = None

@@ -7,6 +7,7 @@ the reference are molecule-dataset leftovers outside the hot path and are not pr
 """
 from torch import nn
 
+from mlgnn.dense import linear
 from mlgnn.norm import layer_norm_act
 
 _ACTS = {
@@ -63,7 +64,8 @@ class MLP(nn.Sequential):
 
     def forward(self, x):
         """Same children, same order; a ``LayerNorm`` directly followed by ``ReLU`` runs as ONE
-        fused HIP pass (``mlgnn.norm.layer_norm_act``) instead of two ATen passes."""
+        fused HIP pass (``mlgnn.norm.layer_norm_act``) instead of two ATen passes; ``nn.Linear``
+        children use ``mlgnn.dense.linear`` (library GEMM forward, split-row MFMA weight gradient)."""
         mods = list(self)
         i = 0
         while i < len(mods):
@@ -72,6 +74,9 @@ class MLP(nn.Sequential):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = layer_norm_act(x, m.weight, m.bias, m.eps, relu)
                 i += 2 if relu else 1
+            elif type(m) is nn.Linear:
+                x = linear(x, m.weight, m.bias)
+                i += 1
             else:
                 x = m(x)
                 i += 1

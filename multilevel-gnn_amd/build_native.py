@@ -31,7 +31,10 @@ def build(force=False, verbose=True):
     """Compile every csrc/*.hip into ONE shared object next to this package."""
     if not force and not _stale():
         return LIB
+    # -fno-honor-nans/-infinities: plain v_max/v_min without NaN canonicalisation; the kernels use
+    # finite sentinels instead of +-inf (csrc/aggregate.hip)
     cmd = [HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-fno-honor-nans", "-fno-honor-infinities",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + sources() + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -11,7 +11,10 @@
 //
 // HBM-bound (0.25-1 FLOP/byte): algorithmic bytes per launch are E*d*4 (neighbour rows)
 // + E*4 (col) + (N+1)*4 (rowptr) + E*4 (edge scalar) [+ E*d*4 full edge embedding] + N*d*4 (out).
-#include <stdlib.h>
+//
+// Built with -fno-honor-nans -fno-honor-infinities (plain v_max/v_min, no canonicalisation):
+// "minus infinity" sentinels are the finite kNegBig.
+#include <type_traits>
 #include "common.h"
 #include "mlgnn.h"
 
@@ -19,9 +22,13 @@ namespace mlgnn {
 
 constexpr int kUnroll = 4;                 // neighbour rows in flight per lane group and batch
 constexpr float kPowLo = 1e-7f, kPowHi = 1e1f;   // torch_message.py:69
+constexpr float kNegBig = -3.0e38f;
 
 enum Mode { M_IDENTITY = 0, M_WEIGHTED = 1, M_GEN_NONE = 2, M_GEN_RANK1 = 3, M_GEN_FULL = 4 };
 enum Aggr { A_SUM = 0, A_MAX = 2, A_SOFTMAX = 3, A_POWER = 4 };   // MEAN = SUM + epilogue flag
+
+template <int V> using IC = std::integral_constant<int, V>;
+template <bool V> using BC = std::integral_constant<bool, V>;
 
 struct FwdArgs {
   const float* x; const int* rowptr; const int* col;
@@ -45,21 +52,34 @@ __device__ __forceinline__ Scalars read_scalars(const float* t_dev, const float*
 template <int MODE>
 __device__ __forceinline__ constexpr bool is_gen() { return MODE >= M_GEN_NONE; }
 
-// message value for one channel; z is returned for the backward's relu mask
-template <int MODE>
-__device__ __forceinline__ float message(float xj, float w_or_a, float u, float v, float ef, float eps,
-                                         float& z) {
-  if constexpr (MODE == M_IDENTITY) { z = xj; return xj; }
-  else if constexpr (MODE == M_WEIGHTED) { z = xj; return xj * w_or_a; }
-  else {
-    if constexpr (MODE == M_GEN_RANK1) z = xj + fmaf(w_or_a, u, v);
-    else if constexpr (MODE == M_GEN_FULL) z = xj + ef;
-    else z = xj;
-    return fmaxf(z, 0.0f) + eps;
-  }
+// rows of x / out / aux are addressed with 32-bit byte offsets from a uniform base (tensors < 4 GiB,
+// checked on the host): one v_mul + v_add per gathered row instead of 64-bit multiply-adds
+template <int VEC>
+__device__ __forceinline__ void load_row(float (&r)[VEC], const float* base, uint32_t byte_off) {
+  load_vec<VEC>(r, reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+template <int VEC>
+__device__ __forceinline__ void load_row(int (&r)[VEC], const int* base, uint32_t byte_off) {
+  load_vec<VEC>(r, reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byte_off));
 }
 
-template <int VEC, int MODE, int AGGR>
+// pre-activation z of the GEN message for one channel
+template <int MODE>
+__device__ __forceinline__ float pre_act(float xj, float a, float u, float v, float ef) {
+  if constexpr (MODE == M_GEN_RANK1) return xj + fmaf(a, u, v);
+  else if constexpr (MODE == M_GEN_FULL) return xj + ef;
+  else return xj;
+}
+
+template <int MODE, bool ADD_EPS>
+__device__ __forceinline__ float message(float xj, float w_or_a, float u, float v, float ef, float eps) {
+  if constexpr (MODE == M_IDENTITY) return xj;
+  else if constexpr (MODE == M_WEIGHTED) return xj * w_or_a;
+  else if constexpr (ADD_EPS) return fmaxf(pre_act<MODE>(xj, w_or_a, u, v, ef), 0.0f) + eps;
+  else return fmaxf(pre_act<MODE>(xj, w_or_a, u, v, ef), 0.0f);
+}
+
+template <int VEC, int MODE, int AGGR, bool SECOND>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << a.lpr_log2;
@@ -68,14 +88,23 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
   const int cl = lane & (lpr - 1);
   const RowWalk walk = make_row_walk(a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
+  const uint32_t row_bytes = (uint32_t)a.d * 4u;
+  constexpr bool kNeedW = (MODE == M_WEIGHTED || MODE == M_GEN_RANK1);
+
+  // eps is added once per row instead of once per edge: softmax weights are shift invariant,
+  // max and sum commute with the shift (power needs the clamp of m itself and keeps it per edge)
+  constexpr bool kLateEps = is_gen<MODE>() && AGGR != A_POWER;
 
   for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
-    const int c0 = cbase + cl * VEC;
-    const bool cact = c0 < a.d;
+    // lanes past the last channel (d/VEC not a power of two) re-read the last valid chunk and are
+    // only masked at the store, so full batches need no per-lane predication at all
+    const bool cact = cbase + cl * VEC < a.d;
+    const int c0 = min(cbase + cl * VEC, a.d - VEC);
+    const uint32_t c_bytes = (uint32_t)c0 * 4u;
     float eu[VEC], ev[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; }
-    if (MODE == M_GEN_RANK1 && cact) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
+    if (MODE == M_GEN_RANK1) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
 
     for (int r = walk.first; r < walk.r_end; r += walk.stride) {
       const int beg = a.rowptr[r];
@@ -87,78 +116,89 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
       int bpos[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        acc[i] = (AGGR == A_MAX) ? -INFINITY : 0.f;
-        mx[i] = -INFINITY; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1;
+        acc[i] = (AGGR == A_MAX) ? kNegBig : 0.f;
+        mx[i] = kNegBig; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1;
       }
 
       for (int base = beg; base < end; base += kWave) {
         const int cnt = min(kWave, end - base);
-        int my_col = 0, my_eid = 0;
+        uint32_t my_off = 0;
+        int my_eid = 0;
         float my_ew = 0.f;
         if (lane < cnt) {
-          my_col = a.col[base + lane];
-          if (MODE == M_WEIGHTED || MODE == M_GEN_RANK1) my_ew = a.ew[base + lane];
+          my_off = (uint32_t)a.col[base + lane] * row_bytes;
+          if (kNeedW) my_ew = a.ew[base + lane];
           if (MODE == M_GEN_FULL) my_eid = a.eid[base + lane];
         }
-        for (int k = 0; k < cnt; k += groups * kUnroll) {
-          float xv[kUnroll][VEC], ef[kUnroll][VEC], wa[kUnroll];
-          bool valid[kUnroll];
-#pragma unroll
-          for (int u = 0; u < kUnroll; ++u) {
-            const int idx = k + u * groups + sub;
-            valid[u] = (idx < cnt) && cact;
-            const int j = __shfl(my_col, idx & (kWave - 1));
-            wa[u] = __shfl(my_ew, idx & (kWave - 1));
-            const int e0 = __shfl(my_eid, idx & (kWave - 1));
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) { xv[u][i] = 0.f; ef[u][i] = 0.f; }
-            if (valid[u]) {
-              load_vec<VEC>(xv[u], a.x + (size_t)j * a.d + c0);
-              if (MODE == M_GEN_FULL) load_vec<VEC>(ef[u], a.efull + (size_t)e0 * a.d + c0);
-            }
-          }
+
+        // one batch = kUnroll neighbours per lane group; FULL batches carry no validity masks
+        auto batch = [&](auto full_c, const int k) {
+          constexpr bool FULL = decltype(full_c)::value;
           float m[kUnroll][VEC];
+          bool valid[kUnroll];
+          {
+            float xv[kUnroll][VEC], ef[kUnroll][VEC], wa[kUnroll];
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < kUnroll; ++u) {
+              const int idx = k + u * groups + sub;
+              valid[u] = FULL || (idx < cnt);
+              const int src = idx & (kWave - 1);
+              const uint32_t off = (uint32_t)__shfl((int)my_off, src) + c_bytes;
+              wa[u] = kNeedW ? __shfl(my_ew, src) : 0.f;
+              const int e0 = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-              float z;
-              m[u][i] = message<MODE>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i], a.eps, z);
+              for (int i = 0; i < VEC; ++i) { xv[u][i] = 0.f; ef[u][i] = 0.f; }
+              if (FULL || valid[u]) {
+                load_row<VEC>(xv[u], a.x, off);
+                if (MODE == M_GEN_FULL) load_vec<VEC>(ef[u], a.efull + (size_t)e0 * a.d + c0);
+              }
             }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+              for (int i = 0; i < VEC; ++i)
+                m[u][i] = message<MODE, !kLateEps>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i], a.eps);
+          }
 
           if constexpr (AGGR == A_SUM) {
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) acc[i] += valid[u] ? m[u][i] : 0.f;
+              for (int i = 0; i < VEC; ++i) acc[i] += (FULL || valid[u]) ? m[u][i] : 0.f;
           } else if constexpr (AGGR == A_MAX) {
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
               const int pos = base + k + u * groups + sub;
 #pragma unroll
               for (int i = 0; i < VEC; ++i)
-                if (valid[u] && m[u][i] > acc[i]) { acc[i] = m[u][i]; bpos[i] = pos; }
+                if ((FULL || valid[u]) && m[u][i] > acc[i]) { acc[i] = m[u][i]; bpos[i] = pos; }
             }
           } else if constexpr (AGGR == A_SOFTMAX) {
             // online softmax, one rescale per batch of kUnroll neighbours; units: log2
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-              float zmax = mx[i];
+              if (!FULL && !valid[0]) break;     // a lane group without a live neighbour in the tail batch
+              // t*m is monotone in m: the batch extremum of m (max for t >= 0, min for t < 0) gives it
+              float ext = m[0][i];
+              if (sc.t_log2e >= 0.f) {                 // wave-uniform
 #pragma unroll
-              for (int u = 0; u < kUnroll; ++u)
-                zmax = valid[u] ? fmaxf(zmax, sc.t_log2e * m[u][i]) : zmax;
-              if (zmax > -INFINITY) {
-                const float rs = fast_exp2(mx[i] - zmax);     // 0 on the first batch (mx = -inf)
-                float s = acc[i] * rs, s1 = w1[i] * rs, s2 = w2[i] * rs;
+                for (int u = 1; u < kUnroll; ++u) ext = (FULL || valid[u]) ? fmaxf(ext, m[u][i]) : ext;
+              } else {
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-                  const float pe = valid[u] ? fast_exp2(sc.t_log2e * m[u][i] - zmax) : 0.f;
-                  s += pe;
-                  s1 = fmaf(pe, m[u][i], s1);
-                  s2 = fmaf(pe * m[u][i], m[u][i], s2);
-                }
-                acc[i] = s; w1[i] = s1; w2[i] = s2; mx[i] = zmax;
+                for (int u = 1; u < kUnroll; ++u) ext = (FULL || valid[u]) ? fminf(ext, m[u][i]) : ext;
               }
+              const float zmax = fmaxf(mx[i], sc.t_log2e * ext);
+              const float rs = fast_exp2(mx[i] - zmax);     // 0 on the first batch (mx = kNegBig)
+              float s = acc[i] * rs, s1 = w1[i] * rs, s2 = SECOND ? w2[i] * rs : 0.f;
+#pragma unroll
+              for (int u = 0; u < kUnroll; ++u) {
+                float pe = fast_exp2(fmaf(sc.t_log2e, m[u][i], -zmax));
+                if (!FULL) pe = valid[u] ? pe : 0.f;
+                s += pe;
+                s1 = fmaf(pe, m[u][i], s1);
+                if (SECOND) s2 = fmaf(pe * m[u][i], m[u][i], s2);
+              }
+              acc[i] = s; w1[i] = s1; w2[i] = s2; mx[i] = zmax;
             }
           } else {  // A_POWER
 #pragma unroll
@@ -168,11 +208,16 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
                 const float mc = fminf(fmaxf(m[u][i], kPowLo), kPowHi);
                 const float l2 = fast_log2(mc);
                 const float pw = fast_exp2(sc.p * l2);
-                acc[i] += valid[u] ? pw : 0.f;
-                w2[i] += valid[u] ? pw * l2 * kLn2 : 0.f;
+                acc[i] += (FULL || valid[u]) ? pw : 0.f;
+                if (SECOND) w2[i] += (FULL || valid[u]) ? pw * l2 * kLn2 : 0.f;
               }
           }
-        }
+        };
+
+        const int step = groups * kUnroll;
+        int k = 0;
+        for (; k + step <= cnt; k += step) batch(BC<true>{}, k);
+        if (k < cnt) batch(BC<false>{}, k);
       }
 
       // ---- combine the lane groups (xor-shuffle over the group bits) ----
@@ -183,26 +228,23 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
             acc[i] += __shfl_xor(acc[i], off);
           } else if constexpr (AGGR == A_POWER) {
             acc[i] += __shfl_xor(acc[i], off);
-            w2[i] += __shfl_xor(w2[i], off);
+            if (SECOND) w2[i] += __shfl_xor(w2[i], off);
           } else if constexpr (AGGR == A_MAX) {
             const float ov = __shfl_xor(acc[i], off);
             const int op = __shfl_xor(bpos[i], off);
             // larger value wins; on a tie the earlier edge (torch_scatter CPU keeps the first)
             const bool take = (op >= 0) && (bpos[i] < 0 || ov > acc[i] || (ov == acc[i] && op < bpos[i]));
             if (take) { acc[i] = ov; bpos[i] = op; }
-          } else {  // SOFTMAX
+          } else {  // SOFTMAX: a group that saw no edge has (mx, S, W) = (kNegBig, 0, 0)
             const float om = __shfl_xor(mx[i], off);
             const float os = __shfl_xor(acc[i], off);
             const float o1 = __shfl_xor(w1[i], off);
-            const float o2 = __shfl_xor(w2[i], off);
             const float nm = fmaxf(mx[i], om);
-            if (nm > -INFINITY) {
-              const float sa = fast_exp2(mx[i] - nm), sb = fast_exp2(om - nm);
-              acc[i] = acc[i] * sa + os * sb;
-              w1[i] = w1[i] * sa + o1 * sb;
-              w2[i] = w2[i] * sa + o2 * sb;
-              mx[i] = nm;
-            }
+            const float sa = fast_exp2(mx[i] - nm), sb = fast_exp2(om - nm);
+            acc[i] = acc[i] * sa + os * sb;
+            w1[i] = w1[i] * sa + o1 * sb;
+            if (SECOND) { const float o2 = __shfl_xor(w2[i], off); w2[i] = w2[i] * sa + o2 * sb; }
+            mx[i] = nm;
           }
         }
       }
@@ -211,26 +253,29 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
       if (sub == 0 && cact) {
         float o[VEC], ax[VEC], ax2[VEC];
         int am[VEC];
-        const float inv = 1.0f / (float)max(deg, 1);
+        const float inv = __builtin_amdgcn_rcpf((float)max(deg, 1));
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           ax[i] = 0.f; ax2[i] = 0.f; am[i] = -1;
           if constexpr (AGGR == A_SUM) {
-            o[i] = a.mean ? acc[i] * inv : acc[i];
+            const float tot = kLateEps ? fmaf((float)deg, a.eps, acc[i]) : acc[i];
+            o[i] = a.mean ? tot * inv : tot;
           } else if constexpr (AGGR == A_MAX) {
-            o[i] = (bpos[i] >= 0) ? acc[i] : 0.f;
+            o[i] = (bpos[i] >= 0) ? acc[i] + (kLateEps ? a.eps : 0.f) : 0.f;
             am[i] = bpos[i];
           } else if constexpr (AGGR == A_SOFTMAX) {
             if (deg > 0) {
-              const float rs = 1.0f / acc[i];
-              o[i] = w1[i] * rs;
-              ax[i] = mx[i] + fast_log2(acc[i]);
-              ax2[i] = w2[i] * rs;
+              const float rs = __builtin_amdgcn_rcpf(acc[i]);
+              const float o0 = w1[i] * rs;                       // sum_e w_e relu(z_e)
+              o[i] = o0 + a.eps;
+              // lse of t*(relu(z)+eps), sum_e w_e (relu(z_e)+eps)^2
+              ax[i] = mx[i] + fast_log2(acc[i]) + sc.t_log2e * a.eps;
+              ax2[i] = fmaf(a.eps, fmaf(2.f, o0, a.eps), w2[i] * rs);
             } else { o[i] = 0.f; }
           } else {  // POWER
             const float mu = acc[i] * inv;
             const float muc = fminf(fmaxf(mu, kPowLo), kPowHi);
-            o[i] = fast_exp2(fast_log2(muc) / sc.p);
+            o[i] = fast_exp2(fast_log2(muc) * __builtin_amdgcn_rcpf(sc.p));
             ax[i] = mu;
             ax2[i] = w2[i] * inv;
           }
@@ -239,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
         store_vec<VEC>(a.out + off, o);
         if (AGGR == A_MAX && a.argmax) store_vec<VEC>(a.argmax + off, am);
         if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_vec<VEC>(a.aux + off, ax);
-        if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux2) store_vec<VEC>(a.aux2 + off, ax2);
+        if (SECOND && a.aux2) store_vec<VEC>(a.aux2 + off, ax2);
       }
     }
   }
@@ -258,7 +303,7 @@ struct BwdArgs {
   float t; float p; float eps;
 };
 
-template <int VEC, int MODE, int AGGR>
+template <int VEC, int MODE, int AGGR, bool LEARN_T>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
   __shared__ float red[kWavesPerBlock][2][kWave * VEC];
   const int lane = threadIdx.x & (kWave - 1);
@@ -269,14 +314,17 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
   const int cl = lane & (lpr - 1);
   const RowWalk walk = make_row_walk(a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
+  const uint32_t row_bytes = (uint32_t)a.d * 4u;
+  constexpr bool kNeedW = (MODE == M_WEIGHTED || MODE == M_GEN_RANK1);
 
   for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
-    const int c0 = cbase + cl * VEC;
-    const bool cact = c0 < a.d;
+    const bool cact = cbase + cl * VEC < a.d;          // inactive lanes shadow the last chunk (see forward)
+    const int c0 = min(cbase + cl * VEC, a.d - VEC);
+    const uint32_t c_bytes = (uint32_t)c0 * 4u;
     float eu[VEC], ev[VEC], gu[VEC], gv[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; gu[i] = 0.f; gv[i] = 0.f; }
-    if (MODE == M_GEN_RANK1 && cact) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
+    if (MODE == M_GEN_RANK1) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
 
     for (int r = walk.first; r < walk.r_end; r += walk.stride) {
       const int beg = a.rowptr_t[r];
@@ -284,21 +332,25 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
       float xj[VEC], gx[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { xj[i] = 0.f; gx[i] = 0.f; }
-      if (is_gen<MODE>() && cact && end > beg) load_vec<VEC>(xj, a.x + (size_t)r * a.d + c0);
+      if (is_gen<MODE>() && end > beg) load_vec<VEC>(xj, a.x + (size_t)r * a.d + c0);
 
       for (int base = beg; base < end; base += kWave) {
         const int cnt = min(kWave, end - base);
-        int my_dst = 0, my_pos = 0, my_eid = 0;
+        uint32_t my_off = 0;
+        int my_pos = 0, my_eid = 0;
         float my_ew = 0.f, my_inv = 1.f;
         if (lane < cnt) {
-          my_dst = a.col_t[base + lane];
+          const int dst = a.col_t[base + lane];
+          my_off = (uint32_t)dst * row_bytes;
           if (AGGR == A_MAX) my_pos = a.pos_t[base + lane];
-          if (MODE == M_WEIGHTED || MODE == M_GEN_RANK1) my_ew = a.ew_t[base + lane];
+          if (kNeedW) my_ew = a.ew_t[base + lane];
           if (MODE == M_GEN_FULL) my_eid = a.eid_t[base + lane];
           if (AGGR == A_SUM && a.mean)
-            my_inv = 1.0f / (float)max(a.rowptr[my_dst + 1] - a.rowptr[my_dst], 1);
+            my_inv = __builtin_amdgcn_rcpf((float)max(a.rowptr[dst + 1] - a.rowptr[dst], 1));
         }
-        for (int k = 0; k < cnt; k += groups * kUnroll) {
+
+        auto batch = [&](auto full_c, const int k) {
+          constexpr bool FULL = decltype(full_c)::value;
           float ga[kUnroll][VEC], gb[kUnroll][VEC], gc[kUnroll][VEC], ef[kUnroll][VEC];
           int ai[kUnroll][VEC];
           float wa[kUnroll], inv[kUnroll];
@@ -307,21 +359,20 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) {
             const int idx = k + u * groups + sub;
-            valid[u] = (idx < cnt) && cact;
-            const int src_lane = idx & (kWave - 1);
-            const int i_dst = __shfl(my_dst, src_lane);
-            wa[u] = __shfl(my_ew, src_lane);
-            inv[u] = __shfl(my_inv, src_lane);
-            pos[u] = __shfl(my_pos, src_lane);
-            e0[u] = __shfl(my_eid, src_lane);
+            valid[u] = FULL || (idx < cnt);
+            const int src = idx & (kWave - 1);
+            const uint32_t off = (uint32_t)__shfl((int)my_off, src) + c_bytes;
+            wa[u] = kNeedW ? __shfl(my_ew, src) : 0.f;
+            inv[u] = (AGGR == A_SUM) ? __shfl(my_inv, src) : 1.f;
+            pos[u] = (AGGR == A_MAX) ? __shfl(my_pos, src) : 0;
+            e0[u] = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { ga[u][i] = 0.f; gb[u][i] = 0.f; gc[u][i] = 0.f; ef[u][i] = 0.f; ai[u][i] = -2; }
-            if (valid[u]) {
-              const size_t off = (size_t)i_dst * a.d + c0;
-              load_vec<VEC>(ga[u], a.go + off);
-              if (AGGR == A_SOFTMAX) load_vec<VEC>(gb[u], a.aux + off);
-              if (AGGR == A_SOFTMAX && a.learn_t) load_vec<VEC>(gc[u], a.out + off);
-              if (AGGR == A_MAX) load_vec<VEC>(ai[u], a.argmax + off);
+            if (FULL || valid[u]) {
+              load_row<VEC>(ga[u], a.go, off);
+              if (AGGR == A_SOFTMAX) load_row<VEC>(gb[u], a.aux, off);
+              if (AGGR == A_SOFTMAX && LEARN_T) load_row<VEC>(gc[u], a.out, off);
+              if (AGGR == A_MAX) load_row<VEC>(ai[u], a.argmax, off);
               if (MODE == M_GEN_FULL) load_vec<VEC>(ef[u], a.efull + (size_t)e0[u] * a.d + c0);
             }
           }
@@ -330,17 +381,19 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
             float dz[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-              float z;
-              const float m = message<MODE>(xj[i], wa[u], eu[i], ev[i], ef[u][i], a.eps, z);
-              float coef;
+              float coef, z = 0.f, m = 0.f;
+              if constexpr (is_gen<MODE>()) {
+                z = pre_act<MODE>(xj[i], wa[u], eu[i], ev[i], ef[u][i]);
+                m = fmaxf(z, 0.f) + a.eps;
+              }
               if constexpr (AGGR == A_SUM) {
                 coef = ga[u][i] * inv[u];
               } else if constexpr (AGGR == A_MAX) {
                 coef = (ai[u][i] == pos[u]) ? ga[u][i] : 0.f;
               } else if constexpr (AGGR == A_SOFTMAX) {
-                const float w = fast_exp2(sc.t_log2e * m - gb[u][i]);
+                const float w = fast_exp2(fmaf(sc.t_log2e, m, -gb[u][i]));
                 coef = ga[u][i] * w;
-                if (a.learn_t) coef *= fmaf(sc.t, m - gc[u][i], 1.0f);
+                if (LEARN_T) coef *= fmaf(sc.t, m - gc[u][i], 1.0f);
               } else {  // POWER: ga carries q (see mlgnn.h)
                 const float mc = fminf(fmaxf(m, kPowLo), kPowHi);
                 const bool inr = (m >= kPowLo) && (m <= kPowHi);
@@ -348,13 +401,18 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
               }
               if constexpr (MODE == M_WEIGHTED) coef *= wa[u];
               if constexpr (is_gen<MODE>()) coef = (z > 0.f) ? coef : 0.f;
-              dz[i] = valid[u] ? coef : 0.f;
+              dz[i] = (FULL || valid[u]) ? coef : 0.f;
               gx[i] += dz[i];
               if constexpr (MODE == M_GEN_RANK1) { gu[i] = fmaf(wa[u], dz[i], gu[i]); gv[i] += dz[i]; }
             }
-            if (MODE == M_GEN_FULL && valid[u]) store_vec<VEC>(a.ge + (size_t)e0[u] * a.d + c0, dz);
+            if (MODE == M_GEN_FULL && valid[u] && cact) store_vec<VEC>(a.ge + (size_t)e0[u] * a.d + c0, dz);
           }
-        }
+        };
+
+        const int step = groups * kUnroll;
+        int k = 0;
+        for (; k + step <= cnt; k += step) batch(BC<true>{}, k);
+        if (k < cnt) batch(BC<false>{}, k);
       }
       for (int off = lpr; off < kWave; off <<= 1)
 #pragma unroll
@@ -368,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { gu[i] += __shfl_xor(gu[i], off); gv[i] += __shfl_xor(gv[i], off); }
       __syncthreads();
-      if (sub == 0) {
+      if (sub == 0) {     // red[] is indexed by the lane's nominal column; shadow lanes land past d and are skipped below
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { red[wave][0][cl * VEC + i] = gu[i]; red[wave][1][cl * VEC + i] = gv[i]; }
       }
@@ -438,34 +496,28 @@ static int pick_aggr(int aggr) {
 }
 
 static bool is_gen_mode(int mode) { return mode >= M_GEN_NONE; }
-
-// development knob (not part of the ABI): override the lanes-per-row split to explore the
-// channel-chunk / L2-footprint trade-off
-static int lpr_override(int dflt) {
-  const char* e = getenv("MLGNN_LPR_LOG2");
-  if (!e) return dflt;
-  const int v = atoi(e);
-  return (v >= 0 && v <= 6 && v <= dflt) ? v : dflt;
-}
-
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-#define MLGNN_DISPATCH_AGGR(KERNEL, VEC, MODE, aggr_id, ...)                                   \
-  switch (aggr_id) {                                                                            \
-    case A_SUM: hipLaunchKernelGGL((KERNEL<VEC, MODE, A_SUM>), __VA_ARGS__); break;             \
-    case A_MAX: hipLaunchKernelGGL((KERNEL<VEC, MODE, A_MAX>), __VA_ARGS__); break;             \
-    case A_SOFTMAX: hipLaunchKernelGGL((KERNEL<VEC, MODE, A_SOFTMAX>), __VA_ARGS__); break;     \
-    default: hipLaunchKernelGGL((KERNEL<VEC, MODE, A_POWER>), __VA_ARGS__); break;              \
+// f(IC<MODE>, IC<AGGR>) for the valid (mode, aggregator) pairs
+template <int MODE, typename F>
+static void for_aggr(int ag, F&& f) {
+  switch (ag) {
+    case A_SUM: f(IC<MODE>{}, IC<A_SUM>{}); break;
+    case A_MAX: f(IC<MODE>{}, IC<A_MAX>{}); break;
+    case A_SOFTMAX: f(IC<MODE>{}, IC<A_SOFTMAX>{}); break;
+    default: f(IC<MODE>{}, IC<A_POWER>{}); break;
   }
-
-#define MLGNN_DISPATCH_MODE(KERNEL, VEC, mode_id, aggr_id, ...)                                 \
-  switch (mode_id) {                                                                            \
-    case M_IDENTITY: hipLaunchKernelGGL((KERNEL<VEC, M_IDENTITY, A_SUM>), __VA_ARGS__); break;  \
-    case M_WEIGHTED: hipLaunchKernelGGL((KERNEL<VEC, M_WEIGHTED, A_SUM>), __VA_ARGS__); break;  \
-    case M_GEN_NONE: MLGNN_DISPATCH_AGGR(KERNEL, VEC, M_GEN_NONE, aggr_id, __VA_ARGS__) break;  \
-    case M_GEN_RANK1: MLGNN_DISPATCH_AGGR(KERNEL, VEC, M_GEN_RANK1, aggr_id, __VA_ARGS__) break;\
-    default: MLGNN_DISPATCH_AGGR(KERNEL, VEC, M_GEN_FULL, aggr_id, __VA_ARGS__) break;          \
+}
+template <typename F>
+static void for_mode_aggr(int mode, int ag, F&& f) {
+  switch (mode) {
+    case M_IDENTITY: f(IC<M_IDENTITY>{}, IC<A_SUM>{}); break;
+    case M_WEIGHTED: f(IC<M_WEIGHTED>{}, IC<A_SUM>{}); break;
+    case M_GEN_NONE: for_aggr<M_GEN_NONE>(ag, f); break;
+    case M_GEN_RANK1: for_aggr<M_GEN_RANK1>(ag, f); break;
+    default: for_aggr<M_GEN_FULL>(ag, f); break;
   }
+}
 
 }  // namespace mlgnn
 
@@ -483,9 +535,11 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
                                        const void* efull, const int32_t* eid,
                                        void* out, float* aux, float* aux2, int32_t* argmax,
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode,
-                                       int aggr, float t, float p, const float* t_dev, const float* p_dev, float eps, void* stream) {
+                                       int aggr, float t, float p, const float* t_dev, const float* p_dev,
+                                       float eps, void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
+  if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;      // 32-bit row offsets: [N,d] tensors < 4 GiB
   const int mode = pick_mode(msg, edge_mode);
   const int ag = pick_aggr(aggr);
   if (mode < 0 || ag < 0) return MLGNN_E_MODE;
@@ -508,13 +562,19 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
                     (!eu || aligned16(eu)) && (!ev || aligned16(ev));
   const dim3 grid(grid_for_rows(N)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
-  if (vec4) {
-    a.lpr_log2 = lpr_override(lanes_per_row_log2(d, 4));
-    MLGNN_DISPATCH_MODE(csr_aggregate_fwd_kernel, 4, mode, ag, grid, block, 0, s, a)
-  } else {
-    a.lpr_log2 = lanes_per_row_log2(d, 1);
-    MLGNN_DISPATCH_MODE(csr_aggregate_fwd_kernel, 1, mode, ag, grid, block, 0, s, a)
-  }
+  const bool second = (aux2 != nullptr) && (ag == A_SOFTMAX || ag == A_POWER);
+  a.lpr_log2 = lanes_per_row_log2(d, vec4 ? 4 : 1);
+  for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
+    constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
+    constexpr bool kHasSecond = (AGGR == A_SOFTMAX || AGGR == A_POWER);
+    if (vec4) {
+      if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<4, MODE, AGGR, kHasSecond>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<4, MODE, AGGR, false>), grid, block, 0, s, a);
+    } else {
+      if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<1, MODE, AGGR, kHasSecond>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<1, MODE, AGGR, false>), grid, block, 0, s, a);
+    }
+  });
   return (int)hipGetLastError();
 }
 
@@ -527,10 +587,11 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                                        void* grad_x, void* grad_efull, float* grad_uv,
                                        float* workspace, int64_t workspace_floats,
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode,
-                                       int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev, float eps,
-                                       void* stream) {
+                                       int aggr, int learn_t, float t, float p, const float* t_dev,
+                                       const float* p_dev, float eps, void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
+  if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
   const int mode = pick_mode(msg, edge_mode);
   const int ag = pick_aggr(aggr);
   if (mode < 0 || ag < 0) return MLGNN_E_MODE;
@@ -561,18 +622,23 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                     (!eu || aligned16(eu)) && (!ev || aligned16(ev));
   const dim3 grid(nblk), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
-  if (vec4) {
-    a.lpr_log2 = lpr_override(lanes_per_row_log2(d, 4));
-    MLGNN_DISPATCH_MODE(csr_aggregate_bwd_kernel, 4, mode, ag, grid, block, 0, s, a)
-  } else {
-    a.lpr_log2 = lanes_per_row_log2(d, 1);
-    MLGNN_DISPATCH_MODE(csr_aggregate_bwd_kernel, 1, mode, ag, grid, block, 0, s, a)
-  }
+  a.lpr_log2 = lanes_per_row_log2(d, vec4 ? 4 : 1);
+  const bool lt = learn_t != 0 && ag == A_SOFTMAX;
+  for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
+    constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
+    constexpr bool kCanLearn = (AGGR == A_SOFTMAX);
+    if (vec4) {
+      if (kCanLearn && lt) hipLaunchKernelGGL((csr_aggregate_bwd_kernel<4, MODE, AGGR, kCanLearn>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((csr_aggregate_bwd_kernel<4, MODE, AGGR, false>), grid, block, 0, s, a);
+    } else {
+      if (kCanLearn && lt) hipLaunchKernelGGL((csr_aggregate_bwd_kernel<1, MODE, AGGR, kCanLearn>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((csr_aggregate_bwd_kernel<1, MODE, AGGR, false>), grid, block, 0, s, a);
+    }
+  });
   int err = (int)hipGetLastError();
   if (err) return err;
   if (mode == M_GEN_RANK1) {
-    const int cols = 2 * (int)d;
-    launch_reduce_partials(workspace, grad_uv, nblk, cols, s);
+    launch_reduce_partials(workspace, grad_uv, nblk, 2 * (int)d, s);
     err = (int)hipGetLastError();
   }
   return err;

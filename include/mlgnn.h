@@ -181,6 +181,20 @@ int mlgnn_linear_wgrad(const void* grad_out, const void* x, float* grad_w_b, flo
                        int64_t workspace_floats, int64_t N, int64_t M, int64_t K, int dtype,
                        void* stream);
 
+/*
+ * DiffPool soft-assignment contraction, fused forward (one workgroup per batch element, fp32 MFMA).
+ * Replaces: torch_geometric.nn.dense_diff_pool as called from models/diff_pooling.py:64:
+ *   S = softmax(s_logits, -1);  x_out = S^T z;  adj_out = S^T adj S;
+ *   partial[b] = { sum (adj - S S^T)^2 , sum_n sum_k -S log(S + 1e-15) }   (caller: sqrt / numel, mean)
+ * z [B,N,C], s_logits [B,N,K], adj [N,N] (adj_batched = 0) or [B,N,N]; s_out [B,N,K] (saved for
+ * the backward), x_out [B,K,C], adj_out [B,K,K], partial [B,2].
+ * Supported while N <= 160, K <= 48, C <= 64 (mlgnn_diffpool_fwd_supported); MLGNN_E_SHAPE otherwise.
+ */
+int mlgnn_diffpool_fwd_supported(int64_t N, int64_t K, int64_t C);
+int mlgnn_diffpool_fwd(const void* z, const void* adj, const void* s_logits, void* s_out,
+                       void* x_out, void* adj_out, float* partial, int64_t B, int64_t N,
+                       int64_t K, int64_t C, int adj_batched, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

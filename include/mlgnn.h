@@ -195,6 +195,20 @@ int mlgnn_diffpool_fwd(const void* z, const void* adj, const void* s_logits, voi
                        void* x_out, void* adj_out, float* partial, int64_t B, int64_t N,
                        int64_t K, int64_t C, int adj_batched, int dtype, void* stream);
 
+/*
+ * COO -> CSR (by destination) + transposed CSR (by source), on the device, stable in COO order.
+ * Replaces: the per-layer gather/scatter index handling of MessagePassing.propagate
+ * (models/gcn_lib/sparse/torch_vertex.py:82,277) by one topology sort per batch.
+ * edge_index [2,E] int64 row-major (row 0 = source j, row 1 = destination i), node ids in [0,N).
+ * Outputs (int32): rowptr [N+1], col [E], eid [E], rowptr_t [N+1], col_t [E], pos_t [E], eid_t [E].
+ * workspace: mlgnn_coo_to_csr_workspace_bytes(N, E) bytes.
+ */
+int64_t mlgnn_coo_to_csr_workspace_bytes(int64_t N, int64_t E);
+int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
+                     int32_t* rowptr, int32_t* col, int32_t* eid,
+                     int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,8 @@ SIGNATURES = {
     "mlgnn_linear_wgrad": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_diffpool_fwd_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_diffpool_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _P]),
+    "mlgnn_coo_to_csr_workspace_bytes": (_I64, [_I64, _I64]),
+    "mlgnn_coo_to_csr": (_INT, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
 }
 
 ERRORS = {-1: "MLGNN_E_NULL", -2: "MLGNN_E_SHAPE", -3: "MLGNN_E_MODE", -4: "MLGNN_E_DTYPE",

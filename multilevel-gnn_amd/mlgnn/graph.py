@@ -23,11 +23,39 @@ class CSRGraph:
         if N >= 2 ** 31 or E >= 2 ** 31:
             raise ValueError("int32 index range exceeded")
         dev = edge_index.device
+        self.num_nodes, self.num_edges, self.device = N, E, dev
+        if edge_index.is_cuda:
+            self._build_device(edge_index)
+        else:
+            self._build_host(edge_index)
+        self._deg = None
+        self._scalar_cache = {}
+
+    def _build_device(self, edge_index):
+        """Two stable radix sorts on the GPU (``mlgnn_coo_to_csr``), enqueued on the current stream."""
+        from . import _lib
+        N, E, dev = self.num_nodes, self.num_edges, self.device
+        ei = edge_index.to(torch.int64).contiguous()
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.rowptr, self.rowptr_t = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
+        self.col, self.eid = torch.empty(E, **i32), torch.empty(E, **i32)
+        self.col_t, self.pos_t, self.eid_t = torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(E, **i32)
+        nbytes = int(_lib.lib.mlgnn_coo_to_csr_workspace_bytes(N, E))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        rc = _lib.lib.mlgnn_coo_to_csr(ei.data_ptr(), E, N, self.rowptr.data_ptr(), _lib.ptr(self.col),
+                                       _lib.ptr(self.eid), self.rowptr_t.data_ptr(), _lib.ptr(self.col_t),
+                                       _lib.ptr(self.pos_t), _lib.ptr(self.eid_t), ws.data_ptr(), nbytes,
+                                       torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_coo_to_csr")
+
+    def _build_host(self, edge_index):
+        """Same layout from torch ops on the CPU: for data-loader workers that pre-sort a batch
+        (``batch.csr``) and for the host-side layout tests.  Never used for device tensors."""
+        N = self.num_nodes
         src, dst = edge_index[0].long(), edge_index[1].long()
         order = torch.sort(dst, stable=True).indices
         col = src[order]
         order_t = torch.sort(col, stable=True).indices
-        self.num_nodes, self.num_edges, self.device = N, E, dev
         self.rowptr = self._ptr(dst, N)
         self.col = col.to(torch.int32)
         self.eid = order.to(torch.int32)
@@ -35,8 +63,14 @@ class CSRGraph:
         self.col_t = dst[order][order_t].to(torch.int32)
         self.pos_t = order_t.to(torch.int32)
         self.eid_t = order[order_t].to(torch.int32)
-        self._deg = None
-        self._scalar_cache = {}
+
+    def to(self, device):
+        """Move a host-built graph to the GPU (index arrays only)."""
+        for name in ("rowptr", "col", "eid", "rowptr_t", "col_t", "pos_t", "eid_t"):
+            setattr(self, name, getattr(self, name).to(device))
+        self.device = torch.device(device)
+        self._deg, self._scalar_cache = None, {}
+        return self
 
     @staticmethod
     def _ptr(index, N):

@@ -82,6 +82,8 @@ int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d);
  *   argmax  [N,d]   MAX: by-destination edge position of the winner, -1 for an empty row
  *   t, p            softmax temperature / power exponent; when t_dev / p_dev is non-NULL the value is
  *                   read from that device address instead (learnable parameters: no host sync)
+ *   add_root        non-zero: out = x + aggregate (GENConv's h = x + m, torch_vertex.py:89, same pass);
+ *                   the backward then adds grad_out to grad_x.  Not combinable with learn_t.
  */
 int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t* col,
                             const float* ew, const float* eu, const float* ev,
@@ -89,7 +91,7 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
                             void* out, float* aux, float* aux2, int32_t* argmax,
                             int64_t N, int64_t d, int dtype, int msg, int edge_mode,
                             int aggr, float t, float p, const float* t_dev, const float* p_dev,
-                            float eps, void* stream);
+                            float eps, int add_root, void* stream);
 
 /*
  * Backward of the above with respect to x (and the edge term), atomic-free, on the
@@ -117,7 +119,7 @@ int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out
                             float* workspace, int64_t workspace_floats,
                             int64_t N, int64_t d, int dtype, int msg, int edge_mode,
                             int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev,
-                            float eps, void* stream);
+                            float eps, int add_root, void* stream);
 
 /*
  * Gene -> pathway learnable-projection pooling.

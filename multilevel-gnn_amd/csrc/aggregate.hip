@@ -35,7 +35,7 @@ struct FwdArgs {
   const float* ew; const float* eu; const float* ev; const float* efull; const int* eid;
   float* out; float* aux; float* aux2; int* argmax;
   const float* t_dev; const float* p_dev;
-  int N; int d; int lpr_log2; int mean;
+  int N; int d; int lpr_log2; int mean; int add_root;
   float t; float p; float eps;
 };
 
@@ -281,6 +281,12 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
           }
         }
         const size_t off = (size_t)r * a.d + c0;
+        if (a.add_root) {            // h = x_i + m_i (GENConv.forward, torch_vertex.py:89) in the same pass
+          float xr[VEC];
+          load_vec<VEC>(xr, a.x + off);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] += xr[i];
+        }
         store_vec<VEC>(a.out + off, o);
         if (AGGR == A_MAX && a.argmax) store_vec<VEC>(a.argmax + off, am);
         if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_vec<VEC>(a.aux + off, ax);
@@ -299,7 +305,7 @@ struct BwdArgs {
   const float* ew_t; const float* eu; const float* ev; const float* efull; const int* eid_t;
   float* gx; float* ge; float* ws;
   const float* t_dev; const float* p_dev;
-  int N; int d; int lpr_log2; int mean; int learn_t;
+  int N; int d; int lpr_log2; int mean; int learn_t; int add_root;
   float t; float p; float eps;
 };
 
@@ -417,7 +423,15 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
       for (int off = lpr; off < kWave; off <<= 1)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) gx[i] += __shfl_xor(gx[i], off);
-      if (sub == 0 && cact) store_vec<VEC>(a.gx + (size_t)r * a.d + c0, gx);
+      if (sub == 0 && cact) {
+        if (a.add_root) {            // identity branch of h = x + m
+          float gr[VEC];
+          load_vec<VEC>(gr, a.go + (size_t)r * a.d + c0);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) gx[i] += gr[i];
+        }
+        store_vec<VEC>(a.gx + (size_t)r * a.d + c0, gx);
+      }
     }
 
     if constexpr (MODE == M_GEN_RANK1) {
@@ -536,7 +550,7 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
                                        void* out, float* aux, float* aux2, int32_t* argmax,
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode,
                                        int aggr, float t, float p, const float* t_dev, const float* p_dev,
-                                       float eps, void* stream) {
+                                       float eps, int add_root, void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;      // 32-bit row offsets: [N,d] tensors < 4 GiB
@@ -555,7 +569,7 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   a.x = (const float*)x; a.rowptr = rowptr; a.col = col; a.ew = ew; a.eu = eu; a.ev = ev;
   a.efull = (const float*)efull; a.eid = eid; a.out = (float*)out; a.aux = aux; a.aux2 = aux2;
   a.argmax = argmax; a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN);
-  a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev;
+  a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
 
   const bool vec4 = (d % 4 == 0) && aligned16(x) && aligned16(out) && (!efull || aligned16(efull)) &&
                     (!aux || aligned16(aux)) && (!aux2 || aligned16(aux2)) && (!argmax || aligned16(argmax)) &&
@@ -588,7 +602,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                                        float* workspace, int64_t workspace_floats,
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode,
                                        int aggr, int learn_t, float t, float p, const float* t_dev,
-                                       const float* p_dev, float eps, void* stream) {
+                                       const float* p_dev, float eps, int add_root, void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
@@ -614,7 +628,8 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   a.ew_t = ew_t; a.eu = eu; a.ev = ev; a.efull = (const float*)efull; a.eid_t = eid_t;
   a.gx = (float*)grad_x; a.ge = (float*)grad_efull; a.ws = workspace;
   a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN); a.learn_t = learn_t;
-  a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev;
+  a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
+  if (add_root && learn_t) return MLGNN_E_MODE;       // `out` must be the bare aggregate for d/dt
 
   const bool vec4 = (d % 4 == 0) && aligned16(grad_out) && aligned16(grad_x) && (!x || aligned16(x)) &&
                     (!out || aligned16(out)) && (!aux || aligned16(aux)) && (!argmax || aligned16(argmax)) &&

@@ -114,7 +114,7 @@ class RankOneEdge:
 
 class _GenAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t, p, eps, learn_t, learn_p):
+    def forward(ctx, x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t, p, eps, learn_t, learn_p, add_root):
         x = _dev_f32(x, "x")
         N, d = x.shape
         if graph.num_nodes != N:
@@ -140,20 +140,20 @@ class _GenAggregate(torch.autograd.Function):
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), _lib.ptr(eu), _lib.ptr(ev),
             _lib.ptr(efull), graph.eid.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),
             _lib.ptr(argmax), N, d, DTYPE_F32, MSG_GEN, edge_mode, aggr_id, float(t), float(p),
-            _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), _stream())
+            _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), int(add_root), _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         if timer is not None:
             timer.stop("csr_aggregate_fwd/%s/%s" % (_AGGR_NAMES[aggr_id], _EDGE_NAMES[edge_mode]), t0,
                        algorithmic_bytes(N, graph.num_edges, d, aggr_id, edge_mode))
         ctx.graph, ctx.ew_pair = graph, ew_pair
-        ctx.cfg = (aggr_id, edge_mode, float(t), float(p), float(eps), bool(learn_t), bool(learn_p))
+        ctx.cfg = (aggr_id, edge_mode, float(t), float(p), float(eps), bool(learn_t), bool(learn_p), bool(add_root))
         ctx.save_for_backward(x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev)
         return out
 
     @staticmethod
     def backward(ctx, go):
         x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev = ctx.saved_tensors
-        aggr_id, edge_mode, t, p, eps, learn_t, learn_p = ctx.cfg
+        aggr_id, edge_mode, t, p, eps, learn_t, learn_p, add_root = ctx.cfg
         g = ctx.graph
         N, d = x.shape
         go = _dev_f32(go, "grad_out")
@@ -185,23 +185,26 @@ class _GenAggregate(torch.autograd.Function):
             _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), g.eid_t.data_ptr(),
             gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
             N, d, DTYPE_F32, MSG_GEN, edge_mode, aggr_id, int(learn_t), t, p,
-            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, _stream())
+            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         if timer is not None:
             timer.stop("csr_aggregate_bwd/%s/%s" % (_AGGR_NAMES[aggr_id], _EDGE_NAMES[edge_mode]), t0,
                        algorithmic_bytes(N, g.num_edges, d, aggr_id, edge_mode, backward=True, learn_t=learn_t))
         geu = guv[0] if guv is not None else None
         gev = guv[1] if guv is not None else None
-        return gx, geu, gev, ge, grad_t, grad_p, None, None, None, None, None, None, None, None
+        return gx, geu, gev, ge, grad_t, grad_p, None, None, None, None, None, None, None, None, None
 
 
-def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, learn_t=False, learn_p=False):
+def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, learn_t=False, learn_p=False,
+                  add_root=False):
     """``aggregate(relu(x_j + e_ij) + eps)`` over incoming edges -- GENConv.message + aggregate
     (torch_vertex.py:94-101, torch_message.py:44-85) in one kernel.
 
     ``edge``: ``None`` | :class:`RankOneEdge` (already composed to width d) | ``[E, d]`` tensor (COO order).
     ``t``/``p``: float, or the 1-element parameter when ``learn_t``/``learn_p``.
     ``*_sum`` variants return the un-scaled value; the caller applies ``deg ** sigmoid(y)``.
+    ``add_root``: return ``x + aggregate`` from the same pass (GENConv's ``h = x + m``); ignored
+    (done as a separate add) when the aggregate itself is needed for a learnable ``t``/``p``.
     """
     if not isinstance(graph, CSRGraph):
         raise TypeError("graph must be a CSRGraph")
@@ -216,8 +219,11 @@ def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, l
     p_par = p if torch.is_tensor(p) else None
     t_val = 1.0 if t_par is not None else t
     p_val = 1.0 if p_par is not None else p
-    return _GenAggregate.apply(x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t_val, p_val, eps,
-                               bool(learn_t) and t_par is not None, bool(learn_p) and p_par is not None)
+    lt, lp = bool(learn_t) and t_par is not None, bool(learn_p) and p_par is not None
+    fuse_root = bool(add_root) and not lt and not lp and aggr_id != AGGR_POWER
+    out = _GenAggregate.apply(x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t_val, p_val, eps,
+                              lt, lp, fuse_root)
+    return out + x if (add_root and not fuse_root) else out
 
 
 class _WeightedAggregate(torch.autograd.Function):
@@ -232,7 +238,7 @@ class _WeightedAggregate(torch.autograd.Function):
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), None, None, None, None,
             out.data_ptr(), None, None, None, N, d, DTYPE_F32, msg, EDGE_NONE, aggr_id, 1.0, 1.0, None, None,
-            0.0, _stream())
+            0.0, 0, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         ctx.graph, ctx.ew_pair, ctx.cfg = graph, ew_pair, (msg, aggr_id, N, d)
         return out
@@ -247,7 +253,7 @@ class _WeightedAggregate(torch.autograd.Function):
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
             g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, gx.data_ptr(), None, None, None, 0,
-            N, d, DTYPE_F32, msg, EDGE_NONE, aggr_id, 0, 1.0, 1.0, None, None, 0.0, _stream())
+            N, d, DTYPE_F32, msg, EDGE_NONE, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         return gx, None, None, None
 

@@ -40,13 +40,17 @@ class GenMessagePassing(nn.Module):
         if aggr in ('softmax_sum', 'power_sum'):
             self.y = nn.Parameter(torch.Tensor([y]), requires_grad=learn_y)
 
-    def reduce_messages(self, x, graph, edge, eps):
-        """``aggregate(relu(x_j + e_ij) + eps)`` for every destination node (torch_message.py:44-85)."""
+    def reduce_messages(self, x, graph, edge, eps, add_root=False):
+        """``aggregate(relu(x_j + e_ij) + eps)`` for every destination node (torch_message.py:44-85);
+        ``add_root`` returns ``x + aggregate`` (GENConv's ``h``) from the same kernel pass."""
+        scaled = self.aggr in ('softmax_sum', 'power_sum')
         out = gen_aggregate(x, graph, edge, aggr=self.aggr, t=getattr(self, "t", 1.0), p=getattr(self, "p", 1.0),
-                            eps=eps, learn_t=self.learn_t, learn_p=self.learn_p)
-        if self.aggr in ('softmax_sum', 'power_sum'):
+                            eps=eps, learn_t=self.learn_t, learn_p=self.learn_p, add_root=add_root and not scaled)
+        if scaled:
             self.sigmoid_y = torch.sigmoid(self.y)
             out = torch.pow(graph.in_degree.unsqueeze(1), self.sigmoid_y) * out
+            if add_root:
+                out = out + x
         return out
 
 

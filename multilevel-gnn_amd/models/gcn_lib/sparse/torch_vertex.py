@@ -55,10 +55,11 @@ class GENConv(GenMessagePassing):
         else:
             edge = None
         flat = x.flatten(1)
-        m = self.reduce_messages(flat, graph, edge, self.eps)
-        if self.msg_norm is not None:
-            m = self.msg_norm(x, m)
-        return self.feature_encoder(x + m.reshape(x.shape))
+        if self.msg_norm is None:
+            h = self.reduce_messages(flat, graph, edge, self.eps, add_root=True)       # x + m in one pass
+        else:
+            h = x + self.msg_norm(x, self.reduce_messages(flat, graph, edge, self.eps)).reshape(x.shape)
+        return self.feature_encoder(h.reshape(x.shape))
 
 
 class Linear(nn.Module):

@@ -173,3 +173,31 @@ def test_weighted_mean_aggregate(weighted, d):
     assert_close(out, ref, TOL, "weighted mean fwd")
     (out * cot.to(dev)).sum().backward()
     assert_close(xg.grad, x.grad, TOL, "weighted mean grad")
+
+
+@pytest.mark.parametrize("aggr", ["softmax", "max", "mean", "add", "power"])
+@pytest.mark.parametrize("d", [32, 100, 128])
+def test_add_root_fusion(aggr, d):
+    """out = x + aggregate from one pass (and grad_x = grad_out + aggregate-backward) equals the two-step form."""
+    from mlgnn import CSRGraph, RankOneEdge, gen_aggregate
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(d)
+    N, E = 500, 6000
+    ei = _graph(gen, N, E, hub=True).to(dev)
+    g = CSRGraph(ei, N)
+    a = torch.rand(E, generator=gen).to(dev)
+    u, v = (torch.randn(d, generator=gen) * 0.4).to(dev), (torch.randn(d, generator=gen) * 0.1).to(dev)
+    cot = torch.randn(N, d, generator=gen).to(dev)
+    res = []
+    for fused in (True, False):
+        x = torch.randn(N, d, generator=torch.Generator().manual_seed(1)).to(dev).requires_grad_(True)
+        uu, vv = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
+        if fused:
+            h = gen_aggregate(x, g, RankOneEdge(a, uu, vv), aggr=aggr, p=2.0, add_root=True)
+        else:
+            h = x + gen_aggregate(x, g, RankOneEdge(a, uu, vv), aggr=aggr, p=2.0)
+        gr = torch.autograd.grad((h * cot).sum(), [x, uu, vv])
+        res.append((h.detach(), gr))
+    assert_close(res[0][0], res[1][0], 1e-6, "fused root add fwd")
+    for ga, gb in zip(res[0][1], res[1][1]):
+        assert_close(ga, gb, 1e-5, "fused root add grad")

@@ -89,11 +89,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  MLGNN_BENCH_BACKEND=gloo is a rehearsal aid only (several ranks sharing
+    # the single GPU of a development box); the measured configuration is nccl (= RCCL over xGMI).
+    backend = os.environ.get("MLGNN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mlgnn import ops
     from mlgnn import workload as W
@@ -161,6 +168,7 @@ def main():
                                    "bwd + grad all-reduce + Adam" % (args.nodes, args.edges, B, args.hidden, args.aggr,
                                                                       args.members),
                        "graphs_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "collective_backend": backend if world > 1 else None,
                        "final_loss": final_loss},
         }
         if timer is not None:

@@ -35,6 +35,15 @@ for (K, O) in [(128, 256), (256, 128), (3, 128)]:
     r["dX=go@Wt.t()"] = timed(lambda: go @ Wt.t())
     r["dW=go.t()@x"] = timed(lambda: go.t() @ x)
     r["dWt=x.t()@go"] = timed(lambda: x.t() @ go)
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multilevel-gnn_amd"))
+    from mlgnn import _lib
+    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, O, K))
+    ws = torch.empty(n, device=dev)
+    outb = torch.empty(O * K + O, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    r["mlgnn_linear_wgrad"] = timed(lambda: _lib.lib.mlgnn_linear_wgrad(go.data_ptr(), x.data_ptr(), outb.data_ptr(),
+                                                                         ws.data_ptr(), n, N, O, K, 0, st))
     print("K=%d O=%d  (%.1f GFLOP)" % (K, O, fl))
     for k, v in r.items():
         print("   %-18s %7.3f ms  %6.1f TF/s" % (k, v, fl / v))

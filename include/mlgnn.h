@@ -211,6 +211,20 @@ int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
                      int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/*
+ * MsgNorm fused with GENConv's root add:  h = x + normalize(m, p=2, dim=1) * ||x||_2 * scale[0]
+ * Replaces: MsgNorm.forward (models/gcn_lib/sparse/torch_message.py:175-179) + h = x + m
+ * (models/gcn_lib/sparse/torch_vertex.py:86-89).  x, m, h [rows, d] fp32, d <= 256, d % 4 == 0;
+ * scale: device pointer to the (learnable) scalar.  Backward returns grad_x, grad_m and
+ * grad_scale[1]; workspace: mlgnn_msgnorm_bwd_workspace_floats(rows, d) floats.
+ */
+int64_t mlgnn_msgnorm_bwd_workspace_floats(int64_t rows, int64_t d);
+int mlgnn_msgnorm_add_fwd(const void* x, const void* m, const float* scale, void* h,
+                          int64_t rows, int64_t d, int dtype, void* stream);
+int mlgnn_msgnorm_add_bwd(const void* grad_h, const void* x, const void* m, const float* scale,
+                          void* grad_x, void* grad_m, float* grad_scale, float* workspace,
+                          int64_t workspace_floats, int64_t rows, int64_t d, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

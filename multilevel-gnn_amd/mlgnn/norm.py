@@ -52,3 +52,39 @@ def layer_norm_act(x, weight, bias, eps=1e-5, relu=False):
         return _LayerNormAct.apply(x, weight, bias, eps, relu)
     y = F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
     return F.relu(y) if relu else y
+
+
+class _MsgNormAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m, scale):
+        x, m = x.contiguous(), m.contiguous()
+        rows, d = x.shape
+        h = torch.empty_like(x)
+        rc = _lib.lib.mlgnn_msgnorm_add_fwd(x.data_ptr(), m.data_ptr(), scale.data_ptr(), h.data_ptr(), rows, d,
+                                            DTYPE_F32, _stream())
+        _lib.check(rc, "mlgnn_msgnorm_add_fwd")
+        ctx.save_for_backward(x, m, scale)
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        x, m, scale = ctx.saved_tensors
+        rows, d = x.shape
+        gh = gh.contiguous()
+        gx, gm = torch.empty_like(x), torch.empty_like(m)
+        gs = torch.empty(1, dtype=torch.float32, device=x.device)
+        n = int(_lib.lib.mlgnn_msgnorm_bwd_workspace_floats(rows, d))
+        ws = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
+        rc = _lib.lib.mlgnn_msgnorm_add_bwd(gh.data_ptr(), x.data_ptr(), m.data_ptr(), scale.data_ptr(),
+                                            gx.data_ptr(), gm.data_ptr(), gs.data_ptr(), ws.data_ptr(), n, rows, d,
+                                            DTYPE_F32, _stream())
+        _lib.check(rc, "mlgnn_msgnorm_add_bwd")
+        return gx, gm, (gs if ctx.needs_input_grad[2] else None)
+
+
+def msg_norm_add(x, m, scale):
+    """``x + normalize(m, dim=1) * ||x|| * scale`` (MsgNorm + GENConv root add, torch_message.py:175-179,
+    torch_vertex.py:86-89) in one HIP pass each way; ATen ops for widths the kernel does not cover."""
+    if fused_supported(x) and m.shape == x.shape:
+        return _MsgNormAdd.apply(x, m, scale)
+    return x + F.normalize(m, p=2.0, dim=1) * x.norm(p=2, dim=1, keepdim=True) * scale

@@ -13,6 +13,7 @@ from torch import nn
 
 from mlgnn import RankOneEdge, as_graph, weighted_mean_aggregate
 from mlgnn.graph import sage_graph
+from mlgnn.norm import msg_norm_add
 from .torch_message import GenMessagePassing, MsgNorm
 from .torch_nn import MLP
 
@@ -58,7 +59,7 @@ class GENConv(GenMessagePassing):
         if self.msg_norm is None:
             h = self.reduce_messages(flat, graph, edge, self.eps, add_root=True)       # x + m in one pass
         else:
-            h = x + self.msg_norm(x, self.reduce_messages(flat, graph, edge, self.eps)).reshape(x.shape)
+            h = msg_norm_add(flat, self.reduce_messages(flat, graph, edge, self.eps), self.msg_norm.msg_scale)
         return self.feature_encoder(h.reshape(x.shape))
 
 

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] stress run: ONE synthetic graph N=200 000 nodes / E=3 000 000 edges (ER, seed 7),
+d=256, 28-layer DeeperGCN (res+, LayerNorm, softmax aggregation), then dense_diff_pool on a 4096-node
+pooled graph with 1024 clusters.  fp32 (the bf16 storage path of that config is not implemented yet:
+DESIGN.md section 8).  Prints per-kernel algorithmic GB/s from HIP-event timing and the step time.
+
+  python tools/stress.py [--layers 28] [--hidden 256]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multilevel-gnn_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=200000)
+    ap.add_argument("--edges", type=int, default=3000000)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--steps", type=int, default=3)
+    a = ap.parse_args()
+    from _util import make_args
+    from mlgnn import ops
+    from mlgnn.dense import dense_diff_pool
+    from models import get_model
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(7)
+    ei = torch.randint(0, a.nodes, (2, a.edges), generator=gen)
+    batch = SimpleNamespace(x=torch.randn(a.nodes, 3, generator=gen).to(dev), edge_index=ei.to(dev),
+                            edge_attr=torch.rand(a.edges, 1, generator=gen).to(dev),
+                            batch=torch.zeros(a.nodes, dtype=torch.long, device=dev), age=torch.zeros(1, device=dev),
+                            pathway_node_attr=None, node_size=torch.tensor([a.nodes], device=dev))
+    args = make_args(num_layers=a.layers, hidden_channels=a.hidden, dropout=0.0, conv_encode_edge=True,
+                     use_edge_attr=True, use_column="w", global_edge="none", gcn_aggr="softmax", block="res+",
+                     norm="layer", graph_pooling="mean", pathway_readout=None)
+    torch.manual_seed(0)
+    model = get_model("deepergcn")(args).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(batch)
+        (-torch.log(out[:, 0] + 1e-9)).sum().backward()
+        opt.step()
+
+    step()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.KERNEL_TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    ops.KERNEL_TIMER = None
+    res = {"config": "N=%d E=%d d=%d layers=%d fp32" % (a.nodes, a.edges, a.hidden, a.layers),
+           "step_ms": dt * 1e3, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "kernels": {}}
+    for name, d in timer.summary().items():
+        gbs = d["bytes"] / (d["avg_ms"] * 1e-3) / 1e9
+        res["kernels"][name] = {"launches": d["launches"], "avg_ms": round(d["avg_ms"], 4),
+                                "algorithmic_GB": round(d["bytes"] / 1e9, 3), "GBps": round(gbs, 1),
+                                "frac_of_8TBps": round(gbs / 8000.0, 3)}
+
+    # DiffPool at the stress size: library GEMM path (N=4096 > 160)
+    P, K, C = 4096, 1024, a.hidden
+    z = torch.randn(1, P, C, device=dev, requires_grad=True)
+    s = torch.randn(1, P, K, device=dev, requires_grad=True)
+    adj = torch.rand(P, P, device=dev)
+
+    def pool():
+        x, aa, l, e = dense_diff_pool(z, adj, s)
+        (x.sum() + aa.sum() + l + e).backward()
+
+    pool()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        pool()
+    torch.cuda.synchronize()
+    dtp = (time.perf_counter() - t0) / 5
+    flop_fwd = 2 * K * P * C + 2 * K * P * P + 2 * K * K * P + 2 * P * P * K
+    res["diffpool_4096_1024"] = {"fwd_bwd_ms": dtp * 1e3, "fwd_GFLOP": flop_fwd / 1e9,
+                                 "approx_TFLOPs_fwd_bwd": 3 * flop_fwd / dtp / 1e12, "path": "library GEMMs (fp32)"}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from mlgnn import RankOneEdge, as_graph, weighted_mean_aggregate
+from mlgnn.dense import linear
 from mlgnn.graph import sage_graph
 from mlgnn.norm import msg_norm_add
 from .torch_message import GenMessagePassing, MsgNorm
@@ -110,7 +111,7 @@ class SAGEConv(nn.Module):
         agg = weighted_mean_aggregate(x, graph, weight, mean=True)
         if self.relative:
             agg = agg - x                    # every node has its self loop: mean_j(x_i) = x_i
-        aggr_out = F.linear(agg, self.lin_r.weight)
+        aggr_out = linear(agg, self.lin_r.weight)          # tall-matrix weight gradient on the MFMA kernel
         if self.bias is not None:
             aggr_out = aggr_out + self.bias
         out = self.nn(torch.cat((x, aggr_out), dim=1))

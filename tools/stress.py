@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     a = ap.parse_args()
     from _util import make_args
     from mlgnn import ops
@@ -44,12 +45,16 @@ def main():
                      norm="layer", graph_pooling="mean", pathway_readout=None)
     torch.manual_seed(0)
     model = get_model("deepergcn")(args).to(dev)
+    if a.dtype == "bf16":                      # bf16 weights + activations; aggregation arithmetic stays fp32
+        model.to(torch.bfloat16)
+        batch.x = batch.x.to(torch.bfloat16)
+        batch.age = batch.age.to(torch.bfloat16)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 
     def step():
         opt.zero_grad(set_to_none=True)
         out = model(batch)
-        (-torch.log(out[:, 0] + 1e-9)).sum().backward()
+        (-torch.log(out[:, 0].float() + 1e-9)).sum().backward()
         opt.step()
 
     step()
@@ -62,7 +67,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     ops.KERNEL_TIMER = None
-    res = {"config": "N=%d E=%d d=%d layers=%d fp32" % (a.nodes, a.edges, a.hidden, a.layers),
+    res = {"config": "N=%d E=%d d=%d layers=%d %s" % (a.nodes, a.edges, a.hidden, a.layers, a.dtype),
            "step_ms": dt * 1e3, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "kernels": {}}
     for name, d in timer.summary().items():
         gbs = d["bytes"] / (d["avg_ms"] * 1e-3) / 1e9

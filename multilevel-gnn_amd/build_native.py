@@ -27,18 +27,34 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
+         # plain v_max/v_min without NaN canonicalisation; the kernels use finite sentinels instead
+         # of +-inf (csrc/aggregate_common.h)
+         "-fno-honor-nans", "-fno-honor-infinities"]
+
+
 def build(force=False, verbose=True):
-    """Compile every csrc/*.hip into ONE shared object next to this package."""
+    """Compile every csrc/*.hip (in parallel, one hipcc per translation unit) and link ONE shared
+    object next to the package."""
     if not force and not _stale():
         return LIB
-    # -fno-honor-nans/-infinities: plain v_max/v_min without NaN canonicalisation; the kernels use
-    # finite sentinels instead of +-inf (csrc/aggregate.hip)
-    cmd = [HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-honor-nans", "-fno-honor-infinities",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + sources() + ["-o", LIB + ".tmp"]
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    jobs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        cmd = [HIPCC] + FLAGS + inc + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((obj, cmd, subprocess.Popen(cmd)))
+    failed = [cmd for _, cmd, proc in jobs if proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    link = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + [obj for obj, _, _ in jobs] + ["-o", LIB + ".tmp"]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

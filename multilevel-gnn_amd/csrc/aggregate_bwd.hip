@@ -1,0 +1,276 @@
+// Backward of the fused message + aggregation kernels (see aggregate_fwd.hip for the lane layout):
+// one wavefront per SOURCE node on the transposed CSR, atomic-free; plus the fixed-order partial
+// reduction shared by every kernel that sums per-workgroup partials.
+#include "aggregate_common.h"
+
+namespace mlgnn {
+
+// ------------------------------------------------------------------------------------------------
+// backward: one wave per SOURCE node j, walking its outgoing edges (j -> i)
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {                      // go / x / out / efull / gx / ge are T; aux, argmax, ws fp32 / int32
+  const void* go; const void* x; const void* out; const float* aux; const int* argmax;
+  const int* rowptr_t; const int* col_t; const int* pos_t; const int* rowptr;
+  const float* ew_t; const float* eu; const float* ev; const void* efull; const int* eid_t;
+  void* gx; void* ge; float* ws;
+  const float* t_dev; const float* p_dev;
+  int N; int d; int lpr_log2; int mean; int learn_t; int add_root;
+  float t; float p; float eps;
+};
+
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T>
+__global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
+  __shared__ float red[kWavesPerBlock][2][kWave * VEC];
+  const T* GO = static_cast<const T*>(a.go);
+  const T* X = static_cast<const T*>(a.x);
+  const T* OUTS = static_cast<const T*>(a.out);
+  const T* EF = static_cast<const T*>(a.efull);
+  T* GX = static_cast<T*>(a.gx);
+  T* GE = static_cast<T*>(a.ge);
+  constexpr uint32_t kWide = 4u / (uint32_t)sizeof(T);      // fp32 side arrays (lse, argmax): byte offset scale
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int lpr = 1 << a.lpr_log2;
+  const int groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2;
+  const int cl = lane & (lpr - 1);
+  const RowWalk walk = make_row_walk(a.N);
+  const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
+  const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
+  constexpr bool kNeedW = (MODE == M_WEIGHTED || MODE == M_GEN_RANK1);
+
+  for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
+    const bool cact = cbase + cl * VEC < a.d;          // inactive lanes shadow the last chunk (see forward)
+    const int c0 = min(cbase + cl * VEC, a.d - VEC);
+    const uint32_t c_bytes = (uint32_t)c0 * (uint32_t)sizeof(T);
+    float eu[VEC], ev[VEC], gu[VEC], gv[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; gu[i] = 0.f; gv[i] = 0.f; }
+    if (MODE == M_GEN_RANK1) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
+
+    for (int r = walk.first; r < walk.r_end; r += walk.stride) {
+      const int beg = a.rowptr_t[r];
+      const int end = a.rowptr_t[r + 1];
+      float xj[VEC], gx[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { xj[i] = 0.f; gx[i] = 0.f; }
+      if (is_gen<MODE>() && end > beg) load_t<T, VEC>(xj, X + (size_t)r * a.d + c0);
+
+      for (int base = beg; base < end; base += kWave) {
+        const int cnt = min(kWave, end - base);
+        uint32_t my_off = 0;
+        int my_pos = 0, my_eid = 0;
+        float my_ew = 0.f, my_inv = 1.f;
+        if (lane < cnt) {
+          const int dst = a.col_t[base + lane];
+          my_off = (uint32_t)dst * row_bytes;
+          if (AGGR == A_MAX) my_pos = a.pos_t[base + lane];
+          if (kNeedW) my_ew = a.ew_t[base + lane];
+          if (MODE == M_GEN_FULL) my_eid = a.eid_t[base + lane];
+          if (AGGR == A_SUM && a.mean)
+            my_inv = __builtin_amdgcn_rcpf((float)max(a.rowptr[dst + 1] - a.rowptr[dst], 1));
+        }
+
+        auto batch = [&](auto full_c, const int k) {
+          constexpr bool FULL = decltype(full_c)::value;
+          float ga[kUnroll][VEC], gb[kUnroll][VEC], gc[kUnroll][VEC], ef[kUnroll][VEC];
+          int ai[kUnroll][VEC];
+          float wa[kUnroll], inv[kUnroll];
+          int pos[kUnroll], e0[kUnroll];
+          bool valid[kUnroll];
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            const int idx = k + u * groups + sub;
+            valid[u] = FULL || (idx < cnt);
+            const int src = idx & (kWave - 1);
+            const uint32_t off = (uint32_t)__shfl((int)my_off, src) + c_bytes;
+            wa[u] = kNeedW ? __shfl(my_ew, src) : 0.f;
+            inv[u] = (AGGR == A_SUM) ? __shfl(my_inv, src) : 1.f;
+            pos[u] = (AGGR == A_MAX) ? __shfl(my_pos, src) : 0;
+            e0[u] = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { ga[u][i] = 0.f; gb[u][i] = 0.f; gc[u][i] = 0.f; ef[u][i] = 0.f; ai[u][i] = -2; }
+            if (FULL || valid[u]) {
+              load_row<T, VEC>(ga[u], GO, off);
+              if (AGGR == A_SOFTMAX) load_row<float, VEC>(gb[u], a.aux, off * kWide);
+              if (AGGR == A_SOFTMAX && LEARN_T) load_row<T, VEC>(gc[u], OUTS, off);
+              if (AGGR == A_MAX) load_row<VEC>(ai[u], a.argmax, off * kWide);
+              if (MODE == M_GEN_FULL) load_t<T, VEC>(ef[u], EF + (size_t)e0[u] * a.d + c0);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            float dz[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              float coef, z = 0.f, m = 0.f;
+              if constexpr (is_gen<MODE>()) {
+                z = pre_act<MODE>(xj[i], wa[u], eu[i], ev[i], ef[u][i]);
+                m = fmaxf(z, 0.f) + a.eps;
+              }
+              if constexpr (AGGR == A_SUM) {
+                coef = ga[u][i] * inv[u];
+              } else if constexpr (AGGR == A_MAX) {
+                coef = (ai[u][i] == pos[u]) ? ga[u][i] : 0.f;
+              } else if constexpr (AGGR == A_SOFTMAX) {
+                const float w = fast_exp2(fmaf(sc.t_log2e, m, -gb[u][i]));
+                coef = ga[u][i] * w;
+                if (LEARN_T) coef *= fmaf(sc.t, m - gc[u][i], 1.0f);
+              } else {  // POWER: ga carries q (see mlgnn.h)
+                const float mc = fminf(fmaxf(m, kPowLo), kPowHi);
+                const bool inr = (m >= kPowLo) && (m <= kPowHi);
+                coef = inr ? ga[u][i] * fast_exp2((sc.p - 1.0f) * fast_log2(mc)) : 0.f;
+              }
+              if constexpr (MODE == M_WEIGHTED) coef *= wa[u];
+              if constexpr (is_gen<MODE>()) coef = (z > 0.f) ? coef : 0.f;
+              dz[i] = (FULL || valid[u]) ? coef : 0.f;
+              gx[i] += dz[i];
+              if constexpr (MODE == M_GEN_RANK1) { gu[i] = fmaf(wa[u], dz[i], gu[i]); gv[i] += dz[i]; }
+            }
+            if (MODE == M_GEN_FULL && valid[u] && cact) store_t<T, VEC>(GE + (size_t)e0[u] * a.d + c0, dz);
+          }
+        };
+
+        const int step = groups * kUnroll;
+        int k = 0;
+        for (; k + step <= cnt; k += step) batch(BC<true>{}, k);
+        if (k < cnt) batch(BC<false>{}, k);
+      }
+      for (int off = lpr; off < kWave; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gx[i] += __shfl_xor(gx[i], off);
+      if (sub == 0 && cact) {
+        if (a.add_root) {            // identity branch of h = x + m
+          float gr[VEC];
+          load_t<T, VEC>(gr, GO + (size_t)r * a.d + c0);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) gx[i] += gr[i];
+        }
+        store_t<T, VEC>(GX + (size_t)r * a.d + c0, gx);
+      }
+    }
+
+    if constexpr (MODE == M_GEN_RANK1) {
+      // per-workgroup partial of d loss/d u, d loss/d v  ->  ws[block][2][d]; summed by a second launch
+      for (int off = lpr; off < kWave; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { gu[i] += __shfl_xor(gu[i], off); gv[i] += __shfl_xor(gv[i], off); }
+      __syncthreads();
+      if (sub == 0) {     // red[] is indexed by the lane's nominal column; shadow lanes land past d and are skipped below
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { red[wave][0][cl * VEC + i] = gu[i]; red[wave][1][cl * VEC + i] = gv[i]; }
+      }
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 2 * lpr * VEC; idx += kBlock) {
+        const int which = idx / (lpr * VEC), c = idx % (lpr * VEC);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) s += red[w][which][c];
+        if (cbase + c < a.d) a.ws[((size_t)blockIdx.x * 2 + which) * a.d + cbase + c] = s;
+      }
+    }
+  }
+}
+
+// ws[nblk][cols] -> out[cols] in a fixed summation order (bitwise reproducible).  One workgroup of
+// 1024 threads owns 32 columns: 32 row slices x 32 columns, each thread sums every 32nd row with
+// independent (pipelined) loads, then the 32 slices are folded through LDS in slice order.
+constexpr int kRedCols = 32, kRedSlices = 32;
+__global__ __launch_bounds__(kRedCols * kRedSlices) void reduce_partials_kernel(const float* __restrict__ ws,
+                                                                                 float* __restrict__ out,
+                                                                                 int nblk, int cols) {
+  __shared__ float part[kRedSlices][kRedCols + 1];
+  const int cl = threadIdx.x % kRedCols;
+  const int slice = threadIdx.x / kRedCols;
+  const int c = blockIdx.x * kRedCols + cl;
+  float s = 0.f;
+  if (c < cols)
+    for (int b = slice; b < nblk; b += kRedSlices) s += ws[(size_t)b * cols + c];
+  part[slice][cl] = s;
+  __syncthreads();
+  if (slice == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < kRedSlices; ++k) t += part[k][cl];
+    out[c] = t;
+  }
+}
+
+void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + kRedCols - 1) / kRedCols), dim3(kRedCols * kRedSlices),
+                     0, stream, ws, out, nblk, cols);
+}
+
+}  // namespace mlgnn
+
+using namespace mlgnn;
+
+extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out, const float* aux,
+                                       const int32_t* argmax,
+                                       const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
+                                       const int32_t* rowptr,
+                                       const float* ew_t, const float* eu, const float* ev,
+                                       const void* efull, const int32_t* eid_t,
+                                       void* grad_x, void* grad_efull, float* grad_uv,
+                                       float* workspace, int64_t workspace_floats,
+                                       int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                                       int aggr, int learn_t, float t, float p, const float* t_dev,
+                                       const float* p_dev, float eps, int add_root, void* stream) {
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
+  if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
+  if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
+  const int mode = pick_mode(msg, edge_mode);
+  const int ag = pick_aggr(aggr);
+  if (mode < 0 || ag < 0) return MLGNN_E_MODE;
+  if (!is_gen_mode(mode) && ag != A_SUM) return MLGNN_E_MODE;
+  if (N == 0) return 0;
+  if (!grad_out || !rowptr_t || !grad_x) return MLGNN_E_NULL;   // col_t may be NULL iff E == 0
+  if (is_gen_mode(mode) && !x) return MLGNN_E_NULL;
+  if (aggr == MLGNN_AGGR_MEAN && !rowptr) return MLGNN_E_NULL;
+  if (ag == A_MAX && !argmax) return MLGNN_E_NULL;
+  if (ag == A_SOFTMAX && (!aux || (learn_t && !out))) return MLGNN_E_NULL;
+  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew_t && col_t) return MLGNN_E_NULL;
+  if (mode == M_GEN_RANK1 && (!eu || !ev || !grad_uv || !workspace)) return MLGNN_E_NULL;
+  if (mode == M_GEN_FULL && col_t && (!efull || !eid_t || !grad_efull)) return MLGNN_E_NULL;
+  const int nblk = grid_for_rows(N);
+  if (mode == M_GEN_RANK1 && workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
+
+  BwdArgs a;
+  a.go = grad_out; a.x = x; a.out = out; a.aux = aux;
+  a.argmax = argmax; a.rowptr_t = rowptr_t; a.col_t = col_t; a.pos_t = pos_t; a.rowptr = rowptr;
+  a.ew_t = ew_t; a.eu = eu; a.ev = ev; a.efull = efull; a.eid_t = eid_t;
+  a.gx = grad_x; a.ge = grad_efull; a.ws = workspace;
+  a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN); a.learn_t = learn_t;
+  a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
+  if (add_root && learn_t) return MLGNN_E_MODE;       // `out` must be the bare aggregate for d/dt
+
+  const bool al = aligned16(grad_out) && aligned16(grad_x) && (!x || aligned16(x)) &&
+                  (!out || aligned16(out)) && (!aux || aligned16(aux)) && (!argmax || aligned16(argmax)) &&
+                  (!efull || aligned16(efull)) && (!grad_efull || aligned16(grad_efull)) &&
+                  (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  const bool bf16 = dtype == MLGNN_DTYPE_BF16;
+  const int vec = bf16 ? ((d % 8 == 0 && al) ? 8 : 1) : ((d % 4 == 0 && al) ? 4 : 1);
+  const dim3 grid(nblk), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  a.lpr_log2 = lanes_per_row_log2(d, vec);
+  const bool lt = learn_t != 0 && ag == A_SOFTMAX;
+  for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
+    constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
+    constexpr bool kCanLearn = (AGGR == A_SOFTMAX);
+    auto launch = [&](auto t_c, auto vec_c) {
+      using T = typename decltype(t_c)::type;
+      constexpr int VEC = decltype(vec_c)::value;
+      if (kCanLearn && lt) hipLaunchKernelGGL((csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, kCanLearn>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false>), grid, block, 0, s, a);
+    };
+    if (bf16) { if (vec == 8) launch(TypeTag<bf16_t>{}, IC<8>{}); else launch(TypeTag<bf16_t>{}, IC<1>{}); }
+    else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
+  });
+  int err = (int)hipGetLastError();
+  if (err) return err;
+  if (mode == M_GEN_RANK1) {
+    launch_reduce_partials(workspace, grad_uv, nblk, 2 * (int)d, s);
+    err = (int)hipGetLastError();
+  }
+  return err;
+}

@@ -1,0 +1,117 @@
+// Shared pieces of the CSR aggregation kernels (forward: aggregate_fwd.hip, backward: aggregate_bwd.hip).
+#pragma once
+#include <type_traits>
+#include "common.h"
+#include "mlgnn.h"
+
+namespace mlgnn {
+
+constexpr int kUnroll = 4;                 // neighbour rows in flight per lane group and batch
+constexpr float kPowLo = 1e-7f, kPowHi = 1e1f;   // torch_message.py:69
+constexpr float kNegBig = -3.0e38f;
+
+enum Mode { M_IDENTITY = 0, M_WEIGHTED = 1, M_GEN_NONE = 2, M_GEN_RANK1 = 3, M_GEN_FULL = 4 };
+enum Aggr { A_SUM = 0, A_MAX = 2, A_SOFTMAX = 3, A_POWER = 4 };   // MEAN = SUM + epilogue flag
+
+template <int V> using IC = std::integral_constant<int, V>;
+template <typename T> struct TypeTag { using type = T; };
+template <bool V> using BC = std::integral_constant<bool, V>;
+
+struct FwdArgs {                      // x / efull / out are T (fp32 or bf16); everything else fp32 / int32
+  const void* x; const int* rowptr; const int* col;
+  const float* ew; const float* eu; const float* ev; const void* efull; const int* eid;
+  void* out; float* aux; float* aux2; int* argmax;
+  const float* t_dev; const float* p_dev;
+  int N; int d; int lpr_log2; int mean; int add_root;
+  float t; float p; float eps;
+};
+
+// t / p either immediate or read from device memory (learnable parameters: no host sync)
+struct Scalars { float t, t_log2e, p; };
+__device__ __forceinline__ Scalars read_scalars(const float* t_dev, const float* p_dev, float t, float p) {
+  Scalars s;
+  s.t = t_dev ? t_dev[0] : t;
+  s.p = p_dev ? p_dev[0] : p;
+  s.t_log2e = s.t * kLog2e;
+  return s;
+}
+
+template <int MODE>
+__device__ __forceinline__ constexpr bool is_gen() { return MODE >= M_GEN_NONE; }
+
+// rows of x / out / aux are addressed with 32-bit byte offsets from a uniform base (tensors < 4 GiB,
+// checked on the host): one v_mul + v_add per gathered row instead of 64-bit multiply-adds
+template <typename T, int VEC>
+__device__ __forceinline__ void load_row(float (&r)[VEC], const T* base, uint32_t byte_off) {
+  load_t<T, VEC>(r, reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+template <int VEC>
+__device__ __forceinline__ void load_row(int (&r)[VEC], const int* base, uint32_t byte_off) {
+  load_vec<VEC>(r, reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+
+// pre-activation z of the GEN message for one channel
+template <int MODE>
+__device__ __forceinline__ float pre_act(float xj, float a, float u, float v, float ef) {
+  if constexpr (MODE == M_GEN_RANK1) return xj + fmaf(a, u, v);
+  else if constexpr (MODE == M_GEN_FULL) return xj + ef;
+  else return xj;
+}
+
+template <int MODE, bool ADD_EPS>
+__device__ __forceinline__ float message(float xj, float w_or_a, float u, float v, float ef, float eps) {
+  if constexpr (MODE == M_IDENTITY) return xj;
+  else if constexpr (MODE == M_WEIGHTED) return xj * w_or_a;
+  else if constexpr (ADD_EPS) return fmaxf(pre_act<MODE>(xj, w_or_a, u, v, ef), 0.0f) + eps;
+  else return fmaxf(pre_act<MODE>(xj, w_or_a, u, v, ef), 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+inline int pick_mode(int msg, int edge_mode) {
+  if (msg == MLGNN_MSG_IDENTITY) return M_IDENTITY;
+  if (msg == MLGNN_MSG_WEIGHTED) return M_WEIGHTED;
+  if (msg == MLGNN_MSG_GEN) {
+    if (edge_mode == MLGNN_EDGE_NONE) return M_GEN_NONE;
+    if (edge_mode == MLGNN_EDGE_RANK1) return M_GEN_RANK1;
+    if (edge_mode == MLGNN_EDGE_FULL) return M_GEN_FULL;
+  }
+  return -1;
+}
+
+inline int pick_aggr(int aggr) {
+  switch (aggr) {
+    case MLGNN_AGGR_SUM: case MLGNN_AGGR_MEAN: return A_SUM;
+    case MLGNN_AGGR_MAX: return A_MAX;
+    case MLGNN_AGGR_SOFTMAX: return A_SOFTMAX;
+    case MLGNN_AGGR_POWER: return A_POWER;
+  }
+  return -1;
+}
+
+inline bool is_gen_mode(int mode) { return mode >= M_GEN_NONE; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// f(IC<MODE>, IC<AGGR>) for the valid (mode, aggregator) pairs
+template <int MODE, typename F>
+inline void for_aggr(int ag, F&& f) {
+  switch (ag) {
+    case A_SUM: f(IC<MODE>{}, IC<A_SUM>{}); break;
+    case A_MAX: f(IC<MODE>{}, IC<A_MAX>{}); break;
+    case A_SOFTMAX: f(IC<MODE>{}, IC<A_SOFTMAX>{}); break;
+    default: f(IC<MODE>{}, IC<A_POWER>{}); break;
+  }
+}
+template <typename F>
+inline void for_mode_aggr(int mode, int ag, F&& f) {
+  switch (mode) {
+    case M_IDENTITY: f(IC<M_IDENTITY>{}, IC<A_SUM>{}); break;
+    case M_WEIGHTED: f(IC<M_WEIGHTED>{}, IC<A_SUM>{}); break;
+    case M_GEN_NONE: for_aggr<M_GEN_NONE>(ag, f); break;
+    case M_GEN_RANK1: for_aggr<M_GEN_RANK1>(ag, f); break;
+    default: for_aggr<M_GEN_FULL>(ag, f); break;
+  }
+}
+
+}  // namespace mlgnn

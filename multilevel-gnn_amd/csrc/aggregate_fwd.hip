@@ -1,0 +1,303 @@
+// CSR gather-reduce kernels: fused message + neighbour aggregation (forward, by-destination CSR)
+// and its backward (by-source CSR).  One wavefront owns one node row; the 64 lanes are split
+// into G = 64/LPR groups of LPR lanes, each group streaming whole neighbour rows with 16-byte
+// loads (VEC = 4 floats per lane), so one wave-instruction fetches G coalesced rows.  Groups are
+// combined with wavefront shuffles at the end of the row -- no atomics, no LDS in the forward.
+//
+// Reference semantics (paths relative to the reference tree):
+//   message    relu(x_j + e_ij) + eps              models/gcn_lib/sparse/torch_vertex.py:94-101
+//              x_j * w_ij                          models/gcn_lib/sparse/torch_vertex.py:279-281
+//   aggregate  add / mean / max / softmax / power  models/gcn_lib/sparse/torch_message.py:44-85
+//
+// HBM-bound (0.25-1 FLOP/byte): algorithmic bytes per launch are E*d*4 (neighbour rows)
+// + E*4 (col) + (N+1)*4 (rowptr) + E*4 (edge scalar) [+ E*d*4 full edge embedding] + N*d*4 (out).
+//
+// Built with -fno-honor-nans -fno-honor-infinities (plain v_max/v_min, no canonicalisation):
+// "minus infinity" sentinels are the finite kNegBig.
+#include "aggregate_common.h"
+
+namespace mlgnn {
+
+template <typename T, int VEC, int MODE, int AGGR, bool SECOND>
+__global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs a) {
+  const T* X = static_cast<const T*>(a.x);
+  const T* EF = static_cast<const T*>(a.efull);
+  T* OUT = static_cast<T*>(a.out);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << a.lpr_log2;
+  const int groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2;
+  const int cl = lane & (lpr - 1);
+  const RowWalk walk = make_row_walk(a.N);
+  const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
+  const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
+  constexpr bool kNeedW = (MODE == M_WEIGHTED || MODE == M_GEN_RANK1);
+
+  // eps is added once per row instead of once per edge: softmax weights are shift invariant,
+  // max and sum commute with the shift (power needs the clamp of m itself and keeps it per edge)
+  constexpr bool kLateEps = is_gen<MODE>() && AGGR != A_POWER;
+
+  for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
+    // lanes past the last channel (d/VEC not a power of two) re-read the last valid chunk and are
+    // only masked at the store, so full batches need no per-lane predication at all
+    const bool cact = cbase + cl * VEC < a.d;
+    const int c0 = min(cbase + cl * VEC, a.d - VEC);
+    const uint32_t c_bytes = (uint32_t)c0 * (uint32_t)sizeof(T);
+    float eu[VEC], ev[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; }
+    if (MODE == M_GEN_RANK1) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
+
+    for (int r = walk.first; r < walk.r_end; r += walk.stride) {
+      const int beg = a.rowptr[r];
+      const int end = a.rowptr[r + 1];
+      const int deg = end - beg;
+
+      // accumulators: SUM/POWER use acc; MAX uses acc (best) + bpos; SOFTMAX uses mx, acc (S), w1, w2
+      float acc[VEC], mx[VEC], w1[VEC], w2[VEC];
+      int bpos[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        acc[i] = (AGGR == A_MAX) ? kNegBig : 0.f;
+        mx[i] = kNegBig; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1;
+      }
+
+      for (int base = beg; base < end; base += kWave) {
+        const int cnt = min(kWave, end - base);
+        uint32_t my_off = 0;
+        int my_eid = 0;
+        float my_ew = 0.f;
+        if (lane < cnt) {
+          my_off = (uint32_t)a.col[base + lane] * row_bytes;
+          if (kNeedW) my_ew = a.ew[base + lane];
+          if (MODE == M_GEN_FULL) my_eid = a.eid[base + lane];
+        }
+
+        // one batch = kUnroll neighbours per lane group; FULL batches carry no validity masks
+        auto batch = [&](auto full_c, const int k) {
+          constexpr bool FULL = decltype(full_c)::value;
+          float m[kUnroll][VEC];
+          bool valid[kUnroll];
+          {
+            float xv[kUnroll][VEC], ef[kUnroll][VEC], wa[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+              const int idx = k + u * groups + sub;
+              valid[u] = FULL || (idx < cnt);
+              const int src = idx & (kWave - 1);
+              const uint32_t off = (uint32_t)__shfl((int)my_off, src) + c_bytes;
+              wa[u] = kNeedW ? __shfl(my_ew, src) : 0.f;
+              const int e0 = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) { xv[u][i] = 0.f; ef[u][i] = 0.f; }
+              if (FULL || valid[u]) {
+                load_row<T, VEC>(xv[u], X, off);
+                if (MODE == M_GEN_FULL) load_t<T, VEC>(ef[u], EF + (size_t)e0 * a.d + c0);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+              for (int i = 0; i < VEC; ++i)
+                m[u][i] = message<MODE, !kLateEps>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i], a.eps);
+          }
+
+          if constexpr (AGGR == A_SUM) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[i] += (FULL || valid[u]) ? m[u][i] : 0.f;
+          } else if constexpr (AGGR == A_MAX) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+              const int pos = base + k + u * groups + sub;
+#pragma unroll
+              for (int i = 0; i < VEC; ++i)
+                if ((FULL || valid[u]) && m[u][i] > acc[i]) { acc[i] = m[u][i]; bpos[i] = pos; }
+            }
+          } else if constexpr (AGGR == A_SOFTMAX) {
+            // online softmax, one rescale per batch of kUnroll neighbours; units: log2
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              if (!FULL && !valid[0]) break;     // a lane group without a live neighbour in the tail batch
+              // t*m is monotone in m: the batch extremum of m (max for t >= 0, min for t < 0) gives it
+              float ext = m[0][i];
+              if (sc.t_log2e >= 0.f) {                 // wave-uniform
+#pragma unroll
+                for (int u = 1; u < kUnroll; ++u) ext = (FULL || valid[u]) ? fmaxf(ext, m[u][i]) : ext;
+              } else {
+#pragma unroll
+                for (int u = 1; u < kUnroll; ++u) ext = (FULL || valid[u]) ? fminf(ext, m[u][i]) : ext;
+              }
+              const float zmax = fmaxf(mx[i], sc.t_log2e * ext);
+              const float rs = fast_exp2(mx[i] - zmax);     // 0 on the first batch (mx = kNegBig)
+              float s = acc[i] * rs, s1 = w1[i] * rs, s2 = SECOND ? w2[i] * rs : 0.f;
+#pragma unroll
+              for (int u = 0; u < kUnroll; ++u) {
+                float pe = fast_exp2(fmaf(sc.t_log2e, m[u][i], -zmax));
+                if (!FULL) pe = valid[u] ? pe : 0.f;
+                s += pe;
+                s1 = fmaf(pe, m[u][i], s1);
+                if (SECOND) s2 = fmaf(pe * m[u][i], m[u][i], s2);
+              }
+              acc[i] = s; w1[i] = s1; w2[i] = s2; mx[i] = zmax;
+            }
+          } else {  // A_POWER
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) {
+                const float mc = fminf(fmaxf(m[u][i], kPowLo), kPowHi);
+                const float l2 = fast_log2(mc);
+                const float pw = fast_exp2(sc.p * l2);
+                acc[i] += (FULL || valid[u]) ? pw : 0.f;
+                if (SECOND) w2[i] += (FULL || valid[u]) ? pw * l2 * kLn2 : 0.f;
+              }
+          }
+        };
+
+        const int step = groups * kUnroll;
+        int k = 0;
+        for (; k + step <= cnt; k += step) batch(BC<true>{}, k);
+        if (k < cnt) batch(BC<false>{}, k);
+      }
+
+      // ---- combine the lane groups (xor-shuffle over the group bits) ----
+      for (int off = lpr; off < kWave; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          if constexpr (AGGR == A_SUM) {
+            acc[i] += __shfl_xor(acc[i], off);
+          } else if constexpr (AGGR == A_POWER) {
+            acc[i] += __shfl_xor(acc[i], off);
+            if (SECOND) w2[i] += __shfl_xor(w2[i], off);
+          } else if constexpr (AGGR == A_MAX) {
+            const float ov = __shfl_xor(acc[i], off);
+            const int op = __shfl_xor(bpos[i], off);
+            // larger value wins; on a tie the earlier edge (torch_scatter CPU keeps the first)
+            const bool take = (op >= 0) && (bpos[i] < 0 || ov > acc[i] || (ov == acc[i] && op < bpos[i]));
+            if (take) { acc[i] = ov; bpos[i] = op; }
+          } else {  // SOFTMAX: a group that saw no edge has (mx, S, W) = (kNegBig, 0, 0)
+            const float om = __shfl_xor(mx[i], off);
+            const float os = __shfl_xor(acc[i], off);
+            const float o1 = __shfl_xor(w1[i], off);
+            const float nm = fmaxf(mx[i], om);
+            const float sa = fast_exp2(mx[i] - nm), sb = fast_exp2(om - nm);
+            acc[i] = acc[i] * sa + os * sb;
+            w1[i] = w1[i] * sa + o1 * sb;
+            if (SECOND) { const float o2 = __shfl_xor(w2[i], off); w2[i] = w2[i] * sa + o2 * sb; }
+            mx[i] = nm;
+          }
+        }
+      }
+
+      // ---- epilogue: group 0 writes the row ----
+      if (sub == 0 && cact) {
+        float o[VEC], ax[VEC], ax2[VEC];
+        int am[VEC];
+        const float inv = __builtin_amdgcn_rcpf((float)max(deg, 1));
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          ax[i] = 0.f; ax2[i] = 0.f; am[i] = -1;
+          if constexpr (AGGR == A_SUM) {
+            const float tot = kLateEps ? fmaf((float)deg, a.eps, acc[i]) : acc[i];
+            o[i] = a.mean ? tot * inv : tot;
+          } else if constexpr (AGGR == A_MAX) {
+            o[i] = (bpos[i] >= 0) ? acc[i] + (kLateEps ? a.eps : 0.f) : 0.f;
+            am[i] = bpos[i];
+          } else if constexpr (AGGR == A_SOFTMAX) {
+            if (deg > 0) {
+              const float rs = __builtin_amdgcn_rcpf(acc[i]);
+              const float o0 = w1[i] * rs;                       // sum_e w_e relu(z_e)
+              o[i] = o0 + a.eps;
+              // lse of t*(relu(z)+eps), sum_e w_e (relu(z_e)+eps)^2
+              ax[i] = mx[i] + fast_log2(acc[i]) + sc.t_log2e * a.eps;
+              ax2[i] = fmaf(a.eps, fmaf(2.f, o0, a.eps), w2[i] * rs);
+            } else { o[i] = 0.f; }
+          } else {  // POWER
+            const float mu = acc[i] * inv;
+            const float muc = fminf(fmaxf(mu, kPowLo), kPowHi);
+            o[i] = fast_exp2(fast_log2(muc) * __builtin_amdgcn_rcpf(sc.p));
+            ax[i] = mu;
+            ax2[i] = w2[i] * inv;
+          }
+        }
+        const size_t off = (size_t)r * a.d + c0;
+        if (a.add_root) {            // h = x_i + m_i (GENConv.forward, torch_vertex.py:89) in the same pass
+          float xr[VEC];
+          load_t<T, VEC>(xr, X + off);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] += xr[i];
+        }
+        store_t<T, VEC>(OUT + off, o);
+        if (AGGR == A_MAX && a.argmax) store_vec<VEC>(a.argmax + off, am);
+        if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_vec<VEC>(a.aux + off, ax);
+        if (SECOND && a.aux2) store_vec<VEC>(a.aux2 + off, ax2);
+      }
+    }
+  }
+}
+
+}  // namespace mlgnn
+
+using namespace mlgnn;
+
+extern "C" int mlgnn_version(void) { return MLGNN_ABI_VERSION; }
+
+extern "C" int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d) {
+  if (N < 0 || d < 0) return MLGNN_E_SHAPE;
+  return (int64_t)grid_for_rows(N) * 2 * d;
+}
+
+extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t* col,
+                                       const float* ew, const float* eu, const float* ev,
+                                       const void* efull, const int32_t* eid,
+                                       void* out, float* aux, float* aux2, int32_t* argmax,
+                                       int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                                       int aggr, float t, float p, const float* t_dev, const float* p_dev,
+                                       float eps, int add_root, void* stream) {
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
+  if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
+  if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;      // 32-bit row offsets: [N,d] tensors < 4 GiB
+  const int mode = pick_mode(msg, edge_mode);
+  const int ag = pick_aggr(aggr);
+  if (mode < 0 || ag < 0) return MLGNN_E_MODE;
+  if (!is_gen_mode(mode) && ag != A_SUM) return MLGNN_E_MODE;
+  if (N == 0) return 0;
+  if (!x || !rowptr || !out) return MLGNN_E_NULL;   // col may be NULL iff the graph has no edge
+  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew && col) return MLGNN_E_NULL;
+  if (mode == M_GEN_RANK1 && (!eu || !ev)) return MLGNN_E_NULL;
+  if (mode == M_GEN_FULL && col && (!efull || !eid)) return MLGNN_E_NULL;
+  if (ag == A_POWER && !p_dev && !(p != 0.0f)) return MLGNN_E_MODE;
+
+  FwdArgs a;
+  a.x = x; a.rowptr = rowptr; a.col = col; a.ew = ew; a.eu = eu; a.ev = ev;
+  a.efull = efull; a.eid = eid; a.out = out; a.aux = aux; a.aux2 = aux2;
+  a.argmax = argmax; a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN);
+  a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
+
+  const bool al = aligned16(x) && aligned16(out) && (!efull || aligned16(efull)) &&
+                  (!aux || aligned16(aux)) && (!aux2 || aligned16(aux2)) && (!argmax || aligned16(argmax)) &&
+                  (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  const bool bf16 = dtype == MLGNN_DTYPE_BF16;
+  // channels per lane: 16-byte accesses (4 x fp32 / 8 x bf16) when the width allows, scalar otherwise
+  const int vec = bf16 ? ((d % 8 == 0 && al) ? 8 : 1) : ((d % 4 == 0 && al) ? 4 : 1);
+  const dim3 grid(grid_for_rows(N)), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  const bool second = (aux2 != nullptr) && (ag == A_SOFTMAX || ag == A_POWER);
+  a.lpr_log2 = lanes_per_row_log2(d, vec);
+  for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
+    constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
+    constexpr bool kHasSecond = (AGGR == A_SOFTMAX || AGGR == A_POWER);
+    auto launch = [&](auto t_c, auto vec_c) {
+      using T = typename decltype(t_c)::type;
+      constexpr int VEC = decltype(vec_c)::value;
+      if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, kHasSecond>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, false>), grid, block, 0, s, a);
+    };
+    if (bf16) { if (vec == 8) launch(TypeTag<bf16_t>{}, IC<8>{}); else launch(TypeTag<bf16_t>{}, IC<1>{}); }
+    else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
+  });
+  return (int)hipGetLastError();
+}
+

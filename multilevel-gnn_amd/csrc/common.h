@@ -153,7 +153,7 @@ inline int lanes_per_row_log2(int64_t d, int vec) {
   return l;
 }
 
-// ws[nblk][cols] -> out[cols] in a fixed summation order (defined in aggregate.hip)
+// ws[nblk][cols] -> out[cols] in a fixed summation order (defined in aggregate_bwd.hip)
 void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream);
 
 }  // namespace mlgnn

@@ -73,3 +73,28 @@ def test_full_size_properties():
     xs = x[30000:40000].contiguous()
     alone = gen_aggregate(xs, g1, RankOneEdge(one.edge_attr[:, 0], u, v), aggr="softmax")
     assert_close(alone, sm[30000:40000], 1e-5, "graphs in a batch are independent")
+
+
+def test_three_level_gnn_full_size_graphs_match_oracle():
+    """BASELINE configs[1] at its real per-graph size (N=10 000, E=160 000, d=128, G=25 000), two graphs:
+    the oracle's literal [E,d] op sequence finishes in a few seconds on the CPU."""
+    from mlgnn import workload as W
+    from oracle import workload as OW
+    torch.manual_seed(11)
+    n, e, members = 10000, 160000, 25000
+    model = W.ThreeLevelGNN(hidden=128, aggr="softmax", n_members=members)
+    match, seg = W.membership(n, members)
+    cpu_batch = W.collate([5, 6], n, e, match, seg, "cpu")
+    sd = {k: v.detach().clone().requires_grad_(k != "pathway_adj") for k, v in model.state_dict().items()}
+    ref_loss = OW.training_loss(sd, cpu_batch, aggr="softmax")
+    names = [k for k, v in sd.items() if v.requires_grad]
+    ref_grads = dict(zip(names, torch.autograd.grad(ref_loss, [sd[k] for k in names], allow_unused=True)))
+    model.to("cuda:0")
+    loss = W.training_loss(model, W.collate([5, 6], n, e, match, seg, "cuda:0"))
+    assert_close(loss, ref_loss, 1e-4, "loss")
+    loss.backward()
+    for name, p in model.named_parameters():
+        g = ref_grads[name]
+        g = torch.zeros_like(sd[name]) if g is None else g
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert_close(got, g, 1e-4, "grad " + name)

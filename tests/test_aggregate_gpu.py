@@ -201,3 +201,24 @@ def test_add_root_fusion(aggr, d):
     assert_close(res[0][0], res[1][0], 1e-6, "fused root add fwd")
     for ga, gb in zip(res[0][1], res[1][1]):
         assert_close(ga, gb, 1e-5, "fused root add grad")
+
+
+def test_softmax_large_magnitudes_do_not_overflow():
+    """Messages of several hundred (t*m far beyond the exp range) must go through the running-max shift."""
+    from mlgnn import CSRGraph, gen_aggregate
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(9)
+    N, E, d = 200, 3000, 32
+    ei = _graph(gen, N, E, hub=True)
+    x = torch.randn(N, d, generator=gen) * 150.0
+    cot = torch.randn(N, d, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    ref = G.gen_aggregate(torch.relu(xr[ei[0]]) + 1e-7, ei[1], N, "softmax", t=2.0)
+    (ref * cot).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    out = gen_aggregate(xd, CSRGraph(ei.to(dev), N), None, aggr="softmax", t=2.0)
+    assert bool(torch.isfinite(out).all())
+    assert_close(out, ref, TOL, "large-magnitude softmax fwd")
+    (out * cot.to(dev)).sum().backward()
+    assert bool(torch.isfinite(xd.grad).all())
+    assert_close(xd.grad, xr.grad, TOL, "large-magnitude softmax grad")

@@ -6,9 +6,8 @@
 // whose output is 128x256: the library picks a 32x32-tile kernel without split-K (~39 TFLOP/s
 // measured).  Here the rows are split over the chip (one slab per workgroup), each wave keeps its
 // share of the [M,K] output in fp32 MFMA accumulators (v_mfma_f32_32x32x2_f32: exact fp32 FMA
-// chain), operands go straight from global memory into the MFMA operand registers (lane l of the
-// A operand = grad_out[row + (l>>5)][m0 + (l&31)]: each half-wave reads one full 128-B line), and
-// per-slab partials are summed in a fixed order by reduce_partials (bitwise reproducible).
+// chain), operand tiles are double-buffered through LDS, and per-slab partials are summed in a
+// fixed order by reduce_partials (bitwise reproducible).
 //
 // MFMA-bound: 2*N*M*K FLOP at the 157 TFLOP/s fp32-matrix peak; reads A and B once from HBM.
 #include "common.h"
@@ -18,16 +17,27 @@ namespace mlgnn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kTile = 32;
-constexpr int kWgUnroll = 4;      // k-steps (2 rows each) whose operand loads are issued together
 
 struct WgradArgs {
   const float* a; const float* b; float* ws;
   int N; int M; int K; int rows_per_block; int out_cols;   // out_cols = M*K + M
 };
 
-// wave layout WM x WK, tiles per wave TM x TK
-template <int WM, int WK, int TM, int TK>
+// wave layout WM x WK, tiles per wave TM x TK.  Row slab of the workgroup is walked in stages of
+// kStageRows rows: both operand tiles of a stage ([rows, M] of grad_out and [rows, K] of x, zero
+// padded to the tile grid) are fetched with 16-byte coalesced loads into registers while the previous
+// stage is being multiplied out of LDS, then written to the other LDS buffer (classic double
+// buffering; one barrier per stage).  MFMA operands are single ds_read_b32 per lane: lane l reads
+// tile[2*kk + (l>>5)][col0 + (l&31)] -- 32 consecutive floats per half-wave, conflict free.
+constexpr int kStageRows = 32;
+
+template <int WM, int WK, int TM, int TK, bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void linear_wgrad_kernel(const WgradArgs p) {
+  constexpr int MP = WM * TM * kTile, KP = WK * TK * kTile, W = MP + KP;   // padded operand widths
+  constexpr int kChunks = kStageRows * W / 4;                               // float4 chunks per stage
+  constexpr int kPerThread = (kChunks + kBlock - 1) / kBlock;
+  __shared__ float4 tile4[2][kStageRows * W / 4];
+
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   const int wm = wave / WK, wk = wave % WK;
@@ -45,36 +55,86 @@ __global__ __launch_bounds__(kBlock) void linear_wgrad_kernel(const WgradArgs p)
 #pragma unroll
   for (int i = 0; i < TM; ++i) bsum[i] = 0.f;
 
-  bool a_ok[TM], b_ok[TK];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) a_ok[i] = (m_base + i * kTile + l31) < p.M;
-#pragma unroll
-  for (int j = 0; j < TK; ++j) b_ok[j] = (k_base + j * kTile + l31) < p.K;
-
   const int r_begin = blockIdx.x * p.rows_per_block;
   const int r_end = min(p.N, r_begin + p.rows_per_block);
-  for (int r0 = r_begin; r0 < r_end; r0 += 2 * kWgUnroll) {
-    float av[kWgUnroll][TM], bv[kWgUnroll][TK];
+
+  float4 stage[kPerThread];
+  // global -> registers: chunk c covers columns [4*(c % (W/4)), +4) of stage row c / (W/4).
+  // ALIGNED (M % 4 == 0 and K % 4 == 0): straight-line code -- clamped addresses, unconditional 16-byte
+  // loads, zeroing by select -- so the loads stay in flight across the multiply (no control flow for the
+  // compiler's waitcnt insertion to be conservative about).
+  static_assert(kChunks % kBlock == 0, "stage must split evenly over the workgroup");
+  auto fetch = [&](int r0) {
 #pragma unroll
-    for (int u = 0; u < kWgUnroll; ++u) {
-      const int row = r0 + 2 * u + half;
-      const bool rok = row < r_end;
-      const float* ap = p.a + (size_t)row * p.M + m_base + l31;
-      const float* bp = p.b + (size_t)row * p.K + k_base + l31;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[u][i] = (rok && a_ok[i]) ? ap[i * kTile] : 0.f;
-#pragma unroll
-      for (int j = 0; j < TK; ++j) bv[u][j] = (rok && b_ok[j]) ? bp[j * kTile] : 0.f;
+    for (int q = 0; q < kPerThread; ++q) {
+      const int c = threadIdx.x + q * kBlock;
+      const int row = r0 + c / (W / 4);
+      const int col = (c % (W / 4)) * 4;
+      const bool is_a = col < MP;
+      const int cc = is_a ? col : col - MP;
+      const int width = is_a ? p.M : p.K;
+      if constexpr (ALIGNED) {
+        const bool live = (row < r_end) && (cc < width);
+        const int rc = min(row, p.N - 1), ccc = min(cc, width - 4);
+        const float4 v = *reinterpret_cast<const float4*>((is_a ? p.a : p.b) + (size_t)rc * width + ccc);
+        stage[q] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < r_end) {
+          const float* src = (is_a ? p.a : p.b) + (size_t)row * width + cc;
+          if (cc < width) v.x = src[0];
+          if (cc + 1 < width) v.y = src[1];
+          if (cc + 2 < width) v.z = src[2];
+          if (cc + 3 < width) v.w = src[3];
+        }
+        stage[q] = v;
+      }
     }
+  };
+  auto commit = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < kWgUnroll; ++u) {
+    for (int q = 0; q < kPerThread; ++q) {
+      tile4[buf][threadIdx.x + q * kBlock] = stage[q];
+    }
+  };
+  auto multiply = [&](int buf) {
+    const float* t = reinterpret_cast<const float*>(tile4[buf]);
+    // operands of k-step kk+1 are read from LDS while the MFMAs of k-step kk issue
+    float av[2][TM], bv[2][TK];
+    auto read_ops = [&](int set, int kk) {
+      const float* row = t + (2 * kk + half) * W;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[set][i] = row[m_base + i * kTile + l31];
+#pragma unroll
+      for (int j = 0; j < TK; ++j) bv[set][j] = row[MP + k_base + j * kTile + l31];
+    };
+    read_ops(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < kStageRows / 2; ++kk) {
+      const int cur = kk & 1;
+      if (kk + 1 < kStageRows / 2) read_ops(cur ^ 1, kk + 1);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        bsum[i] += av[u][i];
+        bsum[i] += av[cur][i];
 #pragma unroll
         for (int j = 0; j < TK; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
       }
+    }
+  };
+
+  if (r_begin < r_end) {
+    fetch(r_begin);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int r0 = r_begin; r0 < r_end; r0 += kStageRows) {
+      const bool more = r0 + kStageRows < r_end;
+      if (more) fetch(r0 + kStageRows);        // in flight while this stage is multiplied
+      multiply(buf);
+      if (more) commit(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
     }
   }
 
@@ -129,7 +189,8 @@ static int wgrad_blocks(int64_t N) {
 
 #define MLGNN_WG_CASE(WM_, WK_, TM_, TK_)                                                            \
   if (pl.wm == WM_ && pl.wk == WK_ && pl.tm == TM_ && pl.tk == TK_) {                                \
-    hipLaunchKernelGGL((linear_wgrad_kernel<WM_, WK_, TM_, TK_>), grid, block, 0, s, a);             \
+    if (aligned) hipLaunchKernelGGL((linear_wgrad_kernel<WM_, WK_, TM_, TK_, true>), grid, block, 0, s, a);   \
+    else hipLaunchKernelGGL((linear_wgrad_kernel<WM_, WK_, TM_, TK_, false>), grid, block, 0, s, a);        \
     launched = true;                                                                                 \
   }
 #define MLGNN_WG_LAYOUT(WM_, WK_)                                                                    \
@@ -164,11 +225,12 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, float* gr
   a.a = (const float*)grad_out; a.b = (const float*)x; a.ws = workspace;
   a.N = (int)N; a.M = (int)M; a.K = (int)K; a.out_cols = cols;
   int rpb = (int)((N + nblk - 1) / nblk);
-  rpb = (rpb + 2 * kWgUnroll - 1) / (2 * kWgUnroll) * (2 * kWgUnroll);
+  rpb = (rpb + kStageRows - 1) / kStageRows * kStageRows;
   a.rows_per_block = rpb;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(nblk), block(kBlock);
   bool launched = false;
+  const bool aligned = (M % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
   MLGNN_WG_LAYOUT(2, 2) MLGNN_WG_LAYOUT(4, 1) MLGNN_WG_LAYOUT(1, 4)
   if (!launched) return MLGNN_E_SHAPE;
   int err = (int)hipGetLastError();

@@ -204,13 +204,15 @@ int mlgnn_diffpool_fwd(const void* z, const void* adj, const void* s_logits, voi
  * (models/gcn_lib/sparse/torch_vertex.py:82,277) by one topology sort per batch.
  * edge_index [2,E] int64 row-major (row 0 = source j, row 1 = destination i), node ids in [0,N).
  * Outputs (int32): rowptr [N+1], col [E], eid [E], rowptr_t [N+1], col_t [E], pos_t [E], eid_t [E].
+ * bad_ids (nullable, int32[1]): number of node ids outside [0,N); such ids are clamped so that no
+ * later kernel reads out of bounds -- the caller decides when to look at the counter.
  * workspace: mlgnn_coo_to_csr_workspace_bytes(N, E) bytes.
  */
 int64_t mlgnn_coo_to_csr_workspace_bytes(int64_t N, int64_t E);
 int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
                      int32_t* rowptr, int32_t* col, int32_t* eid,
                      int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t,
-                     void* workspace, int64_t workspace_bytes, void* stream);
+                     int32_t* bad_ids, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * MsgNorm fused with GENConv's root add:  h = x + normalize(m, p=2, dim=1) * ||x||_2 * scale[0]

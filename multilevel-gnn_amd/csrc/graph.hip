@@ -13,10 +13,20 @@
 
 namespace mlgnn {
 
+// node ids outside [0, N) are clamped (the aggregation kernels must never read out of bounds) and
+// counted in *bad, which the host may inspect later (CSRGraph.validate) without a sync here
+__device__ __forceinline__ int checked_id(int64_t v, int N, int* bad) {
+  if (v < 0 || v >= N) {
+    if (bad) atomicAdd(bad, 1);
+    return v < 0 ? 0 : N - 1;
+  }
+  return (int)v;
+}
+
 __global__ void csr_prepare_kernel(const int64_t* __restrict__ key64, int* __restrict__ key32,
-                                   int* __restrict__ iota, int64_t n) {
+                                   int* __restrict__ iota, int64_t n, int N, int* bad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { key32[i] = (int)key64[i]; iota[i] = (int)i; }
+  if (i < n) { key32[i] = checked_id(key64[i], N, bad); iota[i] = (int)i; }
 }
 
 // rowptr[i] = first position whose sorted key is >= i  (keys sorted ascending, length n, rows N)
@@ -29,9 +39,9 @@ __global__ void csr_rowptr_kernel(const int* __restrict__ keys, int* __restrict_
 }
 
 __global__ void gather_i64_to_i32_kernel(const int64_t* __restrict__ src, const int* __restrict__ idx,
-                                         int* __restrict__ out, int64_t n) {
+                                         int* __restrict__ out, int64_t n, int N, int* bad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (int)src[idx[i]];
+  if (i < n) out[i] = checked_id(src[idx[i]], N, bad);
 }
 
 __global__ void iota_kernel(int* __restrict__ out, int64_t n) {
@@ -73,12 +83,13 @@ extern "C" int64_t mlgnn_coo_to_csr_workspace_bytes(int64_t N, int64_t E) {
 extern "C" int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
                                 int32_t* rowptr, int32_t* col, int32_t* eid,
                                 int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t,
-                                void* workspace, int64_t workspace_bytes, void* stream) {
+                                int32_t* bad_ids, void* workspace, int64_t workspace_bytes, void* stream) {
   if (N < 0 || E < 0 || N > INT32_MAX || E > INT32_MAX) return MLGNN_E_SHAPE;
   if (!rowptr || !rowptr_t) return MLGNN_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   const int threads = 256;
   const unsigned gE1 = (unsigned)((E + 1 + threads - 1) / threads);
+  if (bad_ids) (void)hipMemsetAsync(bad_ids, 0, 4, s);
   if (E == 0) {
     if (N >= 0) {
       (void)hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 4, s);
@@ -101,11 +112,11 @@ extern "C" int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
   const int64_t* dst64 = edge_index + E;
 
   // ---- by destination: stable sort of (dst, position) -------------------------------------------
-  hipLaunchKernelGGL(csr_prepare_kernel, dim3(gE), dim3(threads), 0, s, dst64, key_in, val_in, E);
+  hipLaunchKernelGGL(csr_prepare_kernel, dim3(gE), dim3(threads), 0, s, dst64, key_in, val_in, E, (int)N, bad_ids);
   hipError_t err = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key_in, key_out, val_in, eid, (int)E, 0, bits, s);
   if (err != hipSuccess) return (int)err;
   hipLaunchKernelGGL(csr_rowptr_kernel, dim3(gE1), dim3(threads), 0, s, key_out, rowptr, E, (int)N);
-  hipLaunchKernelGGL(gather_i64_to_i32_kernel, dim3(gE), dim3(threads), 0, s, src64, eid, col, E);
+  hipLaunchKernelGGL(gather_i64_to_i32_kernel, dim3(gE), dim3(threads), 0, s, src64, eid, col, E, (int)N, bad_ids);
   // dst in by-destination order stays in key_out until the second sort has consumed `col`;
   // copy it aside into key_in (free now) because the second sort overwrites key_out
   (void)hipMemcpyAsync(key_in, key_out, (size_t)E * 4, hipMemcpyDeviceToDevice, s);

@@ -30,7 +30,7 @@ SIGNATURES = {
     "mlgnn_diffpool_fwd_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_diffpool_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _P]),
     "mlgnn_coo_to_csr_workspace_bytes": (_I64, [_I64, _I64]),
-    "mlgnn_coo_to_csr": (_INT, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mlgnn_coo_to_csr": (_INT, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mlgnn_msgnorm_bwd_workspace_floats": (_I64, [_I64, _I64]),
     "mlgnn_msgnorm_add_fwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _INT, _P]),
     "mlgnn_msgnorm_add_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P]),

@@ -42,17 +42,28 @@ class CSRGraph:
         self.col_t, self.pos_t, self.eid_t = torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(E, **i32)
         nbytes = int(_lib.lib.mlgnn_coo_to_csr_workspace_bytes(N, E))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        self._bad_ids = torch.zeros(1, **i32)
         rc = _lib.lib.mlgnn_coo_to_csr(ei.data_ptr(), E, N, self.rowptr.data_ptr(), _lib.ptr(self.col),
                                        _lib.ptr(self.eid), self.rowptr_t.data_ptr(), _lib.ptr(self.col_t),
-                                       _lib.ptr(self.pos_t), _lib.ptr(self.eid_t), ws.data_ptr(), nbytes,
-                                       torch.cuda.current_stream().cuda_stream)
+                                       _lib.ptr(self.pos_t), _lib.ptr(self.eid_t), self._bad_ids.data_ptr(),
+                                       ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_coo_to_csr")
+
+    def validate(self):
+        """Raise if the edge list named a node outside ``[0, num_nodes)`` (the device build clamps such
+        ids and counts them; reading the counter synchronises, so this is opt-in)."""
+        bad = getattr(self, "_bad_ids", None)
+        if bad is not None and int(bad.item()) != 0:
+            raise ValueError("%d edge endpoints outside [0, %d)" % (int(bad.item()), self.num_nodes))
+        return self
 
     def _build_host(self, edge_index):
         """Same layout from torch ops on the CPU: for data-loader workers that pre-sort a batch
         (``batch.csr``) and for the host-side layout tests.  Never used for device tensors."""
         N = self.num_nodes
         src, dst = edge_index[0].long(), edge_index[1].long()
+        if edge_index.numel() and (int(edge_index.min()) < 0 or int(edge_index.max()) >= N):
+            raise ValueError("edge endpoints outside [0, %d)" % N)
         order = torch.sort(dst, stable=True).indices
         col = src[order]
         order_t = torch.sort(col, stable=True).indices

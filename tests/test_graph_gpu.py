@@ -32,3 +32,14 @@ def test_int32_edge_index_and_noncontiguous_input():
     dev = CSRGraph(ei.to("cuda:0").to(torch.int32), 50)
     for f in FIELDS:
         assert torch.equal(getattr(host, f), getattr(dev, f).cpu()), f
+
+
+def test_out_of_range_ids_are_clamped_and_reported():
+    from mlgnn import CSRGraph, gen_aggregate
+    ei = torch.tensor([[0, 1, 7, 2], [1, -3, 2, 0]], device="cuda:0")        # 7 and -3 are not nodes of a 4-node graph
+    g = CSRGraph(ei, 4)
+    out = gen_aggregate(torch.ones(4, 8, device="cuda:0"), g, None, aggr="add")   # must not fault
+    assert bool(torch.isfinite(out).all())
+    with pytest.raises(ValueError, match="outside"):
+        g.validate()
+    CSRGraph(torch.tensor([[0, 1], [1, 0]], device="cuda:0"), 2).validate()

@@ -26,7 +26,10 @@ class Membership:
             row = torch.where(gene_pca_match >= 0, row, torch.full_like(row, -1))
         else:
             row = torch.remainder(row, n_rows)              # negative index wraps like the reference's x[idx]
-        seg = (raw_indice.long() + offs * n_segments).reshape(-1)
+        # an index past the last node row would be an IndexError in the reference; here it must never
+        # become an out-of-bounds read, so it is treated as an absent member
+        row = torch.where(row >= n_rows, torch.full_like(row, -1), row)
+        seg = (raw_indice.long().clamp(0, n_segments - 1) + offs * n_segments).reshape(-1)
         row = row.reshape(-1)
         order = torch.sort(seg, stable=True).indices
         self.seg_mem = order.to(torch.int32)

@@ -199,6 +199,18 @@ int mlgnn_diffpool_fwd(const void* z, const void* adj, const void* s_logits, voi
                        int64_t K, int64_t C, int adj_batched, int dtype, void* stream);
 
 /*
+ * Backward of mlgnn_diffpool_fwd, one fused MFMA launch.  s_softmax = the forward's s_out;
+ * grad_x [B,K,C], grad_adj_out [B,K,K] = cotangents of x_out / adj_out;
+ * coef (device, float[2]) = { grad_link / (numel(adj) * ||adj - S S^T||_F),  grad_ent / (B*N) };
+ * outputs grad_z [B,N,C], grad_s [B,N,K] (w.r.t. the logits) and, when non-NULL, grad_adj [B,N,N]
+ * per batch element (the caller sums over the batch for a shared adjacency).
+ */
+int mlgnn_diffpool_bwd(const void* z, const void* adj, const void* s_softmax, const void* grad_x,
+                       const void* grad_adj_out, const float* coef, void* grad_z, void* grad_s,
+                       void* grad_adj, int64_t B, int64_t N, int64_t K, int64_t C,
+                       int adj_batched, int dtype, void* stream);
+
+/*
  * COO -> CSR (by destination) + transposed CSR (by source), on the device, stable in COO order.
  * Replaces: the per-layer gather/scatter index handling of MessagePassing.propagate
  * (models/gcn_lib/sparse/torch_vertex.py:82,277) by one topology sort per batch.

@@ -150,6 +150,152 @@ __global__ __launch_bounds__(kBlock) void diffpool_fwd_kernel(const DpArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward of the contraction, same one-workgroup-per-pooled-graph layout.  With S the saved softmax,
+// g = grad of X', h = grad of A', cl = grad_link / (numel * ||A - S S^T||_F), ce = grad_ent / (B N):
+//   dZ = S g
+//   dS = Z g^T + (A S) h^T + (A^T S) h - cl (A S + A^T S - 2 S (S^T S)) - ce (log(S + eps) + S / (S + eps))
+//   ds = S * (dS - rowsum(dS * S))                                   (softmax backward)
+//   dA = (S h) S^T + cl (A - S S^T)                                  (only when the adjacency needs it)
+// ((D + D^T) S with D = A - S S^T is expanded so that the [N,N] matrix D never has to be stored.)
+// LDS: S, A S, A^T S, dS (4 x 31 KB) + S^T S (9 KB); Z, g, h and A are read from global memory
+// directly in MFMA operand layout.
+// ------------------------------------------------------------------------------------------------
+struct DpBwdArgs {
+  const float* z; const float* adj; const float* s; const float* gx; const float* ga; const float* coef;
+  float* gz; float* gs; float* gadj;
+  int N; int K; int C; int adj_batched;
+};
+
+__global__ __launch_bounds__(kBlock) void diffpool_bwd_kernel(const DpBwdArgs p) {
+  __shared__ float S[kDpMaxN][kDpSK];
+  __shared__ float AS[kDpMaxN][kDpSK];
+  __shared__ float AtS[kDpMaxN][kDpSK];
+  __shared__ float GS[kDpMaxN][kDpSK];
+  __shared__ float SS[kDpMaxK][kDpSK];
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid / kWave;
+  const int N = p.N, K = p.K, C = p.C;
+  const float* zb = p.z + (size_t)b * N * C;
+  const float* sb = p.s + (size_t)b * N * K;
+  const float* ab = p.adj + (p.adj_batched ? (size_t)b * N * N : 0);
+  const float* gxb = p.gx + (size_t)b * K * C;
+  const float* gab = p.ga + (size_t)b * K * K;
+  const float cl = p.coef[0], ce = p.coef[1];
+  const int NP = (N + 15) & ~15, KP = (K + 15) & ~15;
+  const int Nt = NP / 16, Kt = KP / 16, Ct = (C + 15) / 16;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  for (int idx = tid; idx < NP * KP; idx += kBlock) {
+    const int r = idx / KP, k = idx % KP;
+    S[r][k] = (r < N && k < K) ? sb[(size_t)r * K + k] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- A S, A^T S  [N,K]  and  S^T S  [K,K] ------------------------------------------------------
+  for (int t = wave; t < 2 * Nt * Kt + Kt * Kt; t += kWavesPerBlock) {
+    if (t < 2 * Nt * Kt) {
+      const bool tr = t >= Nt * Kt;
+      const int tt = tr ? t - Nt * Kt : t;
+      const int i0 = (tt / Kt) * 16, j0 = (tt % Kt) * 16;
+      const f32x4 acc = tile_gemm(N,
+          [&](int i, int k) {
+            if (i0 + i >= N || k >= N) return 0.f;
+            return tr ? ab[(size_t)k * N + i0 + i] : ab[(size_t)(i0 + i) * N + k];
+          },
+          [&](int k, int j) { return k < N ? S[k][j0 + j] : 0.f; });
+#pragma unroll
+      for (int r = 0; r < 4; ++r) (tr ? AtS : AS)[i0 + lq * 4 + r][j0 + l15] = acc[r];
+    } else {
+      const int tt = t - 2 * Nt * Kt;
+      const int i0 = (tt / Kt) * 16, j0 = (tt % Kt) * 16;
+      const f32x4 acc = tile_gemm(N,
+          [&](int i, int k) { return k < N ? S[k][i0 + i] : 0.f; },
+          [&](int k, int j) { return k < N ? S[k][j0 + j] : 0.f; });
+#pragma unroll
+      for (int r = 0; r < 4; ++r) SS[i0 + lq * 4 + r][j0 + l15] = acc[r];
+    }
+  }
+  __syncthreads();
+
+  // ---- dS tiles [N,K] -----------------------------------------------------------------------------
+  for (int t = wave; t < Nt * Kt; t += kWavesPerBlock) {
+    const int i0 = (t / Kt) * 16, j0 = (t % Kt) * 16;
+    f32x4 acc = tile_gemm(C,                                                     // Z g^T
+        [&](int i, int k) { return (i0 + i < N && k < C) ? zb[(size_t)(i0 + i) * C + k] : 0.f; },
+        [&](int k, int j) { return (j0 + j < K && k < C) ? gxb[(size_t)(j0 + j) * C + k] : 0.f; });
+    const f32x4 t1 = tile_gemm(K,                                                // (A S) h^T
+        [&](int i, int k) { return k < KP ? AS[i0 + i][k] : 0.f; },
+        [&](int k, int j) { return (j0 + j < K && k < K) ? gab[(size_t)(j0 + j) * K + k] : 0.f; });
+    const f32x4 t2 = tile_gemm(K,                                                // (A^T S) h
+        [&](int i, int k) { return k < KP ? AtS[i0 + i][k] : 0.f; },
+        [&](int k, int j) { return (j0 + j < K && k < K) ? gab[(size_t)k * K + j0 + j] : 0.f; });
+    const f32x4 t3 = tile_gemm(K,                                                // S (S^T S)
+        [&](int i, int k) { return k < KP ? S[i0 + i][k] : 0.f; },
+        [&](int k, int j) { return k < KP ? SS[k][j0 + j] : 0.f; });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + lq * 4 + r, col = j0 + l15;
+      const float sv = S[row][col];
+      float g = acc[r] + t1[r] + t2[r] - cl * (AS[row][col] + AtS[row][col] - 2.f * t3[r]);
+      g -= ce * (__logf(sv + kDpEps) + sv / (sv + kDpEps));
+      GS[row][col] = (row < N && col < K) ? g : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- softmax backward, one thread per node row -------------------------------------------------
+  for (int r = tid; r < N; r += kBlock) {
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot = fmaf(GS[r][k], S[r][k], dot);
+    for (int k = 0; k < K; ++k) p.gs[((size_t)b * N + r) * K + k] = S[r][k] * (GS[r][k] - dot);
+  }
+
+  // ---- dZ = S g  [N,C] ----------------------------------------------------------------------------
+  for (int t = wave; t < Nt * Ct; t += kWavesPerBlock) {
+    const int i0 = (t / Ct) * 16, j0 = (t % Ct) * 16;
+    const f32x4 acc = tile_gemm(K,
+        [&](int i, int k) { return k < KP ? S[i0 + i][k] : 0.f; },
+        [&](int k, int j) { return (k < K && j0 + j < C) ? gxb[(size_t)k * C + j0 + j] : 0.f; });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + lq * 4 + r, col = j0 + l15;
+      if (row < N && col < C) p.gz[((size_t)b * N + row) * C + col] = acc[r];
+    }
+  }
+
+  // ---- dA = (S h) S^T + cl (A - S S^T)  [N,N] -------------------------------------------------------
+  if (p.gadj) {
+    __syncthreads();                       // AS is free now: reuse it for P = S h
+    for (int t = wave; t < Nt * Kt; t += kWavesPerBlock) {
+      const int i0 = (t / Kt) * 16, j0 = (t % Kt) * 16;
+      const f32x4 acc = tile_gemm(K,
+          [&](int i, int k) { return k < KP ? S[i0 + i][k] : 0.f; },
+          [&](int k, int j) { return (k < K && j0 + j < K) ? gab[(size_t)k * K + j0 + j] : 0.f; });
+#pragma unroll
+      for (int r = 0; r < 4; ++r) AS[i0 + lq * 4 + r][j0 + l15] = acc[r];
+    }
+    __syncthreads();
+    float* gb = p.gadj + (size_t)b * N * N;
+    for (int t = wave; t < Nt * Nt; t += kWavesPerBlock) {
+      const int i0 = (t / Nt) * 16, j0 = (t % Nt) * 16;
+      const f32x4 pst = tile_gemm(K,
+          [&](int i, int k) { return k < KP ? AS[i0 + i][k] : 0.f; },
+          [&](int k, int j) { return k < KP ? S[j0 + j][k] : 0.f; });
+      const f32x4 sst = tile_gemm(K,
+          [&](int i, int k) { return k < KP ? S[i0 + i][k] : 0.f; },
+          [&](int k, int j) { return k < KP ? S[j0 + j][k] : 0.f; });
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lq * 4 + r, col = j0 + l15;
+        if (row < N && col < N) gb[(size_t)row * N + col] = pst[r] + cl * (ab[(size_t)row * N + col] - sst[r]);
+      }
+    }
+  }
+}
+
 }  // namespace mlgnn
 
 using namespace mlgnn;
@@ -170,5 +316,22 @@ extern "C" int mlgnn_diffpool_fwd(const void* z, const void* adj, const void* s_
   a.s_out = (float*)s_out; a.x_out = (float*)x_out; a.a_out = (float*)adj_out; a.partial = partial;
   a.N = (int)N; a.K = (int)K; a.C = (int)C; a.adj_batched = adj_batched;
   hipLaunchKernelGGL(diffpool_fwd_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_diffpool_bwd(const void* z, const void* adj, const void* s_softmax, const void* grad_x,
+                                  const void* grad_adj_out, const float* coef, void* grad_z, void* grad_s,
+                                  void* grad_adj, int64_t B, int64_t N, int64_t K, int64_t C,
+                                  int adj_batched, int dtype, void* stream) {
+  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (B < 0 || B > INT32_MAX || !mlgnn_diffpool_fwd_supported(N, K, C)) return MLGNN_E_SHAPE;
+  if (B == 0) return 0;
+  if (!z || !adj || !s_softmax || !grad_x || !grad_adj_out || !coef || !grad_z || !grad_s) return MLGNN_E_NULL;
+  DpBwdArgs a;
+  a.z = (const float*)z; a.adj = (const float*)adj; a.s = (const float*)s_softmax;
+  a.gx = (const float*)grad_x; a.ga = (const float*)grad_adj_out; a.coef = coef;
+  a.gz = (float*)grad_z; a.gs = (float*)grad_s; a.gadj = (float*)grad_adj;
+  a.N = (int)N; a.K = (int)K; a.C = (int)C; a.adj_batched = adj_batched;
+  hipLaunchKernelGGL(diffpool_bwd_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

@@ -61,8 +61,7 @@ def dense_sage(x, adj, w_rel, w_root, b_root, normalize=True):
 
 
 class _DiffPoolFused(torch.autograd.Function):
-    """Forward: one fused MFMA launch (``mlgnn_diffpool_fwd``).  Backward: the closed-form
-    gradients below as batched library GEMMs (a fused backward kernel is future work)."""
+    """Forward and backward are one fused fp32-MFMA launch each (``mlgnn_diffpool_fwd`` / ``_bwd``)."""
 
     @staticmethod
     def forward(ctx, z, adj, s):
@@ -89,26 +88,22 @@ class _DiffPoolFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gx, ga, g_link, g_ent):
         z, adj, S, norm = ctx.saved_tensors
-        B, N, _ = z.shape
-        A = adj if adj.dim() == 3 else adj.unsqueeze(0)
-        St = S.transpose(1, 2)
-        gz = torch.matmul(S, gx)                                        # X' = S^T Z
-        gS = torch.matmul(z, gx.transpose(1, 2))
-        AS, AtS = torch.matmul(A, S), torch.matmul(A.transpose(1, 2), S)
-        gS = gS + torch.matmul(AS, ga.transpose(1, 2)) + torch.matmul(AtS, ga)   # A' = S^T A S
-        D = A - torch.matmul(S, St)                                     # link = ||D||_F / numel
-        coef = g_link / (adj.numel() * norm)
-        gS = gS - coef * torch.matmul(D + D.transpose(1, 2), S)
-        gS = gS - (g_ent / (B * N)) * (torch.log(S + DIFFPOOL_EPS) + S / (S + DIFFPOOL_EPS))   # entropy
-        gs = S * (gS - (gS * S).sum(-1, keepdim=True))                  # softmax
-        gA = None
-        if ctx.needs_input_grad[1]:
-            gA = torch.matmul(torch.matmul(S, ga), St) + coef * D
-            if adj.dim() == 2:
-                gA = gA.sum(0)
-            elif adj.shape[0] == 1 and B > 1:
-                gA = gA.sum(0, keepdim=True)
-        return gz, gA, gs
+        B, N, C = z.shape
+        K = S.shape[2]
+        batched = adj.dim() == 3 and adj.shape[0] == B and B > 1
+        coef = torch.stack([g_link / (adj.numel() * norm), g_ent / (B * N)]).to(torch.float32).contiguous()
+        gz = torch.empty_like(z)
+        gs = torch.empty_like(S)
+        need_adj = ctx.needs_input_grad[1]
+        gadj = torch.empty((B, N, N), dtype=z.dtype, device=z.device) if need_adj else None
+        gx, ga = gx.contiguous(), ga.contiguous()
+        rc = _lib.lib.mlgnn_diffpool_bwd(z.data_ptr(), adj.data_ptr(), S.data_ptr(), gx.data_ptr(), ga.data_ptr(),
+                                         coef.data_ptr(), gz.data_ptr(), gs.data_ptr(), _lib.ptr(gadj), B, N, K, C,
+                                         int(batched), 0, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_diffpool_bwd")
+        if need_adj and not batched:
+            gadj = gadj.sum(0, keepdim=True).reshape(adj.shape)          # shared adjacency
+        return gz, gadj, gs
 
 
 def _diff_pool_library(z, adj, s):

@@ -240,6 +240,17 @@ int mlgnn_msgnorm_add_bwd(const void* grad_h, const void* x, const void* m, cons
                           void* grad_x, void* grad_m, float* grad_scale, float* workspace,
                           int64_t workspace_floats, int64_t rows, int64_t d, int dtype, void* stream);
 
+/*
+ * Per-graph readout: out[b,:] = sum | mean | max over the rows [ptr[b], ptr[b+1]) of x.
+ * Replaces: global_{add,mean,max}_pool (models/deepergcn.py:148-155,319).  kind: 0 sum, 1 mean, 2 max;
+ * an empty graph gives 0; max also returns argmax [B,d] (row index, -1 when empty; first maximal row).
+ * x [N,d] fp32 with d % 4 == 0; workspace: mlgnn_segment_pool_workspace_bytes(B, d) bytes.
+ */
+int64_t mlgnn_segment_pool_workspace_bytes(int64_t B, int64_t d);
+int mlgnn_segment_pool_fwd(const void* x, const int32_t* ptr, void* out, int32_t* argmax,
+                           void* workspace, int64_t workspace_bytes, int64_t B, int64_t d,
+                           int kind, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

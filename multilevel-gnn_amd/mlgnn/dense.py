@@ -9,6 +9,25 @@ DIFFPOOL_EPS = 1e-15
 WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bottleneck
 
 
+def tall_matmul_nt(a, bt, bias=None):
+    """``a [N,R] @ bt[J,R]^T (+ bias)`` through the split-precision bf16-MFMA kernel (``csrc/tallgemm.hip``).
+    The caller checks :func:`tall_matmul_supported` first."""
+    N, R = a.shape
+    J = bt.shape[0]
+    a, bt = a.contiguous(), bt.contiguous()
+    out = torch.empty((N, J), dtype=torch.float32, device=a.device)
+    nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(R, J))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+    rc = _lib.lib.mlgnn_tallgemm_nt(a.data_ptr(), bt.data_ptr(), _lib.ptr(bias), out.data_ptr(), ws.data_ptr(),
+                                    nbytes, N, R, J, 0, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mlgnn_tallgemm_nt")
+    return out
+
+
+def tall_matmul_supported(N, R, J):
+    return bool(_lib.lib.mlgnn_tallgemm_supported(N, R, J))
+
+
 class _TallLinear(torch.autograd.Function):
     """``y = x W^T + b`` for a tall ``x [N, K]``: forward and ``dX`` are library GEMMs, the
     weight/bias gradient (reduction over the N node rows) is the split-row fp32-MFMA kernel."""
@@ -17,6 +36,8 @@ class _TallLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if tall_matmul_supported(x.shape[0], x.shape[1], weight.shape[0]):
+            return tall_matmul_nt(x, weight, bias.contiguous() if bias is not None else None)
         # addmm on the transposed view picks a faster library kernel than F.linear for these tall
         # shapes (tools/bench_gemm.py: 0.41 vs 0.45 ms at [640k,128] x [128,256])
         return torch.addmm(bias, x, weight.t()) if bias is not None else torch.mm(x, weight.t())
@@ -27,7 +48,12 @@ class _TallLinear(torch.autograd.Function):
         go = go.contiguous()
         N, K = x.shape
         M = weight.shape[0]
-        gx = go.matmul(weight) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if tall_matmul_supported(N, M, K):
+                gx = tall_matmul_nt(go, weight.t().contiguous())          # go [N,M] @ (W^T)[K,M]^T
+            else:
+                gx = go.matmul(weight)
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K))

@@ -1,0 +1,49 @@
+"""Split-precision (bf16 x 3) tall GEMM on the bf16 matrix cores vs fp64: layout exactness on integer
+data, error statistics on random data (must sit far inside the 1e-4 parity budget)."""
+import pytest
+import torch
+
+from _util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,R,J", [(33, 16, 32), (1000, 128, 256), (4097, 256, 128), (70000, 128, 128),
+                                   (5000, 64, 64), (9999, 48, 32), (2048, 512, 64)])
+def test_layout_is_exact_on_small_integers(N, R, J):
+    """Small integers are exact in bf16, so any wrong lane/row/column mapping shows up as an exact mismatch."""
+    from mlgnn.dense import tall_matmul_nt, tall_matmul_supported
+    assert tall_matmul_supported(N, R, J)
+    gen = torch.Generator().manual_seed(N)
+    a = torch.randint(-4, 5, (N, R), generator=gen).float()
+    bt = torch.randint(-3, 4, (J, R), generator=gen).float()
+    bt[:, 0] += torch.arange(J) % 5                              # asymmetric: a transposed tile cannot pass
+    bias = torch.randint(-2, 3, (J,), generator=gen).float()
+    ref = a @ bt.t() + bias
+    out = tall_matmul_nt(a.cuda(), bt.cuda(), bias.cuda())
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-4, 300.0])
+def test_split_precision_error(scale):
+    from mlgnn.dense import tall_matmul_nt
+    gen = torch.Generator().manual_seed(1)
+    N, R, J = 20000, 256, 128
+    a = torch.randn(N, R, generator=gen) * scale
+    bt = torch.randn(J, R, generator=gen) * 0.1
+    ref = a.double() @ bt.double().t()
+    out = tall_matmul_nt(a.cuda(), bt.cuda()).cpu().double()
+    lib = (a.cuda() @ bt.cuda().t()).cpu().double()
+    denom = float(ref.abs().max())
+    err = float((out - ref).abs().max()) / denom
+    err_lib = float((lib - ref).abs().max()) / denom
+    rms = float((out - ref).pow(2).mean().sqrt()) / float(ref.pow(2).mean().sqrt())
+    print("bf16x3 max err %.2e (rms %.2e), fp32 library %.2e" % (err, rms, err_lib))
+    assert err < 1e-5 and rms < 3e-6
+
+
+def test_unsupported_shapes_are_reported():
+    from mlgnn.dense import tall_matmul_supported
+    assert not tall_matmul_supported(1000, 128, 96)          # J not a power-of-two multiple of 32
+    assert not tall_matmul_supported(1000, 100, 64)          # R % 16
+    assert not tall_matmul_supported(1000, 512, 256)         # weight image > 128 KiB

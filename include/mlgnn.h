@@ -252,10 +252,12 @@ int mlgnn_segment_pool_fwd(const void* x, const int32_t* ptr, void* out, int32_t
                            int kind, int dtype, void* stream);
 
 /*
- * Tall-skinny fp32 GEMM on the bf16 matrix cores with 3-way split precision (bf16x3, fp32 accumulate):
- *   c[N,J] = a[N,R] * bt[J,R]^T (+ bias[J]),  N >> R,J;  R % 16 == 0, J in {32,64,128,256}, R*J*4 <= 128 KiB
+ * Tall-skinny fp32 GEMM on the fp16 matrix cores with power-of-two scaled hi/lo split precision
+ * (3 MFMAs per product, fp32 accumulate):
+ *   c[N,J] = a[N,R] * bt[J,R]^T (+ bias[J]),  N >> R,J;  R in {16,32,64,128,256}, J in {32,64,128,256},
+ *   R*J*4 <= 128 KiB
  * Replaces: forward and input gradient of the nn.Linear layers of MLP
- * (models/gcn_lib/sparse/torch_nn.py:54-75).  Relative error per product <= 3*2^-18 (see csrc/tallgemm.hip).
+ * (models/gcn_lib/sparse/torch_nn.py:54-75).  Relative error per product <= 3*2^-22 (see csrc/tallgemm.hip).
  * workspace: mlgnn_tallgemm_workspace_bytes(R, J) bytes (split weight image).
  */
 int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J);

@@ -1,79 +1,137 @@
-// Tall-skinny fp32 GEMM on the bf16 matrix cores with 3-way split precision:
+// Tall-skinny fp32 GEMM on the fp16 matrix cores with scaled 2-way split precision:
 //     C[N,J] = A[N,R] * Bt[J,R]^T (+ bias[J]),     N >> R, J  (R, J <= 256)
 //
 // Reference: the nn.Linear layers of MLP (models/gcn_lib/sparse/torch_nn.py:54-75) applied to every
 // node row -- forward (A = activations, Bt = weight) and input gradient (A = grad_out, Bt = weight^T).
-// The fp32 MFMA runs at 1/16 of the bf16 rate, and a 640 000 x 128 x 256 product is MFMA-bound on it
-// (~0.4 ms on the library); in bf16 the same product is HBM-bound.  Each fp32 operand is split as
-//   a = a_hi + a_lo,  a_hi = bf16(a),  a_lo = bf16(a - a_hi)        (|a - a_hi - a_lo| <= 2^-18 |a|)
-// and the product is accumulated in fp32 from three MFMAs: a_hi b_hi + a_lo b_hi + a_hi b_lo
-// (dropped: a_lo b_lo <= 2^-18 |ab|).  Worst-case relative error per product 3 * 2^-18 = 1.1e-5,
-// ~4e-6 typical -- inside the 1e-4 parity budget (tests hold the layer and model outputs to it).
+// The fp32 MFMA runs at 1/16 of the 16-bit rate, and a 640 000 x 128 x 256 product is MFMA-bound on it
+// (~0.4 ms on the library); on the 16-bit cores the same product is HBM-bound.
+//
+// Numerics.  Every operand is first scaled by an exact power of two so that its largest magnitude lands
+// in [2^13, 2^14) -- per ROW for A (the row maximum is known once the wave holds the row), globally for
+// Bt -- and then split  x = x_hi + x_lo,  x_hi = fp16(x),  x_lo = fp16(x - x_hi).  With the scaling
+// x_lo stays a normal fp16 number for every element within 2^-17 of the maximum, so
+// |x - x_hi - x_lo| <= 2^-22 |x| there and <= 2^-39 max|x| below.  The product is accumulated in fp32
+// from three MFMAs, a_hi b_hi + a_lo b_hi + a_hi b_lo (each 11 x 11 bit product is exact in fp32; the
+// dropped a_lo b_lo is <= 2^-22 |ab|), and un-scaled by the exact powers of two: relative error per
+// product <= 3 * 2^-22 = 7e-7, the size of fp32 rounding in an ordinary fp32 GEMM.  (A bf16 x 3 split
+// was measured first: 4.4e-6 rms, which cost a bias gradient summed over 493 000 rows its 1e-4 parity.)
 //
 // Persistent workgroups (one per CU): the split weight (J*R*4 bytes, <= 128 KB) sits in LDS for the
-// whole launch, already in MFMA B-fragment order; each wave streams 32-row tiles of A straight from
-// global memory (two 16-byte loads per lane and k-step, next k-step prefetched), splits them in
-// registers and issues 3 MFMAs (v_mfma_f32_32x32x16_bf16) per 32-column tile and k-step.
+// whole launch, already in MFMA B-fragment order; each wave streams its 32-row tile of A twice with
+// 16-byte loads (lane l = row l&31, k-half l>>5): once for the row maxima, once -- from L1/L2 -- through
+// the k-step loop that scales, splits and issues 3 MFMAs (v_mfma_f32_32x32x16_f16) per 32-column tile.
 // HBM-bound: reads N*R*4, writes N*J*4.
 #include "common.h"
 #include "mlgnn.h"
 
 namespace mlgnn {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kTgMaxLds = 128 * 1024;      // split weight image
+constexpr int kTgHeader = 4;               // f16x8 slots (64 B) in front of the image: [0] = 1 / weight scale
 
-// Bt [J,R] fp32 -> frag[kstep][tile][hi|lo][lane][8] bf16: lane l of tile t, k-step s holds
-// Bt[32 t + (l & 31)][16 s + 8 (l >> 5) + j], j = 0..7  (B operand of v_mfma_f32_32x32x16_bf16)
-__global__ void tallgemm_split_weight_kernel(const float* __restrict__ bt, bf16x8* __restrict__ frag,
-                                             int J, int R) {
+// power of two s with  max * s in [2^13, 2^14)  and its inverse; max = 0 or denormal -> 1
+__device__ __forceinline__ void pow2_scale(float max_abs, float& s, float& inv) {
+  int e = (int)((__builtin_bit_cast(uint32_t, max_abs) >> 23) & 0xff);       // biased exponent
+  e = min(max(e, 20), 234);
+  s = __builtin_bit_cast(float, (uint32_t)(254 + 13 - e) << 23);             // 2^(13 - (e - 127))
+  inv = __builtin_bit_cast(float, (uint32_t)(e - 13) << 23);                 // 2^((e - 127) - 13)
+}
+
+// one workgroup: max |Bt| -> header
+__global__ __launch_bounds__(kBlock) void tallgemm_weight_scale_kernel(const float* __restrict__ bt, float* header,
+                                                                       int n) {
+  __shared__ float red[kBlock];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) m = fmaxf(m, fabsf(bt[i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float s, inv;
+    pow2_scale(red[0], s, inv);
+    header[0] = inv;
+    header[1] = s;
+  }
+}
+
+// Bt [J,R] fp32 -> frag[kstep][tile][hi|lo][lane][8] fp16: lane l of tile t, k-step s holds
+// Bt[32 t + (l & 31)][16 s + 8 (l >> 5) + j] * scale, j = 0..7  (B operand of v_mfma_f32_32x32x16_f16)
+__global__ void tallgemm_split_weight_kernel(const float* __restrict__ bt, f16x8* __restrict__ image, int J, int R) {
   const int tiles = J / 32, ksteps = R / 16;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (kstep, tile, lane)
   if (idx >= ksteps * tiles * 64) return;
+  const float scale = reinterpret_cast<const float*>(image)[1];
   const int lane = idx & 63, t = (idx >> 6) % tiles, s = (idx >> 6) / tiles;
   const float* src = bt + (size_t)(32 * t + (lane & 31)) * R + 16 * s + 8 * (lane >> 5);
-  bf16x8 hi, lo;
+  f16x8 hi, lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float v = src[j];
-    const __bf16 h = (__bf16)v;
+    const float v = src[j] * scale;
+    const _Float16 h = (_Float16)v;
     hi[j] = h;
-    lo[j] = (__bf16)(v - (float)h);
+    lo[j] = (_Float16)(v - (float)h);
   }
-  const size_t base = ((size_t)(s * tiles + t) * 2) * 64 + lane;
-  frag[base] = hi;
-  frag[base + 64] = lo;
+  const size_t base = kTgHeader + ((size_t)(s * tiles + t) * 2) * 64 + lane;
+  image[base] = hi;
+  image[base + 64] = lo;
 }
 
 struct TgArgs {
-  const float* a; const bf16x8* wfrag; const float* bias; float* c;
+  const float* a; const f16x8* image; const float* bias; float* c;
   int N; int R; int J;
 };
 
-template <int JT>       // 32-column tiles per wave = J / 32
-__global__ __launch_bounds__(kBlock) void tallgemm_kernel(const TgArgs p) {
-  extern __shared__ bf16x8 wlds[];
+constexpr int kTgBlock = 512;              // 8 waves: two per SIMD share the LDS image and hide each other's loads
+constexpr int kTgWaves = kTgBlock / kWave;
+
+template <int JT, int KS>       // 32-column tiles = J / 32, 16-deep k-steps = R / 16
+__global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
+  extern __shared__ f16x8 wlds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  const int ksteps = p.R / 16;
   const int r31 = lane & 31, h = lane >> 5;
+  constexpr int R = 16 * KS;
 
   // the split weight, once per workgroup
-  const int n_frag = ksteps * JT * 2 * 64;
-  for (int i = threadIdx.x; i < n_frag; i += kBlock) wlds[i] = p.wfrag[i];
+  constexpr int n_frag = KS * JT * 2 * 64;
+  for (int i = threadIdx.x; i < n_frag; i += kTgBlock) wlds[i] = p.image[kTgHeader + i];
   __syncthreads();
+  const float inv_b = reinterpret_cast<const float*>(p.image)[0];
 
   float bias[JT];
 #pragma unroll
   for (int t = 0; t < JT; ++t) bias[t] = p.bias ? p.bias[32 * t + r31] : 0.f;
 
   const int n_tiles = (p.N + 31) / 32;                       // 32-row tiles, dealt round robin to the waves
-  for (int tile = blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
+  const int t_stride = gridDim.x * kTgWaves;
+
+  // Lane l owns half of row l & 31: k = 16 s + 8 (l >> 5) + j.  Two passes over the wave's 32-row tile:
+  // (1) stream the rows once for the row maxima (nothing is kept -- holding a whole 1 KB row per lane
+  // spills); (2) the k-step loop re-reads them (the tile is 16-32 KB: L1 / L2 hits), scales, splits and
+  // multiplies, with the next k-step's 32 bytes per lane prefetched.
+  for (int tile = blockIdx.x * kTgWaves + wave; tile < n_tiles; tile += t_stride) {
     const int row0 = tile * 32;
     const int arow = min(row0 + r31, p.N - 1);                 // rows past N re-read the last row, never stored
-    const float* ap = p.a + (size_t)arow * p.R + 8 * h;
+    const float* ap = p.a + (size_t)arow * R + 8 * h;
+
+    float m = 0.f;
+#pragma unroll 2
+    for (int s = 0; s < KS; ++s) {
+      const float4 q0 = *reinterpret_cast<const float4*>(ap + 16 * s);
+      const float4 q1 = *reinterpret_cast<const float4*>(ap + 16 * s + 4);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w))));
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));                            // the other half of the row
+    float sa, inv_a;
+    pow2_scale(m, sa, inv_a);
+    const float unscale = inv_a * inv_b;
 
     f32x16 acc[JT];
 #pragma unroll
@@ -83,39 +141,51 @@ __global__ __launch_bounds__(kBlock) void tallgemm_kernel(const TgArgs p) {
 
     float4 n0 = *reinterpret_cast<const float4*>(ap);
     float4 n1 = *reinterpret_cast<const float4*>(ap + 4);
-    for (int s = 0; s < ksteps; ++s) {
-      const float v[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
-      if (s + 1 < ksteps) {                                    // prefetch the next k-step of this row
+#pragma unroll 1                                               // keep ONE k-step of A live: a full unroll spills
+    for (int s = 0; s < KS; ++s) {
+      const float e[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+      if (s + 1 < KS) {
         n0 = *reinterpret_cast<const float4*>(ap + 16 * (s + 1));
         n1 = *reinterpret_cast<const float4*>(ap + 16 * (s + 1) + 4);
       }
-      bf16x8 ahi, alo;
+      f16x8 ahi, alo;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const __bf16 hh = (__bf16)v[j];
+        const float x = e[j] * sa;
+        const _Float16 hh = (_Float16)x;
         ahi[j] = hh;
-        alo[j] = (__bf16)(v[j] - (float)hh);
+        alo[j] = (_Float16)(x - (float)hh);
       }
-      const bf16x8* wf = wlds + (size_t)(s * JT) * 2 * 64 + lane;
+      const f16x8* wf = wlds + (size_t)(s * JT) * 2 * 64 + lane;
 #pragma unroll
       for (int t = 0; t < JT; ++t) {
-        const bf16x8 bhi = wf[t * 128];
-        const bf16x8 blo = wf[t * 128 + 64];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[t], 0, 0, 0);
+        const f16x8 bhi = wf[t * 128];
+        const f16x8 blo = wf[t * 128 + 64];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[t], 0, 0, 0);
       }
     }
 
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);
+    // the row scale lives in the lane that loaded that row
 #pragma unroll
-    for (int t = 0; t < JT; ++t)
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float us = __shfl(unscale, rr);
+      const int row = row0 + rr;
+      if (row < p.N) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < p.N) p.c[(size_t)row * p.J + 32 * t + r31] = acc[t][r] + bias[t];
+        for (int t = 0; t < JT; ++t) p.c[(size_t)row * p.J + 32 * t + r31] = fmaf(acc[t][r], us, bias[t]);
       }
+    }
   }
+}
+
+static bool tg_dims_ok(int64_t R, int64_t J) {
+  const bool j_ok = (J == 32 || J == 64 || J == 128 || J == 256);
+  const bool r_ok = (R == 16 || R == 32 || R == 64 || R == 128 || R == 256);
+  return j_ok && r_ok && R * J * 4 <= kTgMaxLds;
 }
 
 }  // namespace mlgnn
@@ -123,14 +193,13 @@ __global__ __launch_bounds__(kBlock) void tallgemm_kernel(const TgArgs p) {
 using namespace mlgnn;
 
 extern "C" int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J) {
-  const bool j_ok = (J == 32 || J == 64 || J == 128 || J == 256);
-  return (N > 0 && R >= 16 && R % 16 == 0 && R <= 1024 && j_ok && R * J * 4 <= kTgMaxLds) ? 1 : 0;
+  return (N > 0 && N <= INT32_MAX && tg_dims_ok(R, J)) ? 1 : 0;
 }
 
-// workspace: the split weight image, R*J*4 bytes
+// workspace: header + the split weight image
 extern "C" int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J) {
   if (R <= 0 || J <= 0) return MLGNN_E_SHAPE;
-  return R * J * 4;
+  return R * J * 4 + kTgHeader * 16;
 }
 
 extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, void* c, void* workspace,
@@ -139,34 +208,39 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   if (N < 0 || N > INT32_MAX) return MLGNN_E_SHAPE;
   if (N == 0) return 0;
-  if (!mlgnn_tallgemm_supported(N, R, J)) return MLGNN_E_SHAPE;
+  if (!tg_dims_ok(R, J)) return MLGNN_E_SHAPE;
   if (!a || !bt || !c || !workspace) return MLGNN_E_NULL;
-  if (workspace_bytes < R * J * 4) return MLGNN_E_WORKSPACE;
+  if (workspace_bytes < R * J * 4 + kTgHeader * 16) return MLGNN_E_WORKSPACE;
   if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0) return MLGNN_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tallgemm_weight_scale_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)bt,
+                     (float*)workspace, (int)(R * J));
   const int n_frag_lanes = (int)(R / 16) * (int)(J / 32) * 64;
   hipLaunchKernelGGL(tallgemm_split_weight_kernel, dim3((n_frag_lanes + 255) / 256), dim3(256), 0, s,
-                     (const float*)bt, (bf16x8*)workspace, (int)J, (int)R);
+                     (const float*)bt, (f16x8*)workspace, (int)J, (int)R);
   int err = (int)hipGetLastError();
   if (err) return err;
   TgArgs p;
-  p.a = (const float*)a; p.wfrag = (const bf16x8*)workspace; p.bias = bias; p.c = (float*)c;
+  p.a = (const float*)a; p.image = (const f16x8*)workspace; p.bias = bias; p.c = (float*)c;
   p.N = (int)N; p.R = (int)R; p.J = (int)J;
   const size_t lds = (size_t)R * J * 4;
   const int64_t tiles = (N + 31) / 32;
-  int grid = (int)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  int grid = (int)((tiles + kTgWaves - 1) / kTgWaves);
   if (grid > 256) grid = 256;                      // persistent: one workgroup per CU
-  const dim3 g(grid), b(kBlock);
-#define MLGNN_TG_LAUNCH(JT_)                                                                          \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_>),                     \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds);                   \
-  hipLaunchKernelGGL((tallgemm_kernel<JT_>), g, b, lds, s, p);
-  switch (J / 32) {
-    case 1: MLGNN_TG_LAUNCH(1) break;
-    case 2: MLGNN_TG_LAUNCH(2) break;
-    case 4: MLGNN_TG_LAUNCH(4) break;
-    default: MLGNN_TG_LAUNCH(8) break;
+  const dim3 g(grid), b(kTgBlock);
+  bool launched = false;
+#define MLGNN_TG_CASE(JT_, KS_)                                                                       \
+  if (!launched && J == 32 * JT_ && R == 16 * KS_) {                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_>),              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds);                 \
+    hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_>), g, b, lds, s, p);                                  \
+    launched = true;                                                                                  \
   }
-#undef MLGNN_TG_LAUNCH
+#define MLGNN_TG_ROW(JT_) MLGNN_TG_CASE(JT_, 1) MLGNN_TG_CASE(JT_, 2) MLGNN_TG_CASE(JT_, 4) MLGNN_TG_CASE(JT_, 8)
+  MLGNN_TG_ROW(1) MLGNN_TG_ROW(2) MLGNN_TG_ROW(4) MLGNN_TG_ROW(8)
+  MLGNN_TG_CASE(1, 16) MLGNN_TG_CASE(2, 16) MLGNN_TG_CASE(4, 16)          // 256 x 256 exceeds the LDS image
+#undef MLGNN_TG_ROW
+#undef MLGNN_TG_CASE
+  if (!launched) return MLGNN_E_SHAPE;
   return (int)hipGetLastError();
 }

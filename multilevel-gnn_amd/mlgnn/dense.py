@@ -10,7 +10,7 @@ WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bot
 
 
 def tall_matmul_nt(a, bt, bias=None):
-    """``a [N,R] @ bt[J,R]^T (+ bias)`` through the split-precision bf16-MFMA kernel (``csrc/tallgemm.hip``).
+    """``a [N,R] @ bt[J,R]^T (+ bias)`` through the scaled split-precision fp16-MFMA kernel (``csrc/tallgemm.hip``).
     The caller checks :func:`tall_matmul_supported` first."""
     N, R = a.shape
     J = bt.shape[0]

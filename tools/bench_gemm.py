@@ -44,6 +44,10 @@ for (K, O) in [(128, 256), (256, 128), (3, 128)]:
     st = torch.cuda.current_stream().cuda_stream
     r["mlgnn_linear_wgrad"] = timed(lambda: _lib.lib.mlgnn_linear_wgrad(go.data_ptr(), x.data_ptr(), outb.data_ptr(),
                                                                          ws.data_ptr(), n, N, O, K, 0, st))
+    from mlgnn.dense import tall_matmul_nt, tall_matmul_supported
+    if tall_matmul_supported(N, K, O):
+        r["tallgemm fwd (x,W,b)"] = timed(lambda: tall_matmul_nt(x, W, b))
+        r["tallgemm dX (go,Wt)"] = timed(lambda: tall_matmul_nt(go, Wt))
     print("K=%d O=%d  (%.1f GFLOP)" % (K, O, fl))
     for k, v in r.items():
         print("   %-18s %7.3f ms  %6.1f TF/s" % (k, v, fl / v))

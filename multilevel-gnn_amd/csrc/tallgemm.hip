@@ -40,33 +40,33 @@ __device__ __forceinline__ void pow2_scale(float max_abs, float& s, float& inv) 
   inv = __builtin_bit_cast(float, (uint32_t)(e - 13) << 23);                 // 2^((e - 127) - 13)
 }
 
-// one workgroup: max |Bt| -> header
-__global__ __launch_bounds__(kBlock) void tallgemm_weight_scale_kernel(const float* __restrict__ bt, float* header,
-                                                                       int n) {
-  __shared__ float red[kBlock];
-  float m = 0.f;
-  for (int i = threadIdx.x; i < n; i += kBlock) m = fmaxf(m, fabsf(bt[i]));
-  red[threadIdx.x] = m;
-  __syncthreads();
-  for (int off = kBlock / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    float s, inv;
-    pow2_scale(red[0], s, inv);
-    header[0] = inv;
-    header[1] = s;
-  }
-}
-
 // Bt [J,R] fp32 -> frag[kstep][tile][hi|lo][lane][8] fp16: lane l of tile t, k-step s holds
-// Bt[32 t + (l & 31)][16 s + 8 (l >> 5) + j] * scale, j = 0..7  (B operand of v_mfma_f32_32x32x16_f16)
-__global__ void tallgemm_split_weight_kernel(const float* __restrict__ bt, f16x8* __restrict__ image, int J, int R) {
+// Bt[32 t + (l & 31)][16 s + 8 (l >> 5) + j] * scale, j = 0..7  (B operand of v_mfma_f32_32x32x16_f16).
+// Every workgroup first reduces max |Bt| over the whole (<= 128 KB, L2 resident) weight itself -- cheaper
+// than a separate one-workgroup launch in front -- and workgroup 0 records 1/scale in the header.
+__global__ __launch_bounds__(kBlock) void tallgemm_split_weight_kernel(const float* __restrict__ bt,
+                                                                       f16x8* __restrict__ image, int J, int R) {
+  __shared__ float red[kWavesPerBlock];
+  const int n4 = J * R / 4;                                     // R % 16 == 0
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n4; i += kBlock) {
+    const float4 q = reinterpret_cast<const float4*>(bt)[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w))));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < kWavesPerBlock; ++w) m = fmaxf(m, red[w]);
+  float scale, inv;
+  pow2_scale(m, scale, inv);
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(image)[0] = inv;
+
   const int tiles = J / 32, ksteps = R / 16;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (kstep, tile, lane)
   if (idx >= ksteps * tiles * 64) return;
-  const float scale = reinterpret_cast<const float*>(image)[1];
   const int lane = idx & 63, t = (idx >> 6) % tiles, s = (idx >> 6) / tiles;
   const float* src = bt + (size_t)(32 * t + (lane & 31)) * R + 16 * s + 8 * (lane >> 5);
   f16x8 hi, lo;
@@ -211,10 +211,9 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
   if (!tg_dims_ok(R, J)) return MLGNN_E_SHAPE;
   if (!a || !bt || !c || !workspace) return MLGNN_E_NULL;
   if (workspace_bytes < R * J * 4 + kTgHeader * 16) return MLGNN_E_WORKSPACE;
-  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0) return MLGNN_E_ALIGN;
+  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bt) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
+    return MLGNN_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(tallgemm_weight_scale_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)bt,
-                     (float*)workspace, (int)(R * J));
   const int n_frag_lanes = (int)(R / 16) * (int)(J / 32) * 64;
   hipLaunchKernelGGL(tallgemm_split_weight_kernel, dim3((n_frag_lanes + 255) / 256), dim3(256), 0, s,
                      (const float*)bt, (f16x8*)workspace, (int)J, (int)R);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 1
+#define MLGNN_ABI_VERSION 2
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -44,8 +44,9 @@ extern "C" {
 
 /* edge term e_e of MLGNN_MSG_GEN */
 #define MLGNN_EDGE_NONE  0    /* e_e = 0                                                         */
-#define MLGNN_EDGE_RANK1 1    /* e_e[c] = a_e*u[c] + v[c]: scalar raw attribute through the two  *
-                               * stacked Linear encoders deepergcn.py:90,213 + torch_vertex.py:68,77 */
+#define MLGNN_EDGE_RANK1 1    /* e_e[c] = sum_k a_e[k]*U[k][c] + v[c]: edge_rank (1, 2, 4 or 8)  *
+                               * raw attributes per edge through the two stacked Linear encoders  *
+                               * deepergcn.py:87-90,213 + torch_vertex.py:68,77, kept factored    */
 #define MLGNN_EDGE_FULL  2    /* e_e = efull[eid_e, :]: materialised [E,d] embedding             */
 
 /* aggregator: GenMessagePassing.aggregate, torch_message.py:44-85 */
@@ -60,8 +61,9 @@ extern "C" {
 
 int mlgnn_version(void);
 
-/* Number of float elements of workspace mlgnn_csr_aggregate_bwd needs for [.,d] channels. */
-int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d);
+/* Number of float elements of workspace mlgnn_csr_aggregate_bwd needs for [.,d] channels and a
+ * factored edge term of edge_rank attributes (0 when the edge mode is not EDGE_RANK1). */
+int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int edge_rank);
 
 /*
  * Fused message + aggregation over the incoming edges of every node.
@@ -71,9 +73,10 @@ int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d);
  *
  *   x       [N,d]   node features (rows gathered by col)
  *   rowptr  [N+1], col [E]                 CSR by destination
- *   ew      [E]     per-edge scalar in CSR order: weight (MSG_WEIGHTED) or raw attribute a_e
- *                   (EDGE_RANK1); NULL otherwise
- *   eu, ev  [d]     rank-1 edge term (EDGE_RANK1)
+ *   ew      [E] / [E,edge_rank]  per-edge scalars in CSR order: weight (MSG_WEIGHTED) or the raw
+ *                   attribute row a_e, zero padded to edge_rank columns (EDGE_RANK1); NULL otherwise
+ *   eu [edge_rank,d], ev [d]     factored edge term (EDGE_RANK1); edge_rank in {1,2,4,8}, ignored
+ *                   for the other edge modes
  *   efull   [E0,d], eid [E]               materialised edge embedding + COO position (EDGE_FULL)
  *   out     [N,d]
  *   aux     [N,d]   SOFTMAX: log2-sum-exp of t*m per (node,channel); POWER: mean(clamp(m)^p)
@@ -90,7 +93,7 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
                             const float* ew, const float* eu, const float* ev,
                             const void* efull, const int32_t* eid,
                             void* out, float* aux, float* aux2, int32_t* argmax,
-                            int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                            int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                             int aggr, float t, float p, const float* t_dev, const float* p_dev,
                             float eps, int add_root, void* stream);
 
@@ -103,12 +106,12 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
  *   x, out, aux, argmax: as produced / consumed by the forward
  *   rowptr_t [N+1], col_t [E] (destination), pos_t [E] (by-destination position)
  *   rowptr   [N+1]  by-destination row pointer (in-degree for MEAN)
- *   ew_t [E], eid_t [E]: ew / eid permuted to by-source order
+ *   ew_t [E] / [E,edge_rank], eid_t [E]: ew / eid permuted to by-source order
  *   grad_x   [N,d]
  *   grad_efull [E0,d]  EDGE_FULL: d loss / d efull, written at eid (every row written once)
- *   grad_uv  [2,d]     EDGE_RANK1: d loss / d eu, d loss / d ev
+ *   grad_uv  [edge_rank+1,d]  EDGE_RANK1: d loss / d eu (edge_rank rows), then d loss / d ev
  *   learn_t  non-zero: SOFTMAX weights carry gradient (torch_message.py:51-52)
- *   workspace: mlgnn_csr_aggregate_bwd_workspace_floats(N,d) floats (EDGE_RANK1 only)
+ *   workspace: mlgnn_csr_aggregate_bwd_workspace_floats(N,d,edge_rank) floats (EDGE_RANK1 only)
  */
 int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out, const float* aux,
                             const int32_t* argmax,
@@ -118,7 +121,7 @@ int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out
                             const void* efull, const int32_t* eid_t,
                             void* grad_x, void* grad_efull, float* grad_uv,
                             float* workspace, int64_t workspace_floats,
-                            int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                            int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                             int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev,
                             float eps, int add_root, void* stream);
 

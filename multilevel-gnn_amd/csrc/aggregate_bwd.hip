@@ -20,7 +20,10 @@ struct BwdArgs {                      // go / x / out / efull / gx / ge are T; a
 
 template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
-  __shared__ float red[kWavesPerBlock][2][kWave * VEC];
+  constexpr int RK = rank_of<MODE>();
+  constexpr int ES = edge_scalars<MODE>();
+  constexpr int ESA = ES > 0 ? ES : 1;
+  __shared__ float red[kWavesPerBlock][kWave * VEC];
   const T* GO = static_cast<const T*>(a.go);
   const T* X = static_cast<const T*>(a.x);
   const T* OUTS = static_cast<const T*>(a.out);
@@ -37,16 +40,28 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
   const RowWalk walk = make_row_walk(a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
   const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
-  constexpr bool kNeedW = (MODE == M_WEIGHTED || MODE == M_GEN_RANK1);
 
   for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
     const bool cact = cbase + cl * VEC < a.d;          // inactive lanes shadow the last chunk (see forward)
     const int c0 = min(cbase + cl * VEC, a.d - VEC);
     const uint32_t c_bytes = (uint32_t)c0 * (uint32_t)sizeof(T);
-    float eu[VEC], ev[VEC], gu[VEC], gv[VEC];
+    float eu[VEC][ESA], ev[VEC], gu[VEC][ESA], gv[VEC];   // eu[i][k] = U[k][c0 + i]
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; gu[i] = 0.f; gv[i] = 0.f; }
-    if (MODE == M_GEN_RANK1) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
+    for (int i = 0; i < VEC; ++i) {
+      ev[i] = 0.f; gv[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < ESA; ++k) { eu[i][k] = 0.f; gu[i][k] = 0.f; }
+    }
+    if constexpr (RK > 0) {
+      load_vec<VEC>(ev, a.ev + c0);
+#pragma unroll
+      for (int k = 0; k < RK; ++k) {
+        float row[VEC];
+        load_vec<VEC>(row, a.eu + (size_t)k * a.d + c0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) eu[i][k] = row[i];
+      }
+    }
 
     for (int r = walk.first; r < walk.r_end; r += walk.stride) {
       const int beg = a.rowptr_t[r];
@@ -60,12 +75,16 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
         const int cnt = min(kWave, end - base);
         uint32_t my_off = 0;
         int my_pos = 0, my_eid = 0;
-        float my_ew = 0.f, my_inv = 1.f;
+        float my_ew[ESA], my_inv = 1.f;
+#pragma unroll
+        for (int k = 0; k < ESA; ++k) my_ew[k] = 0.f;
         if (lane < cnt) {
           const int dst = a.col_t[base + lane];
           my_off = (uint32_t)dst * row_bytes;
           if (AGGR == A_MAX) my_pos = a.pos_t[base + lane];
-          if (kNeedW) my_ew = a.ew_t[base + lane];
+          if constexpr (ES > 0) {
+            load_edge_scalars<ES>(my_ew, a.ew_t, (size_t)(base + lane));
+          }
           if (MODE == M_GEN_FULL) my_eid = a.eid_t[base + lane];
           if (AGGR == A_SUM && a.mean)
             my_inv = __builtin_amdgcn_rcpf((float)max(a.rowptr[dst + 1] - a.rowptr[dst], 1));
@@ -75,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
           constexpr bool FULL = decltype(full_c)::value;
           float ga[kUnroll][VEC], gb[kUnroll][VEC], gc[kUnroll][VEC], ef[kUnroll][VEC];
           int ai[kUnroll][VEC];
-          float wa[kUnroll], inv[kUnroll];
+          float wa[kUnroll][ESA], inv[kUnroll];
           int pos[kUnroll], e0[kUnroll];
           bool valid[kUnroll];
 #pragma unroll
@@ -84,7 +103,8 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
             valid[u] = FULL || (idx < cnt);
             const int src = idx & (kWave - 1);
             const uint32_t off = (uint32_t)__shfl((int)my_off, src) + c_bytes;
-            wa[u] = kNeedW ? __shfl(my_ew, src) : 0.f;
+#pragma unroll
+            for (int q = 0; q < ESA; ++q) wa[u][q] = (ES > 0) ? __shfl(my_ew[q], src) : 0.f;
             inv[u] = (AGGR == A_SUM) ? __shfl(my_inv, src) : 1.f;
             pos[u] = (AGGR == A_MAX) ? __shfl(my_pos, src) : 0;
             e0[u] = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
@@ -121,11 +141,15 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
                 const bool inr = (m >= kPowLo) && (m <= kPowHi);
                 coef = inr ? ga[u][i] * fast_exp2((sc.p - 1.0f) * fast_log2(mc)) : 0.f;
               }
-              if constexpr (MODE == M_WEIGHTED) coef *= wa[u];
+              if constexpr (MODE == M_WEIGHTED) coef *= wa[u][0];
               if constexpr (is_gen<MODE>()) coef = (z > 0.f) ? coef : 0.f;
               dz[i] = (FULL || valid[u]) ? coef : 0.f;
               gx[i] += dz[i];
-              if constexpr (MODE == M_GEN_RANK1) { gu[i] = fmaf(wa[u], dz[i], gu[i]); gv[i] += dz[i]; }
+              if constexpr (RK > 0) {
+                gv[i] += dz[i];
+#pragma unroll
+                for (int q = 0; q < RK; ++q) gu[i][q] = fmaf(wa[u][q], dz[i], gu[i][q]);
+              }
             }
             if (MODE == M_GEN_FULL && valid[u] && cact) store_t<T, VEC>(GE + (size_t)e0[u] * a.d + c0, dz);
           }
@@ -150,23 +174,30 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
       }
     }
 
-    if constexpr (MODE == M_GEN_RANK1) {
-      // per-workgroup partial of d loss/d u, d loss/d v  ->  ws[block][2][d]; summed by a second launch
+    if constexpr (RK > 0) {
+      // per-workgroup partial of d loss/d U [RK,d] and d loss/d v [d]  ->  ws[block][RK+1][d]; summed by a second launch
       for (int off = lpr; off < kWave; off <<= 1)
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { gu[i] += __shfl_xor(gu[i], off); gv[i] += __shfl_xor(gv[i], off); }
-      __syncthreads();
-      if (sub == 0) {     // red[] is indexed by the lane's nominal column; shadow lanes land past d and are skipped below
+        for (int i = 0; i < VEC; ++i) {
+          gv[i] += __shfl_xor(gv[i], off);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { red[wave][0][cl * VEC + i] = gu[i]; red[wave][1][cl * VEC + i] = gv[i]; }
-      }
-      __syncthreads();
-      for (int idx = threadIdx.x; idx < 2 * lpr * VEC; idx += kBlock) {
-        const int which = idx / (lpr * VEC), c = idx % (lpr * VEC);
-        float s = 0.f;
+          for (int k = 0; k < RK; ++k) gu[i][k] += __shfl_xor(gu[i][k], off);
+        }
+      // red[] is indexed by the lane's nominal column; shadow lanes land past d and are skipped below
 #pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) s += red[w][which][c];
-        if (cbase + c < a.d) a.ws[((size_t)blockIdx.x * 2 + which) * a.d + cbase + c] = s;
+      for (int which = 0; which <= RK; ++which) {
+        __syncthreads();
+        if (sub == 0) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) red[wave][cl * VEC + i] = (which < RK) ? gu[i][which < RK ? which : 0] : gv[i];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < lpr * VEC; c += kBlock) {
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < kWavesPerBlock; ++w) s += red[w][c];
+          if (cbase + c < a.d) a.ws[((size_t)blockIdx.x * (RK + 1) + which) * a.d + cbase + c] = s;
+        }
       }
     }
   }
@@ -213,13 +244,13 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                                        const void* efull, const int32_t* eid_t,
                                        void* grad_x, void* grad_efull, float* grad_uv,
                                        float* workspace, int64_t workspace_floats,
-                                       int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                                       int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                                        int aggr, int learn_t, float t, float p, const float* t_dev,
                                        const float* p_dev, float eps, int add_root, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
-  const int mode = pick_mode(msg, edge_mode);
+  const int mode = pick_mode(msg, edge_mode, edge_rank);
   const int ag = pick_aggr(aggr);
   if (mode < 0 || ag < 0) return MLGNN_E_MODE;
   if (!is_gen_mode(mode) && ag != A_SUM) return MLGNN_E_MODE;
@@ -229,11 +260,12 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   if (aggr == MLGNN_AGGR_MEAN && !rowptr) return MLGNN_E_NULL;
   if (ag == A_MAX && !argmax) return MLGNN_E_NULL;
   if (ag == A_SOFTMAX && (!aux || (learn_t && !out))) return MLGNN_E_NULL;
-  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew_t && col_t) return MLGNN_E_NULL;
-  if (mode == M_GEN_RANK1 && (!eu || !ev || !grad_uv || !workspace)) return MLGNN_E_NULL;
+  const int rk = rank_of_mode(mode);
+  if ((mode == M_WEIGHTED || rk > 0) && !ew_t && col_t) return MLGNN_E_NULL;
+  if (rk > 0 && (!eu || !ev || !grad_uv || !workspace)) return MLGNN_E_NULL;
   if (mode == M_GEN_FULL && col_t && (!efull || !eid_t || !grad_efull)) return MLGNN_E_NULL;
   const int nblk = grid_for_rows(N);
-  if (mode == M_GEN_RANK1 && workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
+  if (rk > 0 && workspace_floats < (int64_t)nblk * (rk + 1) * d) return MLGNN_E_WORKSPACE;
 
   BwdArgs a;
   a.go = grad_out; a.x = x; a.out = out; a.aux = aux;
@@ -268,8 +300,8 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   });
   int err = (int)hipGetLastError();
   if (err) return err;
-  if (mode == M_GEN_RANK1) {
-    launch_reduce_partials(workspace, grad_uv, nblk, 2 * (int)d, s);
+  if (rk > 0) {
+    launch_reduce_partials(workspace, grad_uv, nblk, (rk + 1) * (int)d, s);
     err = (int)hipGetLastError();
   }
   return err;

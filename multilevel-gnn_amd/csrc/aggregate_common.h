@@ -10,7 +10,21 @@ constexpr int kUnroll = 4;                 // neighbour rows in flight per lane 
 constexpr float kPowLo = 1e-7f, kPowHi = 1e1f;   // torch_message.py:69
 constexpr float kNegBig = -3.0e38f;
 
-enum Mode { M_IDENTITY = 0, M_WEIGHTED = 1, M_GEN_NONE = 2, M_GEN_RANK1 = 3, M_GEN_FULL = 4 };
+// M_GEN_RANK{1,2,4,8}: edge term  e_e[c] = sum_k a_e[k] * U[k][c] + v[c]  with r (padded to 1/2/4/8) raw edge
+// attributes per edge -- the Linear(r -> H) / Linear(H -> d) encoder stack kept factored
+enum Mode { M_IDENTITY = 0, M_WEIGHTED = 1, M_GEN_NONE = 2, M_GEN_RANK1 = 3, M_GEN_FULL = 4,
+            M_GEN_RANK2 = 5, M_GEN_RANK4 = 6, M_GEN_RANK8 = 7 };
+
+template <int MODE>
+__host__ __device__ constexpr int rank_of() {
+  return MODE == M_GEN_RANK1 ? 1 : MODE == M_GEN_RANK2 ? 2 : MODE == M_GEN_RANK4 ? 4 : MODE == M_GEN_RANK8 ? 8 : 0;
+}
+inline int rank_of_mode(int mode) {
+  return mode == M_GEN_RANK1 ? 1 : mode == M_GEN_RANK2 ? 2 : mode == M_GEN_RANK4 ? 4 : mode == M_GEN_RANK8 ? 8 : 0;
+}
+// scalars per edge the kernels read from `ew`: the weight (M_WEIGHTED) or the padded attribute row
+template <int MODE>
+__host__ __device__ constexpr int edge_scalars() { return MODE == M_WEIGHTED ? 1 : rank_of<MODE>(); }
 enum Aggr { A_SUM = 0, A_MAX = 2, A_SOFTMAX = 3, A_POWER = 4 };   // MEAN = SUM + epilogue flag
 
 template <int V> using IC = std::integral_constant<int, V>;
@@ -50,31 +64,53 @@ __device__ __forceinline__ void load_row(int (&r)[VEC], const int* base, uint32_
   load_vec<VEC>(r, reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byte_off));
 }
 
-// pre-activation z of the GEN message for one channel
+// the ES scalars of edge slot e (row e of the [E, ES] table; rows are ES*4-byte aligned)
+template <int ES>
+__device__ __forceinline__ void load_edge_scalars(float* dst, const float* __restrict__ table, size_t e) {
+  if constexpr (ES == 1) dst[0] = table[e];
+  else if constexpr (ES == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(table + e * 2);
+    dst[0] = v.x; dst[1] = v.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < ES; q += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(table + e * ES + q);
+      dst[q] = v.x; dst[q + 1] = v.y; dst[q + 2] = v.z; dst[q + 3] = v.w;
+    }
+  }
+}
+
+// pre-activation z of the GEN message for one channel; a[] = the edge's scalars, u[] = column c of U
 template <int MODE>
-__device__ __forceinline__ float pre_act(float xj, float a, float u, float v, float ef) {
-  if constexpr (MODE == M_GEN_RANK1) return xj + fmaf(a, u, v);
-  else if constexpr (MODE == M_GEN_FULL) return xj + ef;
+__device__ __forceinline__ float pre_act(float xj, const float* a, const float* u, float v, float ef) {
+  if constexpr (rank_of<MODE>() > 0) {
+    float e = v;
+#pragma unroll
+    for (int k = 0; k < rank_of<MODE>(); ++k) e = fmaf(a[k], u[k], e);
+    return xj + e;
+  } else if constexpr (MODE == M_GEN_FULL) return xj + ef;
   else return xj;
 }
 
 template <int MODE, bool ADD_EPS>
-__device__ __forceinline__ float message(float xj, float w_or_a, float u, float v, float ef, float eps) {
+__device__ __forceinline__ float message(float xj, const float* a, const float* u, float v, float ef, float eps) {
   if constexpr (MODE == M_IDENTITY) return xj;
-  else if constexpr (MODE == M_WEIGHTED) return xj * w_or_a;
-  else if constexpr (ADD_EPS) return fmaxf(pre_act<MODE>(xj, w_or_a, u, v, ef), 0.0f) + eps;
-  else return fmaxf(pre_act<MODE>(xj, w_or_a, u, v, ef), 0.0f);
+  else if constexpr (MODE == M_WEIGHTED) return xj * a[0];
+  else if constexpr (ADD_EPS) return fmaxf(pre_act<MODE>(xj, a, u, v, ef), 0.0f) + eps;
+  else return fmaxf(pre_act<MODE>(xj, a, u, v, ef), 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
-inline int pick_mode(int msg, int edge_mode) {
+inline int pick_mode(int msg, int edge_mode, int edge_rank) {
   if (msg == MLGNN_MSG_IDENTITY) return M_IDENTITY;
   if (msg == MLGNN_MSG_WEIGHTED) return M_WEIGHTED;
   if (msg == MLGNN_MSG_GEN) {
     if (edge_mode == MLGNN_EDGE_NONE) return M_GEN_NONE;
-    if (edge_mode == MLGNN_EDGE_RANK1) return M_GEN_RANK1;
+    if (edge_mode == MLGNN_EDGE_RANK1)
+      return edge_rank == 1 ? M_GEN_RANK1 : edge_rank == 2 ? M_GEN_RANK2 : edge_rank == 4 ? M_GEN_RANK4
+             : edge_rank == 8 ? M_GEN_RANK8 : -1;
     if (edge_mode == MLGNN_EDGE_FULL) return M_GEN_FULL;
   }
   return -1;
@@ -110,7 +146,11 @@ inline void for_mode_aggr(int mode, int ag, F&& f) {
     case M_WEIGHTED: f(IC<M_WEIGHTED>{}, IC<A_SUM>{}); break;
     case M_GEN_NONE: for_aggr<M_GEN_NONE>(ag, f); break;
     case M_GEN_RANK1: for_aggr<M_GEN_RANK1>(ag, f); break;
-    default: for_aggr<M_GEN_FULL>(ag, f); break;
+    case M_GEN_RANK2: for_aggr<M_GEN_RANK2>(ag, f); break;
+    case M_GEN_RANK4: for_aggr<M_GEN_RANK4>(ag, f); break;
+    case M_GEN_RANK8: for_aggr<M_GEN_RANK8>(ag, f); break;
+    case M_GEN_FULL: for_aggr<M_GEN_FULL>(ag, f); break;
+    default: break;
   }
 }
 

@@ -31,7 +31,9 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
   const RowWalk walk = make_row_walk(a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
   const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
-  constexpr bool kNeedW = (MODE == M_WEIGHTED || MODE == M_GEN_RANK1);
+  constexpr int RK = rank_of<MODE>();                    // rank of the factored edge term (0: none)
+  constexpr int ES = edge_scalars<MODE>();               // scalars per edge read from ew
+  constexpr int ESA = ES > 0 ? ES : 1;
 
   // eps is added once per row instead of once per edge: softmax weights are shift invariant,
   // max and sum commute with the shift (power needs the clamp of m itself and keeps it per edge)
@@ -43,10 +45,23 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
     const bool cact = cbase + cl * VEC < a.d;
     const int c0 = min(cbase + cl * VEC, a.d - VEC);
     const uint32_t c_bytes = (uint32_t)c0 * (uint32_t)sizeof(T);
-    float eu[VEC], ev[VEC];
+    float eu[VEC][ESA], ev[VEC];                         // eu[i][k] = U[k][c0 + i]
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { eu[i] = 0.f; ev[i] = 0.f; }
-    if (MODE == M_GEN_RANK1) { load_vec<VEC>(eu, a.eu + c0); load_vec<VEC>(ev, a.ev + c0); }
+    for (int i = 0; i < VEC; ++i) {
+      ev[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < ESA; ++k) eu[i][k] = 0.f;
+    }
+    if constexpr (RK > 0) {
+      load_vec<VEC>(ev, a.ev + c0);
+#pragma unroll
+      for (int k = 0; k < RK; ++k) {
+        float row[VEC];
+        load_vec<VEC>(row, a.eu + (size_t)k * a.d + c0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) eu[i][k] = row[i];
+      }
+    }
 
     for (int r = walk.first; r < walk.r_end; r += walk.stride) {
       const int beg = a.rowptr[r];
@@ -66,10 +81,14 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
         const int cnt = min(kWave, end - base);
         uint32_t my_off = 0;
         int my_eid = 0;
-        float my_ew = 0.f;
+        float my_ew[ESA];
+#pragma unroll
+        for (int k = 0; k < ESA; ++k) my_ew[k] = 0.f;
         if (lane < cnt) {
           my_off = (uint32_t)a.col[base + lane] * row_bytes;
-          if (kNeedW) my_ew = a.ew[base + lane];
+          if constexpr (ES > 0) {
+            load_edge_scalars<ES>(my_ew, a.ew, (size_t)(base + lane));
+          }
           if (MODE == M_GEN_FULL) my_eid = a.eid[base + lane];
         }
 
@@ -79,14 +98,15 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
           float m[kUnroll][VEC];
           bool valid[kUnroll];
           {
-            float xv[kUnroll][VEC], ef[kUnroll][VEC], wa[kUnroll];
+            float xv[kUnroll][VEC], ef[kUnroll][VEC], wa[kUnroll][ESA];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
               const int idx = k + u * groups + sub;
               valid[u] = FULL || (idx < cnt);
               const int src = idx & (kWave - 1);
               const uint32_t off = (uint32_t)__shfl((int)my_off, src) + c_bytes;
-              wa[u] = kNeedW ? __shfl(my_ew, src) : 0.f;
+#pragma unroll
+              for (int q = 0; q < ESA; ++q) wa[u][q] = (ES > 0) ? __shfl(my_ew[q], src) : 0.f;
               const int e0 = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
 #pragma unroll
               for (int i = 0; i < VEC; ++i) { xv[u][i] = 0.f; ef[u][i] = 0.f; }
@@ -244,29 +264,29 @@ using namespace mlgnn;
 
 extern "C" int mlgnn_version(void) { return MLGNN_ABI_VERSION; }
 
-extern "C" int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d) {
-  if (N < 0 || d < 0) return MLGNN_E_SHAPE;
-  return (int64_t)grid_for_rows(N) * 2 * d;
+extern "C" int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int edge_rank) {
+  if (N < 0 || d < 0 || edge_rank < 0 || edge_rank > 8) return MLGNN_E_SHAPE;
+  return (int64_t)grid_for_rows(N) * (edge_rank + 1) * d;
 }
 
 extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t* col,
                                        const float* ew, const float* eu, const float* ev,
                                        const void* efull, const int32_t* eid,
                                        void* out, float* aux, float* aux2, int32_t* argmax,
-                                       int64_t N, int64_t d, int dtype, int msg, int edge_mode,
+                                       int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                                        int aggr, float t, float p, const float* t_dev, const float* p_dev,
                                        float eps, int add_root, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;      // 32-bit row offsets: [N,d] tensors < 4 GiB
-  const int mode = pick_mode(msg, edge_mode);
+  const int mode = pick_mode(msg, edge_mode, edge_rank);
   const int ag = pick_aggr(aggr);
   if (mode < 0 || ag < 0) return MLGNN_E_MODE;
   if (!is_gen_mode(mode) && ag != A_SUM) return MLGNN_E_MODE;
   if (N == 0) return 0;
   if (!x || !rowptr || !out) return MLGNN_E_NULL;   // col may be NULL iff the graph has no edge
-  if ((mode == M_WEIGHTED || mode == M_GEN_RANK1) && !ew && col) return MLGNN_E_NULL;
-  if (mode == M_GEN_RANK1 && (!eu || !ev)) return MLGNN_E_NULL;
+  if ((mode == M_WEIGHTED || rank_of_mode(mode) > 0) && !ew && col) return MLGNN_E_NULL;
+  if (rank_of_mode(mode) > 0 && (!eu || !ev)) return MLGNN_E_NULL;
   if (mode == M_GEN_FULL && col && (!efull || !eid)) return MLGNN_E_NULL;
   if (ag == A_POWER && !p_dev && !(p != 0.0f)) return MLGNN_E_MODE;
 

@@ -30,6 +30,7 @@ class CSRGraph:
             self._build_host(edge_index)
         self._deg = None
         self._scalar_cache = {}
+        self._table_cache = {}
 
     def _build_device(self, edge_index):
         """Two stable radix sorts on the GPU (``mlgnn_coo_to_csr``), enqueued on the current stream."""
@@ -80,7 +81,7 @@ class CSRGraph:
         for name in ("rowptr", "col", "eid", "rowptr_t", "col_t", "pos_t", "eid_t"):
             setattr(self, name, getattr(self, name).to(device))
         self.device = torch.device(device)
-        self._deg, self._scalar_cache = None, {}
+        self._deg, self._scalar_cache, self._table_cache = None, {}, {}
         return self
 
     @staticmethod
@@ -106,6 +107,24 @@ class CSRGraph:
             by_dst = flat[self.eid.long()].contiguous()
             hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
             self._scalar_cache = {key: hit}
+        return hit
+
+    def edge_table(self, a, width):
+        """Per-edge attribute rows [E, r] (COO order) zero padded to ``width`` columns ->
+        (by-destination order, by-source order), both [E, width] fp32; cached per tensor."""
+        if a.dim() == 1:
+            a = a[:, None]
+        if a.shape[0] != self.num_edges or a.shape[1] > width:
+            raise ValueError("edge attributes must be [E=%d, <=%d], got %s" % (self.num_edges, width, tuple(a.shape)))
+        key = (a.data_ptr(), a._version, tuple(a.shape), a.stride(), width)
+        hit = self._table_cache.get(key)
+        if hit is None:
+            rows = a.to(torch.float32)
+            if rows.shape[1] != width:
+                rows = torch.nn.functional.pad(rows, (0, width - rows.shape[1]))
+            by_dst = rows[self.eid.long()].contiguous()
+            hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
+            self._table_cache = {key: hit}
         return hit
 
 

@@ -60,12 +60,17 @@ _AGGR_NAMES = {AGGR_SUM: "sum", AGGR_MEAN: "mean", AGGR_MAX: "max", AGGR_SOFTMAX
 _EDGE_NAMES = {EDGE_NONE: "noedge", EDGE_RANK1: "rank1", EDGE_FULL: "full"}
 
 
-def algorithmic_bytes(N, E, d, aggr_id, edge_mode, backward=False, learn_t=False, weighted=False, gen=True, s=4):
+def _edge_name(edge_mode, rank):
+    return "rank%d" % rank if edge_mode == EDGE_RANK1 else _EDGE_NAMES[edge_mode]
+
+
+def algorithmic_bytes(N, E, d, aggr_id, edge_mode, backward=False, learn_t=False, weighted=False, gen=True, s=4,
+                      rank=1):
     """Edge-gather byte count of one launch, no cache credit.
     ``s`` = bytes per activation element (4 fp32, 2 bf16); lse / argmax side arrays are 4-byte."""
     rows = E * d * s                                  # one gathered activation row per edge
     idx = E * 4 + (N + 1) * 4                         # col + rowptr
-    scalar = E * 4 if (edge_mode == EDGE_RANK1 or weighted) else 0
+    scalar = E * 4 * rank if edge_mode == EDGE_RANK1 else (E * 4 if weighted else 0)
     full = (E * d * s + E * 4) if edge_mode == EDGE_FULL else 0
     if not backward:
         extra = N * d * 4 if aggr_id == AGGR_MAX else 0          # argmax write
@@ -104,26 +109,53 @@ def _dev_act(t, what, like=None):
     return t.contiguous()
 
 
-class RankOneEdge:
-    """Edge embedding kept in factored form: ``e_ij = a_ij * weight + bias``.
+class LowRankEdge:
+    """Edge embedding kept in factored form: ``e_ij = weight @ a_ij + bias``.
 
-    ``a`` is the raw scalar edge attribute ``[E]`` in COO order; ``weight``/``bias`` are ``[H]``.
-    This is what ``DeeperGCN.edge_encoder = Linear(1, H)`` (deepergcn.py:90,213) produces, and it
-    stays rank one through ``GENConv.edge_encoder = Linear(H, d)`` (torch_vertex.py:68,77), so the
-    ``[E, d]`` embedding and its 2*E*d*d FLOP GEMM never have to exist.
+    ``a`` holds the raw edge attributes ``[E, r]`` in COO order (r <= 8), ``weight`` is ``[H, r]`` and
+    ``bias`` ``[H]`` -- the parameters of ``DeeperGCN.edge_encoder = Linear(7 or 1, H)``
+    (deepergcn.py:87-90,213).  The factorisation survives ``GENConv.edge_encoder = Linear(H, d)``
+    (torch_vertex.py:68,77), so the ``[E, d]`` embedding and its 2*E*H*d FLOP GEMM per layer never
+    have to exist: the aggregation kernels rebuild ``e_ij`` from r scalars per edge.
     """
+    MAX_RANK = 8
 
     def __init__(self, a, weight, bias):
-        self.a = a.reshape(-1)
+        if a.dim() == 1:
+            a = a[:, None]
+        if weight.dim() == 1:
+            weight = weight[:, None]
+        if a.shape[1] != weight.shape[1]:
+            raise ValueError("edge attributes are [E, %d] but the encoder takes %d columns" % (a.shape[1], weight.shape[1]))
+        if not 1 <= a.shape[1] <= self.MAX_RANK:
+            raise ValueError("factored edge term supports 1..%d attribute columns, got %d" % (self.MAX_RANK, a.shape[1]))
+        self.a = a
         self.weight = weight
         self.bias = bias
 
+    @property
+    def rank(self):
+        return self.a.shape[1]
+
     def through_linear(self, W, b):
-        """Compose with ``Linear``: ``W (a w + c) + b = a (W w) + (W c + b)``."""
-        return RankOneEdge(self.a, torch.mv(W, self.weight), torch.mv(W, self.bias) + (0 if b is None else b))
+        """Compose with ``Linear``: ``W (U a + c) + b = (W U) a + (W c + b)``."""
+        return LowRankEdge(self.a, torch.mm(W, self.weight), torch.mv(W, self.bias) + (0 if b is None else b))
 
     def dense(self):
-        return self.a[:, None] * self.weight[None, :] + self.bias[None, :]
+        return torch.addmm(self.bias, self.a.to(self.weight.dtype), self.weight.t())
+
+
+class RankOneEdge(LowRankEdge):
+    """``e_ij = a_ij * weight + bias`` with a scalar attribute ``a [E]`` and ``weight``/``bias`` ``[H]``
+    (``Linear(1, H)``: the ``use_column`` configurations)."""
+
+    def __init__(self, a, weight, bias):
+        super().__init__(a.reshape(-1, 1), weight.reshape(-1, 1), bias)
+
+
+def padded_rank(r):
+    """Kernel instantiations exist for 1, 2, 4 and 8 scalars per edge; attributes are zero padded."""
+    return 1 if r <= 1 else 2 if r <= 2 else 4 if r <= 4 else 8
 
 
 class _GenAggregate(torch.autograd.Function):
@@ -141,8 +173,16 @@ class _GenAggregate(torch.autograd.Function):
         efull = _dev_act(efull, "efull", like=x)
         if efull is not None and tuple(efull.shape) != (graph.num_edges, d):
             raise ValueError("edge embedding must be [E, d]")
-        if eu is not None and (eu.numel() != d or ev.numel() != d):
-            raise ValueError("rank-1 edge vectors must be [d]")
+        rank = 0
+        if eu is not None:
+            if eu.dim() != 2 or eu.shape[1] != d or ev.numel() != d:
+                raise ValueError("factored edge term must be eu [r, d], ev [d]")
+            rank = padded_rank(eu.shape[0])
+            ctx.uv_rows = eu.shape[0]
+            if eu.shape[0] != rank:                                   # pad with zero rows to the kernel's rank
+                eu = torch.cat([eu, eu.new_zeros(rank - eu.shape[0], d)], dim=0)
+            if ew_pair[0].shape != (graph.num_edges, rank):
+                raise ValueError("edge attribute table must be [E, %d]" % rank)
         out = torch.empty_like(x)
         want_bwd = any(ctx.needs_input_grad)
         f32 = dict(dtype=torch.float32, device=x.device)
@@ -160,21 +200,22 @@ class _GenAggregate(torch.autograd.Function):
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), _lib.ptr(eu), _lib.ptr(ev),
             _lib.ptr(efull), graph.eid.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),
-            _lib.ptr(argmax), N, d, dtype_id, MSG_GEN, edge_mode, aggr_id, float(t), float(p),
+            _lib.ptr(argmax), N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, float(t), float(p),
             _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), int(add_root), _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         if timer is not None:
-            timer.stop("csr_aggregate_fwd/%s/%s" % (_AGGR_NAMES[aggr_id], _EDGE_NAMES[edge_mode]), t0,
-                       algorithmic_bytes(N, graph.num_edges, d, aggr_id, edge_mode, s=x.element_size()))
+            timer.stop("csr_aggregate_fwd/%s/%s" % (_AGGR_NAMES[aggr_id], _edge_name(edge_mode, rank)), t0,
+                       algorithmic_bytes(N, graph.num_edges, d, aggr_id, edge_mode, s=x.element_size(),
+                                         rank=max(rank, 1)))
         ctx.graph, ctx.ew_pair = graph, ew_pair
-        ctx.cfg = (aggr_id, edge_mode, float(t), float(p), float(eps), bool(learn_t), bool(learn_p), bool(add_root))
+        ctx.cfg = (aggr_id, edge_mode, rank, float(t), float(p), float(eps), bool(learn_t), bool(learn_p), bool(add_root))
         ctx.save_for_backward(x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev)
         return out
 
     @staticmethod
     def backward(ctx, go):
         x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev = ctx.saved_tensors
-        aggr_id, edge_mode, t, p, eps, learn_t, learn_p, add_root = ctx.cfg
+        aggr_id, edge_mode, rank, t, p, eps, learn_t, learn_p, add_root = ctx.cfg
         g = ctx.graph
         N, d = x.shape
         go = _dev_act(go, "grad_out", like=x)
@@ -197,9 +238,9 @@ class _GenAggregate(torch.autograd.Function):
         guv = ws = None
         ws_n = 0
         if edge_mode == EDGE_RANK1:
-            ws_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_workspace_floats(N, d))
+            ws_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_workspace_floats(N, d, rank))
             ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
-            guv = torch.empty((2, d), dtype=torch.float32, device=x.device)
+            guv = torch.empty((rank + 1, d), dtype=torch.float32, device=x.device)
         ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
         timer = KERNEL_TIMER
         t0 = timer.start() if timer is not None else None
@@ -208,15 +249,15 @@ class _GenAggregate(torch.autograd.Function):
             g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(), g.rowptr.data_ptr(),
             _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), g.eid_t.data_ptr(),
             gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
-            N, d, dtype_id, MSG_GEN, edge_mode, aggr_id, int(learn_t), t, p,
+            N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, int(learn_t), t, p,
             _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         if timer is not None:
-            timer.stop("csr_aggregate_bwd/%s/%s" % (_AGGR_NAMES[aggr_id], _EDGE_NAMES[edge_mode]), t0,
+            timer.stop("csr_aggregate_bwd/%s/%s" % (_AGGR_NAMES[aggr_id], _edge_name(edge_mode, rank)), t0,
                        algorithmic_bytes(N, g.num_edges, d, aggr_id, edge_mode, backward=True, learn_t=learn_t,
-                                         s=x.element_size()))
-        geu = guv[0].to(ctx.uv_dtype) if guv is not None else None
-        gev = guv[1].to(ctx.uv_dtype) if guv is not None else None
+                                         s=x.element_size(), rank=max(rank, 1)))
+        geu = guv[:ctx.uv_rows].to(ctx.uv_dtype) if guv is not None else None
+        gev = guv[rank].to(ctx.uv_dtype) if guv is not None else None
         return gx, geu, gev, ge, grad_t, grad_p, None, None, None, None, None, None, None, None, None
 
 
@@ -225,7 +266,7 @@ def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, l
     """``aggregate(relu(x_j + e_ij) + eps)`` over incoming edges -- GENConv.message + aggregate
     (torch_vertex.py:94-101, torch_message.py:44-85) in one kernel.
 
-    ``edge``: ``None`` | :class:`RankOneEdge` (already composed to width d) | ``[E, d]`` tensor (COO order).
+    ``edge``: ``None`` | :class:`LowRankEdge` / :class:`RankOneEdge` (already composed to width d) | ``[E, d]`` tensor (COO order).
     ``t``/``p``: float, or the 1-element parameter when ``learn_t``/``learn_p``.
     ``*_sum`` variants return the un-scaled value; the caller applies ``deg ** sigmoid(y)``.
     ``add_root``: return ``x + aggregate`` from the same pass (GENConv's ``h = x + m``); ignored
@@ -235,9 +276,11 @@ def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, l
         raise TypeError("graph must be a CSRGraph")
     aggr_id = AGGR_IDS[aggr]
     eu = ev = efull = ew_pair = None
-    if isinstance(edge, RankOneEdge):
-        eu, ev = edge.weight, edge.bias
-        ew_pair = graph.edge_scalar(edge.a)
+    if isinstance(edge, LowRankEdge):
+        if edge.weight.shape[0] != x.shape[1]:
+            raise ValueError("factored edge term has width %d, features have %d" % (edge.weight.shape[0], x.shape[1]))
+        eu, ev = edge.weight.t(), edge.bias                           # [r, d], [d]
+        ew_pair = graph.edge_table(edge.a, padded_rank(edge.rank))
     elif edge is not None:
         efull = edge
     t_par = t if torch.is_tensor(t) else None
@@ -262,7 +305,7 @@ class _WeightedAggregate(torch.autograd.Function):
         ew = ew_pair[0] if ew_pair is not None else None
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), None, None, None, None,
-            out.data_ptr(), None, None, None, N, d, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, aggr_id, 1.0, 1.0, None, None,
+            out.data_ptr(), None, None, None, N, d, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, 0, aggr_id, 1.0, 1.0, None, None,
             0.0, 0, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         ctx.graph, ctx.ew_pair, ctx.cfg = graph, ew_pair, (msg, aggr_id, N, d)
@@ -278,7 +321,7 @@ class _WeightedAggregate(torch.autograd.Function):
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
             g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, gx.data_ptr(), None, None, None, 0,
-            N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, _stream())
+            N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, 0, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         return gx, None, None, None
 

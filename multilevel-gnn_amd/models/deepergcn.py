@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from mlgnn import CSRGraph, RankOneEdge
+from mlgnn import CSRGraph, LowRankEdge
 from mlgnn.dense import linear
 from mlgnn.norm import layer_norm_act
 from mlgnn.pool import global_pool
@@ -113,13 +113,14 @@ class DeeperGCN(torch.nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def _edge_term(self, edge_attr):
-        """Model-level edge embedding (deepergcn.py:212-215), kept factored when it is rank one."""
+        """Model-level edge embedding (deepergcn.py:212-215), kept factored (<= 8 raw attribute columns:
+        both the 7-column default and the single ``use_column`` one) so no [E, H] tensor is built."""
         if not self.use_edge_attr:
             return None
         if self.global_edge == "onehot":
             return self.edge_encoder(edge_attr.to(torch.long))               # [E, 1, H]
-        if edge_attr.dim() == 2 and edge_attr.shape[1] == 1:
-            return RankOneEdge(edge_attr[:, 0], self.edge_encoder.weight[:, 0], self.edge_encoder.bias)
+        if edge_attr.dim() == 2 and 1 <= edge_attr.shape[1] <= LowRankEdge.MAX_RANK:
+            return LowRankEdge(edge_attr, self.edge_encoder.weight, self.edge_encoder.bias)
         return self.edge_encoder(edge_attr)
 
     def _pathway_rows(self, node_size):

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from mlgnn import RankOneEdge, as_graph, weighted_mean_aggregate
+from mlgnn import LowRankEdge, as_graph, weighted_mean_aggregate
 from mlgnn.dense import linear
 from mlgnn.graph import sage_graph
 from mlgnn.norm import msg_norm_add
@@ -43,12 +43,12 @@ class GENConv(GenMessagePassing):
 
     def forward(self, x, edge_index, edge_attr=None):
         """``edge_index``: COO ``[2, E]`` or a prebuilt :class:`mlgnn.CSRGraph`.
-        ``edge_attr``: ``[E, d_e]`` tensor, or a :class:`mlgnn.RankOneEdge` (scalar raw attribute
+        ``edge_attr``: ``[E, d_e]`` tensor, or a :class:`mlgnn.LowRankEdge` (raw attributes
         kept factored through the Linear encoders: no ``[E, d]`` tensor, no edge GEMM)."""
         if self.pca_only:
             return self.feature_encoder(x)
         graph = as_graph(edge_index, x.shape[0])
-        if isinstance(edge_attr, RankOneEdge):
+        if isinstance(edge_attr, LowRankEdge):
             edge = edge_attr.through_linear(self.edge_encoder.weight, self.edge_encoder.bias) \
                 if self.encode_edge else edge_attr
         elif edge_attr is not None:

@@ -311,10 +311,13 @@ def fx_deepergcn(ref):
              dict(gcn_aggr="max", block="plain", graph_pooling="sum", num_layer_head=2, use_age=True),
              dict(gcn_aggr="softmax", pathway_global_node=True, pathway_readout="maxpool", pre_concat_age=True,
                   pre_readout_drop=True, use_age=True, num_layer_head=2),
-             dict(gcn_aggr="softmax", global_edge="onehot", pathway_edge_num=5)]
+             dict(gcn_aggr="softmax", global_edge="onehot", pathway_edge_num=5),
+             # use_column None: the 7-column edge attribute through Linear(7, hidden) (deepergcn.py:90)
+             dict(gcn_aggr="softmax", use_column=None),
+             dict(gcn_aggr="max", use_column=None, block="res", msg_norm=True, learn_msg_scale=True)]
     for ci, over in enumerate(cases):
         a = default_args(ref, **dict(base, **over))
-        ei, ea, bvec = small_graph(gen, 2, 64, 256)
+        ei, ea, bvec = small_graph(gen, 2, 64, 256, edge_dim=7 if a.use_column is None else 1)
         if a.global_edge == "onehot":
             ea = torch.randint(0, 5, (ei.shape[1], 1), generator=gen).to(torch.float32)
         torch.manual_seed(500 + ci)
@@ -398,12 +401,11 @@ def fx_diffpool(ref):
 def main():
     ref = _reference()
     torch.set_num_threads(4)
-    fx_aggregators(ref)
-    fx_genconv(ref)
-    fx_sage(ref)
-    fx_deepergcn(ref)
-    fx_multilevel(ref)
-    fx_diffpool(ref)
+    only = set(sys.argv[1:])               # e.g. `make_golden.py deepergcn` regenerates one family
+    for name, fx in [("aggregators", fx_aggregators), ("genconv", fx_genconv), ("sage", fx_sage),
+                     ("deepergcn", fx_deepergcn), ("multilevel", fx_multilevel), ("diffpool", fx_diffpool)]:
+        if not only or name in only:
+            fx(ref)
 
 
 if __name__ == "__main__":

@@ -25,16 +25,19 @@ def _graph(gen, N, E, hub=False, isolated=2):
 
 
 def _run_case(N, E, d, aggr, edge_kind, t=1.0, p=2.0, learn=False, hub=False, seed=0):
-    from mlgnn import CSRGraph, RankOneEdge, gen_aggregate
+    from mlgnn import CSRGraph, LowRankEdge, RankOneEdge, gen_aggregate
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(seed)
     ei = _graph(gen, N, E, hub)
+    rank = int(edge_kind[4:]) if edge_kind.startswith("rank") else 0
     x = torch.randn(N, d, generator=gen)
     a = torch.rand(E, generator=gen)
     u = torch.randn(d, generator=gen) * 0.5
     v = torch.randn(d, generator=gen) * 0.2
     ef = torch.randn(E, d, generator=gen) * 0.5
     cot = torch.randn(N, d, generator=gen)
+    ar = torch.rand(E, max(rank, 1), generator=gen)               # [E, r] raw attributes (rank > 1)
+    ur = torch.randn(d, max(rank, 1), generator=gen) * 0.4        # Linear(r, d).weight
     tt = torch.tensor([t]) if learn else t
     pp = torch.tensor([p]) if learn else p
 
@@ -43,6 +46,9 @@ def _run_case(N, E, d, aggr, edge_kind, t=1.0, p=2.0, learn=False, hub=False, se
     if edge_kind == "rank1":
         leaves["u"], leaves["v"] = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
         e = a[:, None] * leaves["u"] + leaves["v"]
+    elif rank > 1:
+        leaves["U"], leaves["v"] = ur.clone().requires_grad_(True), v.clone().requires_grad_(True)
+        e = torch.nn.functional.linear(ar, leaves["U"], leaves["v"])
     elif edge_kind == "full":
         leaves["ef"] = ef.clone().requires_grad_(True)
         e = leaves["ef"]
@@ -60,6 +66,8 @@ def _run_case(N, E, d, aggr, edge_kind, t=1.0, p=2.0, learn=False, hub=False, se
     graph = CSRGraph(ei.to(dev), N)
     if edge_kind == "rank1":
         edge = RankOneEdge(a.to(dev), gl["u"], gl["v"])
+    elif rank > 1:
+        edge = LowRankEdge(ar.to(dev), gl["U"], gl["v"])
     elif edge_kind == "full":
         edge = gl["ef"]
     else:
@@ -82,6 +90,31 @@ AGGRS = ["add", "mean", "max", "softmax", "softmax_sg", "power"]
 @pytest.mark.parametrize("edge_kind", ["none", "rank1", "full"])
 def test_gen_aggregate_d128(aggr, edge_kind):
     _run_case(300, 4000, 128, aggr, edge_kind, hub=True)
+
+
+@pytest.mark.parametrize("aggr", AGGRS)
+@pytest.mark.parametrize("rank", [2, 3, 4, 7, 8])
+def test_gen_aggregate_low_rank_edge(aggr, rank):
+    # 7 = the reference's default edge attribute width (deepergcn.py:87-90: Linear(7, hidden))
+    _run_case(300, 4000, 128, aggr, "rank%d" % rank, hub=True, seed=rank)
+
+
+@pytest.mark.parametrize("d", [1, 6, 36, 200, 320])
+def test_low_rank_edge_widths(d):
+    _run_case(130, 1500, d, "softmax", "rank7", hub=True, seed=d)
+    _run_case(130, 1500, d, "max", "rank2", hub=True, seed=d + 1)
+
+
+def test_low_rank_edge_learnable_t():
+    _run_case(200, 3000, 32, "softmax", "rank7", t=0.6, learn=True)
+
+
+def test_low_rank_edge_rejects_wide_attributes():
+    from mlgnn import LowRankEdge
+    with pytest.raises(ValueError):
+        LowRankEdge(torch.zeros(4, 9), torch.zeros(8, 9), torch.zeros(8))
+    with pytest.raises(ValueError):
+        LowRankEdge(torch.zeros(4, 3), torch.zeros(8, 2), torch.zeros(8))
 
 
 @pytest.mark.parametrize("d", [1, 3, 4, 16, 32, 64, 96, 100, 256, 320])

@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multilevel-gnn_amd"))
-from mlgnn import CSRGraph, RankOneEdge, gen_aggregate  # noqa: E402
+from mlgnn import CSRGraph, LowRankEdge, RankOneEdge, gen_aggregate  # noqa: E402
 
 
 def er_batch(n_graphs, n, e, dev, seed=1000):
@@ -51,15 +51,21 @@ def main():
     u = torch.randn(d, device=dev) * 0.5
     v = torch.randn(d, device=dev) * 0.1
     ef = torch.randn(E, d, device=dev) * 0.5
+    ea7 = torch.rand(E, 7, device=dev)                       # the reference's default 7-column attribute
+    u7 = torch.randn(d, 7, device=dev) * 0.3
     fwd_bytes = E * d * 4 + E * 4 + (N + 1) * 4 + E * 4 + N * d * 4
     print("N=%d E=%d d=%d  CSR build %.2f ms  fwd algorithmic bytes %.1f MB" % (N, E, d, t_csr, fwd_bytes / 1e6))
     for aggr in ("softmax", "max", "mean"):
-        for kind in ("rank1", "full"):
+        for kind in ("rank1", "rank7", "full"):
             xr = x.clone().requires_grad_(True)
             if kind == "rank1":
                 ur, vr = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
                 edge = RankOneEdge(ea, ur, vr)
                 fb = fwd_bytes
+            elif kind == "rank7":
+                ur, vr = u7.clone().requires_grad_(True), v.clone().requires_grad_(True)
+                edge = LowRankEdge(ea7, ur, vr)
+                fb = fwd_bytes + E * 4 * 7                    # 8 padded scalars per edge instead of 1
             else:
                 edge = ef.clone().requires_grad_(True)
                 fb = fwd_bytes - E * 4 + E * d * 4 + E * 4

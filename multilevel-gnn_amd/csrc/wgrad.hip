@@ -4,39 +4,89 @@
 // Reference: autograd of nn.Linear inside MLP (models/gcn_lib/sparse/torch_nn.py:54-75, the dense
 // epilogue of every conv) -- a "TN" GEMM whose reduction dimension is the 640 000 node rows and
 // whose output is 128x256: the library picks a 32x32-tile kernel without split-K (~39 TFLOP/s
-// measured).  Here the rows are split over the chip (one slab per workgroup), each wave keeps its
-// share of the [M,K] output in fp32 MFMA accumulators (v_mfma_f32_32x32x2_f32: exact fp32 FMA
-// chain), operand tiles are double-buffered through LDS, and per-slab partials are summed in a
-// fixed order by reduce_partials (bitwise reproducible).
+// measured).  Here the rows are split over the chip (one slab per workgroup) and each wave keeps its
+// share of the [M,K] output in MFMA accumulators; per-slab partials are summed in a fixed order by
+// reduce_partials (bitwise reproducible).
 //
-// MFMA-bound: 2*N*M*K FLOP at the 157 TFLOP/s fp32-matrix peak; reads A and B once from HBM.
+// Arithmetic: every fp32 operand is split exactly into three bf16 terms x = h + m + l (8 significand
+// bits each, fp32's exponent range: gradients need no scaling) and the product is accumulated in fp32
+// from the six leading partial products hh + hm + mh + hl + lh + mm on v_mfma_f32_32x32x16_bf16.  The
+// dropped terms (ml, lm, ll) are <= 2^-24 relative, i.e. the result carries fp32-level error
+// (~2e-7 relative per product, tests/test_wgrad_gpu.py) at 6/16 of the fp32-MFMA cost per FLOP -- fast
+// enough that the kernel is bound by reading A and B once from HBM.  db is summed in plain fp32.
+#include <type_traits>
+
 #include "common.h"
 #include "mlgnn.h"
 
 namespace mlgnn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int kTile = 32;
 
 struct WgradArgs {
   const float* a; const float* b; float* ws;
-  int N; int M; int K; int rows_per_block; int out_cols;   // out_cols = M*K + M
+  int N; int M; int K; int out_cols;      // out_cols = M*K + M
+  int row0;                               // first row of this launch
+  int rows;                               // rows of this launch (a multiple of the stage when !MASKED)
+  int slot0;                              // workspace slot of workgroup 0
 };
 
-// wave layout WM x WK, tiles per wave TM x TK.  Row slab of the workgroup is walked in stages of
-// kStageRows rows: both operand tiles of a stage ([rows, M] of grad_out and [rows, K] of x, zero
-// padded to the tile grid) are fetched with 16-byte coalesced loads into registers while the previous
-// stage is being multiplied out of LDS, then written to the other LDS buffer (classic double
-// buffering; one barrier per stage).  MFMA operands are single ds_read_b32 per lane: lane l reads
-// tile[2*kk + (l>>5)][col0 + (l&31)] -- 32 consecutive floats per half-wave, conflict free.
-constexpr int kStageRows = 32;
+// Stage = 32 rows when the operand tiles fit the LDS budget (64 KB single buffered, 144 KB double buffered),
+// 16 rows for the widest layouts.
+constexpr int kSlabAlign = 32;          // the fast launch covers a multiple of this many rows (both stage sizes)
+constexpr int stage_rows(int W, bool db) { return db ? (W <= 384 ? 32 : 16) : (W <= 320 ? 32 : 16); }
+constexpr bool lds_fits(int W, bool db) { return (db ? 12 : 6) * stage_rows(W, db) * W <= 160 * 1024; }
 
-template <int WM, int WK, int TM, int TK, bool ALIGNED>
-__global__ __launch_bounds__(kBlock) void linear_wgrad_kernel(const WgradArgs p) {
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+// exact three-way split of 8 floats, two at a time (v_cvt_pk_bf16_f32 rounds to nearest even; the
+// widening back is a shift / mask of the packed word)
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+  u32x4 hw, mw, lw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 x = {v[2 * j], v[2 * j + 1]};
+    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+    const f32x2 r1 = {x[0] - __builtin_bit_cast(float, hp << 16), x[1] - __builtin_bit_cast(float, hp & 0xffff0000u)};
+    const uint32_t mp = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    const f32x2 r2 = {r1[0] - __builtin_bit_cast(float, mp << 16), r1[1] - __builtin_bit_cast(float, mp & 0xffff0000u)};
+    const uint32_t lp = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
+    hw[j] = hp; mw[j] = mp; lw[j] = lp;
+  }
+  h = __builtin_bit_cast(bf16x8, hw); m = __builtin_bit_cast(bf16x8, mw); l = __builtin_bit_cast(bf16x8, lw);
+}
+
+// NW waves per workgroup laid out WM x WK over the output, TM x TK tiles of 32x32 per wave.  The row slab of
+// the workgroup is walked in stages of 32 (16) rows.  Work item of the loader = (operand column, group of
+// 8 consecutive rows): 8 dword loads (each coalesced across the lanes: consecutive lanes hold consecutive
+// columns), split into the three bf16 planes in registers, one 16-byte LDS write per plane.  LDS layout
+// [plane][row group][column][8 rows] is exactly the MFMA operand layout (lane l: column l & 31, rows
+// 8 (l >> 5) .. +8 of a 16-row k-step), so operand reads are linear ds_read_b128 and writes linear
+// ds_write_b128: no bank conflicts, no padding.  The loads of stage s+1 are issued before stage s is
+// multiplied and converted after it.  DB: two LDS buffers and one barrier per stage (the 8-wave kernel runs
+// one workgroup per CU, so conversion and MFMA of different waves overlap inside the workgroup); otherwise one
+// buffer, two barriers, and several workgroups per CU overlap each other.
+// MASKED = false: the launch covers whole stages of unpadded operands (M, K multiples of 32): loads are
+// `global_load_dword v, v_offset, s[row base]` with the per-thread byte offset fixed for the whole kernel and
+// one scalar row base per load, and nothing is masked.  MASKED = true: row clamps and zero fill (tile padding,
+// the last N % 32 rows).
+template <int NW, int WM, int WK, int TM, int TK, bool DB, bool MASKED>
+__global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArgs p) {
+  static_assert(WM * WK == NW, "wave layout must cover the workgroup");
+  constexpr int kThreads = NW * kWave;
   constexpr int MP = WM * TM * kTile, KP = WK * TK * kTile, W = MP + KP;   // padded operand widths
-  constexpr int kChunks = kStageRows * W / 4;                               // float4 chunks per stage
-  constexpr int kPerThread = (kChunks + kBlock - 1) / kBlock;
-  __shared__ float4 tile4[2][kStageRows * W / 4];
+  constexpr int kStageRows = stage_rows(W, DB), kGroups = kStageRows / 8;
+  static_assert(lds_fits(W, DB), "operand tiles exceed LDS");
+  constexpr int UA = MP * kGroups, UB = KP * kGroups;                       // (column, row group) items per stage
+  constexpr int PA = (UA + kThreads - 1) / kThreads, PB = (UB + kThreads - 1) / kThreads;
+  constexpr int kPlane = kGroups * W;                                       // 16-byte entries per plane
+  constexpr int kBuf = 3 * kPlane;
+  __shared__ bf16x8 tile[(DB ? 2 : 1) * kBuf];
+  static_assert(sizeof(bf16x8) == 16, "operand entry is one ds_read_b128");
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -51,95 +101,170 @@ __global__ __launch_bounds__(kBlock) void linear_wgrad_kernel(const WgradArgs p)
     for (int j = 0; j < TK; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float bsum[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) bsum[i] = 0.f;
 
-  const int r_begin = blockIdx.x * p.rows_per_block;
-  const int r_end = min(p.N, r_begin + p.rows_per_block);
+  // slab of this workgroup: stages [s_begin, s_end) of the launch, balanced to within one stage
+  const int n_stages = (p.rows + kStageRows - 1) / kStageRows;
+  const int s_begin = (int)((int64_t)n_stages * blockIdx.x / gridDim.x);
+  const int s_end = (int)((int64_t)n_stages * (blockIdx.x + 1) / gridDim.x);
+  const int r_begin = p.row0 + s_begin * kStageRows;
+  const int r_end = min(p.row0 + p.rows, p.row0 + s_end * kStageRows);
 
-  float4 stage[kPerThread];
-  // global -> registers: chunk c covers columns [4*(c % (W/4)), +4) of stage row c / (W/4).
-  // ALIGNED (M % 4 == 0 and K % 4 == 0): straight-line code -- clamped addresses, unconditional 16-byte
-  // loads, zeroing by select -- so the loads stay in flight across the multiply (no control flow for the
-  // compiler's waitcnt insertion to be conservative about).
-  static_assert(kChunks % kBlock == 0, "stage must split evenly over the workgroup");
-  auto fetch = [&](int r0) {
+  // per-thread work items, fixed for the whole kernel
+  struct Unit { uint32_t off; int lds; int col; int grp; bool live; };
+  Unit ua[PA], ub[PB];
 #pragma unroll
-    for (int q = 0; q < kPerThread; ++q) {
-      const int c = threadIdx.x + q * kBlock;
-      const int row = r0 + c / (W / 4);
-      const int col = (c % (W / 4)) * 4;
-      const bool is_a = col < MP;
-      const int cc = is_a ? col : col - MP;
-      const int width = is_a ? p.M : p.K;
-      if constexpr (ALIGNED) {
-        const bool live = (row < r_end) && (cc < width);
-        const int rc = min(row, p.N - 1), ccc = min(cc, width - 4);
-        const float4 v = *reinterpret_cast<const float4*>((is_a ? p.a : p.b) + (size_t)rc * width + ccc);
-        stage[q] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < r_end) {
-          const float* src = (is_a ? p.a : p.b) + (size_t)row * width + cc;
-          if (cc < width) v.x = src[0];
-          if (cc + 1 < width) v.y = src[1];
-          if (cc + 2 < width) v.z = src[2];
-          if (cc + 3 < width) v.w = src[3];
-        }
-        stage[q] = v;
+  for (int q = 0; q < PA; ++q) {
+    const int u = threadIdx.x + q * kThreads;
+    const int uc = min(u, UA - 1);
+    ua[q].col = uc % MP; ua[q].grp = uc / MP;
+    ua[q].live = u < UA && ua[q].col < p.M;
+    ua[q].lds = ua[q].grp * W + ua[q].col;
+    ua[q].off = (uint32_t)(ua[q].grp * 8 * p.M + min(ua[q].col, p.M - 1)) * 4u;
+  }
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int u = threadIdx.x + q * kThreads;
+    const int uc = min(u, UB - 1);
+    ub[q].col = uc % KP; ub[q].grp = uc / KP;
+    ub[q].live = u < UB && ub[q].col < p.K;
+    ub[q].lds = ub[q].grp * W + MP + ub[q].col;
+    ub[q].off = (uint32_t)(ub[q].grp * 8 * p.K + min(ub[q].col, p.K - 1)) * 4u;
+  }
+
+  constexpr int kSets = DB ? 2 : 1;               // DB: two stages of loads in flight (register sets by stage parity)
+  float sa[kSets][PA][8], sb[kSets][PB][8];
+  float bsum[PA];                                   // fp32 column sums of the A columns this thread loads
+#pragma unroll
+  for (int q = 0; q < PA; ++q) bsum[q] = 0.f;
+
+  // fetch only issues loads (no use of the loaded values): they stay in flight across the multiply of the
+  // previous stage
+  auto fetch = [&](auto set_c, int r0) {
+    constexpr int S = decltype(set_c)::value;
+    if constexpr (!MASKED) {
+      const char* arow = reinterpret_cast<const char*>(p.a + (size_t)r0 * p.M);      // uniform
+      const char* brow = reinterpret_cast<const char*>(p.b + (size_t)r0 * p.K);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const char* aj = arow + (size_t)j * p.M * 4;
+        const char* bj = brow + (size_t)j * p.K * 4;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) sa[S][q][j] = *reinterpret_cast<const float*>(aj + ua[q].off);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) sb[S][q][j] = *reinterpret_cast<const float*>(bj + ub[q].off);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int q = 0; q < PA; ++q)
+          sa[S][q][j] = p.a[(size_t)min(r0 + ua[q].grp * 8 + j, p.N - 1) * p.M + min(ua[q].col, p.M - 1)];
+#pragma unroll
+        for (int q = 0; q < PB; ++q)
+          sb[S][q][j] = p.b[(size_t)min(r0 + ub[q].grp * 8 + j, p.N - 1) * p.K + min(ub[q].col, p.K - 1)];
       }
     }
   };
-  auto commit = [&](int buf) {
+  // valid == false (a stage past the end of the slab, DB pipeline only): the stage is committed as zeros, so
+  // multiplying it is a no-op and the loop body stays free of branches (see below)
+  auto commit_one = [&](bf16x8* t, const Unit& un, float (&st)[8], int r0, bool valid, float* sum) {
+    if constexpr (MASKED) {
 #pragma unroll
-    for (int q = 0; q < kPerThread; ++q) {
-      tile4[buf][threadIdx.x + q * kBlock] = stage[q];
+      for (int j = 0; j < 8; ++j) st[j] = (un.live && r0 + un.grp * 8 + j < r_end) ? st[j] : 0.f;
     }
+    if constexpr (DB) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) st[j] = valid ? st[j] : 0.f;
+    }
+    if (sum) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += st[j];
+      *sum += s;
+    }
+    bf16x8 h, m, l;
+    split3(st, h, m, l);
+    t[un.lds] = h; t[kPlane + un.lds] = m; t[2 * kPlane + un.lds] = l;
+  };
+  auto commit = [&](auto set_c, int buf, int r0, bool valid) {
+    constexpr int S = decltype(set_c)::value;
+    bf16x8* t = tile + buf * kBuf;
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+      if (UA % kThreads == 0 || threadIdx.x + q * kThreads < UA) commit_one(t, ua[q], sa[S][q], r0, valid, &bsum[q]);
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (UB % kThreads == 0 || threadIdx.x + q * kThreads < UB) commit_one(t, ub[q], sb[S][q], r0, valid, nullptr);
   };
   auto multiply = [&](int buf) {
-    const float* t = reinterpret_cast<const float*>(tile4[buf]);
-    // operands of k-step kk+1 are read from LDS while the MFMAs of k-step kk issue
-    float av[2][TM], bv[2][TK];
-    auto read_ops = [&](int set, int kk) {
-      const float* row = t + (2 * kk + half) * W;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[set][i] = row[m_base + i * kTile + l31];
+    for (int kk = 0; kk < kStageRows / 16; ++kk) {
+      const bf16x8* g = tile + buf * kBuf + (2 * kk + half) * W;
+      bf16x8 a[TM][3], b[TK][3];
 #pragma unroll
-      for (int j = 0; j < TK; ++j) bv[set][j] = row[MP + k_base + j * kTile + l31];
-    };
-    read_ops(0, 0);
+      for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-    for (int kk = 0; kk < kStageRows / 2; ++kk) {
-      const int cur = kk & 1;
-      if (kk + 1 < kStageRows / 2) read_ops(cur ^ 1, kk + 1);
+        for (int i = 0; i < TM; ++i) a[i][pl] = g[pl * kPlane + m_base + i * kTile + l31];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        bsum[i] += av[cur][i];
-#pragma unroll
-        for (int j = 0; j < TK; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TK; ++j) b[j][pl] = g[pl * kPlane + MP + k_base + j * kTile + l31];
       }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+          f32x16 c = acc[i][j];                       // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
     }
   };
 
+  // DB: stage i lives in register set i & 1 and LDS buffer i & 1; the loads of stage i+2 are issued as soon as
+  // stage i has been converted, i.e. two stages ahead of the MFMAs that will consume them.  The loop body has
+  // no branches: a stage index past the end re-reads the last stage (cache hit) and is committed as zeros, so
+  // the compiler can count the loads in flight and waits only for the older stage (`s_waitcnt vmcnt(n)` with
+  // the newer stage's loads still outstanding) -- with conditional fetches it falls back to vmcnt(0), which
+  // serialises load latency and MFMAs.  Single buffered: one stage ahead (the other workgroups of the CU cover
+  // the rest of the latency).
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
   if (r_begin < r_end) {
-    fetch(r_begin);
-    commit(0);
-    __syncthreads();
-    int buf = 0;
-    for (int r0 = r_begin; r0 < r_end; r0 += kStageRows) {
-      const bool more = r0 + kStageRows < r_end;
-      if (more) fetch(r0 + kStageRows);        // in flight while this stage is multiplied
-      multiply(buf);
-      if (more) commit(buf ^ 1);
+    if constexpr (DB) {
+      const int n = (r_end - r_begin + kStageRows - 1) / kStageRows;
+      auto row_of = [&](int i) { return r_begin + min(i, n - 1) * kStageRows; };
+      fetch(P0{}, row_of(0));
+      fetch(P1{}, row_of(1));
+      commit(P0{}, 0, row_of(0), true);
       __syncthreads();
-      buf ^= 1;
+      for (int i = 0; i < n; i += 2) {
+        fetch(P0{}, row_of(i + 2));
+        multiply(0);                                        // stage i
+        commit(P1{}, 1, row_of(i + 1), i + 1 < n);
+        __syncthreads();
+        fetch(P1{}, row_of(i + 3));
+        multiply(1);                                        // stage i + 1 (zeros when past the end)
+        commit(P0{}, 0, row_of(i + 2), i + 2 < n);
+        __syncthreads();
+      }
+    } else {
+      fetch(P0{}, r_begin);
+      for (int r0 = r_begin; r0 < r_end; r0 += kStageRows) {
+        commit(P0{}, 0, r0, true);
+        __syncthreads();
+        if (r0 + kStageRows < r_end) fetch(P0{}, r0 + kStageRows);
+        multiply(0);
+        __syncthreads();
+      }
     }
   }
 
-  // partial of this slab: ws[block][m*K + k] and ws[block][M*K + m]
-  float* out = p.ws + (size_t)blockIdx.x * p.out_cols;
+  // partial of this slab: ws[slot][m*K + k] and ws[slot][M*K + m]
+  float* out = p.ws + (size_t)(p.slot0 + blockIdx.x) * p.out_cols;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -151,62 +276,83 @@ __global__ __launch_bounds__(kBlock) void linear_wgrad_kernel(const WgradArgs p)
         if (m < p.M && k < p.K) out[(size_t)m * p.K + k] = acc[i][j][r];
       }
     }
-  if (wk == 0) {
+  // db: fold the row groups of each A column through LDS (fixed order)
+  float* red = reinterpret_cast<float*>(tile);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const float s = bsum[i] + __shfl_xor(bsum[i], 32);            // even + odd rows
-      const int m = m_base + i * kTile + l31;
-      if (half == 0 && m < p.M) out[(size_t)p.M * p.K + m] = s;
-    }
+  for (int q = 0; q < PA; ++q)
+    if (UA % kThreads == 0 || threadIdx.x + q * kThreads < UA) red[ua[q].grp * MP + ua[q].col] = bsum[q];
+  __syncthreads();
+  for (int m = threadIdx.x; m < p.M; m += kThreads) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) s += red[g * MP + m];
+    out[(size_t)p.M * p.K + m] = s;
   }
 }
 
-struct WgradPlan { int wm, wk, tm, tk; };
+struct WgradPlan { int nw, wm, wk, tm, tk; };
 
-// smallest wave-layout x per-wave tiling that covers tiles_m x tiles_k with <= 8 tiles per wave
+// cheapest (wave layout) x (tiles per wave) that covers tiles_m x tiles_k with <= 4 tiles (64 accumulator
+// registers) per wave: 4 waves up to 16 tiles, 8 waves (double buffered, one workgroup per CU) up to 32
 static bool plan_wgrad(int tiles_m, int tiles_k, WgradPlan* out) {
-  static const int layouts[3][2] = {{2, 2}, {4, 1}, {1, 4}};
-  static const int sizes[3] = {1, 2, 4};
+  static const int layouts[7][3] = {{4, 2, 2}, {4, 4, 1}, {4, 1, 4}, {8, 4, 2}, {8, 2, 4}, {8, 8, 1}, {8, 1, 8}};
+  static const int shapes[6][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {1, 4}, {4, 1}};
   int best = 1 << 30;
   bool found = false;
   for (auto& lay : layouts)
-    for (int tm : sizes)
-      for (int tk : sizes) {
-        if (tm * tk > 8) continue;
-        if (lay[0] * tm < tiles_m || lay[1] * tk < tiles_k) continue;
-        const int cost = (lay[0] * tm) * (lay[1] * tk) * 16 + (tm + tk);     // padded MFMA work, then loads
-        if (cost < best) { best = cost; *out = {lay[0], lay[1], tm, tk}; found = true; }
-      }
+    for (auto& sh : shapes) {
+      const int tm = sh[0], tk = sh[1];
+      if (lay[0] == 8 && tm * tk != 4) continue;                 // 8 waves only where 4 waves run out of registers
+      if (lay[1] * tm < tiles_m || lay[2] * tk < tiles_k) continue;
+      if (!lds_fits((lay[1] * tm + lay[2] * tk) * kTile, lay[0] == 8)) continue;
+      // padded MFMA work, then operand loads per wave, then prefer the smaller workgroup
+      const int cost = ((lay[1] * tm) * (lay[2] * tk) * 16 + (tm + tk)) * 2 + (lay[0] == 8);
+      if (cost < best) { best = cost; *out = {lay[0], lay[1], lay[2], tm, tk}; found = true; }
+    }
   return found;
 }
 
-static int wgrad_blocks(int64_t N) {
+static int wgrad_blocks(int64_t N, const WgradPlan& pl) {
   int64_t b = (N + 511) / 512;            // at least 512 rows per slab
-  if (b > 512) b = 512;                   // 2 workgroups per CU
+  const int64_t cap = pl.nw == 8 ? 256 : 512;     // one 8-wave or two 4-wave workgroups per CU
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }
 
-#define MLGNN_WG_CASE(WM_, WK_, TM_, TK_)                                                            \
-  if (pl.wm == WM_ && pl.wk == WK_ && pl.tm == TM_ && pl.tk == TK_) {                                \
-    if (aligned) hipLaunchKernelGGL((linear_wgrad_kernel<WM_, WK_, TM_, TK_, true>), grid, block, 0, s, a);   \
-    else hipLaunchKernelGGL((linear_wgrad_kernel<WM_, WK_, TM_, TK_, false>), grid, block, 0, s, a);        \
+template <bool MASKED>
+static bool launch_wgrad(const WgradPlan& pl, const WgradArgs& a, int nblk, hipStream_t s) {
+  const dim3 grid(nblk);
+  bool launched = false;
+#define MLGNN_WG_CASE(NW_, WM_, WK_, TM_, TK_)                                                       \
+  if (pl.nw == NW_ && pl.wm == WM_ && pl.wk == WK_ && pl.tm == TM_ && pl.tk == TK_) {                \
+    hipLaunchKernelGGL((linear_wgrad_kernel<NW_, WM_, WK_, TM_, TK_, NW_ == 8, MASKED>), grid,       \
+                       dim3(NW_ * kWave), 0, s, a);                                                  \
     launched = true;                                                                                 \
   }
-#define MLGNN_WG_LAYOUT(WM_, WK_)                                                                    \
-  MLGNN_WG_CASE(WM_, WK_, 1, 1) MLGNN_WG_CASE(WM_, WK_, 1, 2) MLGNN_WG_CASE(WM_, WK_, 1, 4)          \
-  MLGNN_WG_CASE(WM_, WK_, 2, 1) MLGNN_WG_CASE(WM_, WK_, 2, 2) MLGNN_WG_CASE(WM_, WK_, 2, 4)          \
-  MLGNN_WG_CASE(WM_, WK_, 4, 1) MLGNN_WG_CASE(WM_, WK_, 4, 2)
+#define MLGNN_WG_LAYOUT4(WM_, WK_)                                                                   \
+  MLGNN_WG_CASE(4, WM_, WK_, 1, 1) MLGNN_WG_CASE(4, WM_, WK_, 1, 2) MLGNN_WG_CASE(4, WM_, WK_, 2, 1) \
+  MLGNN_WG_CASE(4, WM_, WK_, 2, 2) MLGNN_WG_CASE(4, WM_, WK_, 1, 4) MLGNN_WG_CASE(4, WM_, WK_, 4, 1)
+  MLGNN_WG_LAYOUT4(2, 2) MLGNN_WG_LAYOUT4(4, 1) MLGNN_WG_LAYOUT4(1, 4)
+  MLGNN_WG_CASE(8, 4, 2, 2, 2) MLGNN_WG_CASE(8, 4, 2, 1, 4) MLGNN_WG_CASE(8, 4, 2, 4, 1)
+  MLGNN_WG_CASE(8, 2, 4, 2, 2) MLGNN_WG_CASE(8, 2, 4, 1, 4) MLGNN_WG_CASE(8, 2, 4, 4, 1)
+  MLGNN_WG_CASE(8, 8, 1, 2, 2) MLGNN_WG_CASE(8, 8, 1, 1, 4)          // (8,1,4,1) / (1,8,1,4): 1056-wide tiles exceed LDS
+  MLGNN_WG_CASE(8, 1, 8, 2, 2) MLGNN_WG_CASE(8, 1, 8, 4, 1)
+#undef MLGNN_WG_LAYOUT4
+#undef MLGNN_WG_CASE
+  return launched;
+}
 
 }  // namespace mlgnn
 
 using namespace mlgnn;
 
+// one workspace slot per workgroup of the main launch + one for the masked remainder launch
 extern "C" int64_t mlgnn_linear_wgrad_workspace_floats(int64_t N, int64_t M, int64_t K) {
   if (N < 0 || M <= 0 || K <= 0) return MLGNN_E_SHAPE;
   WgradPlan pl;
   if (!plan_wgrad((int)((M + kTile - 1) / kTile), (int)((K + kTile - 1) / kTile), &pl)) return MLGNN_E_SHAPE;
-  return (int64_t)wgrad_blocks(N) * (M * K + M);
+  return (int64_t)(wgrad_blocks(N, pl) + 1) * (M * K + M);
 }
 
 extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, float* grad_w_b, float* workspace,
@@ -214,27 +360,35 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, float* gr
                                   void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   if (N < 0 || M <= 0 || K <= 0 || N > INT32_MAX || M * K > (1 << 24)) return MLGNN_E_SHAPE;
+  if (N * (M > K ? M : K) * 4 >= ((int64_t)1 << 32)) return MLGNN_E_SHAPE;      // 32-bit byte offsets inside a slab
   WgradPlan pl;
   if (!plan_wgrad((int)((M + kTile - 1) / kTile), (int)((K + kTile - 1) / kTile), &pl)) return MLGNN_E_SHAPE;
   if (!grad_w_b || !workspace) return MLGNN_E_NULL;
   if (N > 0 && (!grad_out || !x)) return MLGNN_E_NULL;
-  const int nblk = wgrad_blocks(N);
+  const int nblk = wgrad_blocks(N, pl);
   const int cols = (int)(M * K + M);
-  if (workspace_floats < (int64_t)nblk * cols) return MLGNN_E_WORKSPACE;
+  if (workspace_floats < (int64_t)(nblk + 1) * cols) return MLGNN_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
   WgradArgs a;
   a.a = (const float*)grad_out; a.b = (const float*)x; a.ws = workspace;
   a.N = (int)N; a.M = (int)M; a.K = (int)K; a.out_cols = cols;
-  int rpb = (int)((N + nblk - 1) / nblk);
-  rpb = (rpb + kStageRows - 1) / kStageRows * kStageRows;
-  a.rows_per_block = rpb;
-  hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(nblk), block(kBlock);
-  bool launched = false;
-  const bool aligned = (M % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
-  MLGNN_WG_LAYOUT(2, 2) MLGNN_WG_LAYOUT(4, 1) MLGNN_WG_LAYOUT(1, 4)
-  if (!launched) return MLGNN_E_SHAPE;
+  // unpadded operands: whole stages go through the unmasked kernel, the last N % 32 rows through the masked one
+  const bool padded = (M % kTile != 0) || (K % kTile != 0);
+  const int main_rows = padded ? 0 : (int)(N / kSlabAlign * kSlabAlign);
+  int slots = 0;
+  if (main_rows > 0) {
+    a.row0 = 0; a.rows = main_rows; a.slot0 = 0;
+    if (!launch_wgrad<false>(pl, a, nblk, s)) return MLGNN_E_SHAPE;
+    slots = nblk;
+  }
+  if (main_rows < N || N == 0) {
+    a.row0 = main_rows; a.rows = (int)N - main_rows; a.slot0 = slots;
+    const int nb = padded ? nblk : 1;
+    if (!launch_wgrad<true>(pl, a, nb, s)) return MLGNN_E_SHAPE;
+    slots += nb;
+  }
   int err = (int)hipGetLastError();
   if (err) return err;
-  launch_reduce_partials(workspace, grad_w_b, nblk, cols, s);
+  launch_reduce_partials(workspace, grad_w_b, slots, cols, s);
   return (int)hipGetLastError();
 }

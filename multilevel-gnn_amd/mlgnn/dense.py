@@ -82,7 +82,11 @@ def dense_sage(x, adj, w_rel, w_root, b_root, normalize=True):
     x = x.unsqueeze(0) if x.dim() == 2 else x
     adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
     agg = torch.matmul(adj, x) / adj.sum(dim=-1, keepdim=True).clamp(min=1)
-    out = F.linear(agg, w_rel) + F.linear(x, w_root, b_root)
+    # both Linears see the [B*n, c] node rows: tall enough for the split-row weight-gradient kernel
+    # (the library's TN GEMM for a 32..64-wide output over 56k rows runs on a handful of workgroups)
+    lead, c = x.shape[:-1], x.shape[-1]
+    out = linear(agg.reshape(-1, c), w_rel) + linear(x.reshape(-1, c), w_root, b_root)
+    out = out.view(*lead, -1)
     return F.normalize(out, p=2.0, dim=-1) if normalize else out
 
 

@@ -1,4 +1,5 @@
-"""Split-row fp32-MFMA weight/bias gradient kernel vs torch autograd on the CPU."""
+"""Split-row weight/bias gradient kernel (three-term bf16 split on MFMA, fp32 accumulation) vs torch
+autograd on the CPU."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -32,6 +33,41 @@ def test_tall_linear_gradients(N, K, M, bias):
     got = torch.autograd.grad((out * cot.to(dev)).sum(), dl)
     for name, g, r in zip(("x", "weight", "bias"), got, gr):
         assert_close(g, r, 1e-4, "linear grad " + name)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-12, 1e9])
+def test_wgrad_keeps_fp32_accuracy_at_any_magnitude(scale):
+    """The bf16 split has fp32's exponent range: tiny (or huge) gradients lose nothing, and the result
+    is as close to the float64 product as an fp32 GEMM would be (the dropped cross terms are 2^-24)."""
+    from mlgnn import _lib
+    N, M, K = 30000, 256, 128
+    gen = torch.Generator().manual_seed(3)
+    g = torch.randn(N, M, generator=gen) * scale
+    g[::7] *= 1e-3                                         # rows of very different magnitude
+    x = torch.randn(N, K, generator=gen)
+    ref = g.double().t() @ x.double()
+    ref_b = g.double().sum(0)
+    mag = (g.double().abs().t() @ x.double().abs())        # size of the terms each output sums
+    dev = "cuda:0"
+    gd, xd = g.to(dev), x.to(dev)
+    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K))
+    ws = torch.empty(n, device=dev)
+    out = torch.empty(M * K + M, device=dev)
+    rc = _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), out.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    got = out[:M * K].view(M, K).cpu().double()
+    err = ((got - ref).abs() / mag).max().item()
+    assert err < 1e-6, err                                 # 2^-20: elementwise, relative to the summed magnitudes
+    lib = (gd.t() @ xd).cpu().double()                     # the library's fp32 GEMM, for scale
+    lib_err = ((lib - ref).abs() / mag).max().item()
+    assert err < 4 * lib_err + 1e-7, (err, lib_err)
+    assert_close(out[M * K:].cpu().double() / scale, ref_b / scale, 1e-5, "bias grad")
+    # bitwise reproducible (fixed summation order)
+    out2 = torch.empty_like(out)
+    _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), out2.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
+                                torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(out, out2)
 
 
 def test_unsupported_shapes_use_library_gemm():

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 2
+#define MLGNN_ABI_VERSION 3
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -61,9 +61,12 @@ extern "C" {
 
 int mlgnn_version(void);
 
-/* Number of float elements of workspace mlgnn_csr_aggregate_bwd needs for [.,d] channels and a
- * factored edge term of edge_rank attributes (0 when the edge mode is not EDGE_RANK1). */
-int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int edge_rank);
+/* Number of float elements of workspace mlgnn_csr_aggregate_bwd needs: per-workgroup partials of a
+ * factored edge term of edge_rank attributes (0 when the edge mode is not EDGE_RANK1) plus, for
+ * AGGR_SOFTMAX without learn_t, the rescaled cotangent [N,d] and per-node shift of the one-row gather
+ * path.  May be 0 (then workspace may be NULL). */
+int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int dtype, int edge_rank,
+                                                 int aggr, int learn_t);
 
 /*
  * Fused message + aggregation over the incoming edges of every node.
@@ -105,13 +108,13 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
  *                   q = grad_out * mu^(1/p-1) * [1e-7<=mu<=10] / clamp(deg,1)  instead.
  *   x, out, aux, argmax: as produced / consumed by the forward
  *   rowptr_t [N+1], col_t [E] (destination), pos_t [E] (by-destination position)
- *   rowptr   [N+1]  by-destination row pointer (in-degree for MEAN)
+ *   rowptr   [N+1]  by-destination row pointer (in-degree for MEAN; nodes with incoming edges for SOFTMAX)
  *   ew_t [E] / [E,edge_rank], eid_t [E]: ew / eid permuted to by-source order
  *   grad_x   [N,d]
  *   grad_efull [E0,d]  EDGE_FULL: d loss / d efull, written at eid (every row written once)
  *   grad_uv  [edge_rank+1,d]  EDGE_RANK1: d loss / d eu (edge_rank rows), then d loss / d ev
  *   learn_t  non-zero: SOFTMAX weights carry gradient (torch_message.py:51-52)
- *   workspace: mlgnn_csr_aggregate_bwd_workspace_floats(N,d,edge_rank) floats (EDGE_RANK1 only)
+ *   workspace: mlgnn_csr_aggregate_bwd_workspace_floats(N,d,dtype,edge_rank,aggr,learn_t) floats
  */
 int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out, const float* aux,
                             const int32_t* argmax,

@@ -13,18 +13,23 @@ struct BwdArgs {                      // go / x / out / efull / gx / ge are T; a
   const int* rowptr_t; const int* col_t; const int* pos_t; const int* rowptr;
   const float* ew_t; const float* eu; const float* ev; const void* efull; const int* eid_t;
   void* gx; void* ge; float* ws;
+  const void* gt; const float* shift; const int* spread;   // softmax shift path (see softmax_shift_kernel)
   const float* t_dev; const float* p_dev;
   int N; int d; int lpr_log2; int mean; int learn_t; int add_root;
   float t; float p; float eps;
 };
 
-template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T>
-__global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
+// SHIFT (softmax without a learnable temperature): the per-(node, channel) normaliser lse[i][c] is split into a
+// per-node scalar s_i and a remainder that softmax_shift_kernel folds into the cotangent,
+//     gt[i][c] = go[i][c] * 2^(s_i - lse[i][c]),      w_e * go = 2^(t m_e - s_i) * gt[i][c],
+// so an edge gathers ONE row (gt) and one scalar instead of two rows (go, lse): half the gather traffic.
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool SHIFT>
+__device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (*red)[kWave * VEC]) {
   constexpr int RK = rank_of<MODE>();
   constexpr int ES = edge_scalars<MODE>();
   constexpr int ESA = ES > 0 ? ES : 1;
-  __shared__ float red[kWavesPerBlock][kWave * VEC];
   const T* GO = static_cast<const T*>(a.go);
+  const T* GT = static_cast<const T*>(a.gt);
   const T* X = static_cast<const T*>(a.x);
   const T* OUTS = static_cast<const T*>(a.out);
   const T* EF = static_cast<const T*>(a.efull);
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
         const int cnt = min(kWave, end - base);
         uint32_t my_off = 0;
         int my_pos = 0, my_eid = 0;
-        float my_ew[ESA], my_inv = 1.f;
+        float my_ew[ESA], my_inv = 1.f, my_shift = 0.f;
 #pragma unroll
         for (int k = 0; k < ESA; ++k) my_ew[k] = 0.f;
         if (lane < cnt) {
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
             load_edge_scalars<ES>(my_ew, a.ew_t, (size_t)(base + lane));
           }
           if (MODE == M_GEN_FULL) my_eid = a.eid_t[base + lane];
+          if constexpr (SHIFT) my_shift = a.shift[dst];
           if (AGGR == A_SUM && a.mean)
             my_inv = __builtin_amdgcn_rcpf((float)max(a.rowptr[dst + 1] - a.rowptr[dst], 1));
         }
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
           constexpr bool FULL = decltype(full_c)::value;
           float ga[kUnroll][VEC], gb[kUnroll][VEC], gc[kUnroll][VEC], ef[kUnroll][VEC];
           int ai[kUnroll][VEC];
-          float wa[kUnroll][ESA], inv[kUnroll];
+          float wa[kUnroll][ESA], inv[kUnroll], sh[kUnroll];
           int pos[kUnroll], e0[kUnroll];
           bool valid[kUnroll];
 #pragma unroll
@@ -106,13 +112,14 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
 #pragma unroll
             for (int q = 0; q < ESA; ++q) wa[u][q] = (ES > 0) ? __shfl(my_ew[q], src) : 0.f;
             inv[u] = (AGGR == A_SUM) ? __shfl(my_inv, src) : 1.f;
+            sh[u] = SHIFT ? __shfl(my_shift, src) : 0.f;
             pos[u] = (AGGR == A_MAX) ? __shfl(my_pos, src) : 0;
             e0[u] = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { ga[u][i] = 0.f; gb[u][i] = 0.f; gc[u][i] = 0.f; ef[u][i] = 0.f; ai[u][i] = -2; }
             if (FULL || valid[u]) {
-              load_row<T, VEC>(ga[u], GO, off);
-              if (AGGR == A_SOFTMAX) load_row<float, VEC>(gb[u], a.aux, off * kWide);
+              load_row<T, VEC>(ga[u], SHIFT ? GT : GO, off);
+              if (AGGR == A_SOFTMAX && !SHIFT) load_row<float, VEC>(gb[u], a.aux, off * kWide);
               if (AGGR == A_SOFTMAX && LEARN_T) load_row<T, VEC>(gc[u], OUTS, off);
               if (AGGR == A_MAX) load_row<VEC>(ai[u], a.argmax, off * kWide);
               if (MODE == M_GEN_FULL) load_t<T, VEC>(ef[u], EF + (size_t)e0[u] * a.d + c0);
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
               } else if constexpr (AGGR == A_MAX) {
                 coef = (ai[u][i] == pos[u]) ? ga[u][i] : 0.f;
               } else if constexpr (AGGR == A_SOFTMAX) {
-                const float w = fast_exp2(fmaf(sc.t_log2e, m, -gb[u][i]));
+                const float w = fast_exp2(fmaf(sc.t_log2e, m, SHIFT ? -sh[u] : -gb[u][i]));
                 coef = ga[u][i] * w;
                 if (LEARN_T) coef *= fmaf(sc.t, m - gc[u][i], 1.0f);
               } else {  // POWER: ga carries q (see mlgnn.h)
@@ -203,6 +210,103 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
   }
 }
 
+constexpr float kMaxSpread = 200.0f;     // log2 units; beyond it 2^(s - lse) could leave the fp32 range
+
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T>
+__global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
+  __shared__ float red[kWavesPerBlock][kWave * VEC];
+  if constexpr (AGGR == A_SOFTMAX && !LEARN_T) {
+    // *a.spread != 0: softmax_shift_kernel met a node whose lse spans more than kMaxSpread across channels; the
+    // two-row path stays as the fallback for such inputs (never seen in practice)
+    const bool shift_ok = a.gt != nullptr && *a.spread == 0;
+    if (shift_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true>(a, red);
+    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false>(a, red);
+  } else {
+    csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false>(a, red);
+  }
+}
+
+// Per destination node i with at least one incoming edge: s_i = (min_c lse + max_c lse) / 2,
+// gt[i][c] = go[i][c] * 2^(s_i - lse[i][c]); *spread is set when some node's max_c lse - min_c lse exceeds
+// kMaxSpread (a plain store of the same value by whoever sees it: no atomics on the common path).
+// With the midpoint shift both factors of w = 2^(t m - s_i) * 2^(s_i - lse) stay within 2^(+-spread/2).
+struct ShiftArgs {
+  const void* go; const float* lse; const int* rowptr; void* gt; float* shift; int* spread;
+  int N; int d; int lpr_log2;
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void softmax_shift_kernel(const ShiftArgs a) {
+  constexpr int kRows = 4;                           // row groups in flight per wave
+  const T* GO = static_cast<const T*>(a.go);
+  T* GT = static_cast<T*>(a.gt);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << a.lpr_log2;
+  const int groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2, cl = lane & (lpr - 1);
+  const int wave_global = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int n_waves = gridDim.x * kWavesPerBlock;
+  const bool one_chunk = a.d <= lpr * VEC;            // the whole row sits in one register chunk (d <= 256 / 512)
+  const bool cact = cl * VEC < a.d;
+  const int c0 = min(cl * VEC, a.d - VEC);
+  float worst = 0.f;
+  for (int r0 = wave_global * groups * kRows; r0 < a.N; r0 += n_waves * groups * kRows) {
+    int row[kRows];
+    bool live[kRows];
+    float lo[kRows], hi[kRows], l[kRows][VEC], g[kRows][VEC];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+      row[k] = r0 + k * groups + sub;
+      const int rc = min(row[k], a.N - 1);
+      live[k] = row[k] < a.N && a.rowptr[rc + 1] > a.rowptr[rc];
+      lo[k] = 3.0e38f; hi[k] = -3.0e38f;
+      if (one_chunk) {
+        load_vec<VEC>(l[k], a.lse + (size_t)rc * a.d + c0);
+        load_t<T, VEC>(g[k], GO + (size_t)rc * a.d + c0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+      const int rc = min(row[k], a.N - 1);
+      if (one_chunk) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { lo[k] = fminf(lo[k], l[k][i]); hi[k] = fmaxf(hi[k], l[k][i]); }
+      } else {
+        for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
+          float t[VEC];
+          load_vec<VEC>(t, a.lse + (size_t)rc * a.d + min(cbase + cl * VEC, a.d - VEC));
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) { lo[k] = fminf(lo[k], t[i]); hi[k] = fmaxf(hi[k], t[i]); }
+        }
+      }
+      for (int off = 1; off < lpr; off <<= 1) {
+        lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+        hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+      }
+      const float s = live[k] ? 0.5f * (lo[k] + hi[k]) : 0.f;
+      if (live[k]) worst = fmaxf(worst, hi[k] - lo[k]);
+      if (one_chunk) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[k][i] = live[k] ? g[k][i] * fast_exp2(s - l[k][i]) : 0.f;
+        if (row[k] < a.N && cact) store_t<T, VEC>(GT + (size_t)row[k] * a.d + c0, g[k]);
+      } else {
+        for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
+          const int cc = min(cbase + cl * VEC, a.d - VEC);
+          float t[VEC], q[VEC];
+          load_vec<VEC>(t, a.lse + (size_t)rc * a.d + cc);
+          load_t<T, VEC>(q, GO + (size_t)rc * a.d + cc);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) q[i] = live[k] ? q[i] * fast_exp2(s - t[i]) : 0.f;
+          if (row[k] < a.N && cbase + cl * VEC < a.d) store_t<T, VEC>(GT + (size_t)row[k] * a.d + cc, q);
+        }
+      }
+      if (row[k] < a.N && cl == 0) a.shift[row[k]] = s;
+    }
+  }
+  for (int off = 1; off < kWave; off <<= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
+  if (lane == 0 && worst > kMaxSpread) *a.spread = 1;       // plain store: every writer stores the same value
+}
+
 // ws[nblk][cols] -> out[cols] in a fixed summation order (bitwise reproducible).  One workgroup of
 // 1024 threads owns 32 columns: 32 row slices x 32 columns, each thread sums every 32nd row with
 // independent (pipelined) loads, then the 32 slices are folded through LDS in slice order.
@@ -262,10 +366,16 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   if (ag == A_SOFTMAX && (!aux || (learn_t && !out))) return MLGNN_E_NULL;
   const int rk = rank_of_mode(mode);
   if ((mode == M_WEIGHTED || rk > 0) && !ew_t && col_t) return MLGNN_E_NULL;
-  if (rk > 0 && (!eu || !ev || !grad_uv || !workspace)) return MLGNN_E_NULL;
+  if (rk > 0 && (!eu || !ev || !grad_uv)) return MLGNN_E_NULL;
   if (mode == M_GEN_FULL && col_t && (!efull || !eid_t || !grad_efull)) return MLGNN_E_NULL;
   const int nblk = grid_for_rows(N);
-  if (rk > 0 && workspace_floats < (int64_t)nblk * (rk + 1) * d) return MLGNN_E_WORKSPACE;
+  const bool bf16 = dtype == MLGNN_DTYPE_BF16;
+  // workspace = [edge-term partials: nblk * (rk+1) * d][softmax shift path: spread (4 floats), s [N], gt [N*d] of T]
+  const int64_t part_floats = rk > 0 ? (int64_t)nblk * (rk + 1) * d : 0;
+  const bool want_shift = ag == A_SOFTMAX && !learn_t;
+  const int64_t n_pad = (N + 3) / 4 * 4;
+  const int64_t shift_floats = want_shift ? 4 + n_pad + (N * d * (bf16 ? 2 : 4) + 3) / 4 : 0;
+  if (part_floats + shift_floats > 0 && (!workspace || workspace_floats < part_floats + shift_floats)) return MLGNN_E_WORKSPACE;
 
   BwdArgs a;
   a.go = grad_out; a.x = x; a.out = out; a.aux = aux;
@@ -280,11 +390,33 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                   (!out || aligned16(out)) && (!aux || aligned16(aux)) && (!argmax || aligned16(argmax)) &&
                   (!efull || aligned16(efull)) && (!grad_efull || aligned16(grad_efull)) &&
                   (!eu || aligned16(eu)) && (!ev || aligned16(ev));
-  const bool bf16 = dtype == MLGNN_DTYPE_BF16;
   const int vec = bf16 ? ((d % 8 == 0 && al) ? 8 : 1) : ((d % 4 == 0 && al) ? 4 : 1);
   const dim3 grid(nblk), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   a.lpr_log2 = lanes_per_row_log2(d, vec);
+  a.gt = nullptr; a.shift = nullptr; a.spread = nullptr;
+  if (want_shift) {
+    float* base = workspace + part_floats;               // 16-byte aligned: part_floats is a multiple of 4 when d % 4 == 0
+    if (!rowptr) return MLGNN_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(base) & 15) == 0 || vec == 1) {
+      ShiftArgs sa;
+      sa.go = grad_out; sa.lse = aux; sa.rowptr = rowptr; sa.N = (int)N; sa.d = (int)d; sa.lpr_log2 = a.lpr_log2;
+      sa.spread = reinterpret_cast<int*>(base); sa.shift = base + 4; sa.gt = base + 4 + n_pad;
+      int err0 = (int)hipMemsetAsync(sa.spread, 0, 16, s);
+      if (err0) return err0;
+      const int rows_per_block = kWavesPerBlock * (kWave >> a.lpr_log2) * 4;
+      int sblk = (int)((N + rows_per_block - 1) / rows_per_block);
+      if (sblk > 8192) sblk = 8192;
+      if (bf16) {
+        if (vec == 8) hipLaunchKernelGGL((softmax_shift_kernel<bf16_t, 8>), dim3(sblk), block, 0, s, sa);
+        else hipLaunchKernelGGL((softmax_shift_kernel<bf16_t, 1>), dim3(sblk), block, 0, s, sa);
+      } else {
+        if (vec == 4) hipLaunchKernelGGL((softmax_shift_kernel<float, 4>), dim3(sblk), block, 0, s, sa);
+        else hipLaunchKernelGGL((softmax_shift_kernel<float, 1>), dim3(sblk), block, 0, s, sa);
+      }
+      a.gt = sa.gt; a.shift = sa.shift; a.spread = sa.spread;
+    }
+  }
   const bool lt = learn_t != 0 && ag == A_SOFTMAX;
   for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
     constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;

@@ -7,6 +7,11 @@
 namespace mlgnn {
 
 constexpr int kUnroll = 4;                 // neighbour rows in flight per lane group and batch
+// rows per wave of the forward's chunked row walk (common.h).  Measured at config 2 (64 x 10k-node graphs):
+// 4..8 rows per wave is best for the memory-bound aggregators (mean 0.51 -> 0.42 ms, max 0.57 -> 0.51 ms vs the
+// strided persistent walk; softmax is VALU-bound either way).  The backward keeps the strided walk: it is bound
+// by per-edge instruction issue, and one edge-term partial per workgroup favours few, long-lived workgroups.
+constexpr int kFwdRowsPerWave = 8;
 constexpr float kPowLo = 1e-7f, kPowHi = 1e1f;   // torch_message.py:69
 constexpr float kNegBig = -3.0e38f;
 

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
   const int groups = kWave >> a.lpr_log2;
   const int sub = lane >> a.lpr_log2;
   const int cl = lane & (lpr - 1);
-  const RowWalk walk = make_row_walk(a.N);
+  const RowWalk walk = make_chunk_walk(a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
   const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
   constexpr int RK = rank_of<MODE>();                    // rank of the factored edge term (0: none)
@@ -264,9 +264,15 @@ using namespace mlgnn;
 
 extern "C" int mlgnn_version(void) { return MLGNN_ABI_VERSION; }
 
-extern "C" int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int edge_rank) {
+extern "C" int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int dtype, int edge_rank,
+                                                            int aggr, int learn_t) {
   if (N < 0 || d < 0 || edge_rank < 0 || edge_rank > 8) return MLGNN_E_SHAPE;
-  return (int64_t)grid_for_rows(N) * (edge_rank + 1) * d;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
+  // per-workgroup partials of the factored edge term + the softmax shift buffers (aggregate_bwd.hip)
+  int64_t n = edge_rank > 0 ? (int64_t)grid_for_rows(N) * (edge_rank + 1) * d : 0;
+  if (aggr == MLGNN_AGGR_SOFTMAX && !learn_t)
+    n += 4 + (N + 3) / 4 * 4 + (N * d * (dtype == MLGNN_DTYPE_BF16 ? 2 : 4) + 3) / 4;
+  return n;
 }
 
 extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t* col,
@@ -302,7 +308,7 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   const bool bf16 = dtype == MLGNN_DTYPE_BF16;
   // channels per lane: 16-byte accesses (4 x fp32 / 8 x bf16) when the width allows, scalar otherwise
   const int vec = bf16 ? ((d % 8 == 0 && al) ? 8 : 1) : ((d % 4 == 0 && al) ? 4 : 1);
-  const dim3 grid(grid_for_rows(N)), block(kBlock);
+  const dim3 grid(grid_for_chunks(N, kFwdRowsPerWave)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   const bool second = (aux2 != nullptr) && (ag == A_SOFTMAX || ag == A_POWER);
   a.lpr_log2 = lanes_per_row_log2(d, vec);

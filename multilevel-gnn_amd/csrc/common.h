@@ -137,6 +137,36 @@ __device__ __forceinline__ RowWalk make_row_walk(int n_rows) {
   return w;
 }
 
+// Chunked variant: workgroup `slot` of an XCD owns the contiguous chunk [slot*C, (slot+1)*C) of that XCD's
+// eighth (C = rows per workgroup, a multiple of 4; wave w takes rows w, w+4, ...).  Workgroups are dispatched
+// in index order, so at any time the resident workgroups of an XCD cover one window of a few thousand
+// consecutive rows that advances ONCE through the eighth: the rows gathered by a graph's nodes are touched
+// in one pass while that graph is the L2's working set, instead of once per generation of resident
+// workgroups as with the strided persistent walk above.
+__device__ __forceinline__ RowWalk make_chunk_walk(int n_rows) {
+  const int xcd = blockIdx.x % kXcds;
+  const int slot = blockIdx.x / kXcds;
+  const int blocks_per_xcd = gridDim.x / kXcds;          // grid is a multiple of 8
+  const int rows_per_xcd = (n_rows + kXcds - 1) / kXcds;
+  int chunk = (rows_per_xcd + blocks_per_xcd - 1) / blocks_per_xcd;
+  chunk = (chunk + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
+  RowWalk w;
+  w.r_begin = xcd * rows_per_xcd;
+  const int x_end = min(n_rows, w.r_begin + rows_per_xcd);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+  w.first = w.r_begin + slot * chunk + wave;
+  w.r_end = min(x_end, w.r_begin + (slot + 1) * chunk);
+  w.stride = kWavesPerBlock;
+  return w;
+}
+
+inline int grid_for_chunks(int64_t n_rows, int rows_per_wave) {
+  const int64_t rows_per_xcd = (n_rows + kXcds - 1) / kXcds;
+  int64_t per_xcd = (rows_per_xcd + (int64_t)kWavesPerBlock * rows_per_wave - 1) / ((int64_t)kWavesPerBlock * rows_per_wave);
+  if (per_xcd < 1) per_xcd = 1;
+  return (int)(per_xcd * kXcds);
+}
+
 inline int grid_for_rows(int64_t n_rows) {
   int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
   blocks = (blocks + kXcds - 1) / kXcds * kXcds;

@@ -13,7 +13,7 @@ _F = _c.c_float
 # name -> (restype, argtypes); mirrors include/mlgnn.h one to one (tests check the export list)
 SIGNATURES = {
     "mlgnn_version": (_INT, []),
-    "mlgnn_csr_aggregate_bwd_workspace_floats": (_I64, [_I64, _I64, _INT]),
+    "mlgnn_csr_aggregate_bwd_workspace_floats": (_I64, [_I64, _I64, _INT, _INT, _INT, _INT]),
     "mlgnn_csr_aggregate_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                        _I64, _I64, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _P]),
     "mlgnn_csr_aggregate_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,

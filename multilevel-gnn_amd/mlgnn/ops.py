@@ -76,14 +76,20 @@ def algorithmic_bytes(N, E, d, aggr_id, edge_mode, backward=False, learn_t=False
         extra = N * d * 4 if aggr_id == AGGR_MAX else 0          # argmax write
         return rows + idx + scalar + full + N * d * s + extra
     gathers = rows                                                   # grad_out rows
-    if aggr_id == AGGR_SOFTMAX:
-        gathers += E * d * 4 + (rows if learn_t else 0)               # lse (+ out) rows for the recompute
+    prepass = 0
+    if aggr_id == AGGR_SOFTMAX and learn_t:
+        gathers += E * d * 4 + rows                                   # lse + out rows for the recompute
+    elif aggr_id == AGGR_SOFTMAX:
+        # one-row path: the gathered row is gt = go * 2^(s - lse) plus the per-node shift s (4 B / edge);
+        # the prepass streams go + lse in and gt + s out once per node
+        gathers += E * 4
+        prepass = N * d * s + N * d * 4 + N * d * s + N * 4 + (N + 1) * 4
     if aggr_id == AGGR_MAX:
         gathers += E * d * 4 + E * 4                                  # argmax rows + pos_t
     if edge_mode == EDGE_FULL:
         full += E * d * s                                             # grad_efull write
     own = (N * d * s if gen else 0) + N * d * s                       # x_j read + grad_x write
-    return gathers + idx + scalar + full + own
+    return gathers + idx + scalar + full + own + prepass
 
 
 def _dev_f32(t, what):
@@ -236,10 +242,12 @@ class _GenAggregate(torch.autograd.Function):
         gx = torch.empty_like(x)
         ge = torch.empty_like(efull) if edge_mode == EDGE_FULL else None
         guv = ws = None
-        ws_n = 0
-        if edge_mode == EDGE_RANK1:
-            ws_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_workspace_floats(N, d, rank))
+        ws_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_workspace_floats(N, d, dtype_id, rank, aggr_id, int(learn_t)))
+        if ws_n < 0:
+            _lib.check(ws_n, "mlgnn_csr_aggregate_bwd_workspace_floats")
+        if ws_n > 0:
             ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
+        if edge_mode == EDGE_RANK1:
             guv = torch.empty((rank + 1, d), dtype=torch.float32, device=x.device)
         ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
         timer = KERNEL_TIMER

@@ -25,11 +25,15 @@ def test_header_and_binding_agree():
 def test_version_and_error_codes():
     from mlgnn import _lib
     lib = _lib.lib
-    assert lib.mlgnn_version() == 2
-    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 1) == 8 * 2 * 128      # 8 workgroups minimum
-    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 8) == 8 * 9 * 128
-    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 9) == -2
-    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(-1, 4, 1) == -2
+    assert lib.mlgnn_version() == 3
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 1, 0, 0) == 8 * 2 * 128      # 8 workgroups minimum
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 8, 0, 0) == 8 * 9 * 128
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 9, 0, 0) == -2
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(-1, 4, 0, 1, 0, 0) == -2
+    # softmax: + spread (4) + per-node shift (12, padded) + rescaled cotangent (10*128 fp32 / bf16)
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 0, 3, 0) == 4 + 12 + 1280
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 1, 0, 3, 0) == 4 + 12 + 640
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 0, 3, 1) == 0
     null = [None] * 12
     # N = 0 is a no-op, bad dtype / mode / NULL pointers are reported, nothing is launched
     assert lib.mlgnn_csr_aggregate_fwd(*null, 0, 8, 0, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None) == 0

@@ -63,6 +63,10 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
       }
     }
 
+    // the sign of the temperature picks the batch extremum (max / min of the messages); it is uniform for the
+    // whole launch, so the row loop is instantiated for both signs and selected once (no branch per batch)
+    auto rows = [&](auto tpos_c) {
+    constexpr bool TPOS = decltype(tpos_c)::value;
     for (int r = walk.first; r < walk.r_end; r += walk.stride) {
       const int beg = a.rowptr[r];
       const int end = a.rowptr[r + 1];
@@ -136,18 +140,16 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
                 if ((FULL || valid[u]) && m[u][i] > acc[i]) { acc[i] = m[u][i]; bpos[i] = pos; }
             }
           } else if constexpr (AGGR == A_SOFTMAX) {
-            // online softmax, one rescale per batch of kUnroll neighbours; units: log2
+            // online softmax, one rescale per batch of kUnroll neighbours; units: log2.  t*m is monotone in m:
+            // the batch extremum of m (max for t >= 0, min for t < 0) gives the extremum of t*m.
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-              if (!FULL && !valid[0]) break;     // a lane group without a live neighbour in the tail batch
-              // t*m is monotone in m: the batch extremum of m (max for t >= 0, min for t < 0) gives it
+              if (!FULL && !valid[0]) break;
               float ext = m[0][i];
-              if (sc.t_log2e >= 0.f) {                 // wave-uniform
 #pragma unroll
-                for (int u = 1; u < kUnroll; ++u) ext = (FULL || valid[u]) ? fmaxf(ext, m[u][i]) : ext;
-              } else {
-#pragma unroll
-                for (int u = 1; u < kUnroll; ++u) ext = (FULL || valid[u]) ? fminf(ext, m[u][i]) : ext;
+              for (int u = 1; u < kUnroll; ++u) {
+                const float cand = TPOS ? fmaxf(ext, m[u][i]) : fminf(ext, m[u][i]);
+                ext = (FULL || valid[u]) ? cand : ext;
               }
               const float zmax = fmaxf(mx[i], sc.t_log2e * ext);
               const float rs = fast_exp2(mx[i] - zmax);     // 0 on the first batch (mx = kNegBig)
@@ -254,6 +256,12 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
         if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_vec<VEC>(a.aux + off, ax);
         if (SECOND && a.aux2) store_vec<VEC>(a.aux2 + off, ax2);
       }
+    }
+    };
+    if constexpr (AGGR == A_SOFTMAX) {
+      if (sc.t_log2e >= 0.f) rows(BC<true>{}); else rows(BC<false>{});
+    } else {
+      rows(BC<true>{});
     }
   }
 }

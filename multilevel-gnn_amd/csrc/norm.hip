@@ -20,6 +20,8 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+constexpr int kLnRows = 4;            // row groups in flight per wave
+
 struct LnArgs {
   const float* x; const float* go; const float* gamma; const float* beta;
   float* out; float* mean; float* rstd; float* gx; float* ws;
@@ -37,25 +39,37 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_fwd_kernel(const LnArgs 
   float g[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
   if (cact) { load_vec<4>(g, a.gamma + c0); load_vec<4>(b, a.beta + c0); }
   const float inv_d = 1.0f / (float)a.d;
-  for (int r0 = wave_global * GROUPS; r0 < a.rows; r0 += n_waves * GROUPS) {
-    const int r = r0 + sub;
-    const bool ok = (r < a.rows) && cact;
-    float v[4] = {0, 0, 0, 0};
-    if (ok) load_vec<4>(v, a.x + (size_t)r * a.d + c0);
-    const float mu = group_sum<LPR_LOG2>(v[0] + v[1] + v[2] + v[3]) * inv_d;
-    float q = 0.f;
+  // kLnRows row groups per wave and iteration: their loads are issued together (the reductions that follow
+  // are dependent chains; one row at a time leaves the memory pipe idle behind them)
+  for (int r0 = wave_global * GROUPS * kLnRows; r0 < a.rows; r0 += n_waves * GROUPS * kLnRows) {
+    float v[kLnRows][4];
+    bool ok[kLnRows];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const float c = cact ? v[i] - mu : 0.f; q = fmaf(c, c, q); }
-    const float rs = rsqrtf(group_sum<LPR_LOG2>(q) * inv_d + a.eps);
-    if (ok) {
-      float o[4];
+    for (int u = 0; u < kLnRows; ++u) {
+      const int r = r0 + u * GROUPS + sub;
+      ok[u] = (r < a.rows) && cact;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float y = fmaf((v[i] - mu) * rs, g[i], b[i]);
-        o[i] = a.relu ? fmaxf(y, 0.f) : y;
+      for (int i = 0; i < 4; ++i) v[u][i] = 0.f;
+      if (ok[u]) load_vec<4>(v[u], a.x + (size_t)r * a.d + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < kLnRows; ++u) {
+      const int r = r0 + u * GROUPS + sub;
+      const float mu = group_sum<LPR_LOG2>(v[u][0] + v[u][1] + v[u][2] + v[u][3]) * inv_d;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float c = cact ? v[u][i] - mu : 0.f; q = fmaf(c, c, q); }
+      const float rs = rsqrtf(group_sum<LPR_LOG2>(q) * inv_d + a.eps);
+      if (ok[u]) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y = fmaf((v[u][i] - mu) * rs, g[i], b[i]);
+          o[i] = a.relu ? fmaxf(y, 0.f) : y;
+        }
+        store_vec<4>(a.out + (size_t)r * a.d + c0, o);
+        if (cl == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
       }
-      store_vec<4>(a.out + (size_t)r * a.d + c0, o);
-      if (cl == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
     }
   }
 }
@@ -73,35 +87,45 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
   float g[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
   if (cact) { load_vec<4>(g, a.gamma + c0); load_vec<4>(b, a.beta + c0); }
   const float inv_d = 1.0f / (float)a.d;
-  for (int r0 = wave_global * GROUPS; r0 < a.rows; r0 += n_waves * GROUPS) {
-    const int r = r0 + sub;
-    const bool ok = (r < a.rows) && cact;
-    float v[4] = {0, 0, 0, 0}, go[4] = {0, 0, 0, 0};
-    float mu = 0.f, rs = 0.f;
-    if (ok) {
-      load_vec<4>(v, a.x + (size_t)r * a.d + c0);
-      load_vec<4>(go, a.go + (size_t)r * a.d + c0);
-      mu = a.mean[r]; rs = a.rstd[r];
-    }
-    float xh[4], gg[4], s1 = 0.f, s2 = 0.f;
+  for (int r0 = wave_global * GROUPS * kLnRows; r0 < a.rows; r0 += n_waves * GROUPS * kLnRows) {
+    float v[kLnRows][4], go[kLnRows][4], mu[kLnRows], rs[kLnRows];
+    bool ok[kLnRows];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      xh[i] = (v[i] - mu) * rs;
-      const float y = fmaf(xh[i], g[i], b[i]);
-      const float gy = (a.relu && !(y > 0.f)) ? 0.f : go[i];
-      dg[i] = fmaf(gy, xh[i], dg[i]);
-      db[i] += gy;
-      gg[i] = gy * g[i];
-      s1 += gg[i];
-      s2 = fmaf(gg[i], xh[i], s2);
-    }
-    s1 = group_sum<LPR_LOG2>(s1) * inv_d;
-    s2 = group_sum<LPR_LOG2>(s2) * inv_d;
-    if (ok) {
-      float o[4];
+    for (int u = 0; u < kLnRows; ++u) {
+      const int r = r0 + u * GROUPS + sub;
+      ok[u] = (r < a.rows) && cact;
+      mu[u] = 0.f; rs[u] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = rs * (gg[i] - s1 - xh[i] * s2);
-      store_vec<4>(a.gx + (size_t)r * a.d + c0, o);
+      for (int i = 0; i < 4; ++i) { v[u][i] = 0.f; go[u][i] = 0.f; }
+      if (ok[u]) {
+        load_vec<4>(v[u], a.x + (size_t)r * a.d + c0);
+        load_vec<4>(go[u], a.go + (size_t)r * a.d + c0);
+        mu[u] = a.mean[r]; rs[u] = a.rstd[r];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kLnRows; ++u) {
+      const int r = r0 + u * GROUPS + sub;
+      float xh[4], gg[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xh[i] = (v[u][i] - mu[u]) * rs[u];
+        const float y = fmaf(xh[i], g[i], b[i]);
+        const float gy = (a.relu && !(y > 0.f)) ? 0.f : go[u][i];
+        dg[i] = fmaf(gy, xh[i], dg[i]);
+        db[i] += gy;
+        gg[i] = gy * g[i];
+        s1 += gg[i];
+        s2 = fmaf(gg[i], xh[i], s2);
+      }
+      s1 = group_sum<LPR_LOG2>(s1) * inv_d;
+      s2 = group_sum<LPR_LOG2>(s2) * inv_d;
+      if (ok[u]) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = rs[u] * (gg[i] - s1 - xh[i] * s2);
+        store_vec<4>(a.gx + (size_t)r * a.d + c0, o);
+      }
     }
   }
   // d gamma / d beta: lane groups -> waves -> one [2,d] partial per workgroup
@@ -125,7 +149,8 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
 
 static int ln_grid(int64_t rows, int lpr_log2) {
   const int groups = kWave >> lpr_log2;
-  int64_t blocks = (rows + (int64_t)groups * kWavesPerBlock - 1) / ((int64_t)groups * kWavesPerBlock);
+  const int64_t per_block = (int64_t)groups * kWavesPerBlock * kLnRows;
+  int64_t blocks = (rows + per_block - 1) / per_block;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
   if (blocks < 1) blocks = 1;
   return (int)blocks;

@@ -217,6 +217,29 @@ int mlgnn_diffpool_bwd(const void* z, const void* adj, const void* s_softmax, co
                        int adj_batched, int dtype, void* stream);
 
 /*
+ * DenseSAGEConv over a batch of small pooled graphs, one fused MFMA launch each way.
+ * Replaces: torch_geometric DenseSAGEConv as used by SAGEConvolutions / DiffPoolLayer
+ * (models/diff_pooling.py:24-32,45-53,58-65):
+ *   y = normalize(lin_rel(A x / clamp(rowsum A, 1)) + lin_root(x), p=2, dim=-1)
+ * x [B,n,C], adj [n,n] (adj_batched = 0) or [B,n,n], w_rel / w_root [O,C], bias [O] or NULL,
+ * y [B,n,O], rinv [B,n] = 1 / max(||out||_2, 1e-12) (saved for the backward; 1 when normalize = 0).
+ * Supported while n <= 160, C <= 128, O <= 64, and n <= 48 when the adjacency gradient is wanted
+ * (mlgnn_dense_sage_supported); MLGNN_E_SHAPE otherwise.
+ * Backward: grad_x [B,n,C]; grad_adj [B,n,n] per batch element or NULL; grad_w = [grad_w_rel (O*C) |
+ * grad_w_root (O*C) | grad_bias (O)]; workspace: mlgnn_dense_sage_bwd_workspace_floats(B,C,O) floats.
+ */
+int mlgnn_dense_sage_supported(int64_t n, int64_t C, int64_t O, int need_grad_adj);
+int64_t mlgnn_dense_sage_bwd_workspace_floats(int64_t B, int64_t C, int64_t O);
+int mlgnn_dense_sage_fwd(const void* x, const void* adj, const void* w_rel, const void* w_root,
+                         const float* bias, void* y, float* rinv, int64_t B, int64_t n, int64_t C,
+                         int64_t O, int adj_batched, int normalize, int dtype, void* stream);
+int mlgnn_dense_sage_bwd(const void* grad_y, const void* y, const float* rinv, const void* x,
+                         const void* adj, const void* w_rel, const void* w_root, void* grad_x,
+                         void* grad_adj, float* grad_w, float* workspace, int64_t workspace_floats,
+                         int64_t B, int64_t n, int64_t C, int64_t O, int adj_batched, int normalize,
+                         int dtype, void* stream);
+
+/*
  * COO -> CSR (by destination) + transposed CSR (by source), on the device, stable in COO order.
  * Replaces: the per-layer gather/scatter index handling of MessagePassing.propagate
  * (models/gcn_lib/sparse/torch_vertex.py:82,277) by one topology sort per batch.

@@ -14,15 +14,16 @@
 // Larger pooled graphs (BASELINE configs[4]) take library GEMMs.
 #include "common.h"
 #include "mlgnn.h"
+#include "tile_gemm.h"
 
 namespace mlgnn {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kDpMaxN = 160, kDpMaxK = 48, kDpMaxC = 64;
 constexpr int kDpSK = kDpMaxK + 1;      // odd strides: row reads and transposed reads both stay
 constexpr int kDpSC = kDpMaxC + 1;      // (nearly) bank-conflict free
 constexpr float kDpEps = 1e-15f;
+// 16 waves per pooled graph (see densesage.hip): independent latency-bound tiles spread over more waves
+constexpr int kDpBlock = 1024, kDpWaves = kDpBlock / kWave;
 
 struct DpArgs {
   const float* z; const float* adj; const float* logits;
@@ -30,25 +31,11 @@ struct DpArgs {
   int N; int K; int C; int adj_batched;
 };
 
-// one 16x16 output tile: acc[i][j] = sum_k a_at(i, k) * b_at(k, j)
-template <typename FA, typename FB>
-__device__ __forceinline__ f32x4 tile_gemm(int kdim, FA a_at, FB b_at) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int l15 = lane & 15, lk = lane >> 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < kdim; k0 += 4) {
-    const float a = a_at(l15, k0 + lk);
-    const float b = b_at(k0 + lk, l15);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-  }
-  return acc;
-}
-
-__global__ __launch_bounds__(kBlock) void diffpool_fwd_kernel(const DpArgs p) {
+__global__ __launch_bounds__(kDpBlock) void diffpool_fwd_kernel(const DpArgs p) {
   __shared__ float S[kDpMaxN][kDpSK];
   __shared__ float T[kDpMaxN][kDpSK];
   __shared__ float Z[kDpMaxN][kDpSC];
-  __shared__ float red[kWavesPerBlock][2];
+  __shared__ float red[kDpWaves][2];
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -61,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void diffpool_fwd_kernel(const DpArgs p) {
 
   // ---- softmax rows -> S (zero padded), entropy; Z -> LDS --------------------------------------
   float ent = 0.f;
-  for (int r = tid; r < NP; r += kBlock) {
+  for (int r = tid; r < NP; r += kDpBlock) {
     if (r < N) {
       float mx = -3.0e38f;
       for (int k = 0; k < K; ++k) mx = fmaxf(mx, lb[(size_t)r * K + k]);
@@ -79,14 +66,14 @@ __global__ __launch_bounds__(kBlock) void diffpool_fwd_kernel(const DpArgs p) {
       for (int k = 0; k < KP; ++k) S[r][k] = 0.f;
     }
   }
-  for (int idx = tid; idx < N * C; idx += kBlock) Z[idx / C][idx % C] = zb[idx];
+  for (int idx = tid; idx < N * C; idx += kDpBlock) Z[idx / C][idx % C] = zb[idx];
   __syncthreads();
 
   const int l15 = lane & 15, lq = lane >> 4;
   const int Nt = NP / 16, Kt = KP / 16, Ct = (C + 15) / 16;
 
   // ---- X' = S^T Z  [K, C] ----------------------------------------------------------------------
-  for (int t = wave; t < Kt * Ct; t += kWavesPerBlock) {
+  for (int t = wave; t < Kt * Ct; t += kDpWaves) {
     const int i0 = (t / Ct) * 16, j0 = (t % Ct) * 16;
     const f32x4 acc = tile_gemm(N,
         [&](int i, int k) { return k < N ? S[k][i0 + i] : 0.f; },
@@ -99,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void diffpool_fwd_kernel(const DpArgs p) {
   }
 
   // ---- T = A S  [N, K] (kept in LDS) ------------------------------------------------------------
-  for (int t = wave; t < Nt * Kt; t += kWavesPerBlock) {
+  for (int t = wave; t < Nt * Kt; t += kDpWaves) {
     const int i0 = (t / Kt) * 16, j0 = (t % Kt) * 16;
     const f32x4 acc = tile_gemm(N,
         [&](int i, int k) { return (i0 + i < N && k < N) ? ab[(size_t)(i0 + i) * N + k] : 0.f; },
@@ -110,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void diffpool_fwd_kernel(const DpArgs p) {
   __syncthreads();
 
   // ---- A' = S^T T  [K, K] -----------------------------------------------------------------------
-  for (int t = wave; t < Kt * Kt; t += kWavesPerBlock) {
+  for (int t = wave; t < Kt * Kt; t += kDpWaves) {
     const int i0 = (t / Kt) * 16, j0 = (t % Kt) * 16;
     const f32x4 acc = tile_gemm(N,
         [&](int i, int k) { return k < N ? S[k][i0 + i] : 0.f; },
@@ -124,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void diffpool_fwd_kernel(const DpArgs p) {
 
   // ---- sum (A - S S^T)^2 ------------------------------------------------------------------------
   float sq = 0.f;
-  for (int t = wave; t < Nt * Nt; t += kWavesPerBlock) {
+  for (int t = wave; t < Nt * Nt; t += kDpWaves) {
     const int i0 = (t / Nt) * 16, j0 = (t % Nt) * 16;
     const f32x4 acc = tile_gemm(K,
         [&](int i, int k) { return k < KP ? S[i0 + i][k] : 0.f; },
@@ -144,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void diffpool_fwd_kernel(const DpArgs p) {
   if (tid == 0) {
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) { a0 += red[w][0]; a1 += red[w][1]; }
+    for (int w = 0; w < kDpWaves; ++w) { a0 += red[w][0]; a1 += red[w][1]; }
     p.partial[2 * b] = a0;
     p.partial[2 * b + 1] = a1;
   }
@@ -167,7 +154,7 @@ struct DpBwdArgs {
   int N; int K; int C; int adj_batched;
 };
 
-__global__ __launch_bounds__(kBlock) void diffpool_bwd_kernel(const DpBwdArgs p) {
+__global__ __launch_bounds__(kDpBlock) void diffpool_bwd_kernel(const DpBwdArgs p) {
   __shared__ float S[kDpMaxN][kDpSK];
   __shared__ float AS[kDpMaxN][kDpSK];
   __shared__ float AtS[kDpMaxN][kDpSK];
@@ -188,14 +175,14 @@ __global__ __launch_bounds__(kBlock) void diffpool_bwd_kernel(const DpBwdArgs p)
   const int Nt = NP / 16, Kt = KP / 16, Ct = (C + 15) / 16;
   const int l15 = lane & 15, lq = lane >> 4;
 
-  for (int idx = tid; idx < NP * KP; idx += kBlock) {
+  for (int idx = tid; idx < NP * KP; idx += kDpBlock) {
     const int r = idx / KP, k = idx % KP;
     S[r][k] = (r < N && k < K) ? sb[(size_t)r * K + k] : 0.f;
   }
   __syncthreads();
 
   // ---- A S, A^T S  [N,K]  and  S^T S  [K,K] ------------------------------------------------------
-  for (int t = wave; t < 2 * Nt * Kt + Kt * Kt; t += kWavesPerBlock) {
+  for (int t = wave; t < 2 * Nt * Kt + Kt * Kt; t += kDpWaves) {
     if (t < 2 * Nt * Kt) {
       const bool tr = t >= Nt * Kt;
       const int tt = tr ? t - Nt * Kt : t;
@@ -221,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void diffpool_bwd_kernel(const DpBwdArgs p)
   __syncthreads();
 
   // ---- dS tiles [N,K] -----------------------------------------------------------------------------
-  for (int t = wave; t < Nt * Kt; t += kWavesPerBlock) {
+  for (int t = wave; t < Nt * Kt; t += kDpWaves) {
     const int i0 = (t / Kt) * 16, j0 = (t % Kt) * 16;
     f32x4 acc = tile_gemm(C,                                                     // Z g^T
         [&](int i, int k) { return (i0 + i < N && k < C) ? zb[(size_t)(i0 + i) * C + k] : 0.f; },
@@ -247,14 +234,14 @@ __global__ __launch_bounds__(kBlock) void diffpool_bwd_kernel(const DpBwdArgs p)
   __syncthreads();
 
   // ---- softmax backward, one thread per node row -------------------------------------------------
-  for (int r = tid; r < N; r += kBlock) {
+  for (int r = tid; r < N; r += kDpBlock) {
     float dot = 0.f;
     for (int k = 0; k < K; ++k) dot = fmaf(GS[r][k], S[r][k], dot);
     for (int k = 0; k < K; ++k) p.gs[((size_t)b * N + r) * K + k] = S[r][k] * (GS[r][k] - dot);
   }
 
   // ---- dZ = S g  [N,C] ----------------------------------------------------------------------------
-  for (int t = wave; t < Nt * Ct; t += kWavesPerBlock) {
+  for (int t = wave; t < Nt * Ct; t += kDpWaves) {
     const int i0 = (t / Ct) * 16, j0 = (t % Ct) * 16;
     const f32x4 acc = tile_gemm(K,
         [&](int i, int k) { return k < KP ? S[i0 + i][k] : 0.f; },
@@ -269,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void diffpool_bwd_kernel(const DpBwdArgs p)
   // ---- dA = (S h) S^T + cl (A - S S^T)  [N,N] -------------------------------------------------------
   if (p.gadj) {
     __syncthreads();                       // AS is free now: reuse it for P = S h
-    for (int t = wave; t < Nt * Kt; t += kWavesPerBlock) {
+    for (int t = wave; t < Nt * Kt; t += kDpWaves) {
       const int i0 = (t / Kt) * 16, j0 = (t % Kt) * 16;
       const f32x4 acc = tile_gemm(K,
           [&](int i, int k) { return k < KP ? S[i0 + i][k] : 0.f; },
@@ -279,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void diffpool_bwd_kernel(const DpBwdArgs p)
     }
     __syncthreads();
     float* gb = p.gadj + (size_t)b * N * N;
-    for (int t = wave; t < Nt * Nt; t += kWavesPerBlock) {
+    for (int t = wave; t < Nt * Nt; t += kDpWaves) {
       const int i0 = (t / Nt) * 16, j0 = (t % Nt) * 16;
       const f32x4 pst = tile_gemm(K,
           [&](int i, int k) { return k < KP ? AS[i0 + i][k] : 0.f; },
@@ -315,7 +302,7 @@ extern "C" int mlgnn_diffpool_fwd(const void* z, const void* adj, const void* s_
   a.z = (const float*)z; a.adj = (const float*)adj; a.logits = (const float*)s_logits;
   a.s_out = (float*)s_out; a.x_out = (float*)x_out; a.a_out = (float*)adj_out; a.partial = partial;
   a.N = (int)N; a.K = (int)K; a.C = (int)C; a.adj_batched = adj_batched;
-  hipLaunchKernelGGL(diffpool_fwd_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(diffpool_fwd_kernel, dim3((unsigned)B), dim3(kDpBlock), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -332,6 +319,6 @@ extern "C" int mlgnn_diffpool_bwd(const void* z, const void* adj, const void* s_
   a.gx = (const float*)grad_x; a.ga = (const float*)grad_adj_out; a.coef = coef;
   a.gz = (float*)grad_z; a.gs = (float*)grad_s; a.gadj = (float*)grad_adj;
   a.N = (int)N; a.K = (int)K; a.C = (int)C; a.adj_batched = adj_batched;
-  hipLaunchKernelGGL(diffpool_bwd_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(diffpool_bwd_kernel, dim3((unsigned)B), dim3(kDpBlock), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

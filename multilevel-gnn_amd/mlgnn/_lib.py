@@ -35,6 +35,11 @@ SIGNATURES = {
     "mlgnn_msgnorm_add_fwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _INT, _P]),
     "mlgnn_msgnorm_add_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_diffpool_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _P]),
+    "mlgnn_dense_sage_supported": (_INT, [_I64, _I64, _I64, _INT]),
+    "mlgnn_dense_sage_bwd_workspace_floats": (_I64, [_I64, _I64, _I64]),
+    "mlgnn_dense_sage_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _INT, _P]),
+    "mlgnn_dense_sage_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
+                                    _I64, _I64, _I64, _I64, _INT, _INT, _INT, _P]),
     "mlgnn_segment_pool_workspace_bytes": (_I64, [_I64, _I64]),
     "mlgnn_segment_pool_fwd": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
     "mlgnn_tallgemm_supported": (_INT, [_I64, _I64, _I64]),

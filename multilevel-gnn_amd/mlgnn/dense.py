@@ -77,16 +77,69 @@ def linear(x, weight, bias=None):
     return F.linear(x, weight, bias)
 
 
+class _DenseSageFused(torch.autograd.Function):
+    """One fused fp32-MFMA launch per direction (``mlgnn_dense_sage_fwd`` / ``_bwd``), one workgroup per pooled graph."""
+
+    @staticmethod
+    def forward(ctx, x, adj, w_rel, w_root, bias, normalize):
+        B, n, C = x.shape
+        O = w_rel.shape[0]
+        x, adj, w_rel, w_root = x.contiguous(), adj.contiguous(), w_rel.contiguous(), w_root.contiguous()
+        batched = adj.dim() == 3 and adj.shape[0] == B and B > 1
+        y = torch.empty((B, n, O), dtype=x.dtype, device=x.device)
+        rinv = torch.empty((B, n), dtype=torch.float32, device=x.device)
+        rc = _lib.lib.mlgnn_dense_sage_fwd(x.data_ptr(), adj.data_ptr(), w_rel.data_ptr(), w_root.data_ptr(),
+                                           _lib.ptr(bias.contiguous() if bias is not None else None), y.data_ptr(),
+                                           rinv.data_ptr(), B, n, C, O, int(batched), int(normalize), 0,
+                                           torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_dense_sage_fwd")
+        ctx.save_for_backward(x, adj, w_rel, w_root, y, rinv)
+        ctx.cfg = (batched, bool(normalize), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, adj, w_rel, w_root, y, rinv = ctx.saved_tensors
+        batched, normalize, has_bias = ctx.cfg
+        B, n, C = x.shape
+        O = w_rel.shape[0]
+        gy = gy.contiguous()
+        need_adj = ctx.needs_input_grad[1]
+        gx = torch.empty_like(x)
+        gadj = torch.empty((B, n, n), dtype=x.dtype, device=x.device) if need_adj else None
+        gw = torch.empty(2 * O * C + O, dtype=torch.float32, device=x.device)
+        ws_n = int(_lib.lib.mlgnn_dense_sage_bwd_workspace_floats(B, C, O))
+        ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
+        rc = _lib.lib.mlgnn_dense_sage_bwd(gy.data_ptr(), y.data_ptr(), rinv.data_ptr(), x.data_ptr(), adj.data_ptr(),
+                                           w_rel.data_ptr(), w_root.data_ptr(), gx.data_ptr(), _lib.ptr(gadj),
+                                           gw.data_ptr(), ws.data_ptr(), ws_n, B, n, C, O, int(batched),
+                                           int(normalize), 0, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_dense_sage_bwd")
+        if need_adj and not batched:
+            gadj = gadj.sum(0, keepdim=True).reshape(adj.shape)          # shared adjacency
+        elif need_adj:
+            gadj = gadj.reshape(adj.shape)
+        g_rel = gw[:O * C].view(O, C)
+        g_root = gw[O * C:2 * O * C].view(O, C)
+        g_b = gw[2 * O * C:] if has_bias else None
+        return gx, gadj, g_rel, g_root, g_b, None
+
+
 def dense_sage(x, adj, w_rel, w_root, b_root, normalize=True):
-    """``normalize(W_rel (A x / clamp(rowsum A, 1)) + W_root x + b)``; 2-D ``adj`` broadcasts."""
+    """``normalize(W_rel (A x / clamp(rowsum A, 1)) + W_root x + b)``; 2-D ``adj`` broadcasts.
+    Pooled graphs of up to 160 nodes / 128 input / 64 output channels run as one fused launch."""
     x = x.unsqueeze(0) if x.dim() == 2 else x
     adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
+    B, n, c = x.shape
+    if (x.is_cuda and x.dtype == torch.float32 and adj.dtype == torch.float32 and adj.shape[0] in (1, B)
+            and adj.shape[-1] == n and adj.shape[-2] == n
+            and _lib.lib.mlgnn_dense_sage_supported(n, c, w_rel.shape[0], int(adj.requires_grad))):
+        return _DenseSageFused.apply(x, adj, w_rel, w_root, b_root, bool(normalize))
     agg = torch.matmul(adj, x) / adj.sum(dim=-1, keepdim=True).clamp(min=1)
     # both Linears see the [B*n, c] node rows: tall enough for the split-row weight-gradient kernel
     # (the library's TN GEMM for a 32..64-wide output over 56k rows runs on a handful of workgroups)
-    lead, c = x.shape[:-1], x.shape[-1]
     out = linear(agg.reshape(-1, c), w_rel) + linear(x.reshape(-1, c), w_root, b_root)
-    out = out.view(*lead, -1)
+    out = out.view(B, n, -1)
     return F.normalize(out, p=2.0, dim=-1) if normalize else out
 
 

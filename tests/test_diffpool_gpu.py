@@ -51,3 +51,63 @@ def test_large_pooled_graphs_take_library_gemms():
     assert_close(a, ar, 1e-4)
     assert_close(l, lr, 1e-4)
     assert_close(e, er, 1e-4)
+
+
+@pytest.mark.parametrize("B,n,C,O,batched,grad_adj,normalize,bias", [
+    (4, 146, 128, 37, False, False, True, True),     # level 1 pool: shared pathway adjacency
+    (4, 146, 128, 32, False, False, True, True),     # level 1 embed
+    (3, 37, 32, 32, True, True, True, True),         # after-pool / level 2: the adjacency is DiffPool's output
+    (3, 37, 32, 10, True, True, True, False),
+    (2, 10, 64, 64, True, True, True, True),
+    (2, 160, 128, 64, False, False, False, True),    # limits of the fused kernel, no normalisation
+    (1, 1, 1, 1, True, True, True, True),
+    (5, 23, 7, 5, False, True, True, True),          # odd sizes, shared adjacency that needs a gradient
+    (2, 48, 20, 33, True, True, True, True)])
+def test_dense_sage_fused(B, n, C, O, batched, grad_adj, normalize, bias):
+    from mlgnn.dense import dense_sage
+    from mlgnn import _lib
+    assert _lib.lib.mlgnn_dense_sage_supported(n, C, O, int(grad_adj)) == 1
+    gen = torch.Generator().manual_seed(B * 1000 + n + O)
+    x = torch.randn(B, n, C, generator=gen, requires_grad=True)
+    # NOT symmetric; some rows sum below 1 (clamp active, no gradient through the degree), some above
+    adj = torch.rand(*((B, n, n) if batched else (n, n)), generator=gen)
+    adj = adj * (torch.arange(n)[:, None] % 3 != 0) * (2.0 / max(n, 1)) + adj * (torch.arange(n)[:, None] % 3 == 0)
+    adj = adj.requires_grad_(grad_adj)
+    w_rel = (torch.randn(O, C, generator=gen) * 0.3).requires_grad_(True)
+    w_root = (torch.randn(O, C, generator=gen) * 0.3).requires_grad_(True)
+    b = torch.randn(O, generator=gen).requires_grad_(True) if bias else None
+    cot = torch.randn(B, n, O, generator=gen)
+    leaves = [x, w_rel, w_root] + ([adj] if grad_adj else []) + ([b] if bias else [])
+    ref = P.dense_sage_conv(x, adj, w_rel, w_root, b, normalize)
+    gr = torch.autograd.grad((ref * cot).sum(), leaves)
+
+    dev = "cuda:0"
+    dl = [t.detach().to(dev).requires_grad_(True) for t in leaves]
+    xd, wr, wo = dl[0], dl[1], dl[2]
+    ad = dl[3] if grad_adj else adj.detach().to(dev)
+    bd = dl[-1] if bias else None
+    out = dense_sage(xd, ad, wr, wo, bd, normalize)
+    assert type(out.grad_fn).__name__.startswith("_DenseSageFused"), "the fused path must be the one that runs"
+    assert_close(out, ref, 1e-4, "dense sage fwd")
+    got = torch.autograd.grad((out * cot.to(dev)).sum(), dl)
+    names = ["x", "w_rel", "w_root"] + (["adj"] if grad_adj else []) + (["bias"] if bias else [])
+    for name, g, r in zip(names, got, gr):
+        assert_close(g, r, 1e-4, "dense sage grad " + name)
+
+
+def test_dense_sage_unsupported_shapes_take_the_library_path():
+    from mlgnn.dense import dense_sage
+    dev = "cuda:0"
+    x = torch.randn(2, 200, 16, device=dev, requires_grad=True)          # n > 160
+    adj = torch.rand(200, 200, device=dev)
+    w1, w2, b = torch.randn(8, 16, device=dev), torch.randn(8, 16, device=dev), torch.randn(8, device=dev)
+    out = dense_sage(x, adj, w1, w2, b)
+    assert_close(out, P.dense_sage_conv(x.detach().cpu(), adj.cpu(), w1.cpu(), w2.cpu(), b.cpu()), 1e-4)
+    # an adjacency that needs a gradient on more than 48 nodes: not fused either
+    adj2 = torch.rand(2, 60, 60, device=dev, requires_grad=True)
+    x2 = torch.randn(2, 60, 16, device=dev)
+    out2 = dense_sage(x2, adj2, w1, w2, b)
+    out2.sum().backward()
+    ref_adj = adj2.detach().cpu().requires_grad_(True)
+    P.dense_sage_conv(x2.cpu(), ref_adj, w1.cpu(), w2.cpu(), b.cpu()).sum().backward()
+    assert_close(adj2.grad, ref_adj.grad, 1e-4)

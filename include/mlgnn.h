@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 3
+#define MLGNN_ABI_VERSION 4
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -166,6 +166,8 @@ int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
  *   out = relu?( (x - mean) * rstd * gamma + beta ),  rstd = 1/sqrt(var_biased + eps)
  * mean / rstd [rows] are saved for the backward, which recomputes the ReLU mask from x.
  * grad_gamma_beta [2,d]; workspace: mlgnn_layernorm_bwd_workspace_floats(rows, d) floats.
+ * grad_extra [rows,d] or NULL: a gradient that reaches x on another branch (the identity branch of the
+ * res+ block, deepergcn.py:241), added into grad_x in the same pass.
  */
 int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d);
 int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
@@ -173,7 +175,7 @@ int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta
                             int relu, int dtype, void* stream);
 int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* gamma,
                             const float* beta, const float* mean, const float* rstd,
-                            void* grad_x, float* grad_gamma_beta, float* workspace,
+                            const void* grad_extra, void* grad_x, float* grad_gamma_beta, float* workspace,
                             int64_t workspace_floats, int64_t rows, int64_t d, int relu,
                             int dtype, void* stream);
 
@@ -256,6 +258,16 @@ int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
                      int32_t* bad_ids, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * Raw edge attributes in COO order -> the two CSR orders the aggregation kernels read (`ew`, `ew_t`):
+ * by_dst[e] = attr[eid[e]], by_src[e] = attr[eid_t[e]], each row zero padded from r to `width` columns
+ * (width <= 8).  attr [E0, r] fp32 with a row stride of row_stride floats (a column view is fine).
+ * Replaces: the edge_attr index_select of MessagePassing.propagate (torch_vertex.py:82) -- once per batch.
+ */
+int mlgnn_edge_table_to_csr(const float* attr, int64_t row_stride, int64_t r, int64_t width,
+                            const int32_t* eid, const int32_t* eid_t, float* by_dst, float* by_src,
+                            int64_t E, void* stream);
+
+/*
  * MsgNorm fused with GENConv's root add:  h = x + normalize(m, p=2, dim=1) * ||x||_2 * scale[0]
  * Replaces: MsgNorm.forward (models/gcn_lib/sparse/torch_message.py:175-179) + h = x + m
  * (models/gcn_lib/sparse/torch_vertex.py:86-89).  x, m, h [rows, d] fp32, d <= 256, d % 4 == 0;
@@ -283,16 +295,17 @@ int mlgnn_segment_pool_fwd(const void* x, const int32_t* ptr, void* out, int32_t
 /*
  * Tall-skinny fp32 GEMM on the fp16 matrix cores with power-of-two scaled hi/lo split precision
  * (3 MFMAs per product, fp32 accumulate):
- *   c[N,J] = a[N,R] * bt[J,R]^T (+ bias[J]),  N >> R,J;  R in {16,32,64,128,256}, J in {32,64,128,256},
- *   R*J*4 <= 128 KiB
+ *   c[N,J] = a[N,R] * bt[J,R]^T (+ bias[J]) (+ residual[N,J]),  N >> R,J;  R in {16,32,64,128,256},
+ *   J in {32,64,128,256}, R*J*4 <= 128 KiB;  residual (nullable) = the identity branch of the res+ block
+ *   (h = conv(...) + h, deepergcn.py:241) folded into the epilogue of the conv's last Linear; J <= 128
  * Replaces: forward and input gradient of the nn.Linear layers of MLP
  * (models/gcn_lib/sparse/torch_nn.py:54-75).  Relative error per product <= 3*2^-22 (see csrc/tallgemm.hip).
  * workspace: mlgnn_tallgemm_workspace_bytes(R, J) bytes (split weight image).
  */
 int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J);
 int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J);
-int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, void* c, void* workspace,
-                      int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
+int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual, void* c,
+                      void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,21 @@ __global__ void gather2_kernel(const int* __restrict__ a, const int* __restrict_
   if (i < n) { const int j = idx[i]; out_a[i] = a[j]; out_b[i] = b[j]; }
 }
 
+// attr [E0, r] (row stride `stride` floats, COO order) -> by_dst / by_src [E, width]: row e of the by-destination
+// table is attr[eid[e]], of the by-source table attr[eid_t[e]], zero padded to `width` columns
+__global__ void edge_table_kernel(const float* __restrict__ attr, int64_t stride, int r, int width,
+                                  const int* __restrict__ eid, const int* __restrict__ eid_t,
+                                  float* __restrict__ by_dst, float* __restrict__ by_src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* a = attr + (int64_t)eid[i] * stride;
+  const float* b = attr + (int64_t)eid_t[i] * stride;
+  for (int k = 0; k < width; ++k) {
+    by_dst[i * width + k] = k < r ? a[k] : 0.f;
+    by_src[i * width + k] = k < r ? b[k] : 0.f;
+  }
+}
+
 static int key_bits(int64_t N) {
   int b = 1;
   while (((int64_t)1 << b) < N && b < 31) ++b;
@@ -127,5 +142,17 @@ extern "C" int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
   if (err != hipSuccess) return (int)err;
   hipLaunchKernelGGL(csr_rowptr_kernel, dim3(gE1), dim3(threads), 0, s, key_out, rowptr_t, E, (int)N);
   hipLaunchKernelGGL(gather2_kernel, dim3(gE), dim3(threads), 0, s, key_in, eid, pos_t, col_t, eid_t, E);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_edge_table_to_csr(const float* attr, int64_t row_stride, int64_t r, int64_t width,
+                                       const int32_t* eid, const int32_t* eid_t, float* by_dst, float* by_src,
+                                       int64_t E, void* stream) {
+  if (E < 0 || r < 1 || width < r || width > 8 || row_stride < r) return MLGNN_E_SHAPE;
+  if (E == 0) return 0;
+  if (!attr || !eid || !eid_t || !by_dst || !by_src) return MLGNN_E_NULL;
+  const int threads = 256;
+  hipLaunchKernelGGL(edge_table_kernel, dim3((unsigned)((E + threads - 1) / threads)), dim3(threads), 0,
+                     (hipStream_t)stream, attr, row_stride, (int)r, (int)width, eid, eid_t, by_dst, by_src, E);
   return (int)hipGetLastError();
 }

@@ -23,7 +23,7 @@ __device__ __forceinline__ float group_sum(float v) {
 constexpr int kLnRows = 4;            // row groups in flight per wave
 
 struct LnArgs {
-  const float* x; const float* go; const float* gamma; const float* beta;
+  const float* x; const float* go; const float* gamma; const float* beta; const float* gextra;
   float* out; float* mean; float* rstd; float* gx; float* ws;
   int rows; int d; float eps; int relu;
 };
@@ -124,6 +124,12 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
         float o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = rs[u] * (gg[i] - s1 - xh[i] * s2);
+        if (a.gextra) {                      // gradient arriving at x on the block's identity branch
+          float e[4];
+          load_vec<4>(e, a.gextra + (size_t)r * a.d + c0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] += e[i];
+        }
         store_vec<4>(a.gx + (size_t)r * a.d + c0, o);
       }
     }
@@ -197,7 +203,7 @@ extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const 
 
 extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* gamma,
                                        const float* beta, const float* mean, const float* rstd,
-                                       void* grad_x, float* grad_gamma_beta, float* workspace,
+                                       const void* grad_extra, void* grad_x, float* grad_gamma_beta, float* workspace,
                                        int64_t workspace_floats, int64_t rows, int64_t d, int relu,
                                        int dtype, void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
@@ -207,9 +213,10 @@ extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, cons
   const int nblk = ln_grid(rows, lpr);
   if (workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
   if (rows > 0 && (!grad_out || !x || !gamma || !beta || !mean || !rstd || !grad_x)) return MLGNN_E_NULL;
-  if (!a16(x) || !a16(grad_out) || !a16(grad_x) || !a16(gamma) || !a16(beta)) return MLGNN_E_ALIGN;
+  if (!a16(x) || !a16(grad_out) || !a16(grad_x) || !a16(gamma) || !a16(beta) || !a16(grad_extra)) return MLGNN_E_ALIGN;
   LnArgs a{};
   a.x = (const float*)x; a.go = (const float*)grad_out; a.gamma = gamma; a.beta = beta;
+  a.gextra = (const float*)grad_extra;
   a.mean = (float*)mean; a.rstd = (float*)rstd; a.gx = (float*)grad_x; a.ws = workspace;
   a.rows = (int)rows; a.d = (int)d; a.relu = relu;
   hipStream_t s = (hipStream_t)stream;

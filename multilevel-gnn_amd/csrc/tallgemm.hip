@@ -1,5 +1,5 @@
 // Tall-skinny fp32 GEMM on the fp16 matrix cores with scaled 2-way split precision:
-//     C[N,J] = A[N,R] * Bt[J,R]^T (+ bias[J]),     N >> R, J  (R, J <= 256)
+//     C[N,J] = A[N,R] * Bt[J,R]^T (+ bias[J]) (+ residual[N,J]),     N >> R, J  (R, J <= 256)
 //
 // Reference: the nn.Linear layers of MLP (models/gcn_lib/sparse/torch_nn.py:54-75) applied to every
 // node row -- forward (A = activations, Bt = weight) and input gradient (A = grad_out, Bt = weight^T).
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void tallgemm_split_weight_kernel(const flo
 }
 
 struct TgArgs {
-  const float* a; const f16x8* image; const float* bias; float* c;
+  const float* a; const f16x8* image; const float* bias; const float* res; float* c;
   int N; int R; int J;
 };
 
@@ -133,6 +133,21 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
     pow2_scale(m, sa, inv_a);
     const float unscale = inv_a * inv_b;
 
+    // residual tile (C/D layout: register r of lane (r31, h) is row (r & 3) + 8 (r >> 2) + 4 h, column
+    // 32 t + r31), requested before the k-loop so that its loads are in flight under the MFMAs instead of
+    // being serialised against the stores of the epilogue (JT <= 4: 64 more registers)
+    float res[JT <= 4 ? JT : 1][16];
+    if constexpr (JT <= 4) {
+      if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * h, p.N - 1);
+#pragma unroll
+          for (int t = 0; t < JT; ++t) res[t][r] = p.res[(size_t)row * p.J + 32 * t + r31];
+        }
+      }
+    }
+
     f32x16 acc[JT];
 #pragma unroll
     for (int t = 0; t < JT; ++t)
@@ -176,7 +191,11 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
       const int row = row0 + rr;
       if (row < p.N) {
 #pragma unroll
-        for (int t = 0; t < JT; ++t) p.c[(size_t)row * p.J + 32 * t + r31] = fmaf(acc[t][r], us, bias[t]);
+        for (int t = 0; t < JT; ++t) {
+          float v = fmaf(acc[t][r], us, bias[t]);
+          if constexpr (JT <= 4) { if (p.res) v += res[t][r]; }
+          p.c[(size_t)row * p.J + 32 * t + r31] = v;
+        }
       }
     }
   }
@@ -202,7 +221,8 @@ extern "C" int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J) {
   return R * J * 4 + kTgHeader * 16;
 }
 
-extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, void* c, void* workspace,
+extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual, void* c,
+                                 void* workspace,
                                  int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype,
                                  void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
@@ -210,6 +230,7 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
   if (N == 0) return 0;
   if (!tg_dims_ok(R, J)) return MLGNN_E_SHAPE;
   if (!a || !bt || !c || !workspace) return MLGNN_E_NULL;
+  if (residual && J > 128) return MLGNN_E_SHAPE;            // the fused residual needs its tile in registers
   if (workspace_bytes < R * J * 4 + kTgHeader * 16) return MLGNN_E_WORKSPACE;
   if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bt) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
     return MLGNN_E_ALIGN;
@@ -220,7 +241,8 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
   int err = (int)hipGetLastError();
   if (err) return err;
   TgArgs p;
-  p.a = (const float*)a; p.image = (const f16x8*)workspace; p.bias = bias; p.c = (float*)c;
+  p.a = (const float*)a; p.image = (const f16x8*)workspace; p.bias = bias; p.res = (const float*)residual;
+  p.c = (float*)c;
   p.N = (int)N; p.R = (int)R; p.J = (int)J;
   const size_t lds = (size_t)R * J * 4;
   const int64_t tiles = (N + 31) / 32;

@@ -24,7 +24,7 @@ SIGNATURES = {
                                          _I64, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_layernorm_bwd_workspace_floats": (_I64, [_I64, _I64]),
     "mlgnn_layernorm_act_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _INT, _INT, _P]),
-    "mlgnn_layernorm_act_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
+    "mlgnn_layernorm_act_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
     "mlgnn_linear_wgrad_workspace_floats": (_I64, [_I64, _I64, _I64]),
     "mlgnn_linear_wgrad": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_diffpool_fwd_supported": (_INT, [_I64, _I64, _I64]),
@@ -35,6 +35,7 @@ SIGNATURES = {
     "mlgnn_msgnorm_add_fwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _INT, _P]),
     "mlgnn_msgnorm_add_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_diffpool_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _P]),
+    "mlgnn_edge_table_to_csr": (_INT, [_P, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P]),
     "mlgnn_dense_sage_supported": (_INT, [_I64, _I64, _I64, _INT]),
     "mlgnn_dense_sage_bwd_workspace_floats": (_I64, [_I64, _I64, _I64]),
     "mlgnn_dense_sage_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _INT, _P]),
@@ -44,7 +45,7 @@ SIGNATURES = {
     "mlgnn_segment_pool_fwd": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
     "mlgnn_tallgemm_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_tallgemm_workspace_bytes": (_I64, [_I64, _I64]),
-    "mlgnn_tallgemm_nt": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
+    "mlgnn_tallgemm_nt": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
 }
 
 ERRORS = {-1: "MLGNN_E_NULL", -2: "MLGNN_E_SHAPE", -3: "MLGNN_E_MODE", -4: "MLGNN_E_DTYPE",

@@ -9,16 +9,18 @@ DIFFPOOL_EPS = 1e-15
 WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bottleneck
 
 
-def tall_matmul_nt(a, bt, bias=None):
-    """``a [N,R] @ bt[J,R]^T (+ bias)`` through the scaled split-precision fp16-MFMA kernel (``csrc/tallgemm.hip``).
-    The caller checks :func:`tall_matmul_supported` first."""
+def tall_matmul_nt(a, bt, bias=None, residual=None):
+    """``a [N,R] @ bt[J,R]^T (+ bias) (+ residual [N,J])`` through the scaled split-precision fp16-MFMA kernel
+    (``csrc/tallgemm.hip``).  The caller checks :func:`tall_matmul_supported` first."""
     N, R = a.shape
     J = bt.shape[0]
     a, bt = a.contiguous(), bt.contiguous()
     out = torch.empty((N, J), dtype=torch.float32, device=a.device)
     nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(R, J))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
-    rc = _lib.lib.mlgnn_tallgemm_nt(a.data_ptr(), bt.data_ptr(), _lib.ptr(bias), out.data_ptr(), ws.data_ptr(),
+    if residual is not None:
+        residual = residual.contiguous()
+    rc = _lib.lib.mlgnn_tallgemm_nt(a.data_ptr(), bt.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), out.data_ptr(), ws.data_ptr(),
                                     nbytes, N, R, J, 0, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_tallgemm_nt")
     return out
@@ -33,14 +35,17 @@ class _TallLinear(torch.autograd.Function):
     weight/bias gradient (reduction over the N node rows) is the split-row fp32-MFMA kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, residual):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         if tall_matmul_supported(x.shape[0], x.shape[1], weight.shape[0]):
-            return tall_matmul_nt(x, weight, bias.contiguous() if bias is not None else None)
+            fuse = residual is not None and weight.shape[0] <= 128          # the kernel holds the residual tile in registers
+            out = tall_matmul_nt(x, weight, bias.contiguous() if bias is not None else None, residual if fuse else None)
+            return out if (residual is None or fuse) else out + residual
         # addmm on the transposed view picks a faster library kernel than F.linear for these tall
         # shapes (tools/bench_gemm.py: 0.41 vs 0.45 ms at [640k,128] x [128,256])
-        return torch.addmm(bias, x, weight.t()) if bias is not None else torch.mm(x, weight.t())
+        out = torch.addmm(bias, x, weight.t()) if bias is not None else torch.mm(x, weight.t())
+        return out if residual is None else out + residual
 
     @staticmethod
     def backward(ctx, go):
@@ -64,17 +69,20 @@ class _TallLinear(torch.autograd.Function):
             _lib.check(rc, "mlgnn_linear_wgrad")
             gw = out[:M * K].view(M, K)
             gb = out[M * K:] if ctx.has_bias else None
-        return gx, gw, gb
+        # the residual enters by plain addition: its gradient is the output gradient itself (no copy)
+        return gx, gw, gb, (go if ctx.needs_input_grad[3] else None)
 
 
-def linear(x, weight, bias=None):
-    """``nn.Linear`` forward with the tall-matrix weight-gradient kernel behind it when it applies
-    (2-D fp32 CUDA input, >= 8192 rows, <= 32 output tiles of 32x32); ``F.linear`` otherwise."""
+def linear(x, weight, bias=None, residual=None):
+    """``nn.Linear`` forward (+ ``residual``: the identity branch of a residual block, added in the GEMM
+    epilogue) with the tall-matrix kernels behind it when they apply (2-D fp32 CUDA input, >= 8192 rows,
+    <= 32 output tiles of 32x32); ``F.linear`` otherwise."""
     if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS
             and x.is_contiguous() and torch.is_grad_enabled()
             and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], weight.shape[0], weight.shape[1]) > 0):
-        return _TallLinear.apply(x, weight, bias)
-    return F.linear(x, weight, bias)
+        return _TallLinear.apply(x, weight, bias, residual)
+    out = F.linear(x, weight, bias)
+    return out if residual is None else out + residual
 
 
 class _DenseSageFused(torch.autograd.Function):

@@ -119,11 +119,25 @@ class CSRGraph:
         key = (a.data_ptr(), a._version, tuple(a.shape), a.stride(), width)
         hit = self._table_cache.get(key)
         if hit is None:
-            rows = a.to(torch.float32)
-            if rows.shape[1] != width:
-                rows = torch.nn.functional.pad(rows, (0, width - rows.shape[1]))
-            by_dst = rows[self.eid.long()].contiguous()
-            hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
+            if a.is_cuda and self.eid.is_cuda:
+                from . import _lib
+                rows = a if a.dtype == torch.float32 else a.to(torch.float32)
+                if rows.stride(1) != 1 and rows.shape[1] > 1:
+                    rows = rows.contiguous()
+                by_dst = torch.empty((self.num_edges, width), dtype=torch.float32, device=a.device)
+                by_src = torch.empty_like(by_dst)
+                rc = _lib.lib.mlgnn_edge_table_to_csr(rows.data_ptr(), rows.stride(0), rows.shape[1], width,
+                                                      self.eid.data_ptr(), self.eid_t.data_ptr(), by_dst.data_ptr(),
+                                                      by_src.data_ptr(), self.num_edges,
+                                                      torch.cuda.current_stream().cuda_stream)
+                _lib.check(rc, "mlgnn_edge_table_to_csr")
+                hit = (by_dst, by_src)
+            else:
+                rows = a.to(torch.float32)
+                if rows.shape[1] != width:
+                    rows = torch.nn.functional.pad(rows, (0, width - rows.shape[1]))
+                by_dst = rows[self.eid.long()].contiguous()
+                hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
             self._table_cache = {key: hit}
         return hit
 

@@ -31,17 +31,41 @@ class _LayerNormAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, go):
-        x, weight, bias, mean, rstd = ctx.saved_tensors
-        rows, d = x.shape
-        go = go.contiguous()
-        gx = torch.empty_like(x)
-        ggb = torch.empty((2, d), dtype=torch.float32, device=x.device)
-        n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d))
-        ws = torch.empty(n, dtype=torch.float32, device=x.device)
-        rc = _lib.lib.mlgnn_layernorm_act_bwd(go.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(),
-                                              mean.data_ptr(), rstd.data_ptr(), gx.data_ptr(), ggb.data_ptr(),
-                                              ws.data_ptr(), n, rows, d, int(ctx.relu), DTYPE_F32, _stream())
-        _lib.check(rc, "mlgnn_layernorm_act_bwd")
+        gx, ggb = _ln_backward(ctx, go, None)
+        return gx, ggb[0], ggb[1], None, None
+
+
+def _ln_backward(ctx, go, extra):
+    x, weight, bias, mean, rstd = ctx.saved_tensors
+    rows, d = x.shape
+    go = go.contiguous()
+    if extra is not None:
+        extra = extra.contiguous()
+    gx = torch.empty_like(x)
+    ggb = torch.empty((2, d), dtype=torch.float32, device=x.device)
+    n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d))
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    rc = _lib.lib.mlgnn_layernorm_act_bwd(go.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                          mean.data_ptr(), rstd.data_ptr(), _lib.ptr(extra), gx.data_ptr(),
+                                          ggb.data_ptr(), ws.data_ptr(), n, rows, d, int(ctx.relu), DTYPE_F32,
+                                          _stream())
+    _lib.check(rc, "mlgnn_layernorm_act_bwd")
+    return gx, ggb
+
+
+class _LayerNormActFork(torch.autograd.Function):
+    """``(relu?(LayerNorm(x)), x)``: the second output is the input itself, handed back so that the gradient
+    arriving on the identity branch of a residual block (``h = f(norm(h)) + h``, deepergcn.py:236-241) meets
+    the LayerNorm gradient inside ONE backward pass instead of a separate accumulation kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu):
+        out = _LayerNormAct.forward(ctx, x, weight, bias, eps, relu)
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, go, g_identity):
+        gx, ggb = _ln_backward(ctx, go, g_identity)
         return gx, ggb[0], ggb[1], None, None
 
 
@@ -52,6 +76,14 @@ def layer_norm_act(x, weight, bias, eps=1e-5, relu=False):
         return _LayerNormAct.apply(x, weight, bias, eps, relu)
     y = F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
     return F.relu(y) if relu else y
+
+
+def layer_norm_act_fork(x, weight, bias, eps=1e-5, relu=False):
+    """``(layer_norm_act(x), x)`` for a residual block: use the second value as the identity branch
+    (``h = f(y) + x``) so that its gradient is added inside the LayerNorm backward kernel."""
+    if weight is not None and bias is not None and fused_supported(x) and x.is_contiguous():
+        return _LayerNormActFork.apply(x, weight, bias, eps, relu)
+    return layer_norm_act(x, weight, bias, eps, relu), x
 
 
 class _MsgNormAdd(torch.autograd.Function):

@@ -17,7 +17,7 @@ from torch import nn
 
 from .dense import linear
 from .graph import CSRGraph
-from .norm import layer_norm_act
+from .norm import layer_norm_act, layer_norm_act_fork
 from .ops import RankOneEdge
 from .project import segment_project
 
@@ -115,7 +115,10 @@ class ThreeLevelGNN(nn.Module):
         h = self.gcns[0](h, graph, edge)
         for l in range(1, self.num_layers):
             n = self.norms[l - 1]
-            h = self.gcns[l](layer_norm_act(h, n.weight, n.bias, n.eps, relu=True), graph, edge) + h
+            # h = conv(relu(norm(h))) + h: the add runs in the conv's last GEMM epilogue, its gradient in the
+            # LayerNorm backward kernel
+            y, identity = layer_norm_act_fork(h, n.weight, n.bias, n.eps, relu=True)
+            h = self.gcns[l](y, graph, edge, residual=identity)
         n = self.norms[self.num_layers - 1]
         h = layer_norm_act(h, n.weight, n.bias, n.eps)
         # level 1: gene -> pathway projection pooling (multilevel_gnn.py:212-242)

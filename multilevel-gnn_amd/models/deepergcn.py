@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from mlgnn import CSRGraph, LowRankEdge
 from mlgnn.dense import linear
-from mlgnn.norm import layer_norm_act
+from mlgnn.norm import layer_norm_act, layer_norm_act_fork
 from mlgnn.pool import global_pool
 from .gcn_lib.sparse.torch_vertex import GENConv
 from .gcn_lib.sparse.torch_nn import norm_layer
@@ -169,10 +169,17 @@ class DeeperGCN(torch.nn.Module):
         if self.block == 'res+':
             h = self.gcns[0](h, graph, edge_emb)
             for layer in range(1, L):
-                h2 = F.relu(h) if self.no_inter_norm else self._norm(layer - 1, h, relu=True)
+                m = self.norms[layer - 1]
+                if not self.no_inter_norm and isinstance(m, nn.LayerNorm) and h.dim() == 2:
+                    # the residual add runs in the conv's last GEMM epilogue and its gradient inside the
+                    # LayerNorm backward kernel (same values, two elementwise passes fewer)
+                    h2, identity = layer_norm_act_fork(h, m.weight, m.bias, m.eps, relu=True)
+                else:
+                    h2 = F.relu(h) if self.no_inter_norm else self._norm(layer - 1, h, relu=True)
+                    identity = h
                 if not self.no_inter_drop:
                     h2 = self._drop(h2)
-                h = self.gcns[layer](h2, graph, edge_emb) + h
+                h = self.gcns[layer](h2, graph, edge_emb, residual=identity)
             h = self._norm(L - 1, h)
             if not self.no_inter_drop:
                 h = self._drop(h)

@@ -62,10 +62,11 @@ class MLP(nn.Sequential):
                 layers.append(nn.Dropout2d(drop))
         super().__init__(*layers)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         """Same children, same order; a ``LayerNorm`` directly followed by ``ReLU`` runs as ONE
         fused HIP pass (``mlgnn.norm.layer_norm_act``) instead of two ATen passes; ``nn.Linear``
-        children use ``mlgnn.dense.linear`` (library GEMM forward, split-row MFMA weight gradient)."""
+        children use ``mlgnn.dense.linear`` (split-precision MFMA GEMMs); ``residual`` is added in the last
+        Linear's epilogue."""
         mods = list(self)
         i = 0
         while i < len(mods):
@@ -75,9 +76,12 @@ class MLP(nn.Sequential):
                 x = layer_norm_act(x, m.weight, m.bias, m.eps, relu)
                 i += 2 if relu else 1
             elif type(m) is nn.Linear:
-                x = linear(x, m.weight, m.bias)
+                last = i == len(mods) - 1
+                x = linear(x, m.weight, m.bias, residual if last else None)
+                if last:
+                    residual = None
                 i += 1
             else:
                 x = m(x)
                 i += 1
-        return x
+        return x if residual is None else x + residual

@@ -41,8 +41,9 @@ class GENConv(GenMessagePassing):
             self.edge_encoder = nn.Linear(edge_feat_dim, in_dim)
         self.pca_only = pca_only
 
-    def forward(self, x, edge_index, edge_attr=None):
+    def forward(self, x, edge_index, edge_attr=None, residual=None):
         """``edge_index``: COO ``[2, E]`` or a prebuilt :class:`mlgnn.CSRGraph`.
+        ``residual``: added to the result inside the last Linear's epilogue (the caller's ``conv(...) + h``).
         ``edge_attr``: ``[E, d_e]`` tensor, or a :class:`mlgnn.LowRankEdge` (raw attributes
         kept factored through the Linear encoders: no ``[E, d]`` tensor, no edge GEMM)."""
         if self.pca_only:
@@ -61,7 +62,10 @@ class GENConv(GenMessagePassing):
             h = self.reduce_messages(flat, graph, edge, self.eps, add_root=True)       # x + m in one pass
         else:
             h = msg_norm_add(flat, self.reduce_messages(flat, graph, edge, self.eps), self.msg_norm.msg_scale)
-        return self.feature_encoder(h.reshape(x.shape))
+        if residual is not None and isinstance(self.feature_encoder, MLP):
+            return self.feature_encoder(h.reshape(x.shape), residual=residual)
+        out = self.feature_encoder(h.reshape(x.shape))
+        return out if residual is None else out + residual
 
 
 class Linear(nn.Module):

@@ -43,3 +43,25 @@ def test_out_of_range_ids_are_clamped_and_reported():
     with pytest.raises(ValueError, match="outside"):
         g.validate()
     CSRGraph(torch.tensor([[0, 1], [1, 0]], device="cuda:0"), 2).validate()
+
+
+@pytest.mark.parametrize("r,width", [(1, 1), (7, 8), (2, 2), (3, 4)])
+def test_edge_table_device_gather_matches_host(r, width):
+    """Raw edge attributes -> by-destination / by-source order, zero padded: device kernel vs indexing."""
+    from mlgnn import CSRGraph
+    gen = torch.Generator().manual_seed(r)
+    N, E = 500, 6000
+    ei = torch.randint(0, N, (2, E), generator=gen)
+    attr = torch.rand(E, r, generator=gen)
+    g = CSRGraph(ei.cuda(), N)
+    by_dst, by_src = g.edge_table(attr.cuda(), width)
+    ref_dst = torch.nn.functional.pad(attr, (0, width - r))[g.eid.cpu().long()]
+    ref_src = ref_dst[g.pos_t.cpu().long()]
+    assert torch.equal(by_dst.cpu(), ref_dst) and torch.equal(by_src.cpu(), ref_src)
+    # a strided column view of a wider table (the use_column case) and a float64 table
+    wide = torch.rand(E, 5, generator=gen).cuda()
+    d2, s2 = g.edge_table(wide[:, 2:3], 1)
+    assert torch.equal(d2.cpu()[:, 0], wide.cpu()[:, 2][g.eid.cpu().long()])
+    assert torch.equal(s2.cpu()[:, 0], wide.cpu()[:, 2][g.eid_t.cpu().long()])
+    d3, _ = g.edge_table(attr.double().cuda(), width)
+    assert torch.equal(d3.cpu(), ref_dst)

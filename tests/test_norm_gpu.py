@@ -58,3 +58,33 @@ def test_msg_norm_add(rows, d):
     got = torch.autograd.grad((out * cot.to(dev)).sum(), [xd, md, sd])
     for name, g, r in zip(("x", "m", "scale"), got, gr):
         assert_close(g, r, 1e-4, "msgnorm grad " + name)
+
+
+@pytest.mark.parametrize("rows,d", [(1000, 128), (8193, 256), (37, 12)])
+def test_residual_block_through_fork_and_gemm_epilogue(rows, d):
+    """h' = Linear(relu(LN(h))) + h with the add in the GEMM epilogue and its gradient inside the LayerNorm
+    backward kernel equals the plain composition (values and every gradient)."""
+    import torch.nn.functional as F
+    from mlgnn.dense import linear
+    from mlgnn.norm import layer_norm_act_fork
+    gen = torch.Generator().manual_seed(rows)
+    h = torch.randn(rows, d, generator=gen, requires_grad=True)
+    g = (torch.rand(d, generator=gen) + 0.5).requires_grad_(True)
+    b = torch.randn(d, generator=gen).requires_grad_(True)
+    w = (torch.randn(d, d, generator=gen) * 0.1).requires_grad_(True)
+    wb = torch.randn(d, generator=gen).requires_grad_(True)
+    cot = torch.randn(rows, d, generator=gen)
+    leaves = [h, g, b, w, wb]
+    ref = F.linear(torch.relu(F.layer_norm(h, (d,), g, b, 1e-5)), w, wb) + h
+    gr = torch.autograd.grad((ref * cot).sum(), leaves)
+    dl = [t.detach().cuda().requires_grad_(True) for t in leaves]
+    y, identity = layer_norm_act_fork(dl[0], dl[1], dl[2], 1e-5, relu=True)
+    out = linear(y, dl[3], dl[4], residual=identity)
+    assert_close(out, ref, 1e-4, "residual block fwd")
+    got = torch.autograd.grad((out * cot.cuda()).sum(), dl)
+    for name, a, r in zip(("h", "gamma", "beta", "W", "bias"), got, gr):
+        assert_close(a, r, 1e-4, "residual block grad " + name)
+    # the identity output alone (norm branch unused) still carries its gradient
+    y2, id2 = layer_norm_act_fork(dl[0], dl[1], dl[2], 1e-5, relu=True)
+    (gh,) = torch.autograd.grad((id2 * cot.cuda()).sum() + 0.0 * y2.sum(), [dl[0]])
+    assert_close(gh, cot, 1e-5, "identity branch only")

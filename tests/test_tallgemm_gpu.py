@@ -22,6 +22,13 @@ def test_layout_is_exact_on_small_integers(N, R, J):
     ref = a @ bt.t() + bias
     out = tall_matmul_nt(a.cuda(), bt.cuda(), bias.cuda())
     assert torch.equal(out.cpu(), ref)
+    res = torch.randint(-5, 6, (N, J), generator=gen).float()    # residual branch folded into the epilogue
+    if J <= 128:
+        out = tall_matmul_nt(a.cuda(), bt.cuda(), bias.cuda(), res.cuda())
+        assert torch.equal(out.cpu(), ref + res)
+    else:                                                        # the residual tile must fit in registers
+        with pytest.raises(RuntimeError):
+            tall_matmul_nt(a.cuda(), bt.cuda(), bias.cuda(), res.cuda())
 
 
 @pytest.mark.parametrize("scale", [1.0, 1e-6, 3e4])

@@ -1,4 +1,5 @@
-"""Device COO->CSR build (hipCUB radix sorts) vs the host construction: bit-exact index arrays."""
+"""Device COO->CSR build (counting sort + per-row bitonic fix-up) vs the host construction: bit-exact
+index arrays, whatever order the atomics hand out slots in."""
 import pytest
 import torch
 
@@ -22,6 +23,24 @@ def test_device_csr_matches_host(N, E):
         a, b = getattr(host, f), getattr(dev, f).cpu()
         assert a.dtype == b.dtype == torch.int32 and a.shape == b.shape, f
         assert torch.equal(a, b), f
+
+
+@pytest.mark.parametrize("N,E,hub_in,hub_out", [(3000, 60000, 33, 64), (3000, 60000, 65, 700), (2000, 90000, 4096, 4097),
+                                               (500, 70000, 20000, 15000), (64, 30000, 0, 0)])
+def test_long_rows(N, E, hub_in, hub_out):
+    """Rows of 33..64 edges (one row per wavefront), 65..4096 (LDS network) and beyond (global-memory network),
+    on both the destination and the source side; a dense small graph where every row is long; run twice:
+    the result must not depend on the arrival order of the atomics."""
+    from mlgnn import CSRGraph
+    gen = torch.Generator().manual_seed(E + hub_in)
+    ei = torch.randint(0, N, (2, E), generator=gen)
+    ei[1, :hub_in] = 7                                    # destination hub
+    ei[0, E - hub_out:] = 11                              # source hub
+    host = CSRGraph(ei, N)
+    for _ in range(2):
+        dev = CSRGraph(ei.to("cuda:0"), N)
+        for f in FIELDS:
+            assert torch.equal(getattr(host, f), getattr(dev, f).cpu()), f
 
 
 def test_int32_edge_index_and_noncontiguous_input():

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 4
+#define MLGNN_ABI_VERSION 5
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -87,6 +87,8 @@ int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int dtype
  *   aux2    [N,d]   optional second moment for the learnable temperature / exponent:
  *                   SOFTMAX: sum_e w_e m_e^2 ; POWER: mean(clamp(m)^p * ln clamp(m)); NULL to skip
  *   argmax  [N,d]   MAX: by-destination edge position of the winner, -1 for an empty row
+ *   row_max [N]     optional (NULL to skip): max_c |out[i][c]| per row, for the per-row scaling of the Linear that
+ *                   consumes `out` (mlgnn_tallgemm_nt); only while d fits one channel chunk (d <= 256 fp32)
  *   t, p            softmax temperature / power exponent; when t_dev / p_dev is non-NULL the value is
  *                   read from that device address instead (learnable parameters: no host sync)
  *   add_root        non-zero: out = x + aggregate (GENConv's h = x + m, torch_vertex.py:89, same pass);
@@ -95,7 +97,7 @@ int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int dtype
 int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t* col,
                             const float* ew, const float* eu, const float* ev,
                             const void* efull, const int32_t* eid,
-                            void* out, float* aux, float* aux2, int32_t* argmax,
+                            void* out, float* aux, float* aux2, int32_t* argmax, float* row_max,
                             int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                             int aggr, float t, float p, const float* t_dev, const float* p_dev,
                             float eps, int add_root, void* stream);
@@ -168,14 +170,17 @@ int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
  * grad_gamma_beta [2,d]; workspace: mlgnn_layernorm_bwd_workspace_floats(rows, d) floats.
  * grad_extra [rows,d] or NULL: a gradient that reaches x on another branch (the identity branch of the
  * res+ block, deepergcn.py:241), added into grad_x in the same pass.
+ * row_max [rows] or NULL (both directions): max |.| per row of out / grad_x, handed to the Linear that
+ * consumes it (mlgnn_tallgemm_nt) so that it does not have to read its operand twice.
  */
 int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d);
 int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
-                            float* mean, float* rstd, int64_t rows, int64_t d, float eps,
+                            float* mean, float* rstd, float* row_max, int64_t rows, int64_t d, float eps,
                             int relu, int dtype, void* stream);
 int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* gamma,
                             const float* beta, const float* mean, const float* rstd,
-                            const void* grad_extra, void* grad_x, float* grad_gamma_beta, float* workspace,
+                            const void* grad_extra, void* grad_x, float* row_max, float* grad_gamma_beta,
+                            float* workspace,
                             int64_t workspace_floats, int64_t rows, int64_t d, int relu,
                             int dtype, void* stream);
 
@@ -300,12 +305,14 @@ int mlgnn_segment_pool_fwd(const void* x, const int32_t* ptr, void* out, int32_t
  *   (h = conv(...) + h, deepergcn.py:241) folded into the epilogue of the conv's last Linear; J <= 128
  * Replaces: forward and input gradient of the nn.Linear layers of MLP
  * (models/gcn_lib/sparse/torch_nn.py:54-75).  Relative error per product <= 3*2^-22 (see csrc/tallgemm.hip).
+ * row_max [N] or NULL: max_k |a[i][k]| per row when the producer of `a` already knows it (any upper bound
+ * within a factor of 2 of the true maximum keeps full accuracy); NULL: the kernel streams `a` twice.
  * workspace: mlgnn_tallgemm_workspace_bytes(R, J) bytes (split weight image).
  */
 int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J);
 int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J);
-int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual, void* c,
-                      void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
+int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual,
+                      const float* row_max, void* c, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

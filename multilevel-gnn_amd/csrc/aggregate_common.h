@@ -39,7 +39,7 @@ template <bool V> using BC = std::integral_constant<bool, V>;
 struct FwdArgs {                      // x / efull / out are T (fp32 or bf16); everything else fp32 / int32
   const void* x; const int* rowptr; const int* col;
   const float* ew; const float* eu; const float* ev; const void* efull; const int* eid;
-  void* out; float* aux; float* aux2; int* argmax;
+  void* out; float* aux; float* aux2; int* argmax; float* rowmax;
   const float* t_dev; const float* p_dev;
   int N; int d; int lpr_log2; int mean; int add_root;
   float t; float p; float eps;

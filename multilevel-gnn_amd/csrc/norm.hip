@@ -14,6 +14,13 @@
 namespace mlgnn {
 
 template <int LPR_LOG2>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int off = 1; off < (1 << LPR_LOG2); off <<= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+template <int LPR_LOG2>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
   for (int off = 1; off < (1 << LPR_LOG2); off <<= 1) v += __shfl_xor(v, off);
@@ -24,7 +31,7 @@ constexpr int kLnRows = 4;            // row groups in flight per wave
 
 struct LnArgs {
   const float* x; const float* go; const float* gamma; const float* beta; const float* gextra;
-  float* out; float* mean; float* rstd; float* gx; float* ws;
+  float* out; float* mean; float* rstd; float* gx; float* ws; float* rowmax;
   int rows; int d; float eps; int relu;
 };
 
@@ -60,15 +67,21 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_fwd_kernel(const LnArgs 
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const float c = cact ? v[u][i] - mu : 0.f; q = fmaf(c, c, q); }
       const float rs = rsqrtf(group_sum<LPR_LOG2>(q) * inv_d + a.eps);
+      float om = 0.f;
       if (ok[u]) {
         float o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float y = fmaf((v[u][i] - mu) * rs, g[i], b[i]);
           o[i] = a.relu ? fmaxf(y, 0.f) : y;
+          om = fmaxf(om, fabsf(o[i]));
         }
         store_vec<4>(a.out + (size_t)r * a.d + c0, o);
         if (cl == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
+      }
+      if (a.rowmax) {                          // max |row| for the consumer GEMM's per-row scaling (tallgemm.hip)
+        om = group_max<LPR_LOG2>(om);
+        if (ok[u] && cl == 0) a.rowmax[r] = om;
       }
     }
   }
@@ -120,6 +133,7 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
       }
       s1 = group_sum<LPR_LOG2>(s1) * inv_d;
       s2 = group_sum<LPR_LOG2>(s2) * inv_d;
+      float om = 0.f;
       if (ok[u]) {
         float o[4];
 #pragma unroll
@@ -130,7 +144,13 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
 #pragma unroll
           for (int i = 0; i < 4; ++i) o[i] += e[i];
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) om = fmaxf(om, fabsf(o[i]));
         store_vec<4>(a.gx + (size_t)r * a.d + c0, o);
+      }
+      if (a.rowmax) {
+        om = group_max<LPR_LOG2>(om);
+        if (ok[u] && cl == 0) a.rowmax[r] = om;
       }
     }
   }
@@ -186,7 +206,7 @@ extern "C" int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d)
 }
 
 extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
-                                       float* mean, float* rstd, int64_t rows, int64_t d, float eps,
+                                       float* mean, float* rstd, float* row_max, int64_t rows, int64_t d, float eps,
                                        int relu, int dtype, void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   if (rows < 0 || rows > INT32_MAX || !ln_ok(d)) return MLGNN_E_SHAPE;
@@ -195,6 +215,7 @@ extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const 
   if (!a16(x) || !a16(out) || !a16(gamma) || !a16(beta)) return MLGNN_E_ALIGN;
   LnArgs a{};
   a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.out = (float*)out; a.mean = mean; a.rstd = rstd;
+  a.rowmax = row_max;
   a.rows = (int)rows; a.d = (int)d; a.eps = eps; a.relu = relu;
   const int lpr = lanes_per_row_log2(d, 4);
   MLGNN_LN_LAUNCH(layernorm_act_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), dim3(kBlock), 0, (hipStream_t)stream, a)
@@ -203,7 +224,7 @@ extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const 
 
 extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* gamma,
                                        const float* beta, const float* mean, const float* rstd,
-                                       const void* grad_extra, void* grad_x, float* grad_gamma_beta, float* workspace,
+                                       const void* grad_extra, void* grad_x, float* row_max, float* grad_gamma_beta, float* workspace,
                                        int64_t workspace_floats, int64_t rows, int64_t d, int relu,
                                        int dtype, void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
@@ -217,7 +238,7 @@ extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, cons
   LnArgs a{};
   a.x = (const float*)x; a.go = (const float*)grad_out; a.gamma = gamma; a.beta = beta;
   a.gextra = (const float*)grad_extra;
-  a.mean = (float*)mean; a.rstd = (float*)rstd; a.gx = (float*)grad_x; a.ws = workspace;
+  a.mean = (float*)mean; a.rstd = (float*)rstd; a.gx = (float*)grad_x; a.ws = workspace; a.rowmax = row_max;
   a.rows = (int)rows; a.d = (int)d; a.relu = relu;
   hipStream_t s = (hipStream_t)stream;
   MLGNN_LN_LAUNCH(layernorm_act_bwd_kernel, lpr, dim3(nblk), dim3(kBlock), 0, s, a)

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void tallgemm_split_weight_kernel(const flo
 }
 
 struct TgArgs {
-  const float* a; const f16x8* image; const float* bias; const float* res; float* c;
+  const float* a; const f16x8* image; const float* bias; const float* res; const float* rowmax; float* c;
   int N; int R; int J;
 };
 
@@ -121,14 +121,18 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
     const float* ap = p.a + (size_t)arow * R + 8 * h;
 
     float m = 0.f;
+    if (p.rowmax) {                                             // the producer of A already knows max |row|
+      m = p.rowmax[arow];
+    } else {
 #pragma unroll 2
-    for (int s = 0; s < KS; ++s) {
-      const float4 q0 = *reinterpret_cast<const float4*>(ap + 16 * s);
-      const float4 q1 = *reinterpret_cast<const float4*>(ap + 16 * s + 4);
-      m = fmaxf(m, fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w))));
-      m = fmaxf(m, fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
+      for (int s = 0; s < KS; ++s) {
+        const float4 q0 = *reinterpret_cast<const float4*>(ap + 16 * s);
+        const float4 q1 = *reinterpret_cast<const float4*>(ap + 16 * s + 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
+      }
+      m = fmaxf(m, __shfl_xor(m, 32));                          // the other half of the row
     }
-    m = fmaxf(m, __shfl_xor(m, 32));                            // the other half of the row
     float sa, inv_a;
     pow2_scale(m, sa, inv_a);
     const float unscale = inv_a * inv_b;
@@ -221,8 +225,8 @@ extern "C" int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J) {
   return R * J * 4 + kTgHeader * 16;
 }
 
-extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual, void* c,
-                                 void* workspace,
+extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual,
+                                 const float* row_max, void* c, void* workspace,
                                  int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype,
                                  void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
@@ -242,7 +246,7 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
   if (err) return err;
   TgArgs p;
   p.a = (const float*)a; p.image = (const f16x8*)workspace; p.bias = bias; p.res = (const float*)residual;
-  p.c = (float*)c;
+  p.rowmax = row_max; p.c = (float*)c;
   p.N = (int)N; p.R = (int)R; p.J = (int)J;
   const size_t lds = (size_t)R * J * 4;
   const int64_t tiles = (N + 31) / 32;

@@ -14,7 +14,7 @@ _F = _c.c_float
 SIGNATURES = {
     "mlgnn_version": (_INT, []),
     "mlgnn_csr_aggregate_bwd_workspace_floats": (_I64, [_I64, _I64, _INT, _INT, _INT, _INT]),
-    "mlgnn_csr_aggregate_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "mlgnn_csr_aggregate_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                        _I64, _I64, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _P]),
     "mlgnn_csr_aggregate_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                        _P, _P, _P, _P, _I64,
@@ -23,8 +23,8 @@ SIGNATURES = {
     "mlgnn_segment_project_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                          _I64, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_layernorm_bwd_workspace_floats": (_I64, [_I64, _I64]),
-    "mlgnn_layernorm_act_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _INT, _INT, _P]),
-    "mlgnn_layernorm_act_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
+    "mlgnn_layernorm_act_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _INT, _INT, _P]),
+    "mlgnn_layernorm_act_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
     "mlgnn_linear_wgrad_workspace_floats": (_I64, [_I64, _I64, _I64]),
     "mlgnn_linear_wgrad": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_diffpool_fwd_supported": (_INT, [_I64, _I64, _I64]),
@@ -45,7 +45,7 @@ SIGNATURES = {
     "mlgnn_segment_pool_fwd": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
     "mlgnn_tallgemm_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_tallgemm_workspace_bytes": (_I64, [_I64, _I64]),
-    "mlgnn_tallgemm_nt": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
+    "mlgnn_tallgemm_nt": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
 }
 
 ERRORS = {-1: "MLGNN_E_NULL", -2: "MLGNN_E_SHAPE", -3: "MLGNN_E_MODE", -4: "MLGNN_E_DTYPE",

@@ -4,12 +4,14 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+from .ops import row_max_of
 
 DIFFPOOL_EPS = 1e-15
 WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bottleneck
+ROW_MAX_STATS = {"given": 0, "computed": 0}      # tall GEMMs whose operand came with / without its row maxima
 
 
-def tall_matmul_nt(a, bt, bias=None, residual=None):
+def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None):
     """``a [N,R] @ bt[J,R]^T (+ bias) (+ residual [N,J])`` through the scaled split-precision fp16-MFMA kernel
     (``csrc/tallgemm.hip``).  The caller checks :func:`tall_matmul_supported` first."""
     N, R = a.shape
@@ -20,7 +22,9 @@ def tall_matmul_nt(a, bt, bias=None, residual=None):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
     if residual is not None:
         residual = residual.contiguous()
-    rc = _lib.lib.mlgnn_tallgemm_nt(a.data_ptr(), bt.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), out.data_ptr(), ws.data_ptr(),
+    ROW_MAX_STATS["given" if row_max is not None else "computed"] += 1
+    rc = _lib.lib.mlgnn_tallgemm_nt(a.data_ptr(), bt.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(row_max),
+                                    out.data_ptr(), ws.data_ptr(),
                                     nbytes, N, R, J, 0, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_tallgemm_nt")
     return out
@@ -40,7 +44,8 @@ class _TallLinear(torch.autograd.Function):
         ctx.has_bias = bias is not None
         if tall_matmul_supported(x.shape[0], x.shape[1], weight.shape[0]):
             fuse = residual is not None and weight.shape[0] <= 128          # the kernel holds the residual tile in registers
-            out = tall_matmul_nt(x, weight, bias.contiguous() if bias is not None else None, residual if fuse else None)
+            out = tall_matmul_nt(x, weight, bias.contiguous() if bias is not None else None, residual if fuse else None,
+                                 row_max_of(x))
             return out if (residual is None or fuse) else out + residual
         # addmm on the transposed view picks a faster library kernel than F.linear for these tall
         # shapes (tools/bench_gemm.py: 0.41 vs 0.45 ms at [640k,128] x [128,256])
@@ -56,7 +61,7 @@ class _TallLinear(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             if tall_matmul_supported(N, M, K):
-                gx = tall_matmul_nt(go, weight.t().contiguous())          # go [N,M] @ (W^T)[K,M]^T
+                gx = tall_matmul_nt(go, weight.t().contiguous(), row_max=row_max_of(go))   # go [N,M] @ (W^T)[K,M]^T
             else:
                 gx = go.matmul(weight)
         gw = gb = None

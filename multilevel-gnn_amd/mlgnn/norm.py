@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import DTYPE_F32, _stream
+from .ops import DTYPE_F32, _stream, tag_row_max
 
 
 def fused_supported(x):
@@ -21,9 +21,10 @@ class _LayerNormAct(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         weight, bias = weight.contiguous(), bias.contiguous()
+        ctx.row_max = torch.empty(rows, dtype=torch.float32, device=x.device)
         rc = _lib.lib.mlgnn_layernorm_act_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                                              mean.data_ptr(), rstd.data_ptr(), rows, d, float(eps), int(relu),
-                                              DTYPE_F32, _stream())
+                                              mean.data_ptr(), rstd.data_ptr(), ctx.row_max.data_ptr(), rows, d,
+                                              float(eps), int(relu), DTYPE_F32, _stream())
         _lib.check(rc, "mlgnn_layernorm_act_fwd")
         ctx.relu = bool(relu)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
@@ -45,11 +46,13 @@ def _ln_backward(ctx, go, extra):
     ggb = torch.empty((2, d), dtype=torch.float32, device=x.device)
     n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d))
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    row_max = torch.empty(rows, dtype=torch.float32, device=x.device)
     rc = _lib.lib.mlgnn_layernorm_act_bwd(go.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                                           mean.data_ptr(), rstd.data_ptr(), _lib.ptr(extra), gx.data_ptr(),
-                                          ggb.data_ptr(), ws.data_ptr(), n, rows, d, int(ctx.relu), DTYPE_F32,
-                                          _stream())
+                                          row_max.data_ptr(), ggb.data_ptr(), ws.data_ptr(), n, rows, d,
+                                          int(ctx.relu), DTYPE_F32, _stream())
     _lib.check(rc, "mlgnn_layernorm_act_bwd")
+    tag_row_max(gx, row_max)                   # the gradient usually goes straight into a Linear's backward GEMM
     return gx, ggb
 
 
@@ -73,16 +76,22 @@ def layer_norm_act(x, weight, bias, eps=1e-5, relu=False):
     """``relu?(LayerNorm(x))`` over the last dimension of a 2-D tensor.  Shapes the fused kernel
     does not cover (d > 256 or d % 4 != 0) take ATen's LayerNorm on the same device."""
     if weight is not None and bias is not None and fused_supported(x):
-        return _LayerNormAct.apply(x, weight, bias, eps, relu)
+        return _tag_from_node(_LayerNormAct.apply(x, weight, bias, eps, relu))
     y = F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
     return F.relu(y) if relu else y
+
+
+def _tag_from_node(y):
+    rm = getattr(y.grad_fn, "row_max", None) if y.grad_fn is not None else None
+    return tag_row_max(y, rm) if rm is not None else y
 
 
 def layer_norm_act_fork(x, weight, bias, eps=1e-5, relu=False):
     """``(layer_norm_act(x), x)`` for a residual block: use the second value as the identity branch
     (``h = f(y) + x``) so that its gradient is added inside the LayerNorm backward kernel."""
     if weight is not None and bias is not None and fused_supported(x) and x.is_contiguous():
-        return _LayerNormActFork.apply(x, weight, bias, eps, relu)
+        y, identity = _LayerNormActFork.apply(x, weight, bias, eps, relu)
+        return _tag_from_node(y), identity
     return layer_norm_act(x, weight, bias, eps, relu), x
 
 

@@ -115,6 +115,20 @@ def _dev_act(t, what, like=None):
     return t.contiguous()
 
 
+def tag_row_max(t, row_max):
+    """Attach ``max |row|`` ([N] fp32, written by the kernel that produced ``t``) to a 2-D tensor; the tall GEMM
+    reads it instead of streaming its operand twice.  Tied to the tensor's version: an in-place edit voids it."""
+    t._mlgnn_row_max = (row_max, t._version)
+    return t
+
+
+def row_max_of(t):
+    tag = getattr(t, "_mlgnn_row_max", None)
+    if tag is not None and tag[1] == t._version and tag[0].shape[0] == t.shape[0]:
+        return tag[0]
+    return None
+
+
 class LowRankEdge:
     """Edge embedding kept in factored form: ``e_ij = weight @ a_ij + bias``.
 
@@ -203,10 +217,12 @@ class _GenAggregate(torch.autograd.Function):
             raise TypeError("learnable t / p must stay float32 (keep them out of a bf16 cast)")
         timer = KERNEL_TIMER
         t0 = timer.start() if timer is not None else None
+        # max |row| of the result rides along for the Linear that consumes it (fp32, one channel chunk)
+        rowmax = torch.empty(N, **f32) if (x.dtype == torch.float32 and d <= 256 and d % 4 == 0) else None
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), _lib.ptr(eu), _lib.ptr(ev),
             _lib.ptr(efull), graph.eid.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),
-            _lib.ptr(argmax), N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, float(t), float(p),
+            _lib.ptr(argmax), _lib.ptr(rowmax), N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, float(t), float(p),
             _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), int(add_root), _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         if timer is not None:
@@ -216,6 +232,7 @@ class _GenAggregate(torch.autograd.Function):
         ctx.graph, ctx.ew_pair = graph, ew_pair
         ctx.cfg = (aggr_id, edge_mode, rank, float(t), float(p), float(eps), bool(learn_t), bool(learn_p), bool(add_root))
         ctx.save_for_backward(x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev)
+        ctx.rowmax = rowmax
         return out
 
     @staticmethod
@@ -299,7 +316,12 @@ def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, l
     fuse_root = bool(add_root) and not lt and not lp and aggr_id != AGGR_POWER
     out = _GenAggregate.apply(x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t_val, p_val, eps,
                               lt, lp, fuse_root)
-    return out + x if (add_root and not fuse_root) else out
+    if add_root and not fuse_root:
+        return out + x
+    rm = getattr(out.grad_fn, "rowmax", None) if out.grad_fn is not None else None
+    if rm is not None:
+        tag_row_max(out, rm)
+    return out
 
 
 class _WeightedAggregate(torch.autograd.Function):
@@ -313,7 +335,7 @@ class _WeightedAggregate(torch.autograd.Function):
         ew = ew_pair[0] if ew_pair is not None else None
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), None, None, None, None,
-            out.data_ptr(), None, None, None, N, d, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, 0, aggr_id, 1.0, 1.0, None, None,
+            out.data_ptr(), None, None, None, None, N, d, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, 0, aggr_id, 1.0, 1.0, None, None,
             0.0, 0, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         ctx.graph, ctx.ew_pair, ctx.cfg = graph, ew_pair, (msg, aggr_id, N, d)

@@ -62,9 +62,11 @@ class GENConv(GenMessagePassing):
             h = self.reduce_messages(flat, graph, edge, self.eps, add_root=True)       # x + m in one pass
         else:
             h = msg_norm_add(flat, self.reduce_messages(flat, graph, edge, self.eps), self.msg_norm.msg_scale)
+        if h.shape != x.shape:                    # (a same-shape reshape would drop the row-max tag of the kernel's output)
+            h = h.reshape(x.shape)
         if residual is not None and isinstance(self.feature_encoder, MLP):
-            return self.feature_encoder(h.reshape(x.shape), residual=residual)
-        out = self.feature_encoder(h.reshape(x.shape))
+            return self.feature_encoder(h, residual=residual)
+        out = self.feature_encoder(h)
         return out if residual is None else out + residual
 
 

@@ -25,7 +25,7 @@ def test_header_and_binding_agree():
 def test_version_and_error_codes():
     from mlgnn import _lib
     lib = _lib.lib
-    assert lib.mlgnn_version() == 4
+    assert lib.mlgnn_version() == 5
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 1, 0, 0) == 8 * 2 * 128      # 8 workgroups minimum
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 8, 0, 0) == 8 * 9 * 128
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 9, 0, 0) == -2
@@ -34,7 +34,7 @@ def test_version_and_error_codes():
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 0, 3, 0) == 4 + 12 + 1280
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 1, 0, 3, 0) == 4 + 12 + 640
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 0, 3, 1) == 0
-    null = [None] * 12
+    null = [None] * 13
     # N = 0 is a no-op, bad dtype / mode / NULL pointers are reported, nothing is launched
     assert lib.mlgnn_csr_aggregate_fwd(*null, 0, 8, 0, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None) == 0
     assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 7, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None) == -4

@@ -98,3 +98,22 @@ def test_three_level_gnn_full_size_graphs_match_oracle():
         g = torch.zeros_like(sd[name]) if g is None else g
         got = p.grad if p.grad is not None else torch.zeros_like(p)
         assert_close(got, g, 1e-4, "grad " + name)
+
+
+def test_row_maxima_travel_with_the_activations():
+    """The aggregation / LayerNorm kernels hand max |row| to the Linear that consumes their output, forward and
+    backward, so the tall GEMM does not stream its operand twice: in one training step of the 3-layer model every
+    MLP GEMM except the node encoder's finds its row maxima attached."""
+    from mlgnn import dense
+    from mlgnn.workload import ThreeLevelGNN, collate, membership, training_loss
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    match, seg = membership(2500, 3000)
+    batch = collate(range(4), 2500, 30000, match, seg, device=dev)
+    model = ThreeLevelGNN(hidden=64, num_layers=3, n_members=3000).to(dev)
+    dense.ROW_MAX_STATS["given"] = dense.ROW_MAX_STATS["computed"] = 0
+    training_loss(model, batch).backward()
+    st = dict(dense.ROW_MAX_STATS)
+    # 3 layers x (2 forward + 2 input-gradient GEMMs) = 12 tall GEMMs; the first layer's aggregation output and
+    # every LayerNorm output / gradient carry their maxima
+    assert st["given"] >= 10, st

@@ -88,7 +88,7 @@ int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int dtype
  *                   SOFTMAX: sum_e w_e m_e^2 ; POWER: mean(clamp(m)^p * ln clamp(m)); NULL to skip
  *   argmax  [N,d]   MAX: by-destination edge position of the winner, -1 for an empty row
  *   row_max [N]     optional (NULL to skip): max_c |out[i][c]| per row, for the per-row scaling of the Linear that
- *                   consumes `out` (mlgnn_tallgemm_nt); only while d fits one channel chunk (d <= 256 fp32)
+ *                   consumes `out` (mlgnn_tallgemm_nt); only for d = 4 * 2^k <= 256 (fp32), 8 * 2^k <= 512 (bf16)
  *   t, p            softmax temperature / power exponent; when t_dev / p_dev is non-NULL the value is
  *                   read from that device address instead (learnable parameters: no host sync)
  *   add_root        non-zero: out = x + aggregate (GENConv's h = x + m, torch_vertex.py:89, same pass);

@@ -214,7 +214,6 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
       }
 
       // ---- epilogue: group 0 writes the row ----
-      float om = 0.f;
       if (sub == 0 && cact) {
         float o[VEC], ax[VEC], ax2[VEC];
         int am[VEC];
@@ -256,12 +255,14 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
         if (AGGR == A_MAX && a.argmax) store_vec<VEC>(a.argmax + off, am);
         if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_vec<VEC>(a.aux + off, ax);
         if (SECOND && a.aux2) store_vec<VEC>(a.aux2 + off, ax2);
+        if (a.rowmax) {   // max |row| of the result for the consumer GEMM's per-row scaling.  Only requested when
+                          // d == lpr * VEC: every lane of group 0 is in this branch, so the shuffles are defined
+          float om = 0.f;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) om = fmaxf(om, fabsf(o[i]));
-      }
-      if (a.rowmax) {     // max |row| of the result for the consumer GEMM's per-row scaling (single channel chunk only)
-        for (int off = 1; off < lpr; off <<= 1) om = fmaxf(om, __shfl_xor(om, off));
-        if (sub == 0 && cl == 0) a.rowmax[r] = om;
+          for (int i = 0; i < VEC; ++i) om = fmaxf(om, fabsf(o[i]));
+          for (int sh = 1; sh < lpr; sh <<= 1) om = fmaxf(om, __shfl_xor(om, sh));
+          if (cl == 0) a.rowmax[r] = om;
+        }
       }
     }
     };
@@ -328,7 +329,7 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   const bool second = (aux2 != nullptr) && (ag == A_SOFTMAX || ag == A_POWER);
   a.lpr_log2 = lanes_per_row_log2(d, vec);
   a.rowmax = row_max;
-  if (row_max && d > ((int64_t)vec << a.lpr_log2)) return MLGNN_E_SHAPE;     // row max needs the row in one chunk
+  if (row_max && d != ((int64_t)vec << a.lpr_log2)) return MLGNN_E_SHAPE;    // row max: one chunk, no shadow lanes
   for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
     constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
     constexpr bool kHasSecond = (AGGR == A_SOFTMAX || AGGR == A_POWER);

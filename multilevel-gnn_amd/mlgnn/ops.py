@@ -218,7 +218,7 @@ class _GenAggregate(torch.autograd.Function):
         timer = KERNEL_TIMER
         t0 = timer.start() if timer is not None else None
         # max |row| of the result rides along for the Linear that consumes it (fp32, one channel chunk)
-        rowmax = torch.empty(N, **f32) if (x.dtype == torch.float32 and d <= 256 and d % 4 == 0) else None
+        rowmax = torch.empty(N, **f32) if (x.dtype == torch.float32 and d in (4, 8, 16, 32, 64, 128, 256)) else None
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), _lib.ptr(eu), _lib.ptr(ev),
             _lib.ptr(efull), graph.eid.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),

@@ -13,16 +13,15 @@ struct BwdArgs {                      // go / x / out / efull / gx / ge are T; a
   const int* rowptr_t; const int* col_t; const int* pos_t; const int* rowptr;
   const float* ew_t; const float* eu; const float* ev; const void* efull; const int* eid_t;
   void* gx; void* ge; float* ws;
-  const void* gt; const float* shift; const int* spread;   // softmax shift path (see softmax_shift_kernel)
+  const void* gt; const int* spread;                        // softmax one-row path (see softmax_shift_kernel)
   const float* t_dev; const float* p_dev;
   int N; int d; int lpr_log2; int mean; int learn_t; int add_root;
   float t; float p; float eps;
 };
 
-// SHIFT (softmax without a learnable temperature): the per-(node, channel) normaliser lse[i][c] is split into a
-// per-node scalar s_i and a remainder that softmax_shift_kernel folds into the cotangent,
-//     gt[i][c] = go[i][c] * 2^(s_i - lse[i][c]),      w_e * go = 2^(t m_e - s_i) * gt[i][c],
-// so an edge gathers ONE row (gt) and one scalar instead of two rows (go, lse): half the gather traffic.
+// SHIFT (softmax without a learnable temperature): the normaliser is folded into the cotangent by
+// softmax_shift_kernel,  gt[i][c] = go[i][c] * 2^(-lse[i][c]),  so that  w_e * go = 2^(t m_e) * gt[i][c]  and an
+// edge gathers ONE row (gt) instead of two (go, lse): half the gather traffic, and no per-edge scalar either.
 template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool SHIFT>
 __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (*red)[kWave * VEC]) {
   constexpr int RK = rank_of<MODE>();
@@ -80,7 +79,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
         const int cnt = min(kWave, end - base);
         uint32_t my_off = 0;
         int my_pos = 0, my_eid = 0;
-        float my_ew[ESA], my_inv = 1.f, my_shift = 0.f;
+        float my_ew[ESA], my_inv = 1.f;
 #pragma unroll
         for (int k = 0; k < ESA; ++k) my_ew[k] = 0.f;
         if (lane < cnt) {
@@ -91,7 +90,6 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
             load_edge_scalars<ES>(my_ew, a.ew_t, (size_t)(base + lane));
           }
           if (MODE == M_GEN_FULL) my_eid = a.eid_t[base + lane];
-          if constexpr (SHIFT) my_shift = a.shift[dst];
           if (AGGR == A_SUM && a.mean)
             my_inv = __builtin_amdgcn_rcpf((float)max(a.rowptr[dst + 1] - a.rowptr[dst], 1));
         }
@@ -100,7 +98,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
           constexpr bool FULL = decltype(full_c)::value;
           float ga[kUnroll][VEC], gb[kUnroll][VEC], gc[kUnroll][VEC], ef[kUnroll][VEC];
           int ai[kUnroll][VEC];
-          float wa[kUnroll][ESA], inv[kUnroll], sh[kUnroll];
+          float wa[kUnroll][ESA], inv[kUnroll];
           int pos[kUnroll], e0[kUnroll];
           bool valid[kUnroll];
 #pragma unroll
@@ -112,7 +110,6 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
 #pragma unroll
             for (int q = 0; q < ESA; ++q) wa[u][q] = (ES > 0) ? __shfl(my_ew[q], src) : 0.f;
             inv[u] = (AGGR == A_SUM) ? __shfl(my_inv, src) : 1.f;
-            sh[u] = SHIFT ? __shfl(my_shift, src) : 0.f;
             pos[u] = (AGGR == A_MAX) ? __shfl(my_pos, src) : 0;
             e0[u] = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
 #pragma unroll
@@ -140,7 +137,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
               } else if constexpr (AGGR == A_MAX) {
                 coef = (ai[u][i] == pos[u]) ? ga[u][i] : 0.f;
               } else if constexpr (AGGR == A_SOFTMAX) {
-                const float w = fast_exp2(fmaf(sc.t_log2e, m, SHIFT ? -sh[u] : -gb[u][i]));
+                const float w = SHIFT ? fast_exp2(sc.t_log2e * m) : fast_exp2(fmaf(sc.t_log2e, m, -gb[u][i]));
                 coef = ga[u][i] * w;
                 if (LEARN_T) coef *= fmaf(sc.t, m - gc[u][i], 1.0f);
               } else {  // POWER: ga carries q (see mlgnn.h)
@@ -210,14 +207,16 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
   }
 }
 
-constexpr float kMaxSpread = 200.0f;     // log2 units; beyond it 2^(s - lse) could leave the fp32 range
+// |lse| (log2 units) up to which the two factors 2^(t m) <= 2^lse and 2^(-lse) are taken apart: 2^(+-60) leaves
+// fp32 more than 60 binades on either side for the cotangent itself
+constexpr float kMaxLse = 60.0f;
 
 template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
   __shared__ float red[kWavesPerBlock][kWave * VEC];
   if constexpr (AGGR == A_SOFTMAX && !LEARN_T) {
-    // *a.spread != 0: softmax_shift_kernel met a node whose lse spans more than kMaxSpread across channels; the
-    // two-row path stays as the fallback for such inputs (never seen in practice)
+    // *a.spread != 0: softmax_shift_kernel met a node with |lse| > kMaxLse in some channel; the two-row path
+    // stays as the fallback for such inputs (never seen in practice: lse = log2 sum_e 2^(t m_e))
     const bool shift_ok = a.gt != nullptr && *a.spread == 0;
     if (shift_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true>(a, red);
     else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false>(a, red);
@@ -226,12 +225,11 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
   }
 }
 
-// Per destination node i with at least one incoming edge: s_i = (min_c lse + max_c lse) / 2,
-// gt[i][c] = go[i][c] * 2^(s_i - lse[i][c]); *spread is set when some node's max_c lse - min_c lse exceeds
-// kMaxSpread (a plain store of the same value by whoever sees it: no atomics on the common path).
-// With the midpoint shift both factors of w = 2^(t m - s_i) * 2^(s_i - lse) stay within 2^(+-spread/2).
+// Per destination node i with at least one incoming edge: gt[i][c] = go[i][c] * 2^(-lse[i][c]); *spread is set
+// when some |lse| exceeds kMaxLse (a plain store of the same value by whoever sees it: no atomics on the common
+// path).  Nodes without incoming edges are never gathered; their rows are written as zeros.
 struct ShiftArgs {
-  const void* go; const float* lse; const int* rowptr; void* gt; float* shift; int* spread;
+  const void* go; const float* lse; const int* rowptr; void* gt; int* spread;
   int N; int d; int lpr_log2;
 };
 
@@ -283,11 +281,10 @@ __global__ __launch_bounds__(kBlock) void softmax_shift_kernel(const ShiftArgs a
         lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
         hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
       }
-      const float s = live[k] ? 0.5f * (lo[k] + hi[k]) : 0.f;
-      if (live[k]) worst = fmaxf(worst, hi[k] - lo[k]);
+      if (live[k]) worst = fmaxf(worst, fmaxf(hi[k], -lo[k]));
       if (one_chunk) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) g[k][i] = live[k] ? g[k][i] * fast_exp2(s - l[k][i]) : 0.f;
+        for (int i = 0; i < VEC; ++i) g[k][i] = live[k] ? g[k][i] * fast_exp2(-l[k][i]) : 0.f;
         if (row[k] < a.N && cact) store_t<T, VEC>(GT + (size_t)row[k] * a.d + c0, g[k]);
       } else {
         for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
@@ -296,15 +293,14 @@ __global__ __launch_bounds__(kBlock) void softmax_shift_kernel(const ShiftArgs a
           load_vec<VEC>(t, a.lse + (size_t)rc * a.d + cc);
           load_t<T, VEC>(q, GO + (size_t)rc * a.d + cc);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) q[i] = live[k] ? q[i] * fast_exp2(s - t[i]) : 0.f;
+          for (int i = 0; i < VEC; ++i) q[i] = live[k] ? q[i] * fast_exp2(-t[i]) : 0.f;
           if (row[k] < a.N && cbase + cl * VEC < a.d) store_t<T, VEC>(GT + (size_t)row[k] * a.d + cc, q);
         }
       }
-      if (row[k] < a.N && cl == 0) a.shift[row[k]] = s;
     }
   }
   for (int off = 1; off < kWave; off <<= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
-  if (lane == 0 && worst > kMaxSpread) *a.spread = 1;       // plain store: every writer stores the same value
+  if (lane == 0 && worst > kMaxLse) *a.spread = 1;       // plain store: every writer stores the same value
 }
 
 // ws[nblk][cols] -> out[cols] in a fixed summation order (bitwise reproducible).  One workgroup of
@@ -370,11 +366,10 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   if (mode == M_GEN_FULL && col_t && (!efull || !eid_t || !grad_efull)) return MLGNN_E_NULL;
   const int nblk = grid_for_rows(N);
   const bool bf16 = dtype == MLGNN_DTYPE_BF16;
-  // workspace = [edge-term partials: nblk * (rk+1) * d][softmax shift path: spread (4 floats), s [N], gt [N*d] of T]
+  // workspace = [edge-term partials: nblk * (rk+1) * d][softmax one-row path: flag (4 floats), gt [N*d] of T]
   const int64_t part_floats = rk > 0 ? (int64_t)nblk * (rk + 1) * d : 0;
   const bool want_shift = ag == A_SOFTMAX && !learn_t;
-  const int64_t n_pad = (N + 3) / 4 * 4;
-  const int64_t shift_floats = want_shift ? 4 + n_pad + (N * d * (bf16 ? 2 : 4) + 3) / 4 : 0;
+  const int64_t shift_floats = want_shift ? 4 + (N * d * (bf16 ? 2 : 4) + 3) / 4 : 0;
   if (part_floats + shift_floats > 0 && (!workspace || workspace_floats < part_floats + shift_floats)) return MLGNN_E_WORKSPACE;
 
   BwdArgs a;
@@ -394,14 +389,14 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   const dim3 grid(nblk), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   a.lpr_log2 = lanes_per_row_log2(d, vec);
-  a.gt = nullptr; a.shift = nullptr; a.spread = nullptr;
+  a.gt = nullptr; a.spread = nullptr;
   if (want_shift) {
     float* base = workspace + part_floats;               // 16-byte aligned: part_floats is a multiple of 4 when d % 4 == 0
     if (!rowptr) return MLGNN_E_NULL;
     if ((reinterpret_cast<uintptr_t>(base) & 15) == 0 || vec == 1) {
       ShiftArgs sa;
       sa.go = grad_out; sa.lse = aux; sa.rowptr = rowptr; sa.N = (int)N; sa.d = (int)d; sa.lpr_log2 = a.lpr_log2;
-      sa.spread = reinterpret_cast<int*>(base); sa.shift = base + 4; sa.gt = base + 4 + n_pad;
+      sa.spread = reinterpret_cast<int*>(base); sa.gt = base + 4;
       int err0 = (int)hipMemsetAsync(sa.spread, 0, 16, s);
       if (err0) return err0;
       const int rows_per_block = kWavesPerBlock * (kWave >> a.lpr_log2) * 4;
@@ -414,7 +409,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
         if (vec == 4) hipLaunchKernelGGL((softmax_shift_kernel<float, 4>), dim3(sblk), block, 0, s, sa);
         else hipLaunchKernelGGL((softmax_shift_kernel<float, 1>), dim3(sblk), block, 0, s, sa);
       }
-      a.gt = sa.gt; a.shift = sa.shift; a.spread = sa.spread;
+      a.gt = sa.gt; a.spread = sa.spread;
     }
   }
   const bool lt = learn_t != 0 && ag == A_SOFTMAX;

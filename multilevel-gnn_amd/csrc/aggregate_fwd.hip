@@ -287,7 +287,7 @@ extern "C" int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d
   // per-workgroup partials of the factored edge term + the softmax shift buffers (aggregate_bwd.hip)
   int64_t n = edge_rank > 0 ? (int64_t)grid_for_rows(N) * (edge_rank + 1) * d : 0;
   if (aggr == MLGNN_AGGR_SOFTMAX && !learn_t)
-    n += 4 + (N + 3) / 4 * 4 + (N * d * (dtype == MLGNN_DTYPE_BF16 ? 2 : 4) + 3) / 4;
+    n += 4 + (N * d * (dtype == MLGNN_DTYPE_BF16 ? 2 : 4) + 3) / 4;
   return n;
 }
 

@@ -80,10 +80,9 @@ def algorithmic_bytes(N, E, d, aggr_id, edge_mode, backward=False, learn_t=False
     if aggr_id == AGGR_SOFTMAX and learn_t:
         gathers += E * d * 4 + rows                                   # lse + out rows for the recompute
     elif aggr_id == AGGR_SOFTMAX:
-        # one-row path: the gathered row is gt = go * 2^(s - lse) plus the per-node shift s (4 B / edge);
-        # the prepass streams go + lse in and gt + s out once per node
-        gathers += E * 4
-        prepass = N * d * s + N * d * 4 + N * d * s + N * 4 + (N + 1) * 4
+        # one-row path: the gathered row is gt = go * 2^(-lse); the prepass streams go + lse in and gt out once
+        # per node
+        prepass = N * d * s + N * d * 4 + N * d * s + (N + 1) * 4
     if aggr_id == AGGR_MAX:
         gathers += E * d * 4 + E * 4                                  # argmax rows + pos_t
     if edge_mode == EDGE_FULL:

@@ -30,9 +30,9 @@ def test_version_and_error_codes():
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 8, 0, 0) == 8 * 9 * 128
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 9, 0, 0) == -2
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(-1, 4, 0, 1, 0, 0) == -2
-    # softmax: + spread (4) + per-node shift (12, padded) + rescaled cotangent (10*128 fp32 / bf16)
-    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 0, 3, 0) == 4 + 12 + 1280
-    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 1, 0, 3, 0) == 4 + 12 + 640
+    # softmax: + flag (4) + rescaled cotangent (10*128 fp32 / bf16)
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 0, 3, 0) == 4 + 1280
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 1, 0, 3, 0) == 4 + 640
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 0, 3, 1) == 0
     null = [None] * 13
     # N = 0 is a no-op, bad dtype / mode / NULL pointers are reported, nothing is launched

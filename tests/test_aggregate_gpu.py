@@ -132,6 +132,9 @@ def test_learnable_t_p(aggr, edge_kind):
 def test_negative_temperature_and_large_values():
     _run_case(100, 1200, 64, "softmax", "none", t=-2.5)
     _run_case(100, 1200, 64, "softmax", "rank1", t=8.0)
+    # |lse| far beyond 60 (log2 units): the backward must notice on the device and take the two-row path
+    _run_case(100, 1200, 64, "softmax", "rank1", t=40.0)
+    _run_case(100, 1200, 64, "softmax", "full", t=-40.0)
 
 
 def test_empty_and_tiny_graphs():

@@ -336,6 +336,17 @@ void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hip
 
 using namespace mlgnn;
 
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out, const float* aux,
                                        const int32_t* argmax,
                                        const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
@@ -386,7 +397,8 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                   (!efull || aligned16(efull)) && (!grad_efull || aligned16(grad_efull)) &&
                   (!eu || aligned16(eu)) && (!ev || aligned16(ev));
   const int vec = bf16 ? ((d % 8 == 0 && al) ? 8 : 1) : ((d % 4 == 0 && al) ? 4 : 1);
-  const dim3 grid(nblk), block(kBlock);
+  const dim3 block(kBlock);
+  int launched_blocks = nblk;
   hipStream_t s = (hipStream_t)stream;
   a.lpr_log2 = lanes_per_row_log2(d, vec);
   a.gt = nullptr; a.spread = nullptr;
@@ -419,8 +431,22 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
     auto launch = [&](auto t_c, auto vec_c) {
       using T = typename decltype(t_c)::type;
       constexpr int VEC = decltype(vec_c)::value;
-      if (kCanLearn && lt) hipLaunchKernelGGL((csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, kCanLearn>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false>), grid, block, 0, s, a);
+      auto go = [&](auto kernel) {
+        // The strided walk is one pass over the rows only while every workgroup is resident (otherwise each
+        // generation of workgroups sweeps all graphs again, through a cold L2): size the grid to the occupancy of
+        // this instantiation.
+        static int per_cu = 0;                                  // one static per instantiation
+        if (per_cu == 0) {
+          int n = 0;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, 0) != hipSuccess || n < 1) n = 2;
+          per_cu = n;
+        }
+        int g = per_cu * num_cus() / kXcds * kXcds;
+        launched_blocks = g < nblk ? (g < kXcds ? kXcds : g) : nblk;
+        hipLaunchKernelGGL(kernel, dim3(launched_blocks), block, 0, s, a);
+      };
+      if (kCanLearn && lt) go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, kCanLearn>);
+      else go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false>);
     };
     if (bf16) { if (vec == 8) launch(TypeTag<bf16_t>{}, IC<8>{}); else launch(TypeTag<bf16_t>{}, IC<1>{}); }
     else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
@@ -428,7 +454,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   int err = (int)hipGetLastError();
   if (err) return err;
   if (rk > 0) {
-    launch_reduce_partials(workspace, grad_uv, nblk, (rk + 1) * (int)d, s);
+    launch_reduce_partials(workspace, grad_uv, launched_blocks, (rk + 1) * (int)d, s);
     err = (int)hipGetLastError();
   }
   return err;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 5
+#define MLGNN_ABI_VERSION 6
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -165,7 +165,8 @@ int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
  * Replaces: norm_layer('layer') followed by act_layer('relu') as chained by MLP
  * (models/gcn_lib/sparse/torch_nn.py:27-38,54-75) and by the res+ block (models/deepergcn.py:236-241).
  *   out = relu?( (x - mean) * rstd * gamma + beta ),  rstd = 1/sqrt(var_biased + eps)
- * mean / rstd [rows] are saved for the backward, which recomputes the ReLU mask from x.
+ * mean / rstd [rows] are saved for the backward, which recomputes the ReLU mask from x.  Backward with
+ * mean = NULL: x is already the normalised activation (x - mean) * rstd (mlgnn_tallgemm_nt ln_mode 1).
  * grad_gamma_beta [2,d]; workspace: mlgnn_layernorm_bwd_workspace_floats(rows, d) floats.
  * grad_extra [rows,d] or NULL: a gradient that reaches x on another branch (the identity branch of the
  * res+ block, deepergcn.py:241), added into grad_x in the same pass.
@@ -190,9 +191,12 @@ int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* ga
  * Replaces: the autograd of nn.Linear inside MLP (models/gcn_lib/sparse/torch_nn.py:54-75).
  * grad_out [N,M], x [N,K] fp32; ceil(M/32)*ceil(K/32) <= 32 tiles, otherwise MLGNN_E_SHAPE
  * (the caller then uses a library GEMM).  workspace: mlgnn_linear_wgrad_workspace_floats floats.
+ * x_gamma, x_beta [K] or NULL: x is a layer-normalised activation (mlgnn_tallgemm_nt ln_mode 1) and the Linear's
+ * real input was relu(x_gamma x + x_beta): applied to the operand as it is loaded.
  */
 int64_t mlgnn_linear_wgrad_workspace_floats(int64_t N, int64_t M, int64_t K);
-int mlgnn_linear_wgrad(const void* grad_out, const void* x, float* grad_w_b, float* workspace,
+int mlgnn_linear_wgrad(const void* grad_out, const void* x, const float* x_gamma, const float* x_beta,
+                       float* grad_w_b, float* workspace,
                        int64_t workspace_floats, int64_t N, int64_t M, int64_t K, int dtype,
                        void* stream);
 
@@ -306,12 +310,20 @@ int mlgnn_segment_pool_fwd(const void* x, const int32_t* ptr, void* out, int32_t
  * (models/gcn_lib/sparse/torch_nn.py:54-75).  Relative error per product <= 3*2^-22 (see csrc/tallgemm.hip).
  * row_max [N] or NULL: max_k |a[i][k]| per row when the producer of `a` already knows it (any upper bound
  * within a factor of 2 of the true maximum keeps full accuracy); NULL: the kernel streams `a` twice.
+ * ln_mode (R, J in {64,128,256}): the LayerNorm + ReLU that sits between the two Linears of MLP
+ * (torch_nn.py:54-75) without a pass of its own --
+ *   1: c receives the layer-normalised result xhat = (v - mean(v)) * rstd (no affine), rstd_out [N] = 1/sigma,
+ *      row_max_out [N] = max_j relu(gamma[j] xhat + beta[j])   (gamma, beta [J]; residual must be NULL);
+ *   2: a is such an xhat: relu(gamma[k] a + beta[k]) is applied as it is loaded (gamma, beta [R]; pass the
+ *      producer's row_max_out as row_max);
+ *   0: neither (gamma, beta, rstd_out, row_max_out ignored).
  * workspace: mlgnn_tallgemm_workspace_bytes(R, J) bytes (split weight image).
  */
 int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J);
 int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J);
 int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual,
-                      const float* row_max, void* c, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
+                      const float* row_max, int ln_mode, const float* gamma, const float* beta, float ln_eps,
+                      float* rstd_out, float* row_max_out, void* c, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,23 @@ __device__ __forceinline__ void store_t(T* __restrict__ p, const float (&r)[VEC]
   }
 }
 
+// All-reduce over the 32-lane half of a wavefront without the LDS crossbar: rotations inside each row of 16 lanes
+// are DPP modifiers of the VALU op (row_ror:8/4/2/1), only the last step (row <-> row) is a ds_bpermute.  For
+// epilogues that reduce many values per lane (a `__shfl_xor` ladder is five crossbar trips per value).
+template <int ROR>
+__device__ __forceinline__ float dpp_row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + ROR, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  v += dpp_row_ror<8>(v); v += dpp_row_ror<4>(v); v += dpp_row_ror<2>(v); v += dpp_row_ror<1>(v);
+  return v + __shfl_xor(v, 16);
+}
+__device__ __forceinline__ float half_max(float v) {
+  v = fmaxf(v, dpp_row_ror<8>(v)); v = fmaxf(v, dpp_row_ror<4>(v));
+  v = fmaxf(v, dpp_row_ror<2>(v)); v = fmaxf(v, dpp_row_ror<1>(v));
+  return fmaxf(v, __shfl_xor(v, 16));
+}
+
 // exp2 / log2 on the transcendental unit (v_exp_f32 / v_log_f32, ~1 ulp)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }

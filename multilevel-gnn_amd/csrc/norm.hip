@@ -101,19 +101,19 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
   if (cact) { load_vec<4>(g, a.gamma + c0); load_vec<4>(b, a.beta + c0); }
   const float inv_d = 1.0f / (float)a.d;
   for (int r0 = wave_global * GROUPS * kLnRows; r0 < a.rows; r0 += n_waves * GROUPS * kLnRows) {
-    float v[kLnRows][4], go[kLnRows][4], mu[kLnRows], rs[kLnRows];
+    float v[kLnRows][4], go[kLnRows][4], mu[kLnRows], rs[kLnRows], nsc[kLnRows];
     bool ok[kLnRows];
 #pragma unroll
     for (int u = 0; u < kLnRows; ++u) {
       const int r = r0 + u * GROUPS + sub;
       ok[u] = (r < a.rows) && cact;
-      mu[u] = 0.f; rs[u] = 0.f;
+      mu[u] = 0.f; rs[u] = 0.f; nsc[u] = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { v[u][i] = 0.f; go[u][i] = 0.f; }
       if (ok[u]) {
         load_vec<4>(v[u], a.x + (size_t)r * a.d + c0);
         load_vec<4>(go[u], a.go + (size_t)r * a.d + c0);
-        mu[u] = a.mean[r]; rs[u] = a.rstd[r];
+        mu[u] = a.mean ? a.mean[r] : 0.f; rs[u] = a.rstd[r]; nsc[u] = a.mean ? rs[u] : 1.0f;
       }
     }
 #pragma unroll
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
       float xh[4], gg[4], s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        xh[i] = (v[u][i] - mu[u]) * rs[u];
+        xh[i] = (v[u][i] - mu[u]) * nsc[u];       // nsc = rstd, or 1 with mu = 0 when x is already normalised
         const float y = fmaf(xh[i], g[i], b[i]);
         const float gy = (a.relu && !(y > 0.f)) ? 0.f : go[u][i];
         dg[i] = fmaf(gy, xh[i], dg[i]);
@@ -233,7 +233,7 @@ extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, cons
   const int lpr = lanes_per_row_log2(d, 4);
   const int nblk = ln_grid(rows, lpr);
   if (workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
-  if (rows > 0 && (!grad_out || !x || !gamma || !beta || !mean || !rstd || !grad_x)) return MLGNN_E_NULL;
+  if (rows > 0 && (!grad_out || !x || !gamma || !beta || !rstd || !grad_x)) return MLGNN_E_NULL;
   if (!a16(x) || !a16(grad_out) || !a16(grad_x) || !a16(gamma) || !a16(beta) || !a16(grad_extra)) return MLGNN_E_ALIGN;
   LnArgs a{};
   a.x = (const float*)x; a.go = (const float*)grad_out; a.gamma = gamma; a.beta = beta;

@@ -84,13 +84,21 @@ __global__ __launch_bounds__(kBlock) void tallgemm_split_weight_kernel(const flo
 
 struct TgArgs {
   const float* a; const f16x8* image; const float* bias; const float* res; const float* rowmax; float* c;
+  const float* gamma; const float* beta; float* rstd_out; float* rowmax_out; float ln_eps;
   int N; int R; int J;
 };
 
 constexpr int kTgBlock = 512;              // 8 waves: two per SIMD share the LDS image and hide each other's loads
 constexpr int kTgWaves = kTgBlock / kWave;
 
-template <int JT, int KS>       // 32-column tiles = J / 32, 16-deep k-steps = R / 16
+// LN = 0: plain.  LN = 1: the result rows are layer-normalised in the epilogue -- c receives
+// xhat = (v - mean) * rstd (no affine), rstd_out the per-row 1/sigma and rowmax_out max |relu(gamma xhat + beta)|,
+// i.e. everything the consumer needs to apply LayerNorm's affine map + ReLU on the fly (a wave holds whole
+// result rows: lane (r31, h) has column 32 t + r31 of 16 rows for every tile t).  LN = 2: the A operand is such
+// a normalised activation: relu(gamma[k] a + beta[k]) is applied while it is loaded.  Together they remove the
+// LayerNorm+ReLU pass between the two Linears of the MLP (torch_nn.py:54-75): the hidden activation is written
+// once (normalised) and read by its consumers directly.
+template <int JT, int KS, int LN>       // 32-column tiles = J / 32, 16-deep k-steps = R / 16
 __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
   extern __shared__ f16x8 wlds[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -107,6 +115,24 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
   float bias[JT];
 #pragma unroll
   for (int t = 0; t < JT; ++t) bias[t] = p.bias ? p.bias[32 * t + r31] : 0.f;
+  // LN = 1: affine parameters of this lane's output columns; LN = 2: those of the k index, staged in LDS
+  float og[LN == 1 ? JT : 1], ob[LN == 1 ? JT : 1];
+  float* kg = reinterpret_cast<float*>(wlds + n_frag);         // [R] gamma then [R] beta, behind the image
+  if constexpr (LN == 1) {
+#pragma unroll
+    for (int t = 0; t < JT; ++t) { og[t] = p.gamma[32 * t + r31]; ob[t] = p.beta[32 * t + r31]; }
+  }
+  if constexpr (LN == 2) {
+    for (int i = threadIdx.x; i < R; i += kTgBlock) { kg[i] = p.gamma[i]; kg[R + i] = p.beta[i]; }
+    __syncthreads();
+  }
+  auto activate = [&](float (&e)[8], int s) {                  // LN = 2: a -> relu(gamma[k] a + beta[k])
+    if constexpr (LN == 2) {
+      const float* g = kg + 16 * s + 8 * h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = fmaxf(fmaf(e[j], g[j], g[R + j]), 0.f);
+    }
+  };
 
   const int n_tiles = (p.N + 31) / 32;                       // 32-row tiles, dealt round robin to the waves
   const int t_stride = gridDim.x * kTgWaves;
@@ -128,8 +154,10 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
       for (int s = 0; s < KS; ++s) {
         const float4 q0 = *reinterpret_cast<const float4*>(ap + 16 * s);
         const float4 q1 = *reinterpret_cast<const float4*>(ap + 16 * s + 4);
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w))));
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
+        float e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        activate(e, s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(e[j]));
       }
       m = fmaxf(m, __shfl_xor(m, 32));                          // the other half of the row
     }
@@ -162,7 +190,8 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
     float4 n1 = *reinterpret_cast<const float4*>(ap + 4);
 #pragma unroll 1                                               // keep ONE k-step of A live: a full unroll spills
     for (int s = 0; s < KS; ++s) {
-      const float e[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+      float e[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+      activate(e, s);
       if (s + 1 < KS) {
         n0 = *reinterpret_cast<const float4*>(ap + 16 * (s + 1));
         n1 = *reinterpret_cast<const float4*>(ap + 16 * (s + 1) + 4);
@@ -193,7 +222,32 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
       const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
       const float us = __shfl(unscale, rr);
       const int row = row0 + rr;
-      if (row < p.N) {
+      if constexpr (LN == 1) {
+        // layer-normalise row `row` (its J values sit in acc[0..JT)[r] of the 32 lanes sharing h): two-pass
+        // statistics like layernorm_act_fwd_kernel, reductions over the 32-lane half (DPP rotations + one shuffle)
+        float v[JT], sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) { v[t] = fmaf(acc[t][r], us, bias[t]); sum += v[t]; }
+        sum = half_sum(sum);
+        const float mu = sum * (1.0f / (32 * JT));
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) { v[t] -= mu; q = fmaf(v[t], v[t], q); }
+        q = half_sum(q);
+        const float rs = rsqrtf(q * (1.0f / (32 * JT)) + p.ln_eps);
+        float ym = 0.f;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+          v[t] *= rs;
+          ym = fmaxf(ym, fmaxf(fmaf(v[t], og[t], ob[t]), 0.f));
+        }
+        ym = half_max(ym);
+        if (row < p.N) {
+#pragma unroll
+          for (int t = 0; t < JT; ++t) p.c[(size_t)row * p.J + 32 * t + r31] = v[t];
+          if (r31 == 0) { p.rstd_out[row] = rs; p.rowmax_out[row] = ym; }
+        }
+      } else if (row < p.N) {
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
           float v = fmaf(acc[t][r], us, bias[t]);
@@ -226,7 +280,8 @@ extern "C" int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J) {
 }
 
 extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual,
-                                 const float* row_max, void* c, void* workspace,
+                                 const float* row_max, int ln_mode, const float* gamma, const float* beta,
+                                 float ln_eps, float* rstd_out, float* row_max_out, void* c, void* workspace,
                                  int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype,
                                  void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
@@ -235,6 +290,10 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
   if (!tg_dims_ok(R, J)) return MLGNN_E_SHAPE;
   if (!a || !bt || !c || !workspace) return MLGNN_E_NULL;
   if (residual && J > 128) return MLGNN_E_SHAPE;            // the fused residual needs its tile in registers
+  if (ln_mode < 0 || ln_mode > 2) return MLGNN_E_MODE;
+  if (ln_mode != 0 && (!gamma || !beta)) return MLGNN_E_NULL;
+  if (ln_mode == 1 && (!rstd_out || !row_max_out || residual)) return MLGNN_E_NULL;
+  if (ln_mode != 0 && (R < 64 || J < 64)) return MLGNN_E_SHAPE;      // LN modes are instantiated for 64..256 only
   if (workspace_bytes < R * J * 4 + kTgHeader * 16) return MLGNN_E_WORKSPACE;
   if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bt) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
     return MLGNN_E_ALIGN;
@@ -247,25 +306,36 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
   TgArgs p;
   p.a = (const float*)a; p.image = (const f16x8*)workspace; p.bias = bias; p.res = (const float*)residual;
   p.rowmax = row_max; p.c = (float*)c;
+  p.gamma = gamma; p.beta = beta; p.rstd_out = rstd_out; p.rowmax_out = row_max_out; p.ln_eps = ln_eps;
   p.N = (int)N; p.R = (int)R; p.J = (int)J;
-  const size_t lds = (size_t)R * J * 4;
+  const size_t lds = (size_t)R * J * 4 + (ln_mode == 2 ? (size_t)R * 8 : 0);
   const int64_t tiles = (N + 31) / 32;
   int grid = (int)((tiles + kTgWaves - 1) / kTgWaves);
   if (grid > 256) grid = 256;                      // persistent: one workgroup per CU
   const dim3 g(grid), b(kTgBlock);
   bool launched = false;
-#define MLGNN_TG_CASE(JT_, KS_)                                                                       \
-  if (!launched && J == 32 * JT_ && R == 16 * KS_) {                                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_>),              \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds);                 \
-    hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_>), g, b, lds, s, p);                                  \
+#define MLGNN_TG_LAUNCH(JT_, KS_, LN_)                                                                 \
+  {                                                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, LN_>),         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds + 2048);          \
+    hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, LN_>), g, b, lds, s, p);                             \
     launched = true;                                                                                  \
   }
+#define MLGNN_TG_CASE(JT_, KS_)                                                                       \
+  if (!launched && ln_mode == 0 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 0)
+#define MLGNN_TG_CASE_LN(JT_, KS_)                                                                    \
+  if (!launched && ln_mode == 1 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 1)       \
+  if (!launched && ln_mode == 2 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 2)
 #define MLGNN_TG_ROW(JT_) MLGNN_TG_CASE(JT_, 1) MLGNN_TG_CASE(JT_, 2) MLGNN_TG_CASE(JT_, 4) MLGNN_TG_CASE(JT_, 8)
   MLGNN_TG_ROW(1) MLGNN_TG_ROW(2) MLGNN_TG_ROW(4) MLGNN_TG_ROW(8)
   MLGNN_TG_CASE(1, 16) MLGNN_TG_CASE(2, 16) MLGNN_TG_CASE(4, 16)          // 256 x 256 exceeds the LDS image
+  MLGNN_TG_CASE_LN(2, 4) MLGNN_TG_CASE_LN(2, 8) MLGNN_TG_CASE_LN(2, 16)
+  MLGNN_TG_CASE_LN(4, 4) MLGNN_TG_CASE_LN(4, 8) MLGNN_TG_CASE_LN(4, 16)
+  MLGNN_TG_CASE_LN(8, 4) MLGNN_TG_CASE_LN(8, 8)
 #undef MLGNN_TG_ROW
+#undef MLGNN_TG_CASE_LN
 #undef MLGNN_TG_CASE
+#undef MLGNN_TG_LAUNCH
   if (!launched) return MLGNN_E_SHAPE;
   return (int)hipGetLastError();
 }

@@ -27,6 +27,7 @@ constexpr int kTile = 32;
 
 struct WgradArgs {
   const float* a; const float* b; float* ws;
+  const float* b_gamma; const float* b_beta;      // non-NULL: the B operand is relu(b_gamma[col] * b + b_beta[col])
   int N; int M; int K; int out_cols;      // out_cols = M*K + M
   int row0;                               // first row of this launch
   int rows;                               // rows of this launch (a multiple of the stage when !MASKED)
@@ -133,6 +134,13 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
 
   constexpr int kSets = DB ? 2 : 1;               // DB: two stages of loads in flight (register sets by stage parity)
   float sa[kSets][PA][8], sb[kSets][PB][8];
+  float bg[PB], bb[PB];                             // affine + ReLU applied to the B operand (layer-normalised input)
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int c = min(ub[q].col, p.K - 1);
+    bg[q] = p.b_gamma ? p.b_gamma[c] : 1.f;
+    bb[q] = p.b_gamma ? p.b_beta[c] : 0.f;
+  }
   float bsum[PA];                                   // fp32 column sums of the A columns this thread loads
 #pragma unroll
   for (int q = 0; q < PA; ++q) bsum[q] = 0.f;
@@ -167,7 +175,12 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
   };
   // valid == false (a stage past the end of the slab, DB pipeline only): the stage is committed as zeros, so
   // multiplying it is a no-op and the loop body stays free of branches (see below)
-  auto commit_one = [&](bf16x8* t, const Unit& un, float (&st)[8], int r0, bool valid, float* sum) {
+  auto commit_one = [&](bf16x8* t, const Unit& un, float (&st)[8], int r0, bool valid, float* sum, float g, float b,
+                        bool act) {
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) st[j] = fmaxf(fmaf(st[j], g, b), 0.f);
+    }
     if constexpr (MASKED) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) st[j] = (un.live && r0 + un.grp * 8 + j < r_end) ? st[j] : 0.f;
@@ -191,10 +204,10 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
     bf16x8* t = tile + buf * kBuf;
 #pragma unroll
     for (int q = 0; q < PA; ++q)
-      if (UA % kThreads == 0 || threadIdx.x + q * kThreads < UA) commit_one(t, ua[q], sa[S][q], r0, valid, &bsum[q]);
+      if (UA % kThreads == 0 || threadIdx.x + q * kThreads < UA) commit_one(t, ua[q], sa[S][q], r0, valid, &bsum[q], 1.f, 0.f, false);
 #pragma unroll
     for (int q = 0; q < PB; ++q)
-      if (UB % kThreads == 0 || threadIdx.x + q * kThreads < UB) commit_one(t, ub[q], sb[S][q], r0, valid, nullptr);
+      if (UB % kThreads == 0 || threadIdx.x + q * kThreads < UB) commit_one(t, ub[q], sb[S][q], r0, valid, nullptr, bg[q], bb[q], p.b_gamma != nullptr);
   };
   auto multiply = [&](int buf) {
 #pragma unroll
@@ -355,7 +368,8 @@ extern "C" int64_t mlgnn_linear_wgrad_workspace_floats(int64_t N, int64_t M, int
   return (int64_t)(wgrad_blocks(N, pl) + 1) * (M * K + M);
 }
 
-extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, float* grad_w_b, float* workspace,
+extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const float* x_gamma, const float* x_beta,
+                                  float* grad_w_b, float* workspace,
                                   int64_t workspace_floats, int64_t N, int64_t M, int64_t K, int dtype,
                                   void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
@@ -371,6 +385,8 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, float* gr
   hipStream_t s = (hipStream_t)stream;
   WgradArgs a;
   a.a = (const float*)grad_out; a.b = (const float*)x; a.ws = workspace;
+  a.b_gamma = x_gamma; a.b_beta = x_gamma ? x_beta : nullptr;
+  if (x_gamma && !x_beta) return MLGNN_E_NULL;
   a.N = (int)N; a.M = (int)M; a.K = (int)K; a.out_cols = cols;
   // unpadded operands: whole stages go through the unmasked kernel, the last N % 32 rows through the masked one
   const bool padded = (M % kTile != 0) || (K % kTile != 0);

@@ -11,9 +11,13 @@ WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bot
 ROW_MAX_STATS = {"given": 0, "computed": 0}      # tall GEMMs whose operand came with / without its row maxima
 
 
-def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None):
+def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None):
     """``a [N,R] @ bt[J,R]^T (+ bias) (+ residual [N,J])`` through the scaled split-precision fp16-MFMA kernel
-    (``csrc/tallgemm.hip``).  The caller checks :func:`tall_matmul_supported` first."""
+    (``csrc/tallgemm.hip``).  The caller checks :func:`tall_matmul_supported` first.  ``row_max`` [N]: ``max |a[i]|``
+    when the producer of ``a`` supplied it (see :func:`mlgnn.ops.tag_row_max`).
+    ``ln = ("out", gamma, beta, eps)``: returns ``(xhat, rstd, row_max_y)`` -- the layer-normalised result without
+    the affine map, its 1/sigma and ``max relu(gamma xhat + beta)`` per row.  ``ln = ("in", gamma, beta)``: ``a`` is
+    such an ``xhat``; ``relu(gamma a + beta)`` is applied as it is loaded."""
     N, R = a.shape
     J = bt.shape[0]
     a, bt = a.contiguous(), bt.contiguous()
@@ -23,15 +27,37 @@ def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None):
     if residual is not None:
         residual = residual.contiguous()
     ROW_MAX_STATS["given" if row_max is not None else "computed"] += 1
+    mode, gamma, beta, eps, rstd, rmax = 0, None, None, 0.0, None, None
+    if ln is not None:
+        mode = 1 if ln[0] == "out" else 2
+        gamma, beta = ln[1].contiguous(), ln[2].contiguous()
+        if mode == 1:
+            eps = float(ln[3])
+            rstd = torch.empty(N, dtype=torch.float32, device=a.device)
+            rmax = torch.empty(N, dtype=torch.float32, device=a.device)
     rc = _lib.lib.mlgnn_tallgemm_nt(a.data_ptr(), bt.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(row_max),
-                                    out.data_ptr(), ws.data_ptr(),
-                                    nbytes, N, R, J, 0, torch.cuda.current_stream().cuda_stream)
+                                    mode, _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.ptr(rstd), _lib.ptr(rmax),
+                                    out.data_ptr(), ws.data_ptr(), nbytes, N, R, J, 0,
+                                    torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_tallgemm_nt")
-    return out
+    return (out, rstd, rmax) if mode == 1 else out
 
 
 def tall_matmul_supported(N, R, J):
     return bool(_lib.lib.mlgnn_tallgemm_supported(N, R, J))
+
+
+def _wgrad(go, x, x_gamma=None, x_beta=None):
+    """``(go^T x' [M,K], colsum go [M])`` with ``x' = x`` or ``relu(x_gamma x + x_beta)`` (``csrc/wgrad.hip``)."""
+    N, K = x.shape
+    M = go.shape[1]
+    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K))
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    out = torch.empty(M * K + M, dtype=torch.float32, device=x.device)
+    rc = _lib.lib.mlgnn_linear_wgrad(go.data_ptr(), x.data_ptr(), _lib.ptr(x_gamma), _lib.ptr(x_beta), out.data_ptr(),
+                                     ws.data_ptr(), n, N, M, K, 0, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mlgnn_linear_wgrad")
+    return out[:M * K].view(M, K), out[M * K:]
 
 
 class _TallLinear(torch.autograd.Function):
@@ -66,16 +92,62 @@ class _TallLinear(torch.autograd.Function):
                 gx = go.matmul(weight)
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K))
-            ws = torch.empty(n, dtype=torch.float32, device=x.device)
-            out = torch.empty(M * K + M, dtype=torch.float32, device=x.device)
-            rc = _lib.lib.mlgnn_linear_wgrad(go.data_ptr(), x.data_ptr(), out.data_ptr(), ws.data_ptr(), n,
-                                             N, M, K, 0, torch.cuda.current_stream().cuda_stream)
-            _lib.check(rc, "mlgnn_linear_wgrad")
-            gw = out[:M * K].view(M, K)
-            gb = out[M * K:] if ctx.has_bias else None
+            gw, gb = _wgrad(go, x)
+            gb = gb if ctx.has_bias else None
         # the residual enters by plain addition: its gradient is the output gradient itself (no copy)
         return gx, gw, gb, (go if ctx.needs_input_grad[3] else None)
+
+
+class _FusedMLP2(torch.autograd.Function):
+    """``Linear -> LayerNorm -> ReLU -> Linear (+ residual)`` -- the GENConv MLP (torch_nn.py:54-75,
+    torch_vertex.py:35) -- with the hidden activation written ONCE, layer-normalised by the first GEMM's epilogue;
+    the affine map + ReLU are applied by its consumers as they load it (second GEMM, its weight gradient), so the
+    LayerNorm pass between the two GEMMs does not exist.  The backward is spelled out: weight gradients on the
+    split-row kernel, input gradients on the tall GEMM, LayerNorm backward on the stored normalised activation."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, residual, eps):
+        from .ops import row_max_of as _rm
+        x = x.contiguous()
+        xhat, rstd, rmax = tall_matmul_nt(x, w1, b1, None, _rm(x), ln=("out", gamma, beta, eps))
+        fuse = residual is not None and w2.shape[0] <= 128
+        out = tall_matmul_nt(xhat, w2, b2, residual if fuse else None, rmax, ln=("in", gamma, beta))
+        if residual is not None and not fuse:
+            out = out + residual
+        ctx.save_for_backward(x, xhat, rstd, w1, w2, gamma, beta)
+        ctx.flags = (b1 is not None, b2 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        from .norm import ln_backward_normalised
+        from .ops import row_max_of as _rm
+        x, xhat, rstd, w1, w2, gamma, beta = ctx.saved_tensors
+        has_b1, has_b2 = ctx.flags
+        go = go.contiguous()
+        gw2, gb2 = _wgrad(go, xhat, gamma.contiguous(), beta.contiguous())          # go^T relu(gamma xhat + beta)
+        gy = tall_matmul_nt(go, w2.t().contiguous(), row_max=_rm(go))
+        gh, ggamma, gbeta, gh_max = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
+        gw1, gb1 = _wgrad(gh, x)
+        gx = tall_matmul_nt(gh, w1.t().contiguous(), row_max=gh_max) if ctx.needs_input_grad[0] else None
+        return (gx, gw1, gb1 if has_b1 else None, ggamma, gbeta, gw2, gb2 if has_b2 else None,
+                go if ctx.needs_input_grad[7] else None, None)
+
+
+def fused_mlp2_supported(x, w1, w2):
+    """2-D fp32 CUDA input tall enough for the tall kernels, widths in {64,128,256} with the weight image within LDS."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS
+            and torch.is_grad_enabled()):
+        return False
+    k, h, o = x.shape[1], w1.shape[0], w2.shape[0]
+    ok = (64, 128, 256)
+    return (k in ok and h in ok and o in ok and k * h * 4 <= 128 * 1024 and h * o * 4 <= 128 * 1024 and h <= 256
+            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], h, k) > 0
+            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], o, h) > 0)
+
+
+def fused_mlp2(x, w1, b1, gamma, beta, eps, w2, b2, residual=None):
+    return _FusedMLP2.apply(x, w1, b1, gamma, beta, w2, b2, residual, float(eps))
 
 
 def linear(x, weight, bias=None, residual=None):

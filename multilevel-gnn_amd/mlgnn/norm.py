@@ -56,6 +56,24 @@ def _ln_backward(ctx, go, extra):
     return gx, ggb
 
 
+def ln_backward_normalised(go, xhat, weight, bias, rstd, relu=True):
+    """LayerNorm(+ReLU) backward when the stored activation is already normalised (``xhat``, ``rstd`` from the
+    first GEMM of :class:`mlgnn.dense._FusedMLP2`): ``-> (grad_x, grad_gamma, grad_beta, max |grad_x| per row)``."""
+    rows, d = xhat.shape
+    go = go.contiguous()
+    gx = torch.empty_like(xhat)
+    ggb = torch.empty((2, d), dtype=torch.float32, device=xhat.device)
+    n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d))
+    ws = torch.empty(n, dtype=torch.float32, device=xhat.device)
+    row_max = torch.empty(rows, dtype=torch.float32, device=xhat.device)
+    weight, bias = weight.contiguous(), bias.contiguous()
+    rc = _lib.lib.mlgnn_layernorm_act_bwd(go.data_ptr(), xhat.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                          None, rstd.data_ptr(), None, gx.data_ptr(), row_max.data_ptr(),
+                                          ggb.data_ptr(), ws.data_ptr(), n, rows, d, int(relu), DTYPE_F32, _stream())
+    _lib.check(rc, "mlgnn_layernorm_act_bwd")
+    return gx, ggb[0], ggb[1], row_max
+
+
 class _LayerNormActFork(torch.autograd.Function):
     """``(relu?(LayerNorm(x)), x)``: the second output is the input itself, handed back so that the gradient
     arriving on the identity branch of a residual block (``h = f(norm(h)) + h``, deepergcn.py:236-241) meets

@@ -7,7 +7,7 @@ the reference are molecule-dataset leftovers outside the hot path and are not pr
 """
 from torch import nn
 
-from mlgnn.dense import linear
+from mlgnn.dense import fused_mlp2, fused_mlp2_supported, linear
 from mlgnn.norm import layer_norm_act
 
 _ACTS = {
@@ -68,6 +68,12 @@ class MLP(nn.Sequential):
         children use ``mlgnn.dense.linear`` (split-precision MFMA GEMMs); ``residual`` is added in the last
         Linear's epilogue."""
         mods = list(self)
+        # Linear -> LayerNorm -> ReLU -> Linear (GENConv's MLP): one fused op, no LayerNorm pass in between
+        if (len(mods) == 4 and type(mods[0]) is nn.Linear and isinstance(mods[1], nn.LayerNorm)
+                and mods[1].elementwise_affine and isinstance(mods[2], nn.ReLU) and type(mods[3]) is nn.Linear
+                and fused_mlp2_supported(x, mods[0].weight, mods[3].weight)):
+            return fused_mlp2(x, mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias, mods[1].eps,
+                              mods[3].weight, mods[3].bias, residual)
         i = 0
         while i < len(mods):
             m = mods[i]

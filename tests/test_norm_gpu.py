@@ -88,3 +88,34 @@ def test_residual_block_through_fork_and_gemm_epilogue(rows, d):
     y2, id2 = layer_norm_act_fork(dl[0], dl[1], dl[2], 1e-5, relu=True)
     (gh,) = torch.autograd.grad((id2 * cot.cuda()).sum() + 0.0 * y2.sum(), [dl[0]])
     assert_close(gh, cot, 1e-5, "identity branch only")
+
+
+@pytest.mark.parametrize("rows,k,hdim,o,res", [(9000, 128, 256, 128, True), (8200, 64, 128, 64, False),
+                                             (20011, 128, 256, 128, False), (8192, 64, 256, 128, True),
+                                             (8300, 128, 128, 256, True)])
+def test_fused_mlp2_matches_the_unfused_composition(rows, k, hdim, o, res):
+    """Linear -> LayerNorm -> ReLU -> Linear (+ residual) with the normalised hidden activation stored once
+    (first GEMM's epilogue) and the affine map + ReLU applied by its consumers: values and every gradient."""
+    from mlgnn.dense import fused_mlp2, fused_mlp2_supported
+    gen = torch.Generator().manual_seed(rows + hdim)
+    x = torch.randn(rows, k, generator=gen, requires_grad=True)
+    w1 = (torch.randn(hdim, k, generator=gen) * 0.2).requires_grad_(True)
+    b1 = torch.randn(hdim, generator=gen).requires_grad_(True)
+    g = (torch.rand(hdim, generator=gen) + 0.5).requires_grad_(True)
+    be = (torch.randn(hdim, generator=gen) * 0.3).requires_grad_(True)
+    w2 = (torch.randn(o, hdim, generator=gen) * 0.1).requires_grad_(True)
+    b2 = torch.randn(o, generator=gen).requires_grad_(True)
+    r = torch.randn(rows, o, generator=gen).requires_grad_(True) if res else None
+    cot = torch.randn(rows, o, generator=gen)
+    leaves = [x, w1, b1, g, be, w2, b2] + ([r] if res else [])
+    hid = torch.relu(F.layer_norm(F.linear(x, w1, b1), (hdim,), g, be, 1e-5))
+    ref = F.linear(hid, w2, b2) + (r if res else 0)
+    gr = torch.autograd.grad((ref * cot).sum(), leaves)
+    dl = [t.detach().cuda().requires_grad_(True) for t in leaves]
+    assert fused_mlp2_supported(dl[0], dl[1], dl[5])
+    out = fused_mlp2(dl[0], dl[1], dl[2], dl[3], dl[4], 1e-5, dl[5], dl[6], dl[7] if res else None)
+    assert_close(out, ref, 1e-4, "fused mlp fwd")
+    got = torch.autograd.grad((out * cot.cuda()).sum(), dl)
+    names = ["x", "W1", "b1", "gamma", "beta", "W2", "b2"] + (["residual"] if res else [])
+    for name, a, b in zip(names, got, gr):
+        assert_close(a, b, 1e-4, "fused mlp grad " + name)

@@ -53,7 +53,7 @@ def test_wgrad_keeps_fp32_accuracy_at_any_magnitude(scale):
     n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K))
     ws = torch.empty(n, device=dev)
     out = torch.empty(M * K + M, device=dev)
-    rc = _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), out.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
+    rc = _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), None, None, out.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
                                      torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     got = out[:M * K].view(M, K).cpu().double()
@@ -65,7 +65,7 @@ def test_wgrad_keeps_fp32_accuracy_at_any_magnitude(scale):
     assert_close(out[M * K:].cpu().double() / scale, ref_b / scale, 1e-5, "bias grad")
     # bitwise reproducible (fixed summation order)
     out2 = torch.empty_like(out)
-    _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), out2.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
+    _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), None, None, out2.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
                                 torch.cuda.current_stream().cuda_stream)
     assert torch.equal(out, out2)
 

@@ -48,21 +48,37 @@ def _worker(rank, world, port, q):
         assert bucket.check_views()
         bucket.all_reduce_mean()
     q.put((rank, bucket.flat.clone(), torch.cat([p.detach().reshape(-1) for p in model.parameters()])))
-    dist.barrier()
-    dist.destroy_process_group()
+    try:                                                # teardown only: the results are already with the parent
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        pass
 
 
-def test_flat_bucket_allreduce_matches_single_process():
-    world, port = 2, _free_port()
+def _run_world(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        got = [q.get(timeout=120) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    return got, [p.exitcode for p in procs]
+
+
+def test_flat_bucket_allreduce_matches_single_process():
+    world = 2
+    try:
+        got, codes = _run_world(world)
+    except Exception:                                   # rendezvous on a port that was taken meanwhile: once more
+        got, codes = _run_world(world)
+    assert codes == [0] * world, codes
     model = _model()
     x, y = _data()
     torch.nn.functional.mse_loss(model(x), y).backward()          # global batch of 8 = mean of two shard means

@@ -75,10 +75,16 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
       // accumulators: SUM/POWER use acc; MAX uses acc (best) + bpos; SOFTMAX uses mx, acc (S), w1, w2
       float acc[VEC], mx[VEC], w1[VEC], w2[VEC];
       int bpos[VEC];
+      // FAST (softmax only): no running maximum -- weights 2^(t m) against the fixed reference 0.  Messages are
+      // relu outputs of normalised features, so t m stays far inside fp32's exponent range and the per-batch
+      // max / rescale bookkeeping (a quarter of the kernel's VALU work) buys nothing; the row is redone with the
+      // online recurrence when its sums come out too large or too small to trust (checked below).
+      auto scan = [&](auto fast_c) {
+      constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         acc[i] = (AGGR == A_MAX) ? kNegBig : 0.f;
-        mx[i] = kNegBig; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1;
+        mx[i] = FAST ? 0.f : kNegBig; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1;
       }
 
       for (int base = beg; base < end; base += kWave) {
@@ -140,6 +146,18 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
                 if ((FULL || valid[u]) && m[u][i] > acc[i]) { acc[i] = m[u][i]; bpos[i] = pos; }
             }
           } else if constexpr (AGGR == A_SOFTMAX) {
+            if constexpr (FAST) {
+#pragma unroll
+              for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                  float pe = fast_exp2(sc.t_log2e * m[u][i]);
+                  if (!FULL) pe = valid[u] ? pe : 0.f;
+                  acc[i] += pe;
+                  w1[i] = fmaf(pe, m[u][i], w1[i]);
+                  if (SECOND) w2[i] = fmaf(pe * m[u][i], m[u][i], w2[i]);
+                }
+            } else {
             // online softmax, one rescale per batch of kUnroll neighbours; units: log2.  t*m is monotone in m:
             // the batch extremum of m (max for t >= 0, min for t < 0) gives the extremum of t*m.
 #pragma unroll
@@ -163,6 +181,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
                 if (SECOND) s2 = fmaf(pe * m[u][i], m[u][i], s2);
               }
               acc[i] = s; w1[i] = s1; w2[i] = s2; mx[i] = zmax;
+            }
             }
           } else {  // A_POWER
 #pragma unroll
@@ -199,6 +218,10 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
             // larger value wins; on a tie the earlier edge (torch_scatter CPU keeps the first)
             const bool take = (op >= 0) && (bpos[i] < 0 || ov > acc[i] || (ov == acc[i] && op < bpos[i]));
             if (take) { acc[i] = ov; bpos[i] = op; }
+          } else if constexpr (FAST) {   // SOFTMAX against the fixed reference: plain sums
+            acc[i] += __shfl_xor(acc[i], off);
+            w1[i] += __shfl_xor(w1[i], off);
+            if (SECOND) w2[i] += __shfl_xor(w2[i], off);
           } else {  // SOFTMAX: a group that saw no edge has (mx, S, W) = (kNegBig, 0, 0)
             const float om = __shfl_xor(mx[i], off);
             const float os = __shfl_xor(acc[i], off);
@@ -211,6 +234,17 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
             mx[i] = nm;
           }
         }
+      }
+
+      };   // scan
+      if constexpr (AGGR == A_SOFTMAX) {
+        scan(BC<true>{});
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) bad |= !(acc[i] > 1.0e-30f && acc[i] < 1.0e30f);
+        if (deg > 0 && __builtin_amdgcn_ballot_w64(bad) != 0) scan(BC<false>{});      // wave-uniform: redo the row
+      } else {
+        scan(BC<false>{});
       }
 
       // ---- epilogue: group 0 writes the row ----

@@ -8,10 +8,10 @@ namespace mlgnn {
 
 constexpr int kUnroll = 4;                 // neighbour rows in flight per lane group and batch
 // rows per wave of the forward's chunked row walk (common.h).  Measured at config 2 (64 x 10k-node graphs):
-// 4..8 rows per wave is best for the memory-bound aggregators (mean 0.51 -> 0.42 ms, max 0.57 -> 0.51 ms vs the
-// strided persistent walk; softmax is VALU-bound either way).  The backward keeps the strided walk: it is bound
+// 4 rows per wave is best (2 / 4 / 8: softmax 0.65 / 0.62 / 0.64 ms, mean 0.41 / 0.41 / 0.42 ms; the strided
+// persistent walk: 0.73 / 0.51 ms).  The backward keeps the strided walk: it is bound
 // by per-edge instruction issue, and one edge-term partial per workgroup favours few, long-lived workgroups.
-constexpr int kFwdRowsPerWave = 8;
+constexpr int kFwdRowsPerWave = 4;
 constexpr float kPowLo = 1e-7f, kPowHi = 1e1f;   // torch_message.py:69
 constexpr float kNegBig = -3.0e38f;
 

@@ -35,17 +35,24 @@ struct DsArgs {
   int n; int C; int O; int adj_batched; int normalize; int ws_cols;
 };
 
+// row sums of the adjacency: one wavefront per row, lanes across the columns (coalesced), shuffle reduction
 __device__ __forceinline__ void ds_degrees(const float* ab, int n, float* deg, float* raw) {
-  for (int r = threadIdx.x; r < n; r += kDsBlock) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  for (int r = wave; r < n; r += kDsWaves) {
     float s = 0.f;
-    for (int j = 0; j < n; ++j) s += ab[(size_t)r * n + j];
-    if (raw) raw[r] = s;
-    deg[r] = fmaxf(s, 1.0f);
+    for (int j = lane; j < n; j += kWave) s += ab[(size_t)r * n + j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+      if (raw) raw[r] = s;
+      deg[r] = fmaxf(s, 1.0f);
+    }
   }
 }
 
 __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p) {
   __shared__ float P[kDsMaxN][kDsSO];          // x W_rel^T, then the un-normalised output
+  __shared__ float X[kDsMaxN][kDsMaxC + 1];    // the pooled graph's features, staged once (both products read them)
   __shared__ float deg[kDsMaxN];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid / kWave;
@@ -57,11 +64,16 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
   const int l15 = lane & 15, lq = lane >> 4;
 
   ds_degrees(ab, n, deg, nullptr);
+  for (int idx = tid; idx < NP * C; idx += kDsBlock) {               // coalesced; rows past n are zero
+    const int r = idx / C, c = idx % C;
+    X[r][c] = r < n ? xb[idx] : 0.f;
+  }
+  __syncthreads();
   // ---- P = x W_rel^T  [n, O] ----------------------------------------------------------------------
   for (int t = wave; t < Nt * Ot; t += kDsWaves) {
     const int i0 = (t / Ot) * 16, j0 = (t % Ot) * 16;
     const f32x4 acc = tile_gemm(C,
-        [&](int i, int k) { return (i0 + i < n && k < C) ? xb[(size_t)(i0 + i) * C + k] : 0.f; },
+        [&](int i, int k) { return k < C ? X[i0 + i][k] : 0.f; },
         [&](int k, int j) { return (j0 + j < O && k < C) ? p.w_rel[(size_t)(j0 + j) * C + k] : 0.f; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) P[i0 + lq * 4 + r][j0 + l15] = acc[r];
@@ -76,7 +88,7 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
         [&](int i, int k) { return (i0 + i < n && k < n) ? ab[(size_t)(i0 + i) * n + k] : 0.f; },
         [&](int k, int j) { return k < n ? P[k][j0 + j] : 0.f; });
     const f32x4 root = tile_gemm(C,
-        [&](int i, int k) { return (i0 + i < n && k < C) ? xb[(size_t)(i0 + i) * C + k] : 0.f; },
+        [&](int i, int k) { return k < C ? X[i0 + i][k] : 0.f; },
         [&](int k, int j) { return (j0 + j < O && k < C) ? p.w_root[(size_t)(j0 + j) * C + k] : 0.f; });
     const float bj = (p.bias && j0 + l15 < O) ? p.bias[j0 + l15] : 0.f;
 #pragma unroll

@@ -43,6 +43,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
   const int cl = lane & (lpr - 1);
   const RowWalk walk = make_row_walk(a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
+  const float t_eps = sc.t_log2e * a.eps;
   const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
 
   for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
@@ -74,6 +75,9 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { xj[i] = 0.f; gx[i] = 0.f; }
       if (is_gen<MODE>() && end > beg) load_t<T, VEC>(xj, X + (size_t)r * a.d + c0);
+      float xjv[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) xjv[i] = xj[i] + ev[i];
 
       for (int base = beg; base < end; base += kWave) {
         const int cnt = min(kWave, end - base);
@@ -128,7 +132,12 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
               float coef, z = 0.f, m = 0.f;
-              if constexpr (is_gen<MODE>()) {
+              if constexpr (RK > 0) {               // x_j + v is constant along the row: the fma chain starts from it
+                z = xjv[i];
+#pragma unroll
+                for (int q = 0; q < RK; ++q) z = fmaf(wa[u][q], eu[i][q], z);
+                m = fmaxf(z, 0.f) + a.eps;
+              } else if constexpr (is_gen<MODE>()) {
                 z = pre_act<MODE>(xj[i], wa[u], eu[i], ev[i], ef[u][i]);
                 m = fmaxf(z, 0.f) + a.eps;
               }
@@ -137,7 +146,9 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
               } else if constexpr (AGGR == A_MAX) {
                 coef = (ai[u][i] == pos[u]) ? ga[u][i] : 0.f;
               } else if constexpr (AGGR == A_SOFTMAX) {
-                const float w = SHIFT ? fast_exp2(sc.t_log2e * m) : fast_exp2(fmaf(sc.t_log2e, m, -gb[u][i]));
+                // SHIFT: 2^(t (relu(z) + eps)) with the eps term folded into the fma's addend
+                const float w = SHIFT ? fast_exp2(fmaf(sc.t_log2e, fmaxf(z, 0.f), t_eps))
+                                      : fast_exp2(fmaf(sc.t_log2e, m, -gb[u][i]));
                 coef = ga[u][i] * w;
                 if (LEARN_T) coef *= fmaf(sc.t, m - gc[u][i], 1.0f);
               } else {  // POWER: ga carries q (see mlgnn.h)
@@ -149,8 +160,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
               if constexpr (is_gen<MODE>()) coef = (z > 0.f) ? coef : 0.f;
               dz[i] = (FULL || valid[u]) ? coef : 0.f;
               gx[i] += dz[i];
-              if constexpr (RK > 0) {
-                gv[i] += dz[i];
+              if constexpr (RK > 0) {               // (d loss / d v = sum of all dz: taken from gx once per row, below)
 #pragma unroll
                 for (int q = 0; q < RK; ++q) gu[i][q] = fmaf(wa[u][q], dz[i], gu[i][q]);
               }
@@ -163,6 +173,10 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
         int k = 0;
         for (; k + step <= cnt; k += step) batch(BC<true>{}, k);
         if (k < cnt) batch(BC<false>{}, k);
+      }
+      if constexpr (RK > 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gv[i] += gx[i];          // this lane's share of the row, before the groups merge
       }
       for (int off = lpr; off < kWave; off <<= 1)
 #pragma unroll

@@ -81,6 +81,22 @@ def cpu_baseline(args, model_sd):
                       "(oracle: materialised [E,d] gather -> elementwise -> scatter, no optimizer step)" % (nb, n)}
 
 
+def stream_copy_ceiling(dev, mib=1024, reps=10):
+    """On-box streaming ceiling: device-to-device copy of a buffer far larger than the 256 MiB
+    Infinity Cache, read + written bytes per second, outside the timed region."""
+    src = torch.empty(mib << 20, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record()
+    b.synchronize()
+    return 2.0 * src.numel() * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,6 +238,10 @@ def main():
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac"],
                                "traffic": traffic, "avg_launch_ms": kernels[dom]["avg_ms"],
                                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"]}
+            if world == 1:
+                ceil = stream_copy_ceiling(dev)
+                out["roofline"]["stream_copy_GBps"] = ceil
+                out["roofline"]["frac_of_stream_copy"] = kernels[dom]["achieved_GBps"] / ceil
             out["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, model.state_dict())

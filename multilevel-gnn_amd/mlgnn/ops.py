@@ -157,8 +157,12 @@ class LowRankEdge:
         return self.a.shape[1]
 
     def through_linear(self, W, b):
-        """Compose with ``Linear``: ``W (U a + c) + b = (W U) a + (W c + b)``."""
-        return LowRankEdge(self.a, torch.mm(W, self.weight), torch.mv(W, self.bias) + (0 if b is None else b))
+        """Compose with ``Linear``: ``W (U a + c) + b = (W U) a + (W c + b)``.  The composed factors are fp32
+        whatever the model's storage type (the kernels keep them in fp32 registers anyway; and a [d, H] x [H, r]
+        product in bf16 goes through the GEMM library's per-call heuristics: 2-5 ms of host time each)."""
+        Wf = W.float()
+        cb = torch.mv(Wf, self.bias.float())
+        return LowRankEdge(self.a, torch.mm(Wf, self.weight.float()), cb if b is None else cb + b.float())
 
     def dense(self):
         return torch.addmm(self.bias, self.a.to(self.weight.dtype), self.weight.t())

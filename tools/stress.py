@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--host-profile", action="store_true", help="cProfile one step (host-side time by function)")
     a = ap.parse_args()
     from _util import make_args
     from mlgnn import ops
@@ -59,6 +60,21 @@ def main():
 
     step()
     torch.cuda.synchronize()
+    if a.host_profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        step()
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(12)
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:      # autograd-thread ops too
+            step()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=25, max_name_column_width=60),
+              file=sys.stderr)
     timer = ops.KernelTimer()
     ops.KERNEL_TIMER = timer
     t0 = time.perf_counter()

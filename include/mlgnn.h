@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 6
+#define MLGNN_ABI_VERSION 7
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -161,19 +161,21 @@ int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
                               int dtype, void* stream);
 
 /*
- * Fused LayerNorm (+ ReLU) over [rows, d] fp32, d <= 256 and d % 4 == 0.
+ * Fused LayerNorm (+ ReLU) over [rows, d]: fp32 (d <= 256, d % 4 == 0) or bf16 storage with fp32 statistics and
+ * arithmetic (MLGNN_DTYPE_BF16: x, out, grad_out, grad_extra, grad_x are bf16, d <= 512, d % 8 == 0; gamma, beta,
+ * mean, rstd and the parameter gradients stay fp32).
  * Replaces: norm_layer('layer') followed by act_layer('relu') as chained by MLP
  * (models/gcn_lib/sparse/torch_nn.py:27-38,54-75) and by the res+ block (models/deepergcn.py:236-241).
  *   out = relu?( (x - mean) * rstd * gamma + beta ),  rstd = 1/sqrt(var_biased + eps)
  * mean / rstd [rows] are saved for the backward, which recomputes the ReLU mask from x.  Backward with
  * mean = NULL: x is already the normalised activation (x - mean) * rstd (mlgnn_tallgemm_nt ln_mode 1).
- * grad_gamma_beta [2,d]; workspace: mlgnn_layernorm_bwd_workspace_floats(rows, d) floats.
+ * grad_gamma_beta [2,d]; workspace: mlgnn_layernorm_bwd_workspace_floats(rows, d, dtype) floats.
  * grad_extra [rows,d] or NULL: a gradient that reaches x on another branch (the identity branch of the
  * res+ block, deepergcn.py:241), added into grad_x in the same pass.
  * row_max [rows] or NULL (both directions): max |.| per row of out / grad_x, handed to the Linear that
  * consumes it (mlgnn_tallgemm_nt) so that it does not have to read its operand twice.
  */
-int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d);
+int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d, int dtype);
 int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
                             float* mean, float* rstd, float* row_max, int64_t rows, int64_t d, float eps,
                             int relu, int dtype, void* stream);
@@ -317,10 +319,13 @@ int mlgnn_segment_pool_fwd(const void* x, const int32_t* ptr, void* out, int32_t
  *   2: a is such an xhat: relu(gamma[k] a + beta[k]) is applied as it is loaded (gamma, beta [R]; pass the
  *      producer's row_max_out as row_max);
  *   0: neither (gamma, beta, rstd_out, row_max_out ignored).
- * workspace: mlgnn_tallgemm_workspace_bytes(R, J) bytes (split weight image).
+ * workspace: mlgnn_tallgemm_workspace_bytes(R, J, dtype) bytes (weight image in MFMA fragment order).
+ * MLGNN_DTYPE_BF16 (BASELINE configs[4]): a, bt, residual, c are bf16 (bias stays fp32), one bf16 MFMA per product
+ * with fp32 accumulation and a single rounding at the store; R % 16 == 0, J % 32 == 0 (R <= 1024, J <= 4096, the
+ * weight is cut into column slices of <= 128 KiB that each stream `a` once); ln_mode must be 0, row_max is ignored.
  */
-int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J);
-int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J);
+int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J, int dtype);
+int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J, int dtype);
 int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual,
                       const float* row_max, int ln_mode, const float* gamma, const float* beta, float ln_eps,
                       float* rstd_out, float* row_max_out, void* c, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);

@@ -1,11 +1,12 @@
-// Fused LayerNorm (+ ReLU) forward / backward over [rows, d] fp32, d <= 256, d % 4 == 0.
+// Fused LayerNorm (+ ReLU) forward / backward over [rows, d]: fp32 (d <= 256, d % 4 == 0) or bf16 storage with
+// fp32 arithmetic (d <= 512, d % 8 == 0).
 //
 // Reference: norm_layer('layer') + act_layer('relu') as chained by MLP
 // (models/gcn_lib/sparse/torch_nn.py:27-38,54-75) and by the res+ block
 // (models/deepergcn.py:236-241: norms[l-1](h) -> relu).  ATen runs LayerNorm and ReLU as separate
 // passes forward and three kernels backward; here one pass each way.
 //
-// Lane layout as in the aggregation kernels: LPR = next_pow2(d/4) lanes hold one row (float4 per
+// Lane layout as in the aggregation kernels: LPR = next_pow2(d/VEC) lanes hold one row (16 bytes per
 // lane), a wave works on 64/LPR rows at once, row statistics are xor-shuffle reductions inside
 // the lane group.  HBM-bound: forward 2*rows*d*4 bytes, backward 3*rows*d*4 bytes (+ 8 B/row stats).
 #include "common.h"
@@ -30,53 +31,61 @@ __device__ __forceinline__ float group_sum(float v) {
 constexpr int kLnRows = 4;            // row groups in flight per wave
 
 struct LnArgs {
-  const float* x; const float* go; const float* gamma; const float* beta; const float* gextra;
-  float* out; float* mean; float* rstd; float* gx; float* ws; float* rowmax;
+  const void* x; const void* go; const float* gamma; const float* beta; const void* gextra;
+  void* out; float* mean; float* rstd; void* gx; float* ws; float* rowmax;
   int rows; int d; float eps; int relu;
 };
 
-template <int LPR_LOG2>
+// T = float (VEC 4) or bf16_t (VEC 8): 16 bytes per lane either way; statistics and arithmetic in fp32
+template <typename T, int VEC, int LPR_LOG2>
 __global__ __launch_bounds__(kBlock) void layernorm_act_fwd_kernel(const LnArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, GROUPS = kWave / LPR;
   const int lane = threadIdx.x & (kWave - 1);
-  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * 4;
+  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * VEC;
   const bool cact = c0 < a.d;
   const int wave_global = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
   const int n_waves = gridDim.x * kWavesPerBlock;
-  float g[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-  if (cact) { load_vec<4>(g, a.gamma + c0); load_vec<4>(b, a.beta + c0); }
+  const T* x = static_cast<const T*>(a.x);
+  T* out = static_cast<T*>(a.out);
+  float g[VEC], b[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { g[i] = 0.f; b[i] = 0.f; }
+  if (cact) { load_vec<VEC>(g, a.gamma + c0); load_vec<VEC>(b, a.beta + c0); }
   const float inv_d = 1.0f / (float)a.d;
   // kLnRows row groups per wave and iteration: their loads are issued together (the reductions that follow
   // are dependent chains; one row at a time leaves the memory pipe idle behind them)
   for (int r0 = wave_global * GROUPS * kLnRows; r0 < a.rows; r0 += n_waves * GROUPS * kLnRows) {
-    float v[kLnRows][4];
+    float v[kLnRows][VEC];
     bool ok[kLnRows];
 #pragma unroll
     for (int u = 0; u < kLnRows; ++u) {
       const int r = r0 + u * GROUPS + sub;
       ok[u] = (r < a.rows) && cact;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[u][i] = 0.f;
-      if (ok[u]) load_vec<4>(v[u], a.x + (size_t)r * a.d + c0);
+      for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+      if (ok[u]) load_t<T, VEC>(v[u], x + (size_t)r * a.d + c0);
     }
 #pragma unroll
     for (int u = 0; u < kLnRows; ++u) {
       const int r = r0 + u * GROUPS + sub;
-      const float mu = group_sum<LPR_LOG2>(v[u][0] + v[u][1] + v[u][2] + v[u][3]) * inv_d;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) sum += v[u][i];
+      const float mu = group_sum<LPR_LOG2>(sum) * inv_d;
       float q = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const float c = cact ? v[u][i] - mu : 0.f; q = fmaf(c, c, q); }
+      for (int i = 0; i < VEC; ++i) { const float c = cact ? v[u][i] - mu : 0.f; q = fmaf(c, c, q); }
       const float rs = rsqrtf(group_sum<LPR_LOG2>(q) * inv_d + a.eps);
       float om = 0.f;
       if (ok[u]) {
-        float o[4];
+        float o[VEC];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < VEC; ++i) {
           const float y = fmaf((v[u][i] - mu) * rs, g[i], b[i]);
           o[i] = a.relu ? fmaxf(y, 0.f) : y;
           om = fmaxf(om, fabsf(o[i]));
         }
-        store_vec<4>(a.out + (size_t)r * a.d + c0, o);
+        store_t<T, VEC>(out + (size_t)r * a.d + c0, o);
         if (cl == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
       }
       if (a.rowmax) {                          // max |row| for the consumer GEMM's per-row scaling (tallgemm.hip)
@@ -87,21 +96,27 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_fwd_kernel(const LnArgs 
   }
 }
 
-template <int LPR_LOG2>
+template <typename T, int VEC, int LPR_LOG2>
 __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, GROUPS = kWave / LPR;
-  __shared__ float red[kWavesPerBlock][2][kWave * 4];
+  __shared__ float red[kWavesPerBlock][2][kWave * VEC];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * 4;
+  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * VEC;
   const bool cact = c0 < a.d;
   const int wave_global = blockIdx.x * kWavesPerBlock + wave;
   const int n_waves = gridDim.x * kWavesPerBlock;
-  float g[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
-  if (cact) { load_vec<4>(g, a.gamma + c0); load_vec<4>(b, a.beta + c0); }
+  const T* x = static_cast<const T*>(a.x);
+  const T* gout = static_cast<const T*>(a.go);
+  const T* gextra = static_cast<const T*>(a.gextra);
+  T* gx = static_cast<T*>(a.gx);
+  float g[VEC], b[VEC], dg[VEC], db[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { g[i] = 0.f; b[i] = 0.f; dg[i] = 0.f; db[i] = 0.f; }
+  if (cact) { load_vec<VEC>(g, a.gamma + c0); load_vec<VEC>(b, a.beta + c0); }
   const float inv_d = 1.0f / (float)a.d;
   for (int r0 = wave_global * GROUPS * kLnRows; r0 < a.rows; r0 += n_waves * GROUPS * kLnRows) {
-    float v[kLnRows][4], go[kLnRows][4], mu[kLnRows], rs[kLnRows], nsc[kLnRows];
+    float v[kLnRows][VEC], go[kLnRows][VEC], mu[kLnRows], rs[kLnRows], nsc[kLnRows];
     bool ok[kLnRows];
 #pragma unroll
     for (int u = 0; u < kLnRows; ++u) {
@@ -109,19 +124,19 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
       ok[u] = (r < a.rows) && cact;
       mu[u] = 0.f; rs[u] = 0.f; nsc[u] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { v[u][i] = 0.f; go[u][i] = 0.f; }
+      for (int i = 0; i < VEC; ++i) { v[u][i] = 0.f; go[u][i] = 0.f; }
       if (ok[u]) {
-        load_vec<4>(v[u], a.x + (size_t)r * a.d + c0);
-        load_vec<4>(go[u], a.go + (size_t)r * a.d + c0);
+        load_t<T, VEC>(v[u], x + (size_t)r * a.d + c0);
+        load_t<T, VEC>(go[u], gout + (size_t)r * a.d + c0);
         mu[u] = a.mean ? a.mean[r] : 0.f; rs[u] = a.rstd[r]; nsc[u] = a.mean ? rs[u] : 1.0f;
       }
     }
 #pragma unroll
     for (int u = 0; u < kLnRows; ++u) {
       const int r = r0 + u * GROUPS + sub;
-      float xh[4], gg[4], s1 = 0.f, s2 = 0.f;
+      float xh[VEC], gg[VEC], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < VEC; ++i) {
         xh[i] = (v[u][i] - mu[u]) * nsc[u];       // nsc = rstd, or 1 with mu = 0 when x is already normalised
         const float y = fmaf(xh[i], g[i], b[i]);
         const float gy = (a.relu && !(y > 0.f)) ? 0.f : go[u][i];
@@ -135,18 +150,18 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
       s2 = group_sum<LPR_LOG2>(s2) * inv_d;
       float om = 0.f;
       if (ok[u]) {
-        float o[4];
+        float o[VEC];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = rs[u] * (gg[i] - s1 - xh[i] * s2);
-        if (a.gextra) {                      // gradient arriving at x on the block's identity branch
-          float e[4];
-          load_vec<4>(e, a.gextra + (size_t)r * a.d + c0);
+        for (int i = 0; i < VEC; ++i) o[i] = rs[u] * (gg[i] - s1 - xh[i] * s2);
+        if (gextra) {                        // gradient arriving at x on the block's identity branch
+          float e[VEC];
+          load_t<T, VEC>(e, gextra + (size_t)r * a.d + c0);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] += e[i];
+          for (int i = 0; i < VEC; ++i) o[i] += e[i];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) om = fmaxf(om, fabsf(o[i]));
-        store_vec<4>(a.gx + (size_t)r * a.d + c0, o);
+        for (int i = 0; i < VEC; ++i) om = fmaxf(om, fabsf(o[i]));
+        store_t<T, VEC>(gx + (size_t)r * a.d + c0, o);
       }
       if (a.rowmax) {
         om = group_max<LPR_LOG2>(om);
@@ -158,10 +173,10 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
 #pragma unroll
   for (int off = LPR; off < kWave; off <<= 1)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { dg[i] += __shfl_xor(dg[i], off); db[i] += __shfl_xor(db[i], off); }
+    for (int i = 0; i < VEC; ++i) { dg[i] += __shfl_xor(dg[i], off); db[i] += __shfl_xor(db[i], off); }
   if (sub == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { red[wave][0][c0 + i] = dg[i]; red[wave][1][c0 + i] = db[i]; }
+    for (int i = 0; i < VEC; ++i) { red[wave][0][c0 + i] = dg[i]; red[wave][1][c0 + i] = db[i]; }
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < 2 * a.d; idx += kBlock) {
@@ -183,6 +198,13 @@ static int ln_grid(int64_t rows, int lpr_log2) {
 }
 
 static bool ln_ok(int64_t d) { return d > 0 && d <= 256 && d % 4 == 0; }
+static int ln_vec(int dtype) { return dtype == MLGNN_DTYPE_BF16 ? 8 : 4; }
+// fp32: d <= 256, d % 4 == 0; bf16: d <= 512, d % 8 == 0 (one row per wave at most, 16 bytes per lane)
+static bool ln_ok_t(int64_t d, int dtype) {
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return false;
+  const int v = ln_vec(dtype);
+  return d > 0 && d <= 64 * v && d % v == 0;
+}
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #define MLGNN_LN_LAUNCH(KERNEL, lpr, ...)                                         \
@@ -196,29 +218,45 @@ static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) ==
     default: hipLaunchKernelGGL((KERNEL<6>), __VA_ARGS__); break;                 \
   }
 
+#define MLGNN_LNT_LAUNCH(KERNEL, T, VEC, lpr, ...)                                \
+  switch (lpr) {                                                                  \
+    case 0: hipLaunchKernelGGL((KERNEL<T, VEC, 0>), __VA_ARGS__); break;          \
+    case 1: hipLaunchKernelGGL((KERNEL<T, VEC, 1>), __VA_ARGS__); break;          \
+    case 2: hipLaunchKernelGGL((KERNEL<T, VEC, 2>), __VA_ARGS__); break;          \
+    case 3: hipLaunchKernelGGL((KERNEL<T, VEC, 3>), __VA_ARGS__); break;          \
+    case 4: hipLaunchKernelGGL((KERNEL<T, VEC, 4>), __VA_ARGS__); break;          \
+    case 5: hipLaunchKernelGGL((KERNEL<T, VEC, 5>), __VA_ARGS__); break;          \
+    default: hipLaunchKernelGGL((KERNEL<T, VEC, 6>), __VA_ARGS__); break;         \
+  }
+
 }  // namespace mlgnn
 
 using namespace mlgnn;
 
-extern "C" int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d) {
-  if (rows < 0 || !ln_ok(d)) return MLGNN_E_SHAPE;
-  return (int64_t)ln_grid(rows, lanes_per_row_log2(d, 4)) * 2 * d;
+extern "C" int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d, int dtype) {
+  if (rows < 0 || !ln_ok_t(d, dtype)) return MLGNN_E_SHAPE;
+  return (int64_t)ln_grid(rows, lanes_per_row_log2(d, ln_vec(dtype))) * 2 * d;
 }
 
 extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
                                        float* mean, float* rstd, float* row_max, int64_t rows, int64_t d, float eps,
                                        int relu, int dtype, void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
-  if (rows < 0 || rows > INT32_MAX || !ln_ok(d)) return MLGNN_E_SHAPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
+  if (rows < 0 || rows > INT32_MAX || !ln_ok_t(d, dtype)) return MLGNN_E_SHAPE;
   if (rows == 0) return 0;
   if (!x || !gamma || !beta || !out || !mean || !rstd) return MLGNN_E_NULL;
   if (!a16(x) || !a16(out) || !a16(gamma) || !a16(beta)) return MLGNN_E_ALIGN;
   LnArgs a{};
-  a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.out = (float*)out; a.mean = mean; a.rstd = rstd;
+  a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.mean = mean; a.rstd = rstd;
   a.rowmax = row_max;
   a.rows = (int)rows; a.d = (int)d; a.eps = eps; a.relu = relu;
-  const int lpr = lanes_per_row_log2(d, 4);
-  MLGNN_LN_LAUNCH(layernorm_act_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), dim3(kBlock), 0, (hipStream_t)stream, a)
+  const int lpr = lanes_per_row_log2(d, ln_vec(dtype));
+  const dim3 grid(ln_grid(rows, lpr)), block(kBlock);
+  if (dtype == MLGNN_DTYPE_F32) {
+    MLGNN_LNT_LAUNCH(layernorm_act_fwd_kernel, float, 4, lpr, grid, block, 0, (hipStream_t)stream, a)
+  } else {
+    MLGNN_LNT_LAUNCH(layernorm_act_fwd_kernel, bf16_t, 8, lpr, grid, block, 0, (hipStream_t)stream, a)
+  }
   return (int)hipGetLastError();
 }
 
@@ -227,21 +265,26 @@ extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, cons
                                        const void* grad_extra, void* grad_x, float* row_max, float* grad_gamma_beta, float* workspace,
                                        int64_t workspace_floats, int64_t rows, int64_t d, int relu,
                                        int dtype, void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
-  if (rows < 0 || rows > INT32_MAX || !ln_ok(d)) return MLGNN_E_SHAPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
+  if (rows < 0 || rows > INT32_MAX || !ln_ok_t(d, dtype)) return MLGNN_E_SHAPE;
   if (!grad_gamma_beta || !workspace) return MLGNN_E_NULL;
-  const int lpr = lanes_per_row_log2(d, 4);
+  const int lpr = lanes_per_row_log2(d, ln_vec(dtype));
   const int nblk = ln_grid(rows, lpr);
   if (workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
   if (rows > 0 && (!grad_out || !x || !gamma || !beta || !rstd || !grad_x)) return MLGNN_E_NULL;
   if (!a16(x) || !a16(grad_out) || !a16(grad_x) || !a16(gamma) || !a16(beta) || !a16(grad_extra)) return MLGNN_E_ALIGN;
   LnArgs a{};
-  a.x = (const float*)x; a.go = (const float*)grad_out; a.gamma = gamma; a.beta = beta;
-  a.gextra = (const float*)grad_extra;
-  a.mean = (float*)mean; a.rstd = (float*)rstd; a.gx = (float*)grad_x; a.ws = workspace; a.rowmax = row_max;
+  a.x = x; a.go = grad_out; a.gamma = gamma; a.beta = beta;
+  a.gextra = grad_extra;
+  a.mean = (float*)mean; a.rstd = (float*)rstd; a.gx = grad_x; a.ws = workspace; a.rowmax = row_max;
   a.rows = (int)rows; a.d = (int)d; a.relu = relu;
   hipStream_t s = (hipStream_t)stream;
-  MLGNN_LN_LAUNCH(layernorm_act_bwd_kernel, lpr, dim3(nblk), dim3(kBlock), 0, s, a)
+  const dim3 grid(nblk), block(kBlock);
+  if (dtype == MLGNN_DTYPE_F32) {
+    MLGNN_LNT_LAUNCH(layernorm_act_bwd_kernel, float, 4, lpr, grid, block, 0, s, a)
+  } else {
+    MLGNN_LNT_LAUNCH(layernorm_act_bwd_kernel, bf16_t, 8, lpr, grid, block, 0, s, a)
+  }
   int err = (int)hipGetLastError();
   if (err) return err;
   launch_reduce_partials(workspace, grad_gamma_beta, nblk, 2 * (int)d, s);

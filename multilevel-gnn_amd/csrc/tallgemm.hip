@@ -259,6 +259,11 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
   }
 }
 
+// bf16 storage: csrc/tallgemm_bf16.hip
+int tb_tiles_per_slice(int64_t R, int64_t J);
+int tallgemm_bf16(const void* a, const void* bt, const float* bias, const void* residual, void* c, void* workspace,
+                  int64_t N, int64_t R, int64_t J, hipStream_t s);
+
 static bool tg_dims_ok(int64_t R, int64_t J) {
   const bool j_ok = (J == 32 || J == 64 || J == 128 || J == 256);
   const bool r_ok = (R == 16 || R == 32 || R == 64 || R == 128 || R == 256);
@@ -269,13 +274,16 @@ static bool tg_dims_ok(int64_t R, int64_t J) {
 
 using namespace mlgnn;
 
-extern "C" int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J) {
-  return (N > 0 && N <= INT32_MAX && tg_dims_ok(R, J)) ? 1 : 0;
+extern "C" int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J, int dtype) {
+  if (N <= 0 || N > INT32_MAX) return 0;
+  if (dtype == MLGNN_DTYPE_BF16) return tb_tiles_per_slice(R, J) > 0 ? 1 : 0;
+  return (dtype == MLGNN_DTYPE_F32 && tg_dims_ok(R, J)) ? 1 : 0;
 }
 
-// workspace: header + the split weight image
-extern "C" int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J) {
+// workspace: fp32 -- header + the split weight image; bf16 -- the weight in fragment order
+extern "C" int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J, int dtype) {
   if (R <= 0 || J <= 0) return MLGNN_E_SHAPE;
+  if (dtype == MLGNN_DTYPE_BF16) return R * J * 2;
   return R * J * 4 + kTgHeader * 16;
 }
 
@@ -284,9 +292,19 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
                                  float ln_eps, float* rstd_out, float* row_max_out, void* c, void* workspace,
                                  int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype,
                                  void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || N > INT32_MAX) return MLGNN_E_SHAPE;
   if (N == 0) return 0;
+  if (dtype == MLGNN_DTYPE_BF16) {                          // plain product (+ bias, + residual) only
+    if (ln_mode != 0) return MLGNN_E_MODE;
+    if (tb_tiles_per_slice(R, J) == 0) return MLGNN_E_SHAPE;
+    if (!a || !bt || !c || !workspace) return MLGNN_E_NULL;
+    if (workspace_bytes < R * J * 2) return MLGNN_E_WORKSPACE;
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bt) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0 ||
+        ((reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(residual)) & 3) != 0)
+      return MLGNN_E_ALIGN;
+    return tallgemm_bf16(a, bt, bias, residual, c, workspace, N, R, J, (hipStream_t)stream);
+  }
   if (!tg_dims_ok(R, J)) return MLGNN_E_SHAPE;
   if (!a || !bt || !c || !workspace) return MLGNN_E_NULL;
   if (residual && J > 128) return MLGNN_E_SHAPE;            // the fused residual needs its tile in registers

@@ -22,7 +22,7 @@ SIGNATURES = {
     "mlgnn_segment_project_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                          _I64, _I64, _I64, _I64, _I64, _INT, _P]),
-    "mlgnn_layernorm_bwd_workspace_floats": (_I64, [_I64, _I64]),
+    "mlgnn_layernorm_bwd_workspace_floats": (_I64, [_I64, _I64, _INT]),
     "mlgnn_layernorm_act_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _INT, _INT, _P]),
     "mlgnn_layernorm_act_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
     "mlgnn_linear_wgrad_workspace_floats": (_I64, [_I64, _I64, _I64]),
@@ -43,8 +43,8 @@ SIGNATURES = {
                                     _I64, _I64, _I64, _I64, _INT, _INT, _INT, _P]),
     "mlgnn_segment_pool_workspace_bytes": (_I64, [_I64, _I64]),
     "mlgnn_segment_pool_fwd": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
-    "mlgnn_tallgemm_supported": (_INT, [_I64, _I64, _I64]),
-    "mlgnn_tallgemm_workspace_bytes": (_I64, [_I64, _I64]),
+    "mlgnn_tallgemm_supported": (_INT, [_I64, _I64, _I64, _INT]),
+    "mlgnn_tallgemm_workspace_bytes": (_I64, [_I64, _I64, _INT]),
     "mlgnn_tallgemm_nt": (_INT, [_P, _P, _P, _P, _P, _INT, _P, _P, _F, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
 }
 

@@ -4,7 +4,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import row_max_of
+from .ops import _DTYPE_IDS, row_max_of
 
 DIFFPOOL_EPS = 1e-15
 WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bottleneck
@@ -21,12 +21,16 @@ def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None):
     N, R = a.shape
     J = bt.shape[0]
     a, bt = a.contiguous(), bt.contiguous()
-    out = torch.empty((N, J), dtype=torch.float32, device=a.device)
-    nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(R, J))
+    dt = _DTYPE_IDS[a.dtype]
+    out = torch.empty((N, J), dtype=a.dtype, device=a.device)
+    nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(R, J, dt))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
     if residual is not None:
         residual = residual.contiguous()
-    ROW_MAX_STATS["given" if row_max is not None else "computed"] += 1
+    if bias is not None:
+        bias = bias.float().contiguous()                 # [J]; the kernels add it in fp32
+    if a.dtype == torch.float32:
+        ROW_MAX_STATS["given" if row_max is not None else "computed"] += 1
     mode, gamma, beta, eps, rstd, rmax = 0, None, None, 0.0, None, None
     if ln is not None:
         mode = 1 if ln[0] == "out" else 2
@@ -37,14 +41,14 @@ def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None):
             rmax = torch.empty(N, dtype=torch.float32, device=a.device)
     rc = _lib.lib.mlgnn_tallgemm_nt(a.data_ptr(), bt.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(row_max),
                                     mode, _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.ptr(rstd), _lib.ptr(rmax),
-                                    out.data_ptr(), ws.data_ptr(), nbytes, N, R, J, 0,
+                                    out.data_ptr(), ws.data_ptr(), nbytes, N, R, J, dt,
                                     torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_tallgemm_nt")
     return (out, rstd, rmax) if mode == 1 else out
 
 
-def tall_matmul_supported(N, R, J):
-    return bool(_lib.lib.mlgnn_tallgemm_supported(N, R, J))
+def tall_matmul_supported(N, R, J, dtype=torch.float32):
+    return dtype in _DTYPE_IDS and bool(_lib.lib.mlgnn_tallgemm_supported(N, R, J, _DTYPE_IDS[dtype]))
 
 
 def _wgrad(go, x, x_gamma=None, x_beta=None):
@@ -61,15 +65,18 @@ def _wgrad(go, x, x_gamma=None, x_beta=None):
 
 
 class _TallLinear(torch.autograd.Function):
-    """``y = x W^T + b`` for a tall ``x [N, K]``: forward and ``dX`` are library GEMMs, the
-    weight/bias gradient (reduction over the N node rows) is the split-row fp32-MFMA kernel."""
+    """``y = x W^T + b`` for a tall ``x [N, K]``: forward and ``dX`` on the tall-matrix MFMA kernels
+    (``csrc/tallgemm.hip``: fp32 as split fp16, ``csrc/tallgemm_bf16.hip``: bf16 storage), the fp32
+    weight/bias gradient (reduction over the N node rows) on the split-row kernel (``csrc/wgrad.hip``); the
+    bf16 weight gradient is a library TN GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        if tall_matmul_supported(x.shape[0], x.shape[1], weight.shape[0]):
-            fuse = residual is not None and weight.shape[0] <= 128          # the kernel holds the residual tile in registers
+        if tall_matmul_supported(x.shape[0], x.shape[1], weight.shape[0], x.dtype):
+            # fp32: the kernel holds the residual tile in registers (<= 128 columns); bf16: any width
+            fuse = residual is not None and (weight.shape[0] <= 128 or x.dtype == torch.bfloat16)
             out = tall_matmul_nt(x, weight, bias.contiguous() if bias is not None else None, residual if fuse else None,
                                  row_max_of(x))
             return out if (residual is None or fuse) else out + residual
@@ -86,14 +93,18 @@ class _TallLinear(torch.autograd.Function):
         M = weight.shape[0]
         gx = None
         if ctx.needs_input_grad[0]:
-            if tall_matmul_supported(N, M, K):
+            if tall_matmul_supported(N, M, K, go.dtype):
                 gx = tall_matmul_nt(go, weight.t().contiguous(), row_max=row_max_of(go))   # go [N,M] @ (W^T)[K,M]^T
             else:
                 gx = go.matmul(weight)
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _wgrad(go, x)
-            gb = gb if ctx.has_bias else None
+            if x.dtype == torch.float32:
+                gw, gb = _wgrad(go, x)
+                gb = gb if ctx.has_bias else None
+            else:
+                gw = go.t().mm(x)
+                gb = go.sum(0) if ctx.has_bias else None
         # the residual enters by plain addition: its gradient is the output gradient itself (no copy)
         return gx, gw, gb, (go if ctx.needs_input_grad[3] else None)
 
@@ -157,6 +168,11 @@ def linear(x, weight, bias=None, residual=None):
     if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS
             and x.is_contiguous() and torch.is_grad_enabled()
             and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], weight.shape[0], weight.shape[1]) > 0):
+        return _TallLinear.apply(x, weight, bias, residual)
+    if (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 2
+            and x.shape[0] >= WGRAD_MIN_ROWS and x.is_contiguous()
+            and tall_matmul_supported(x.shape[0], x.shape[1], weight.shape[0], x.dtype)
+            and tall_matmul_supported(x.shape[0], weight.shape[0], x.shape[1], x.dtype)):
         return _TallLinear.apply(x, weight, bias, residual)
     out = F.linear(x, weight, bias)
     return out if residual is None else out + residual

@@ -5,11 +5,21 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import DTYPE_F32, _stream, tag_row_max
+from .ops import _DTYPE_IDS, DTYPE_F32, _stream, tag_row_max
 
 
 def fused_supported(x):
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 0 < x.shape[1] <= 256 and x.shape[1] % 4 == 0
+    """fp32: d <= 256, d % 4 == 0; bf16 storage (fp32 arithmetic): d <= 512, d % 8 == 0."""
+    if not (x.is_cuda and x.dim() == 2):
+        return False
+    if x.dtype == torch.float32:
+        return 0 < x.shape[1] <= 256 and x.shape[1] % 4 == 0
+    return x.dtype == torch.bfloat16 and 0 < x.shape[1] <= 512 and x.shape[1] % 8 == 0
+
+
+def _f32_params(weight, bias):
+    """gamma / beta as the kernels take them: fp32, contiguous (a bf16 model keeps bf16 parameters: [d] casts)."""
+    return weight.float().contiguous(), bias.float().contiguous()
 
 
 class _LayerNormAct(torch.autograd.Function):
@@ -20,11 +30,13 @@ class _LayerNormAct(torch.autograd.Function):
         out = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        weight, bias = weight.contiguous(), bias.contiguous()
-        ctx.row_max = torch.empty(rows, dtype=torch.float32, device=x.device)
+        ctx.param_dtype = weight.dtype
+        weight, bias = _f32_params(weight, bias)
+        # max |row| rides along for the fp32 split-precision GEMM that consumes the result; bf16 has no use for it
+        ctx.row_max = torch.empty(rows, dtype=torch.float32, device=x.device) if x.dtype == torch.float32 else None
         rc = _lib.lib.mlgnn_layernorm_act_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                                              mean.data_ptr(), rstd.data_ptr(), ctx.row_max.data_ptr(), rows, d,
-                                              float(eps), int(relu), DTYPE_F32, _stream())
+                                              mean.data_ptr(), rstd.data_ptr(), _lib.ptr(ctx.row_max), rows, d,
+                                              float(eps), int(relu), _DTYPE_IDS[x.dtype], _stream())
         _lib.check(rc, "mlgnn_layernorm_act_fwd")
         ctx.relu = bool(relu)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
@@ -44,16 +56,18 @@ def _ln_backward(ctx, go, extra):
         extra = extra.contiguous()
     gx = torch.empty_like(x)
     ggb = torch.empty((2, d), dtype=torch.float32, device=x.device)
-    n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d))
+    dt = _DTYPE_IDS[x.dtype]
+    n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d, dt))
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
-    row_max = torch.empty(rows, dtype=torch.float32, device=x.device)
+    row_max = torch.empty(rows, dtype=torch.float32, device=x.device) if x.dtype == torch.float32 else None
     rc = _lib.lib.mlgnn_layernorm_act_bwd(go.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                                           mean.data_ptr(), rstd.data_ptr(), _lib.ptr(extra), gx.data_ptr(),
-                                          row_max.data_ptr(), ggb.data_ptr(), ws.data_ptr(), n, rows, d,
-                                          int(ctx.relu), DTYPE_F32, _stream())
+                                          _lib.ptr(row_max), ggb.data_ptr(), ws.data_ptr(), n, rows, d,
+                                          int(ctx.relu), dt, _stream())
     _lib.check(rc, "mlgnn_layernorm_act_bwd")
-    tag_row_max(gx, row_max)                   # the gradient usually goes straight into a Linear's backward GEMM
-    return gx, ggb
+    if row_max is not None:
+        tag_row_max(gx, row_max)               # the gradient usually goes straight into a Linear's backward GEMM
+    return gx, ggb.to(ctx.param_dtype)
 
 
 def ln_backward_normalised(go, xhat, weight, bias, rstd, relu=True):
@@ -63,7 +77,7 @@ def ln_backward_normalised(go, xhat, weight, bias, rstd, relu=True):
     go = go.contiguous()
     gx = torch.empty_like(xhat)
     ggb = torch.empty((2, d), dtype=torch.float32, device=xhat.device)
-    n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d))
+    n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d, DTYPE_F32))
     ws = torch.empty(n, dtype=torch.float32, device=xhat.device)
     row_max = torch.empty(rows, dtype=torch.float32, device=xhat.device)
     weight, bias = weight.contiguous(), bias.contiguous()
@@ -92,7 +106,7 @@ class _LayerNormActFork(torch.autograd.Function):
 
 def layer_norm_act(x, weight, bias, eps=1e-5, relu=False):
     """``relu?(LayerNorm(x))`` over the last dimension of a 2-D tensor.  Shapes the fused kernel
-    does not cover (d > 256 or d % 4 != 0) take ATen's LayerNorm on the same device."""
+    does not cover (see :func:`fused_supported`) take ATen's LayerNorm on the same device."""
     if weight is not None and bias is not None and fused_supported(x):
         return _tag_from_node(_LayerNormAct.apply(x, weight, bias, eps, relu))
     y = F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
@@ -144,6 +158,6 @@ class _MsgNormAdd(torch.autograd.Function):
 def msg_norm_add(x, m, scale):
     """``x + normalize(m, dim=1) * ||x|| * scale`` (MsgNorm + GENConv root add, torch_message.py:175-179,
     torch_vertex.py:86-89) in one HIP pass each way; ATen ops for widths the kernel does not cover."""
-    if fused_supported(x) and m.shape == x.shape:
+    if fused_supported(x) and x.dtype == torch.float32 and m.shape == x.shape:
         return _MsgNormAdd.apply(x, m, scale)
     return x + F.normalize(m, p=2.0, dim=1) * x.norm(p=2, dim=1, keepdim=True) * scale

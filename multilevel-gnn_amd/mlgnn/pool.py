@@ -48,10 +48,13 @@ def global_pool(x, batch, kind, num_graphs=None):
     device->host sync of ``batch.max() + 1`` the reference pays."""
     B = int(num_graphs) if num_graphs is not None else int(batch.max().item()) + 1
     batch = batch.to(torch.long)
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0:
+    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 2 and x.shape[1] % 4 == 0:
         ptr = torch.zeros(B + 1, dtype=torch.int64, device=x.device)
         torch.cumsum(torch.bincount(batch, minlength=B), 0, out=ptr[1:])
-        return _SegmentPool.apply(x, ptr.to(torch.int32), batch, _KINDS[kind])
+        # bf16 storage: the readout sums thousands of rows per graph, which a bf16 accumulator (ATen's index_add_
+        # on bf16) cannot hold -- reduce in fp32 (one up-cast pass per step), round the [B, d] result once
+        out = _SegmentPool.apply(x.float(), ptr.to(torch.int32), batch, _KINDS[kind])
+        return out.to(x.dtype)
     # widths the kernel does not cover (d % 4 != 0): ATen on the same device
     if kind in ("sum", "add", "mean"):
         out = x.new_zeros((B, x.shape[1])).index_add_(0, batch, x)

@@ -70,3 +70,143 @@ def test_bf16_matches_fp32_kernel_on_rounded_inputs():
     # before the rounding: allow one bf16 ulp (2^-8 relative)
     assert_close(lo.float(), hi, 2 ** -7, "bf16 storage vs fp32 storage")
     assert float((lo != hi.to(torch.bfloat16)).float().mean()) < 0.01
+
+
+# ---- dense path in bf16 storage: tall GEMM (csrc/tallgemm_bf16.hip) and LayerNorm (csrc/norm.hip) --------------
+
+@pytest.mark.parametrize("N,R,J", [(33, 16, 32), (1000, 128, 256), (4097, 256, 512), (9000, 512, 256), (5000, 64, 64),
+                                   (777, 32, 96), (2048, 48, 160), (70000, 256, 128), (100, 1024, 64)])
+def test_bf16_tall_gemm_layout_is_exact_on_small_integers(N, R, J):
+    """Small integers and their dot products (< 2^8 in magnitude after the bias) are exact in bf16, so any wrong
+    lane / row / column / slice mapping -- including the pair-interleaved output columns -- is an exact mismatch."""
+    from mlgnn.dense import tall_matmul_nt, tall_matmul_supported
+    assert tall_matmul_supported(N, R, J, torch.bfloat16)
+    gen = torch.Generator().manual_seed(N + J)
+    a = torch.zeros(N, R)
+    hot = torch.randint(0, R, (N, 3), generator=gen)                  # three non-zeros per row: sums stay small
+    a.scatter_(1, hot, torch.randint(-3, 4, (N, 3), generator=gen).float())
+    bt = torch.randint(-4, 5, (J, R), generator=gen).float()
+    bt[:, 0] += torch.arange(J) % 5                                   # asymmetric: a transposed tile cannot pass
+    bias = torch.randint(-2, 3, (J,), generator=gen).float()
+    ref = a @ bt.t() + bias
+    assert float(ref.abs().max()) < 256
+    bf = lambda t: t.cuda().to(torch.bfloat16)
+    out = tall_matmul_nt(bf(a), bf(bt), bias.cuda())
+    assert out.dtype == torch.bfloat16 and torch.equal(out.float().cpu(), ref)
+    res = torch.randint(-5, 6, (N, J), generator=gen).float()
+    out = tall_matmul_nt(bf(a), bf(bt), bias.cuda(), bf(res))
+    assert float((ref + res).abs().max()) < 256 and torch.equal(out.float().cpu(), ref + res)
+    out = tall_matmul_nt(bf(a), bf(bt))                               # no bias
+    assert torch.equal(out.float().cpu(), a @ bt.t())
+
+
+def test_bf16_tall_gemm_accumulates_in_fp32():
+    """Random data: the only rounding is the final store (relative 2^-9 of each result), not one per product."""
+    from mlgnn.dense import tall_matmul_nt
+    gen = torch.Generator().manual_seed(5)
+    N, R, J = 20000, 512, 256
+    a = torch.randn(N, R, generator=gen).to(torch.bfloat16)
+    bt = (torch.randn(J, R, generator=gen) * 0.1).to(torch.bfloat16)
+    ref = a.double() @ bt.double().t()
+    out = tall_matmul_nt(a.cuda(), bt.cuda()).cpu().double()
+    rel = ((out - ref).abs() / ref.abs().clamp(min=1e-2)).max()
+    assert float(rel) < 2.0 ** -8, float(rel)                         # one bf16 rounding (2^-9) + fp32 accumulation noise
+    assert not tall_matmul_supported_odd()
+
+
+def tall_matmul_supported_odd():
+    from mlgnn.dense import tall_matmul_supported
+    return (tall_matmul_supported(1000, 40, 64, torch.bfloat16) or tall_matmul_supported(1000, 64, 48, torch.bfloat16)
+            or tall_matmul_supported(1000, 2048, 64, torch.bfloat16))
+
+
+@pytest.mark.parametrize("rows,d", [(1, 8), (7, 16), (1000, 64), (2049, 104), (4097, 256), (3000, 512), (70000, 128)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bf16_layer_norm_act(rows, d, relu):
+    """bf16 storage, fp32 statistics: against fp32 LayerNorm on the bf16-rounded input.  The forward differs by the
+    output rounding only; gradients by the roundings of grad_x (parameter gradients are fp32 sums: tight)."""
+    import torch.nn.functional as F
+    from mlgnn.norm import fused_supported, layer_norm_act, layer_norm_act_fork
+    gen = torch.Generator().manual_seed(rows + d)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    x = rb(torch.randn(rows, d, generator=gen) * 2 + 0.5).requires_grad_(True)
+    w = rb(torch.rand(d, generator=gen) + 0.5).requires_grad_(True)
+    b = rb(torch.randn(d, generator=gen) * 0.3).requires_grad_(True)
+    cot, cot2 = rb(torch.randn(rows, d, generator=gen)), rb(torch.randn(rows, d, generator=gen))
+    pre = F.layer_norm(x, (d,), w, b, 1e-5)
+    ref = F.relu(pre) if relu else pre
+    gr = torch.autograd.grad((ref * cot).sum() + (x * cot2).sum(), [x, w, b])
+    # the ReLU mask is recomputed from x in the backward: where the pre-activation is within rounding of zero the
+    # two implementations may legitimately disagree on its sign (a handful of the 9 M elements of the largest case)
+    keep = (pre.detach().abs() > 1e-4) if relu else torch.ones_like(pre, dtype=torch.bool)
+    dev = "cuda:0"
+    xd, wd, bd = (t.detach().to(dev).to(torch.bfloat16).requires_grad_(True) for t in (x, w, b))
+    assert fused_supported(xd)
+    out, ident = layer_norm_act_fork(xd, wd, bd, 1e-5, relu)
+    assert out.dtype == torch.bfloat16
+    assert_close(out.float(), ref, 1e-2, "bf16 ln fwd")
+    got = torch.autograd.grad((out.float() * cot.to(dev)).sum() + (ident.float() * cot2.to(dev)).sum(), [xd, wd, bd])
+    assert all(g.dtype == torch.bfloat16 for g in got)
+    assert_close(got[0].float().cpu() * keep, gr[0] * keep, 1e-2, "bf16 ln grad x (+ identity branch)")
+    assert_close(got[1].float(), gr[1], 1e-2, "bf16 ln grad gamma")
+    assert_close(got[2].float(), gr[2], 1e-2, "bf16 ln grad beta")
+    out2 = layer_norm_act(xd, wd, bd, 1e-5, relu)
+    assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("N,K,M,res", [(9000, 256, 512, False), (8200, 512, 256, True), (10000, 128, 128, True)])
+def test_bf16_linear_forward_backward(N, K, M, res):
+    """mlgnn.dense.linear on bf16 tensors: native forward / input gradient, library weight gradient; against fp32."""
+    from mlgnn.dense import linear
+    gen = torch.Generator().manual_seed(N)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    x = rb(torch.randn(N, K, generator=gen)).requires_grad_(True)
+    w = rb(torch.randn(M, K, generator=gen) * K ** -0.5).requires_grad_(True)
+    b = rb(torch.randn(M, generator=gen) * 0.1).requires_grad_(True)
+    r = rb(torch.randn(N, M, generator=gen)).requires_grad_(True)
+    cot = rb(torch.randn(N, M, generator=gen) * 0.1)
+    ref = x @ w.t() + b + (r if res else 0)
+    gr = torch.autograd.grad((ref * cot).sum(), [x, w, b] + ([r] if res else []))
+    dev = "cuda:0"
+    xd, wd, bd, rd = (t.detach().to(dev).to(torch.bfloat16).requires_grad_(True) for t in (x, w, b, r))
+    out = linear(xd, wd, bd, rd if res else None)
+    assert out.dtype == torch.bfloat16 and out.grad_fn.name().startswith("_TallLinear")
+    assert_close(out.float(), ref, 1e-2, "bf16 linear fwd")
+    got = torch.autograd.grad((out.float() * cot.to(dev)).sum(), [xd, wd, bd] + ([rd] if res else []))
+    for name, g, e in zip(("x", "w", "b", "res"), got, gr):
+        assert g.dtype == torch.bfloat16
+        assert_close(g.float(), e, 2e-2, "bf16 linear grad " + name)
+
+
+def test_bf16_deepergcn_runs_on_native_kernels_and_tracks_fp32():
+    """configs[4]-shaped (small) DeeperGCN in bf16: every tall Linear / LayerNorm of the layer stack goes through
+    the HIP kernels (no ATen layer_norm / addmm on [N, .] tensors), and the prediction tracks the fp32 model."""
+    from types import SimpleNamespace
+    from _util import make_args
+    from models import get_model
+    from torch.profiler import ProfilerActivity, profile
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)
+    N, E, H = 12000, 90000, 256
+    ei = torch.randint(0, N, (2, E), generator=gen)
+    mk = lambda dt: SimpleNamespace(x=torch.randn(N, 3, generator=torch.Generator().manual_seed(1)).to(dev).to(dt),
+                                    edge_index=ei.to(dev),
+                                    edge_attr=torch.rand(E, 1, generator=torch.Generator().manual_seed(2)).to(dev),
+                                    batch=(torch.arange(N) // (N // 4)).clamp(max=3).to(dev), age=torch.zeros(4, device=dev, dtype=dt),
+                                    pathway_node_attr=None, node_size=torch.full((4,), N // 4, device=dev))
+    args = make_args(num_layers=3, hidden_channels=H, dropout=0.0, conv_encode_edge=True, use_edge_attr=True,
+                     use_column="w", global_edge="none", gcn_aggr="softmax", block="res+", norm="layer",
+                     graph_pooling="mean", pathway_readout=None)
+    torch.manual_seed(0)
+    model = get_model("deepergcn")(args).to(dev)
+    ref = model(mk(torch.float32)).detach()
+    model.to(torch.bfloat16)
+    batch = mk(torch.bfloat16)
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        out = model(batch)
+        (-torch.log(out[:, 0].float() + 1e-9)).sum().backward()
+    names = {e.key for e in prof.key_averages()}
+    assert "aten::native_layer_norm" not in names and "aten::native_layer_norm_backward" not in names, names
+    assert out.dtype == torch.bfloat16
+    assert_close(out.float(), ref, 5e-2, "bf16 model vs fp32 model")
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad.float()).all()) for p in model.parameters() if p.requires_grad)

@@ -303,6 +303,11 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
   }
 }
 
+// bf16 storage: csrc/wgrad_bf16.hip
+int wb_slabs(int64_t N, int64_t M, int64_t K);
+int linear_wgrad_bf16(const void* grad_out, const void* x, float* grad_w_b, float* workspace, int64_t N, int64_t M,
+                      int64_t K, hipStream_t s);
+
 struct WgradPlan { int nw, wm, wk, tm, tk; };
 
 // cheapest (wave layout) x (tiles per wave) that covers tiles_m x tiles_k with <= 4 tiles (64 accumulator
@@ -361,8 +366,13 @@ static bool launch_wgrad(const WgradPlan& pl, const WgradArgs& a, int nblk, hipS
 using namespace mlgnn;
 
 // one workspace slot per workgroup of the main launch + one for the masked remainder launch
-extern "C" int64_t mlgnn_linear_wgrad_workspace_floats(int64_t N, int64_t M, int64_t K) {
+extern "C" int64_t mlgnn_linear_wgrad_workspace_floats(int64_t N, int64_t M, int64_t K, int dtype) {
   if (N < 0 || M <= 0 || K <= 0) return MLGNN_E_SHAPE;
+  if (dtype == MLGNN_DTYPE_BF16) {
+    const int slabs = wb_slabs(N, M, K);
+    return slabs > 0 ? (int64_t)slabs * (M * K + M) : (int64_t)MLGNN_E_SHAPE;
+  }
+  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   WgradPlan pl;
   if (!plan_wgrad((int)((M + kTile - 1) / kTile), (int)((K + kTile - 1) / kTile), &pl)) return MLGNN_E_SHAPE;
   return (int64_t)(wgrad_blocks(N, pl) + 1) * (M * K + M);
@@ -372,6 +382,16 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const flo
                                   float* grad_w_b, float* workspace,
                                   int64_t workspace_floats, int64_t N, int64_t M, int64_t K, int dtype,
                                   void* stream) {
+  if (dtype == MLGNN_DTYPE_BF16) {                          // grad_out, x bf16; grad_w_b fp32
+    if (N <= 0 || N > INT32_MAX || M <= 0 || K <= 0) return MLGNN_E_SHAPE;
+    const int slabs = wb_slabs(N, M, K);
+    if (slabs <= 0) return MLGNN_E_SHAPE;
+    if (x_gamma || x_beta) return MLGNN_E_MODE;
+    if (!grad_out || !x || !grad_w_b || !workspace) return MLGNN_E_NULL;
+    if (workspace_floats < (int64_t)slabs * (M * K + M)) return MLGNN_E_WORKSPACE;
+    if (((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return MLGNN_E_ALIGN;
+    return linear_wgrad_bf16(grad_out, x, grad_w_b, workspace, N, M, K, (hipStream_t)stream);
+  }
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   if (N < 0 || M <= 0 || K <= 0 || N > INT32_MAX || M * K > (1 << 24)) return MLGNN_E_SHAPE;
   if (N * (M > K ? M : K) * 4 >= ((int64_t)1 << 32)) return MLGNN_E_SHAPE;      // 32-bit byte offsets inside a slab

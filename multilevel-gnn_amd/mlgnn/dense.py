@@ -55,11 +55,12 @@ def _wgrad(go, x, x_gamma=None, x_beta=None):
     """``(go^T x' [M,K], colsum go [M])`` with ``x' = x`` or ``relu(x_gamma x + x_beta)`` (``csrc/wgrad.hip``)."""
     N, K = x.shape
     M = go.shape[1]
-    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K))
+    dt = _DTYPE_IDS[x.dtype]
+    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K, dt))
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
-    out = torch.empty(M * K + M, dtype=torch.float32, device=x.device)
+    out = torch.empty(M * K + M, dtype=torch.float32, device=x.device)          # fp32 for either storage type
     rc = _lib.lib.mlgnn_linear_wgrad(go.data_ptr(), x.data_ptr(), _lib.ptr(x_gamma), _lib.ptr(x_beta), out.data_ptr(),
-                                     ws.data_ptr(), n, N, M, K, 0, torch.cuda.current_stream().cuda_stream)
+                                     ws.data_ptr(), n, N, M, K, dt, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_linear_wgrad")
     return out[:M * K].view(M, K), out[M * K:]
 
@@ -67,8 +68,8 @@ def _wgrad(go, x, x_gamma=None, x_beta=None):
 class _TallLinear(torch.autograd.Function):
     """``y = x W^T + b`` for a tall ``x [N, K]``: forward and ``dX`` on the tall-matrix MFMA kernels
     (``csrc/tallgemm.hip``: fp32 as split fp16, ``csrc/tallgemm_bf16.hip``: bf16 storage), the fp32
-    weight/bias gradient (reduction over the N node rows) on the split-row kernel (``csrc/wgrad.hip``); the
-    bf16 weight gradient is a library TN GEMM."""
+    weight/bias gradient (reduction over the N node rows) on the split-row kernels (``csrc/wgrad.hip``: fp32 as
+    3 x bf16; ``csrc/wgrad_bf16.hip``: bf16 operands transposed by the LDS read)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
@@ -99,10 +100,10 @@ class _TallLinear(torch.autograd.Function):
                 gx = go.matmul(weight)
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            if x.dtype == torch.float32:
+            if x.dtype == torch.float32 or _lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K, _DTYPE_IDS[x.dtype]) > 0:
                 gw, gb = _wgrad(go, x)
-                gb = gb if ctx.has_bias else None
-            else:
+                gw, gb = gw.to(x.dtype), (gb.to(x.dtype) if ctx.has_bias else None)
+            else:                                    # bf16 widths the transposed-read kernel does not tile
                 gw = go.t().mm(x)
                 gb = go.sum(0) if ctx.has_bias else None
         # the residual enters by plain addition: its gradient is the output gradient itself (no copy)
@@ -153,8 +154,8 @@ def fused_mlp2_supported(x, w1, w2):
     k, h, o = x.shape[1], w1.shape[0], w2.shape[0]
     ok = (64, 128, 256)
     return (k in ok and h in ok and o in ok and k * h * 4 <= 128 * 1024 and h * o * 4 <= 128 * 1024 and h <= 256
-            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], h, k) > 0
-            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], o, h) > 0)
+            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], h, k, 0) > 0
+            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], o, h, 0) > 0)
 
 
 def fused_mlp2(x, w1, b1, gamma, beta, eps, w2, b2, residual=None):
@@ -167,7 +168,7 @@ def linear(x, weight, bias=None, residual=None):
     <= 32 output tiles of 32x32); ``F.linear`` otherwise."""
     if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS
             and x.is_contiguous() and torch.is_grad_enabled()
-            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], weight.shape[0], weight.shape[1]) > 0):
+            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], weight.shape[0], weight.shape[1], 0) > 0):
         return _TallLinear.apply(x, weight, bias, residual)
     if (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 2
             and x.shape[0] >= WGRAD_MIN_ROWS and x.is_contiguous()

@@ -210,3 +210,35 @@ def test_bf16_deepergcn_runs_on_native_kernels_and_tracks_fp32():
     assert out.dtype == torch.bfloat16
     assert_close(out.float(), ref, 5e-2, "bf16 model vs fp32 model")
     assert all(p.grad is not None and bool(torch.isfinite(p.grad.float()).all()) for p in model.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("N,M,K", [(64, 64, 128), (1000, 512, 256), (4129, 256, 512), (33, 128, 128), (9001, 192, 384),
+                                   (70000, 256, 256), (1, 64, 128)])
+def test_bf16_wgrad_is_exact_on_small_integers(N, M, K):
+    """dW = go^T x, db = colsum(go) through the transposed LDS reads: sparse small-integer operands keep every sum
+    exactly representable in fp32, so a wrong row / column / k-half mapping or a lost ragged tail is a mismatch."""
+    from mlgnn.dense import _wgrad
+    gen = torch.Generator().manual_seed(N + M)
+    go = torch.zeros(N, M)
+    go.scatter_(1, torch.randint(0, M, (N, 5), generator=gen), torch.randint(-3, 4, (N, 5), generator=gen).float())
+    x = torch.randint(-4, 5, (N, K), generator=gen).float()
+    x[:, 0] += torch.arange(N) % 3
+    ref_w, ref_b = go.t() @ x, go.sum(0)
+    gw, gb = _wgrad(go.cuda().to(torch.bfloat16), x.cuda().to(torch.bfloat16))
+    assert gw.dtype == torch.float32 and gw.shape == (M, K)
+    assert torch.equal(gw.cpu(), ref_w) and torch.equal(gb.cpu(), ref_b)
+
+
+def test_bf16_wgrad_random_matches_fp64_and_is_deterministic():
+    from mlgnn.dense import _wgrad
+    gen = torch.Generator().manual_seed(9)
+    N, M, K = 50000, 512, 256
+    go = (torch.randn(N, M, generator=gen) * 0.1).to(torch.bfloat16)
+    x = torch.randn(N, K, generator=gen).to(torch.bfloat16)
+    ref = go.double().t() @ x.double()
+    gw, gb = _wgrad(go.cuda(), x.cuda())
+    gw2, gb2 = _wgrad(go.cuda(), x.cuda())
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)                       # fixed summation order
+    err = float((gw.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1e-5, err                                                     # exact products, fp32 accumulation
+    assert_close(gb.cpu(), go.double().sum(0), 1e-5, "bias gradient")

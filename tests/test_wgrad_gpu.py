@@ -50,7 +50,7 @@ def test_wgrad_keeps_fp32_accuracy_at_any_magnitude(scale):
     mag = (g.double().abs().t() @ x.double().abs())        # size of the terms each output sums
     dev = "cuda:0"
     gd, xd = g.to(dev), x.to(dev)
-    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K))
+    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K, 0))
     ws = torch.empty(n, device=dev)
     out = torch.empty(M * K + M, device=dev)
     rc = _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), None, None, out.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
@@ -73,7 +73,7 @@ def test_wgrad_keeps_fp32_accuracy_at_any_magnitude(scale):
 def test_unsupported_shapes_use_library_gemm():
     from mlgnn import _lib
     from mlgnn.dense import linear
-    assert _lib.lib.mlgnn_linear_wgrad_workspace_floats(10000, 256, 256) < 0      # 64 tiles > 32
+    assert _lib.lib.mlgnn_linear_wgrad_workspace_floats(10000, 256, 256, 0) < 0      # 64 tiles > 32
     x = torch.randn(9000, 256, device="cuda:0", requires_grad=True)
     w = torch.randn(256, 256, device="cuda:0", requires_grad=True)
     linear(x, w).sum().backward()

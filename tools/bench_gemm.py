@@ -38,7 +38,7 @@ for (K, O) in [(128, 256), (256, 128), (3, 128)]:
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multilevel-gnn_amd"))
     from mlgnn import _lib
-    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, O, K))
+    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, O, K, 0))
     ws = torch.empty(n, device=dev)
     outb = torch.empty(O * K + O, device=dev)
     st = torch.cuda.current_stream().cuda_stream

@@ -10,23 +10,28 @@
 
 namespace mlgnn {
 
-constexpr int kPoolSlices = 8;
+// row slices per graph: 8 for batches of many graphs, more when the batch has few (configs[4]: one graph of
+// 200 000 nodes would otherwise be read by 8 workgroups), about 1024 workgroups in total
+static int pool_slices(int64_t B) {
+  int64_t s = 1024 / (B > 0 ? B : 1);
+  return (int)(s < 8 ? 8 : (s > 256 ? 256 : s));
+}
 constexpr float kPoolNegBig = -3.0e38f;
 
 struct PoolArgs {
   const float* x; const int* ptr; float* part; int* part_arg; float* out; int* argmax;
-  int B; int d; int lpr_log2; int kind;      // kind: 0 sum, 1 mean, 2 max
+  int B; int d; int lpr_log2; int kind; int slices;      // kind: 0 sum, 1 mean, 2 max
 };
 
 __global__ __launch_bounds__(kBlock) void segment_pool_stage1_kernel(const PoolArgs a) {
   __shared__ float redv[kWavesPerBlock][kWave * 4];
   __shared__ int redi[kWavesPerBlock][kWave * 4];
-  const int b = blockIdx.x / kPoolSlices, s = blockIdx.x % kPoolSlices;
+  const int b = blockIdx.x / a.slices, s = blockIdx.x % a.slices;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int lpr = 1 << a.lpr_log2, groups = kWave >> a.lpr_log2;
   const int sub = lane >> a.lpr_log2, cl = lane & (lpr - 1);
   const int beg = a.ptr[b], end = a.ptr[b + 1];
-  const int len = (end - beg + kPoolSlices - 1) / kPoolSlices;
+  const int len = (end - beg + a.slices - 1) / a.slices;
   const int r0 = beg + s * len, r1 = min(end, r0 + len);
   const bool is_max = a.kind == 2;
   for (int cbase = 0; cbase < a.d; cbase += lpr * 4) {
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void segment_pool_stage1_kernel(const PoolA
         if (is_max) { if (oa >= 0 && (g < 0 || ov > v || (ov == v && oa < g))) { v = ov; g = oa; } }
         else v += ov;
       }
-      const size_t o = ((size_t)b * kPoolSlices + s) * a.d + cbase + c;
+      const size_t o = ((size_t)b * a.slices + s) * a.d + cbase + c;
       a.part[o] = v;
       if (is_max) a.part_arg[o] = g;
     }
@@ -86,8 +91,8 @@ __global__ __launch_bounds__(kBlock) void segment_pool_stage2_kernel(const PoolA
   const bool is_max = a.kind == 2;
   float v = is_max ? kPoolNegBig : 0.f;
   int g = -1;
-  for (int s = 0; s < kPoolSlices; ++s) {
-    const size_t o = ((size_t)b * kPoolSlices + s) * a.d + c;
+  for (int s = 0; s < a.slices; ++s) {
+    const size_t o = ((size_t)b * a.slices + s) * a.d + c;
     if (is_max) { const int oa = a.part_arg[o]; if (oa >= 0 && (g < 0 || a.part[o] > v)) { v = a.part[o]; g = oa; } }
     else v += a.part[o];
   }
@@ -102,26 +107,27 @@ using namespace mlgnn;
 
 extern "C" int64_t mlgnn_segment_pool_workspace_bytes(int64_t B, int64_t d) {
   if (B < 0 || d <= 0) return MLGNN_E_SHAPE;
-  return B * kPoolSlices * d * 8;       // float partials + int32 argmax partials
+  return B * pool_slices(B) * d * 8;       // float partials + int32 argmax partials
 }
 
 extern "C" int mlgnn_segment_pool_fwd(const void* x, const int32_t* ptr, void* out, int32_t* argmax,
                                       void* workspace, int64_t workspace_bytes, int64_t B, int64_t d,
                                       int kind, int dtype, void* stream) {
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
-  if (B < 0 || d <= 0 || d % 4 != 0 || B * kPoolSlices > INT32_MAX) return MLGNN_E_SHAPE;
+  if (B < 0 || d <= 0 || d % 4 != 0 || B * 8 > INT32_MAX) return MLGNN_E_SHAPE;
+  const int slices = pool_slices(B);
   if (kind < 0 || kind > 2) return MLGNN_E_MODE;
   if (B == 0) return 0;
   if (!x || !ptr || !out || !workspace || (kind == 2 && !argmax)) return MLGNN_E_NULL;
-  if (workspace_bytes < B * kPoolSlices * d * 8) return MLGNN_E_WORKSPACE;
+  if (workspace_bytes < B * slices * d * 8) return MLGNN_E_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return MLGNN_E_ALIGN;
   PoolArgs a;
   a.x = (const float*)x; a.ptr = ptr; a.part = (float*)workspace;
-  a.part_arg = (int*)((char*)workspace + (size_t)B * kPoolSlices * d * 4);
-  a.out = (float*)out; a.argmax = argmax; a.B = (int)B; a.d = (int)d; a.kind = kind;
+  a.part_arg = (int*)((char*)workspace + (size_t)B * slices * d * 4);
+  a.out = (float*)out; a.argmax = argmax; a.B = (int)B; a.d = (int)d; a.kind = kind; a.slices = slices;
   a.lpr_log2 = lanes_per_row_log2(d, 4);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(segment_pool_stage1_kernel, dim3((unsigned)(B * kPoolSlices)), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(segment_pool_stage1_kernel, dim3((unsigned)(B * slices)), dim3(kBlock), 0, s, a);
   int err = (int)hipGetLastError();
   if (err) return err;
   hipLaunchKernelGGL(segment_pool_stage2_kernel, dim3((unsigned)((B * d + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);

@@ -10,7 +10,7 @@
 // Layout.  The weight is cut into column slices of JT 32-column tiles whose image (32 JT * R * 2 bytes <= 128 KB)
 // stays in LDS for the whole launch in B-fragment order; blockIdx.y = slice, blockIdx.x = persistent workgroup
 // that deals 32-row tiles of A round robin to its 8 waves.  Lane (r31, h) of a wave owns half of row r31 of
-// the tile: one 16-byte load per k-step (k = 16 s + 8 h ..+8), four k-steps requested ahead of their MFMAs.
+// the tile: one 16-byte load per k-step (k = 16 s + 8 h ..+8), eight k-steps requested ahead of their MFMAs.
 // Output columns are permuted inside each PAIR of tiles -- MFMA column c of tiles (2u, 2u+1) is output column
 // 64 u + 2 c + (0, 1) -- so that a lane packs its two results into one 4-byte store and a half wave writes 128
 // contiguous bytes of a row (2-byte stores of the natural layout would touch 64-byte pieces).  The permutation is
@@ -26,7 +26,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kTbBlock = 512;
 constexpr int kTbWaves = kTbBlock / kWave;
 constexpr int kTbMaxLds = 128 * 1024;
-constexpr int kTbAhead = 4;                 // k-steps of A in flight per wave
+constexpr int kTbAhead = 8;                 // k-steps of A in flight per wave
 
 // output column (within a slice) of MFMA column c of tile t
 template <int JT>
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
       for (int u = 0; u < kTbAhead; ++u) nxt[u] = ap[2 * min(s0 + kTbAhead + u, KS - 1)];   // clamped: no branch
 #pragma unroll
       for (int u = 0; u < kTbAhead; ++u) {
-        if (s0 + u < KS) {                                      // KS is a multiple of kTbAhead except for R = 16, 32
+        if (s0 + u < KS) {                                      // KS is a multiple of kTbAhead from R = 128 on
           const bf16x8 av = __builtin_bit_cast(bf16x8, cur[u]);
           const uint4* wf = wimg + (size_t)(s0 + u) * JT * 64 + lane;
 #pragma unroll

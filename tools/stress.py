@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """BASELINE configs[4] stress run: ONE synthetic graph N=200 000 nodes / E=3 000 000 edges (ER, seed 7),
 d=256, 28-layer DeeperGCN (res+, LayerNorm, softmax aggregation), then dense_diff_pool on a 4096-node
-pooled graph with 1024 clusters.  fp32 (the bf16 storage path of that config is not implemented yet:
-DESIGN.md section 8).  Prints per-kernel algorithmic GB/s from HIP-event timing and the step time.
+pooled graph with 1024 clusters.  ``--dtype bf16`` is the config's named storage type (bf16 activations / weights,
+fp32 accumulation inside every kernel); fp32 is the default.  Prints per-kernel algorithmic GB/s from HIP-event
+timing and the step time; ``--host-profile`` adds host-side profiles of one step.
 
-  python tools/stress.py [--layers 28] [--hidden 256]
+  python tools/stress.py [--layers 28] [--hidden 256] [--dtype bf16]
 """
 import argparse
 import json

@@ -383,11 +383,13 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const flo
                                   int64_t workspace_floats, int64_t N, int64_t M, int64_t K, int dtype,
                                   void* stream) {
   if (dtype == MLGNN_DTYPE_BF16) {                          // grad_out, x bf16; grad_w_b fp32
-    if (N <= 0 || N > INT32_MAX || M <= 0 || K <= 0) return MLGNN_E_SHAPE;
+    if (N < 0 || N > INT32_MAX || M <= 0 || K <= 0) return MLGNN_E_SHAPE;
     const int slabs = wb_slabs(N, M, K);
     if (slabs <= 0) return MLGNN_E_SHAPE;
     if (x_gamma || x_beta) return MLGNN_E_MODE;
-    if (!grad_out || !x || !grad_w_b || !workspace) return MLGNN_E_NULL;
+    if (!grad_w_b || !workspace) return MLGNN_E_NULL;
+    if (N == 0) return (int)hipMemsetAsync(grad_w_b, 0, (size_t)(M * K + M) * sizeof(float), (hipStream_t)stream);
+    if (!grad_out || !x) return MLGNN_E_NULL;
     if (workspace_floats < (int64_t)slabs * (M * K + M)) return MLGNN_E_WORKSPACE;
     if (((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return MLGNN_E_ALIGN;
     return linear_wgrad_bf16(grad_out, x, grad_w_b, workspace, N, M, K, (hipStream_t)stream);

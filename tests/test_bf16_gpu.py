@@ -229,6 +229,13 @@ def test_bf16_wgrad_is_exact_on_small_integers(N, M, K):
     assert torch.equal(gw.cpu(), ref_w) and torch.equal(gb.cpu(), ref_b)
 
 
+def test_bf16_wgrad_of_an_empty_batch_is_zero():
+    from mlgnn.dense import _wgrad
+    gw, gb = _wgrad(torch.empty(0, 128, device="cuda:0", dtype=torch.bfloat16),
+                    torch.empty(0, 256, device="cuda:0", dtype=torch.bfloat16))
+    assert gw.shape == (128, 256) and not bool(gw.any()) and not bool(gb.any())
+
+
 def test_bf16_wgrad_random_matches_fp64_and_is_deterministic():
     from mlgnn.dense import _wgrad
     gen = torch.Generator().manual_seed(9)

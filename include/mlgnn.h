@@ -63,7 +63,8 @@ int mlgnn_version(void);
 
 /* Number of float elements of workspace mlgnn_csr_aggregate_bwd needs: per-workgroup partials of a
  * factored edge term of edge_rank attributes (0 when the edge mode is not EDGE_RANK1) plus, for
- * AGGR_SOFTMAX without learn_t, the rescaled cotangent [N,d] of the one-row gather path.  May be 0 (then workspace may be NULL). */
+ * AGGR_SOFTMAX without learn_t, the rescaled cotangent [N,d] of the one-row gather path, or, for AGGR_MAX with
+ * d % 4 == 0, the one-byte winner slots [N,d] the backward gathers instead of argmax.  May be 0 (then workspace may be NULL). */
 int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int dtype, int edge_rank,
                                                  int aggr, int learn_t);
 

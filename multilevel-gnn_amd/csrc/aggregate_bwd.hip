@@ -14,14 +14,34 @@ struct BwdArgs {                      // go / x / out / efull / gx / ge are T; a
   const float* ew_t; const float* eu; const float* ev; const void* efull; const int* eid_t;
   void* gx; void* ge; float* ws;
   const void* gt; const int* spread;                        // softmax one-row path (see softmax_shift_kernel)
+  const uint8_t* slot8;                                     // max: winner's slot inside its row, 1 byte (max_slot_kernel)
   const float* t_dev; const float* p_dev;
   int N; int d; int lpr_log2; int mean; int learn_t; int add_root;
   float t; float p; float eps;
 };
 
+// VEC one-byte winner slots -> ints
+template <int VEC>
+__device__ __forceinline__ void load_slots(int (&r)[VEC], const uint8_t* p) {
+  if constexpr (VEC == 4) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (int)((w >> (8 * i)) & 0xffu);
+  } else if constexpr (VEC == 8) {
+    const uint2 w = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = (int)((w.x >> (8 * i)) & 0xffu); r[4 + i] = (int)((w.y >> (8 * i)) & 0xffu); }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = (int)p[i];
+  }
+}
+
 // SHIFT (softmax without a learnable temperature): the normaliser is folded into the cotangent by
 // softmax_shift_kernel,  gt[i][c] = go[i][c] * 2^(-lse[i][c]),  so that  w_e * go = 2^(t m_e) * gt[i][c]  and an
 // edge gathers ONE row (gt) instead of two (go, lse): half the gather traffic, and no per-edge scalar either.
+// SHIFT with max: the winning edge of (i, c) is looked up as a 1-byte slot inside row i (max_slot_kernel) instead of
+// the 4-byte by-destination position the forward wrote -- the second gathered row shrinks from 4 d to d bytes.
 template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool SHIFT>
 __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (*red)[kWave * VEC]) {
   constexpr int RK = rank_of<MODE>();
@@ -89,7 +109,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
         if (lane < cnt) {
           const int dst = a.col_t[base + lane];
           my_off = (uint32_t)dst * row_bytes;
-          if (AGGR == A_MAX) my_pos = a.pos_t[base + lane];
+          if (AGGR == A_MAX) my_pos = a.pos_t[base + lane] - (SHIFT ? a.rowptr[dst] : 0);
           if constexpr (ES > 0) {
             load_edge_scalars<ES>(my_ew, a.ew_t, (size_t)(base + lane));
           }
@@ -119,10 +139,11 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { ga[u][i] = 0.f; gb[u][i] = 0.f; gc[u][i] = 0.f; ef[u][i] = 0.f; ai[u][i] = -2; }
             if (FULL || valid[u]) {
-              load_row<T, VEC>(ga[u], SHIFT ? GT : GO, off);
+              load_row<T, VEC>(ga[u], (SHIFT && AGGR == A_SOFTMAX) ? GT : GO, off);
               if (AGGR == A_SOFTMAX && !SHIFT) load_row<float, VEC>(gb[u], a.aux, off * kWide);
               if (AGGR == A_SOFTMAX && LEARN_T) load_row<T, VEC>(gc[u], OUTS, off);
-              if (AGGR == A_MAX) load_row<VEC>(ai[u], a.argmax, off * kWide);
+              if (AGGR == A_MAX && !SHIFT) load_row<VEC>(ai[u], a.argmax, off * kWide);
+              if (AGGR == A_MAX && SHIFT) load_slots<VEC>(ai[u], a.slot8 + off / (uint32_t)sizeof(T));
               if (MODE == M_GEN_FULL) load_t<T, VEC>(ef[u], EF + (size_t)e0[u] * a.d + c0);
             }
           }
@@ -234,9 +255,39 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs
     const bool shift_ok = a.gt != nullptr && *a.spread == 0;
     if (shift_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true>(a, red);
     else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false>(a, red);
+  } else if constexpr (AGGR == A_MAX) {
+    // *a.spread != 0: some node has more than 254 incoming edges, its slots do not fit a byte
+    const bool slots_ok = a.slot8 != nullptr && *a.spread == 0;
+    if (slots_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true>(a, red);
+    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false>(a, red);
   } else {
     csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false>(a, red);
   }
+}
+
+// max: slot8[i][c] = argmax[i][c] - rowptr[i] (the winner's position inside row i; 255 = no incoming edge), one
+// byte per channel; *spread is set when a row is too long for that (in-degree > 254).  Streaming: reads N d 4,
+// writes N d bytes; the backward then gathers d instead of 4 d bytes of winner information per edge.
+struct SlotArgs {
+  const int* argmax; const int* rowptr; uint8_t* slot8; int* spread;
+  int N; int d;
+};
+
+__global__ __launch_bounds__(kBlock) void max_slot_kernel(const SlotArgs a) {
+  const int64_t quads = (int64_t)a.N * a.d / 4;                 // d % 4 == 0 on this path
+  bool too_long = false;
+  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < quads; q += (int64_t)gridDim.x * kBlock) {
+    const int row = (int)(q * 4 / a.d);
+    const int beg = a.rowptr[row], end = a.rowptr[row + 1];
+    too_long |= (end - beg) > 254;
+    const int4 v = reinterpret_cast<const int4*>(a.argmax)[q];
+    const int e[4] = {v.x, v.y, v.z, v.w};
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w |= (uint32_t)(e[i] < 0 ? 255 : min(e[i] - beg, 254)) << (8 * i);
+    reinterpret_cast<uint32_t*>(a.slot8)[q] = w;
+  }
+  if (__any(too_long) && (threadIdx.x & (kWave - 1)) == 0) *a.spread = 1;     // plain store of the same value
 }
 
 // Per destination node i with at least one incoming edge: gt[i][c] = go[i][c] * 2^(-lse[i][c]); *spread is set
@@ -394,7 +445,8 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   // workspace = [edge-term partials: nblk * (rk+1) * d][softmax one-row path: flag (4 floats), gt [N*d] of T]
   const int64_t part_floats = rk > 0 ? (int64_t)nblk * (rk + 1) * d : 0;
   const bool want_shift = ag == A_SOFTMAX && !learn_t;
-  const int64_t shift_floats = want_shift ? 4 + (N * d * (bf16 ? 2 : 4) + 3) / 4 : 0;
+  const bool want_slots = ag == A_MAX && d % 4 == 0;
+  const int64_t shift_floats = want_shift ? 4 + (N * d * (bf16 ? 2 : 4) + 3) / 4 : (want_slots ? 4 + (N * d + 3) / 4 : 0);
   if (part_floats + shift_floats > 0 && (!workspace || workspace_floats < part_floats + shift_floats)) return MLGNN_E_WORKSPACE;
 
   BwdArgs a;
@@ -436,6 +488,21 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
         else hipLaunchKernelGGL((softmax_shift_kernel<float, 1>), dim3(sblk), block, 0, s, sa);
       }
       a.gt = sa.gt; a.spread = sa.spread;
+    }
+  }
+  a.slot8 = nullptr;
+  if (want_slots && rowptr) {
+    float* base = workspace + part_floats;
+    if ((reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+      SlotArgs sa;
+      sa.argmax = argmax; sa.rowptr = rowptr; sa.N = (int)N; sa.d = (int)d;
+      sa.spread = reinterpret_cast<int*>(base); sa.slot8 = reinterpret_cast<uint8_t*>(base + 4);
+      int err0 = (int)hipMemsetAsync(sa.spread, 0, 16, s);
+      if (err0) return err0;
+      int64_t sblk = (N * d / 4 + kBlock - 1) / kBlock;
+      if (sblk > 4096) sblk = 4096;
+      hipLaunchKernelGGL(max_slot_kernel, dim3((unsigned)sblk), block, 0, s, sa);
+      a.slot8 = sa.slot8; a.spread = sa.spread;
     }
   }
   const bool lt = learn_t != 0 && ag == A_SOFTMAX;

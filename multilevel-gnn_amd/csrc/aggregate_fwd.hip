@@ -318,10 +318,11 @@ extern "C" int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d
                                                             int aggr, int learn_t) {
   if (N < 0 || d < 0 || edge_rank < 0 || edge_rank > 8) return MLGNN_E_SHAPE;
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
-  // per-workgroup partials of the factored edge term + the softmax shift buffers (aggregate_bwd.hip)
+  // per-workgroup partials of the factored edge term + the softmax shift / max winner-slot buffers (aggregate_bwd.hip)
   int64_t n = edge_rank > 0 ? (int64_t)grid_for_rows(N) * (edge_rank + 1) * d : 0;
   if (aggr == MLGNN_AGGR_SOFTMAX && !learn_t)
     n += 4 + (N * d * (dtype == MLGNN_DTYPE_BF16 ? 2 : 4) + 3) / 4;
+  if (aggr == MLGNN_AGGR_MAX && d % 4 == 0) n += 4 + (N * d + 3) / 4;      // flag + one-byte winner slots
   return n;
 }
 

@@ -258,3 +258,33 @@ def test_softmax_large_magnitudes_do_not_overflow():
     (out * cot.to(dev)).sum().backward()
     assert bool(torch.isfinite(xd.grad).all())
     assert_close(xd.grad, xr.grad, TOL, "large-magnitude softmax grad")
+
+
+@pytest.mark.parametrize("deg", [1, 253, 254, 255, 300])
+@pytest.mark.parametrize("d", [8, 128, 130])
+def test_max_backward_winner_slots_and_their_fallback(deg, d):
+    """The max backward looks the winning edge up as a one-byte slot inside its row while every in-degree is
+    <= 254 and through the forward's 4-byte positions otherwise (device-side switch): both sides of the
+    boundary, the widest row first / last, widths with and without the vector path; bit-identical gradients."""
+    from mlgnn import CSRGraph, RankOneEdge, gen_aggregate
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(deg + d)
+    N, E = 600, 9000
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = torch.randint(2, N - 2, (E,), generator=gen)                     # ~15 per row; rows 0, 1, N-2, N-1 empty
+    dst[:deg] = N - 3                                                      # one row of (at least) `deg` edges ...
+    dst[deg:2 * deg] = 2                                                   # ... and another at the other end
+    ei = torch.stack([src, dst])
+    x = torch.randn(N, d, generator=gen)
+    a, u, v = torch.rand(E, generator=gen), torch.randn(d, generator=gen) * 0.5, torch.randn(d, generator=gen) * 0.2
+    cot = torch.randn(N, d, generator=gen)
+    xr, ur, vr = (t.clone().requires_grad_(True) for t in (x, u, v))
+    msg = torch.relu(xr[ei[0]] + a[:, None] * ur + vr) + 1e-7
+    ref = G.gen_aggregate(msg, ei[1], N, "max")
+    ref_g = torch.autograd.grad((ref * cot).sum(), [xr, ur, vr])
+    xd, ud, vd = (t.to(dev).requires_grad_(True) for t in (x, u, v))
+    out = gen_aggregate(xd, CSRGraph(ei.to(dev), N), RankOneEdge(a.to(dev), ud, vd), aggr="max")
+    assert_close(out, ref, TOL, "max fwd")
+    got = torch.autograd.grad((out * cot.to(dev)).sum(), [xd, ud, vd])
+    for name, g, r in zip(("x", "u", "v"), got, ref_g):
+        assert_close(g, r, TOL, "max grad %s (deg %d)" % (name, deg))

@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graphs-per-gpu", type=int, default=64)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fix the GLOBAL batch (e.g. 512, BASELINE configs[3]) and give every GPU "
+                         "global/N graphs; default 0 = weak scaling with --graphs-per-gpu each")
     ap.add_argument("--nodes", type=int, default=10000)
     ap.add_argument("--edges", type=int, default=160000)
     ap.add_argument("--hidden", type=int, default=128)
@@ -132,7 +135,10 @@ def main():
     except (RuntimeError, TypeError):
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
-    B = args.graphs_per_gpu
+    strong = args.global_batch > 0
+    if strong and args.global_batch % world != 0:
+        raise SystemExit("--global-batch must be a multiple of the number of GPUs")
+    B = args.global_batch // world if strong else args.graphs_per_gpu
     match, seg = W.membership(args.nodes, args.members)
     pool = []
     for k in range(args.pool_batches):
@@ -207,7 +213,7 @@ def main():
         out = {
             "metric": "graphs/sec fwd+bwd, 3-level GNN on 10k-node d=128 synthetic; HBM GB/s %peak",
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: ER graphs N=%d E=%d x%d per GPU, d=%d, 3 GENConv(%s, res+, LayerNorm) + "
                                    "projection pooling G=%d k=2 + DiffPool 146->37->10, fp32; step = CSR build%s + fwd + "

@@ -4,11 +4,13 @@
 are out of scope for this library."""
 from .deepergcn import DeeperGCN
 from .multilevel_gnn import MultilevelGNN
+from .multilevel_gnn_seq import MultilevelGNNSeq, PathwayHeadSeq  # noqa: F401
 from .diff_pooling import DiffPool, DiffPoolLayer, SAGEConvolutions  # noqa: F401
 
 MODELS = {
     'deepergcn': DeeperGCN,
     'multilevel_gnn': MultilevelGNN,
+    'multilevel_gnn_seq': MultilevelGNNSeq,
 }
 
 

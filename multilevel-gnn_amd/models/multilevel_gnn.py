@@ -47,7 +47,7 @@ class MultilevelGNN(nn.Module):
         self.head_dim = args.head_dim
         self.epoch = None
         self.step = None
-        self.used_omics = args.used_omics
+        self.used_omics = getattr(args, "used_omics", "012")
 
         self.input_drop = nn.Dropout(p=args.input_drop) if args.input_drop is not None else None
         self.input_emb_drop = nn.Dropout(p=args.input_emb_drop) if args.input_emb_drop is not None else None
@@ -93,6 +93,11 @@ class MultilevelGNN(nn.Module):
         if args.dense_gnn:
             args.final_channels = (args.num_layers - 1) * args.hidden_channels + args.final_channels
 
+        self._build_head(args)
+        self.init_weight()
+
+    def _build_head(self, args):
+        """Level 2 (:98-128): conv stack, max-pool, dropout, MLP head -- attributes of the model itself."""
         convs, cin = [], args.final_channels
         for cout, kern in zip(args.conv_channel_list, args.conv_kernel_list):
             convs += [nn.Conv2d(cin, cout, kern, padding=kern // 2), nn.ReLU()]
@@ -105,7 +110,20 @@ class MultilevelGNN(nn.Module):
             ((len(self.used_omics) * self.pca_dim) // self.pca_pool_dim) + (1 if args.use_age else 0)
         self.head = nn.Sequential(nn.Linear(head_in, self.head_dim), nn.ReLU(), nn.Dropout(0.5),
                                   nn.Linear(self.head_dim, 2), nn.Softmax(dim=1))
-        self.init_weight()
+
+    def _apply_head(self, x, age):
+        """:262-291"""
+        for layer in self.conv_model:
+            x = layer(x)
+        if len(self.used_omics) != N_OMICS:
+            cols = [c for o in self.used_omics for c in range(int(o) * self.pca_dim, (int(o) + 1) * self.pca_dim)]
+            x = x[:, :, :, cols]
+        x = self.pooling(x)
+        x = self.drop1(x)
+        x = torch.flatten(x, start_dim=1)
+        if self.args.use_age:
+            x = torch.cat([x, age[:, None]], dim=-1)
+        return self.head(x)
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_batch, x=None, gene_pca_match=None, raw_indice=None, age=None, require_grad=True):
@@ -167,17 +185,7 @@ class MultilevelGNN(nn.Module):
                 x = x[:, :, self.reorder_idxs, :]
 
         pca_feature = x
-        for layer in self.conv_model:
-            x = layer(x)
-        if len(self.used_omics) != N_OMICS:
-            cols = [c for o in self.used_omics for c in range(int(o) * self.pca_dim, (int(o) + 1) * self.pca_dim)]
-            x = x[:, :, :, cols]
-        x = self.pooling(x)
-        x = self.drop1(x)
-        x = torch.flatten(x, start_dim=1)
-        if args.use_age:
-            x = torch.cat([x, age[:, None]], dim=-1)
-        return self.head(x), pca_feature
+        return self._apply_head(x, age), pca_feature
 
     # ------------------------------------------------------------------ parameter surface
     def init_weight(self):

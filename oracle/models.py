@@ -158,10 +158,12 @@ def projection_pool(x_nodes, gene_pca_match, raw_indice, pca_params, info_mask, 
 
 
 def multilevel_gnn_forward(args, sd, batch, node_num, training=False, reorder_idxs=None,
-                           n_pathways=146):
+                           n_pathways=146, head_prefix="", only_mrna_pred=False):
     """``MultilevelGNN.forward`` (multilevel_gnn.py:132-292), default wiring:
     ``reduction_method='linear_projection'``, single edge tensor, ``used_omics='012'``,
-    no ``pca_compare``/``pca_prelinear``.  Returns ``(pred, pca_feature)``."""
+    no ``pca_compare``/``pca_prelinear``.  Returns ``(pred, pca_feature)``.
+    ``head_prefix`` / ``only_mrna_pred``: the ``PathwayHeadSeq`` form of the head (see
+    :func:`multilevel_gnn_seq_forward`)."""
     if args.reduction_method != "linear_projection" or args.pca_compare or args.pca_prelinear:
         raise NotImplementedError
     NN = node_num * 3
@@ -208,19 +210,32 @@ def multilevel_gnn_forward(args, sd, batch, node_num, training=False, reorder_id
         x = x[:, :, reorder_idxs, :]
     pca_feature = x
 
-    n_conv = len([kk for kk in sd if kk.startswith("conv_model.") and kk.endswith(".weight")])
+    hp = head_prefix
+    n_conv = len([kk for kk in sd if kk.startswith(hp + "conv_model.") and kk.endswith(".weight")])
     for i in range(n_conv):
-        w = sd["conv_model.%d.weight" % (2 * i)]
-        x = F.relu(F.conv2d(x, w, sd["conv_model.%d.bias" % (2 * i)], padding=w.shape[-1] // 2))
-    x = F.max_pool2d(x, (args.pathway_pool_dim, args.pca_pool_dim))
-    x = _dropout(x, 0.25 if args.feature_drop else 0.0, training)
+        w = sd[hp + "conv_model.%d.weight" % (2 * i)]
+        x = F.relu(F.conv2d(x, w, sd[hp + "conv_model.%d.bias" % (2 * i)], padding=w.shape[-1] // 2))
+    if only_mrna_pred:                       # PathwayHeadSeq.forward :61-64: first two columns, no dropout
+        x = F.max_pool2d(x[:, :, :, :2], (args.pathway_pool_dim, args.pca_pool_dim))
+    else:
+        x = F.max_pool2d(x, (args.pathway_pool_dim, args.pca_pool_dim))
+        x = _dropout(x, 0.25 if args.feature_drop else 0.0, training)
     x = torch.flatten(x, start_dim=1)
     if args.use_age:
         x = torch.cat([x, batch.age[:, None]], dim=-1)
-    x = F.relu(F.linear(x, sd["head.0.weight"], sd["head.0.bias"]))
+    x = F.relu(F.linear(x, sd[hp + "head.0.weight"], sd[hp + "head.0.bias"]))
     x = _dropout(x, 0.5, training)
-    x = F.linear(x, sd["head.3.weight"], sd["head.3.bias"])
+    x = F.linear(x, sd[hp + "head.3.weight"], sd[hp + "head.3.bias"])
     return F.softmax(x, dim=1), pca_feature      # nn.Softmax() implicit dim=1 for 2-D input
+
+
+def multilevel_gnn_seq_forward(args, sd, batch, node_num, training=False, reorder_idxs=None, n_pathways=146):
+    """``MultilevelGNNSeq.forward`` (multilevel_gnn_seq.py:157-291): the body of ``MultilevelGNN.forward`` up to
+    ``pca_feature``, then ``PathwayHeadSeq`` (:14-68) -- the conv stack, max-pool, ``drop1``, flatten, age, MLP head
+    held by a submodule (``state_dict`` keys ``pathwayhead.conv_model.*`` / ``pathwayhead.head.*``); with
+    ``only_mrna_pred`` the conv output is cut to its first two columns before pooling and ``drop1`` is skipped."""
+    return multilevel_gnn_forward(args, sd, batch, node_num, training, reorder_idxs, n_pathways,
+                                  head_prefix="pathwayhead.", only_mrna_pred=bool(args.only_mrna_pred))
 
 
 def feature_loss(args, sd, pca_feature, pathway_indexs=None):

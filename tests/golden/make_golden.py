@@ -155,9 +155,9 @@ def _reference():
     sys.path.insert(0, REF)
     import opt as ref_opt  # noqa
     from models.gcn_lib.sparse import torch_message, torch_vertex  # noqa
-    from models import deepergcn, multilevel_gnn, diff_pooling  # noqa
+    from models import deepergcn, multilevel_gnn, multilevel_gnn_seq, diff_pooling  # noqa
     return SimpleNamespace(opt=ref_opt, msg=torch_message, vertex=torch_vertex, deepergcn=deepergcn,
-                           mlg=multilevel_gnn, diffpool=diff_pooling)
+                           mlg=multilevel_gnn, mlgseq=multilevel_gnn_seq, diffpool=diff_pooling)
 
 
 # ----------------------------------------------------------------------------
@@ -379,6 +379,50 @@ def fx_multilevel(ref):
              sd=dict(model.state_dict()), grad=g)
 
 
+def fx_mlgseq(ref):
+    """``MultilevelGNNSeq`` (models/multilevel_gnn_seq.py): the same GNN + projection pooling with the conv head
+    factored into ``PathwayHeadSeq`` (state_dict keys ``pathwayhead.*``) and the ``only_mrna_pred`` column cut."""
+    gen = torch.Generator().manual_seed(808)
+    node_num, B, G, S = 40, 2, 900, 438
+    for ci, over in enumerate([dict(), dict(only_mrna_pred=True, use_age=False, gnn_name="rsage", resgnn=False,
+                                            pca_pool_dim=1, pathway_pool_dim=2)]):
+        kw = dict(model="multilevel_gnn_seq", num_layers=2, hidden_channels=16, final_channels=8, final_head=4,
+                  node_embedding=True, node_embedding_dim=16, gnn_name="sage", head_dim=4, use_age=True,
+                  weighted_edge=True, value_att_mask=True, pca_match_mask=True, mutual_info_mask=True,
+                  learnable_pca=True, pca_indep_loss=True, pca_loss=True, feature_drop=False, dropout=0.0,
+                  conv_channel_list=[8, 8], conv_kernel_list=[1, 1])
+        kw.update(over)
+        a = default_args(ref, **kw)
+        torch.manual_seed(900 + ci)
+        model = ref.mlgseq.MultilevelGNNSeq(a)
+        NN = node_num * 3
+        model.node_num = node_num
+        model.node_embedding = nn.Parameter(torch.randn(NN, a.node_embedding_dim, generator=gen) * 0.3)
+        mask = (torch.rand(G, generator=gen) > 0.2).to(torch.float32)
+        comps = torch.randn(int(mask.sum()), a.pca_dim + 1, generator=gen) * 0.2
+        model.set_pca_params(comps, mask)
+        model.set_info_mask(mask[:, None].clone())
+        seg = torch.sort(torch.randint(0, S, (G,), generator=gen))[0]
+        model.set_pathway_indexs(seg.clone())
+        model.eval()
+        ei, ea, _ = small_graph(gen, B, NN, 400, weights=True)
+        match = torch.randint(0, NN, (B, G), generator=gen)
+        match[:, ::11] = -1
+        batch = SimpleNamespace(x=torch.rand(B * NN, 1, generator=gen), edge_index=ei, edge_attr=ea,
+                                gene_pca_match=match, raw_indice=seg[None, :].repeat(B, 1),
+                                age=torch.rand(B, generator=gen))
+        pred, feat = model(batch)
+        floss = model.get_feature_loss(feat)
+        c = probe_weights(pred, gen)
+        named = {"sd." + k: v for k, v in model.named_parameters()}
+        loss = (pred * c).sum() + floss
+        g = grads_of(loss, named)
+        save("mlgseq_%d" % ci, over=np.array(repr(sorted(kw.items()))), node_num=node_num, x=batch.x,
+             edge_index=ei, edge_attr=ea, gene_pca_match=match, raw_indice=batch.raw_indice, age=batch.age,
+             pathway_indexs=seg, pred=pred, pca_feature=feat, feature_loss=floss, cot=c,
+             sd=dict(model.state_dict()), grad=g)
+
+
 def fx_diffpool(ref):
     gen = torch.Generator().manual_seed(606)
     for ci, (Bp, C, hid, outc, nl, apl) in enumerate([(4, 8, 32, 64, 2, 1), (3, 16, 16, 16, 1, 2)]):
@@ -403,7 +447,7 @@ def main():
     torch.set_num_threads(4)
     only = set(sys.argv[1:])               # e.g. `make_golden.py deepergcn` regenerates one family
     for name, fx in [("aggregators", fx_aggregators), ("genconv", fx_genconv), ("sage", fx_sage),
-                     ("deepergcn", fx_deepergcn), ("multilevel", fx_multilevel), ("diffpool", fx_diffpool)]:
+                     ("deepergcn", fx_deepergcn), ("multilevel", fx_multilevel), ("mlgseq", fx_mlgseq), ("diffpool", fx_diffpool)]:
         if not only or name in only:
             fx(ref)
 

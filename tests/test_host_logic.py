@@ -74,6 +74,13 @@ def test_state_dict_keys_match_reference():
         m.set_pca_params(torch.zeros(int((f["sd"]["info_mask"] > 0).sum()), m.pca_dim), f["sd"]["info_mask"][:, 0])
         m.set_info_mask(f["sd"]["info_mask"].clone())
         m.load_state_dict(f["sd"], strict=True)
+    for p in golden_files("mlgseq"):
+        f = load_golden(p)
+        m = get_model("multilevel_gnn_seq")(make_args(**literal(f["over"])))
+        m.node_embedding = torch.nn.Parameter(f["sd"]["node_embedding"].clone())
+        m.load_ckpt({k: torch.as_tensor(v) for k, v in f["sd"].items()})
+        assert sorted(m.state_dict()) == sorted(f["sd"])                  # pathwayhead.* keys, no conv_model.* / head.*
+        m.load_state_dict(f["sd"], strict=True)
 
 
 def test_gbm_parameter_count():

@@ -131,6 +131,30 @@ def test_multilevel_vs_reference(path):
     _check_param_grads(model, f["grad"])
 
 
+@pytest.mark.parametrize("path", golden_files("mlgseq"))
+def test_multilevel_seq_vs_reference(path):
+    """``get_model('multilevel_gnn_seq')``: same state_dict keys as the reference (strict load), same outputs and
+    parameter gradients, head in ``PathwayHeadSeq`` with and without ``only_mrna_pred``."""
+    from models import get_model
+    f = load_golden(path)
+    model = get_model("multilevel_gnn_seq")(make_args(**literal(f["over"])))
+    model.node_num = int(f["node_num"])
+    model.node_embedding = torch.nn.Parameter(f["sd"]["node_embedding"].clone())
+    model.load_ckpt({k: torch.as_tensor(v) for k, v in f["sd"].items()})        # re-creates the projection parameter
+    model.load_state_dict(f["sd"], strict=True)
+    model.set_pathway_indexs(f["pathway_indexs"].to(DEV))
+    model.to(DEV).eval()
+    batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "gene_pca_match",
+                                                          "raw_indice", "age")}))
+    pred, feat = model(batch)
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
+    assert_close(pred, f["pred"], TOL, "pred")
+    fl = model.get_feature_loss(feat)
+    assert_close(fl, f["feature_loss"], TOL, "feature loss")
+    ((pred * f["cot"].to(DEV)).sum() + fl).backward()
+    _check_param_grads(model, f["grad"])
+
+
 @pytest.mark.parametrize("path", golden_files("diffpool"))
 def test_diffpool_vs_reference(path):
     from models import DiffPool

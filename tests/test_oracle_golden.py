@@ -118,6 +118,21 @@ def test_multilevel_matches_reference(path):
     _check_grads((pred * f["cot"]).sum() + fl, {"sd." + k: v for k, v in sd.items()}, f["grad"])
 
 
+@pytest.mark.parametrize("path", golden_files("mlgseq"))
+def test_multilevel_seq_matches_reference(path):
+    """MultilevelGNNSeq (PathwayHeadSeq head, with and without only_mrna_pred) vs the reference's own classes."""
+    f = load_golden(path)
+    args = make_args(**literal(f["over"]))
+    sd = _sd_leaves(f["sd"])
+    assert any(k.startswith("pathwayhead.") for k in sd) and not any(k.startswith("conv_model.") for k in sd)
+    pred, feat = M.multilevel_gnn_seq_forward(args, sd, _batch(f), int(f["node_num"]), training=False)
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
+    assert_close(pred, f["pred"], TOL, "pred")
+    fl = M.feature_loss(args, sd, feat, f["pathway_indexs"])
+    assert_close(fl, f["feature_loss"], TOL, "feature loss")
+    _check_grads((pred * f["cot"]).sum() + fl, {"sd." + k: v for k, v in sd.items()}, f["grad"])
+
+
 @pytest.mark.parametrize("path", golden_files("diffpool"))
 def test_diffpool_matches_reference(path):
     f = load_golden(path)

@@ -308,3 +308,115 @@ def diffpool_cluster_sizes(max_num_nodes, num_layers):
         n = ceil(f * n)
         sizes.append(n)
     return sizes
+
+
+# ----------------------------------------------------------------------------
+# models/vae.py  (VAE(MultilevelGNN): encoder, decoders, predict_head with DiffPool)
+# ----------------------------------------------------------------------------
+def vae_encoder(args, sd, batch, node_num, decoder_type="foreach", n_pathways=146):
+    """``VAE.encoder`` (vae.py:128-208), ``reduction_method='linear_projection'``.  Differences from
+    ``MultilevelGNN.forward`` that are reproduced: the edge attributes are always passed, there is no value mask,
+    the projection weights are always ``learnable_pca_params * info_mask``.  (``dense_gnn`` / ``repeat_mask`` read
+    names the reference never defines there -- they raise ``NameError`` -- and are rejected.)
+    Returns ``(mu, sigma, [loss_std, 0, loss_corr], gene_feature)``; ``q_z = Normal(mu, sigma + 1e-7)``."""
+    if args.reduction_method != "linear_projection" or args.dense_gnn or args.repeat_mask:
+        raise NotImplementedError
+    NN = node_num * 3
+    x = batch.x.reshape(-1, 1)
+    if args.node_embedding:
+        emb = sd["node_embedding"]
+        x = (x.reshape(-1, NN, 1) * emb).reshape(-1, emb.shape[-1])
+    n_layers = len([k for k in sd if k.startswith("gnn_model.") and k.endswith("gconv.lin_r.weight")])
+    for i in range(n_layers):
+        last = i == n_layers - 1
+        y = G.sageconv(x, batch.edge_index, batch.edge_attr, sd, "gnn_model.%d.gconv." % i, act_name=args.gnn_act,
+                       relative=(args.gnn_name.lower() == "rsage"),
+                       normalize=bool(args.gnn_last_norm) if last else False,
+                       mlp_norm=args.gnn_mlp_norm, training=False)
+        x = y + x if args.resgnn else y
+    match = batch.gene_pca_match
+    B = match.shape[0]
+    idx = match + torch.arange(B)[:, None] * NN
+    gene_feature = x[idx]
+    if args.pca_match_mask:
+        gene_feature = gene_feature * torch.where(match >= 0, 1, 0)[:, :, None]
+    k = sd["learnable_pca_params"].shape[1]
+    C = gene_feature.shape[-1]
+    w = sd["learnable_pca_params"] * sd["info_mask"]
+    res = gene_feature.unsqueeze(3).repeat(1, 1, 1, k) * w[:, None, :]                 # [B,G,C,k]
+    res = res.permute(0, 2, 1, 3)                                                      # [B,C,G,k]
+    ridx = batch.raw_indice[:, None, :, None].repeat(1, C, 1, k)
+    pooled = torch.zeros(B, C, n_pathways * 3, k, dtype=res.dtype).scatter_reduce(2, ridx, res, reduce="sum")
+    if decoder_type == "flatten":
+        pooled = pooled.reshape(-1, C, n_pathways, k * 3)
+    x = pooled.permute(0, 2, 1, 3).flatten(2)
+    mu = F.linear(x, sd["enc_mu.weight"], sd["enc_mu.bias"])
+    sigma = torch.exp(F.linear(x, sd["enc_log_sigma.weight"], sd["enc_log_sigma.bias"]))
+    loss_std = -mu.flatten(1).permute(1, 0).std(1).mean()
+    off_diag = torch.ones(mu.shape[-1], mu.shape[-1]) - torch.eye(mu.shape[-1])
+    loss_corr = torch.stack([(torch.corrcoef(m) * off_diag).abs() for m in mu.permute(1, 2, 0)]).mean()
+    return mu, sigma, [loss_std, 0, loss_corr], gene_feature
+
+
+def vae_foreach_decoder(sd, z):
+    """``VAE.foreach_decoder`` (vae.py:216-222): block i = Linear -> ReLU -> Linear on ``z[:, i, :]``, concatenated."""
+    outs = []
+    for i in range(z.shape[1]):
+        hdn = F.relu(F.linear(z[:, i, :], sd["decoder.%d.0.weight" % i], sd["decoder.%d.0.bias" % i]))
+        outs.append(F.linear(hdn, sd["decoder.%d.2.weight" % i], sd["decoder.%d.2.bias" % i]))
+    return torch.cat(outs, dim=-1)
+
+
+def vae_predict_head(args, sd, x, age, adj=None, training=False):
+    """``VAE.predict_head`` (vae.py:233-265) -> ``(pred, pca_feature, link, ent)``; ``adj`` = the matrix stored by
+    ``set_pathway_similarity_matrix`` (similarity + I, :305-306)."""
+    link = ent = 0
+    pca_feature = x
+
+    def convs(v):
+        n_conv = len([kk for kk in sd if kk.startswith("conv_model.") and kk.endswith(".weight")])
+        for i in range(n_conv):
+            w = sd["conv_model.%d.weight" % (2 * i)]
+            v = F.relu(F.conv2d(v, w, sd["conv_model.%d.bias" % (2 * i)], padding=w.shape[-1] // 2))
+        return v
+
+    pooled_by_diffpool = args.reorder_type == "diff_pooling"
+    if pooled_by_diffpool and args.diff_pooling_location == "pathway":
+        b = x.shape[0]
+        x = x.permute(0, 3, 2, 1).reshape(-1, args.pathway_num, args.final_channels)
+    elif pooled_by_diffpool and args.diff_pooling_location == "head":
+        x = convs(x)
+        b = x.shape[0]
+        x = x.permute(0, 3, 2, 1).reshape(-1, args.pathway_num, args.conv_channel_list[-1])
+    else:
+        pooled_by_diffpool = False
+        x = convs(x)
+        if args.reorder_type != "no_pooling":
+            x = F.max_pool2d(x, (args.pathway_pool_dim, args.pca_pool_dim))
+        x = _dropout(x, 0.25 if args.feature_drop else 0.0, training)
+        x = torch.flatten(x, start_dim=1)
+    if pooled_by_diffpool:
+        x, link, ent = diffpool_forward(sd, x, adj, args.diff_pooling_layer, args.after_pooling_layer,
+                                        prefix="diff_pooling.", training=training)
+        x = _dropout(x.reshape(b, -1), 0.25 if args.feature_drop else 0.0, training)
+    if args.use_age:
+        x = torch.cat([x, age[:, None]], dim=-1)
+    x = F.relu(F.linear(x, sd["head.0.weight"], sd["head.0.bias"]))
+    x = _dropout(x, 0.5, training)
+    x = F.linear(x, sd["head.3.weight"], sd["head.3.bias"])
+    return F.softmax(x, dim=1), pca_feature, link, ent
+
+
+def vae_train_step(args, sd, batch, node_num, adj=None, reorder_idxs=None, decoder_type="foreach"):
+    """``VAE.train_step`` / ``eval_step`` without the random ``rsample`` option (vae.py:90-117): the mean half of the
+    encoder output, laid out as ``[B,1,146,3H]`` (``channel_one``) or ``[B,H,146,3]``, through ``predict_head``."""
+    mu, sigma, _, gene_feature = vae_encoder(args, sd, batch, node_num, decoder_type)
+    b = mu.shape[0]
+    if args.channel_one:
+        h = mu.reshape(b, 1, 146, -1)
+    else:
+        h = mu.permute(0, 2, 1).reshape(b, mu.shape[-1], 146, 3)
+    if args.reorder_pathway and reorder_idxs is not None:
+        h = h[:, :, reorder_idxs, :]
+    pred, feat, link, ent = vae_predict_head(args, sd, h, batch.age, adj)
+    return pred, feat, link, ent, gene_feature

@@ -29,6 +29,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -155,9 +156,9 @@ def _reference():
     sys.path.insert(0, REF)
     import opt as ref_opt  # noqa
     from models.gcn_lib.sparse import torch_message, torch_vertex  # noqa
-    from models import deepergcn, multilevel_gnn, multilevel_gnn_seq, diff_pooling  # noqa
+    from models import deepergcn, multilevel_gnn, multilevel_gnn_seq, diff_pooling, vae  # noqa
     return SimpleNamespace(opt=ref_opt, msg=torch_message, vertex=torch_vertex, deepergcn=deepergcn,
-                           mlg=multilevel_gnn, mlgseq=multilevel_gnn_seq, diffpool=diff_pooling)
+                           mlg=multilevel_gnn, mlgseq=multilevel_gnn_seq, diffpool=diff_pooling, vae=vae)
 
 
 # ----------------------------------------------------------------------------
@@ -423,6 +424,74 @@ def fx_mlgseq(ref):
              sd=dict(model.state_dict()), grad=g)
 
 
+def fx_vae(ref):
+    """``VAE`` (models/vae.py): encoder (GNN + projection pooling + mu / sigma heads and its losses), the per-pathway
+    decoders, ``train_step`` -> ``predict_head`` with DiffPool on the pathway graph ('pathway' and 'head' placement) or
+    the conv + max-pool head, ``reconstruct_head`` sizing, and the deterministic parts of ``vae_loss``."""
+    gen = torch.Generator().manual_seed(909)
+    node_num, B, G, S = 40, 3, 900, 438
+    cases = [dict(reorder_type="diff_pooling", diff_pooling_location="pathway"),
+             dict(reorder_type="diff_pooling", diff_pooling_location="head", gnn_name="rsage", resgnn=False,
+                  after_pooling_layer=2, use_age=False, channel_one=True, final_channels=1,
+                  final_head=1),
+             dict(reorder_type="pca", channel_one=True, final_channels=1, final_head=1, pathway_pool_dim=2,
+                  decoder_type="foreach_diffhidden")]
+    for ci, over in enumerate(cases):
+        kw = dict(model="vae", num_layers=2, hidden_channels=16, final_channels=4, final_head=2,
+                  node_embedding=True, node_embedding_dim=16, gnn_name="sage", head_dim=8, use_age=True,
+                  weighted_edge=True, pca_match_mask=True, mutual_info_mask=True, pca_dim=2,
+                  feature_drop=False, dropout=0.0, conv_channel_list=[8, 8], conv_kernel_list=[1, 1],
+                  decoder_type="foreach", decoder_dim=4, diff_pooling_layer=2, diff_pooling_hidden_dim=8,
+                  diff_pooling_output_dim=6, pathway_num=146, after_pooling_layer=1)
+        kw.update(over)
+        a = default_args(ref, **kw)
+        seg = torch.randint(0, S, (G,), generator=gen)
+        seg[:S] = torch.arange(S)                               # every pathway x omics segment owns a decoder
+        seg = torch.sort(seg)[0]
+        torch.manual_seed(950 + ci)
+        model = ref.vae.VAE(a, None, seg)
+        NN = node_num * 3
+        model.node_num = node_num
+        model.node_embedding = nn.Parameter(torch.randn(NN, a.node_embedding_dim, generator=gen) * 0.3)
+        mask = (torch.rand(G, generator=gen) > 0.2).to(torch.float32)
+        first = torch.searchsorted(seg, torch.arange(S))        # one live, matched gene per segment: a segment without
+        mask[first] = 1.0                                       # any gives a constant mu row and a NaN corrcoef
+        model.set_pca_params(torch.randn(int(mask.sum()), a.pca_dim + 1, generator=gen) * 0.2, mask)
+        model.set_info_mask(mask[:, None].clone())
+        model.set_pathway_indexs(seg.clone())
+        sim = np.abs(np.corrcoef(np.random.RandomState(ci).randn(146, 20))) - np.eye(146)
+        model.set_pathway_similarity_matrix(sim)
+        model.reconstruct_head(a)
+        model.eval()
+        ei, ea, _ = small_graph(gen, B, NN, 400, weights=True)
+        match = torch.randint(0, NN, (B, G), generator=gen)
+        match[:, ::11] = -1
+        match[:, first] = torch.randint(0, NN, (B, S), generator=gen)
+        batch = SimpleNamespace(x=torch.rand(B * NN, 1, generator=gen), edge_index=ei, edge_attr=ea,
+                                gene_pca_match=match, raw_indice=seg[None, :].repeat(B, 1),
+                                age=torch.rand(B, generator=gen))
+        named = {"sd." + k: v for k, v in model.named_parameters()}
+        # --- prediction path: train_step -> predict_head
+        pred, feat, l, e, gene_feature = model.train_step(batch)
+        c = probe_weights(pred, gen)
+        l_t, e_t = torch.as_tensor(l, dtype=torch.float32), torch.as_tensor(e, dtype=torch.float32)
+        g_pred = grads_of((pred * c).sum() + 0.7 * l_t + 0.3 * e_t, named)
+        # --- reconstruction path with a given latent sample (rsample() itself is a random draw)
+        q_z, h, enc_losses, _ = model.encoder(batch)
+        z = (q_z.loc + 0.5 * q_z.scale).detach()
+        recon = model.foreach_decoder(q_z.loc + 0.5 * q_z.scale)
+        target = torch.rand(recon.shape, generator=gen)
+        kld = torch.distributions.kl_divergence(q_z, torch.distributions.Normal(0, 1.)).sum(-1).mean()
+        rec = F.mse_loss(recon, target)
+        g_rec = grads_of(rec + 0.1 * kld + enc_losses[0] + enc_losses[2], named)
+        save("vae_%d" % ci, over=np.array(repr(sorted(kw.items()))), node_num=node_num, x=batch.x,
+             edge_index=ei, edge_attr=ea, gene_pca_match=match, raw_indice=batch.raw_indice, age=batch.age,
+             pathway_indexs=seg, similarity=sim.astype(np.float32), pred=pred, pca_feature=feat, link=l_t, ent=e_t,
+             gene_feature=gene_feature, cot=c, embedding=h, loss_std=enc_losses[0], loss_corr=enc_losses[2],
+             z=z, recon=recon, target=target, kld=kld, rec=rec,
+             sd=dict(model.state_dict()), grad_pred=g_pred, grad_rec=g_rec)
+
+
 def fx_diffpool(ref):
     gen = torch.Generator().manual_seed(606)
     for ci, (Bp, C, hid, outc, nl, apl) in enumerate([(4, 8, 32, 64, 2, 1), (3, 16, 16, 16, 1, 2)]):
@@ -447,7 +516,7 @@ def main():
     torch.set_num_threads(4)
     only = set(sys.argv[1:])               # e.g. `make_golden.py deepergcn` regenerates one family
     for name, fx in [("aggregators", fx_aggregators), ("genconv", fx_genconv), ("sage", fx_sage),
-                     ("deepergcn", fx_deepergcn), ("multilevel", fx_multilevel), ("mlgseq", fx_mlgseq), ("diffpool", fx_diffpool)]:
+                     ("deepergcn", fx_deepergcn), ("multilevel", fx_multilevel), ("mlgseq", fx_mlgseq), ("vae", fx_vae), ("diffpool", fx_diffpool)]:
         if not only or name in only:
             fx(ref)
 

@@ -83,6 +83,30 @@ def test_state_dict_keys_match_reference():
         m.load_state_dict(f["sd"], strict=True)
 
 
+def test_vae_surface_and_head_sizing():
+    """VAE state_dict keys / shapes equal the reference's (strict load of its fixtures), ``reconstruct_head`` sizes the
+    head for ceil(146 * 0.25^L) DiffPool clusters (vae.py:278-282), the similarity matrix gets its self loops."""
+    import numpy as np
+    from models import get_model
+    from models.vae import next_power_of_two
+    assert [next_power_of_two(n) for n in (1, 2, 3, 4, 5, 17, 64)] == [1, 2, 4, 4, 8, 32, 64]
+    for p in golden_files("vae"):
+        f = load_golden(p)
+        args = make_args(**literal(f["over"]))
+        m = get_model("vae")(args, None, f["pathway_indexs"])
+        assert get_model("mmd_vae") is get_model("vae")
+        m.node_embedding = torch.nn.Parameter(f["sd"]["node_embedding"].clone())
+        m.set_pca_params(torch.zeros(int((f["sd"]["info_mask"] > 0).sum()), m.pca_dim), f["sd"]["info_mask"][:, 0])
+        m.set_info_mask(f["sd"]["info_mask"].clone())
+        m.reconstruct_head(args)
+        assert sorted(m.state_dict()) == sorted(f["sd"])
+        m.load_state_dict(f["sd"], strict=True)
+        if args.reorder_type == "diff_pooling":
+            assert m.head[0].in_features == args.diff_pooling_output_dim * 10 * 3 * args.pca_dim + int(args.use_age)
+        m.set_pathway_similarity_matrix(np.zeros((146, 146)))
+        assert torch.equal(m.get_pathway_adj(), torch.eye(146))
+
+
 def test_gbm_parameter_count():
     """config/gbm.yaml shape: 2 858 279 parameters incl. the frozen info_mask."""
     from models import get_model

@@ -155,6 +155,69 @@ def test_multilevel_seq_vs_reference(path):
     _check_param_grads(model, f["grad"])
 
 
+def _vae_from_fixture(f):
+    from models import get_model
+    args = make_args(**literal(f["over"]))
+    model = get_model("vae")(args, None, f["pathway_indexs"])
+    model.node_num = int(f["node_num"])
+    model.node_embedding = torch.nn.Parameter(f["sd"]["node_embedding"].clone())
+    model.set_pca_params(torch.zeros(int((f["sd"]["info_mask"] > 0).sum()), model.pca_dim), f["sd"]["info_mask"][:, 0])
+    model.set_info_mask(f["sd"]["info_mask"].clone())
+    model.set_pathway_similarity_matrix(f["similarity"].numpy())
+    model.reconstruct_head(args)
+    model.load_state_dict(f["sd"], strict=True)
+    model.set_pathway_indexs(f["pathway_indexs"].to(DEV))
+    return model.to(DEV).eval()
+
+
+@pytest.mark.parametrize("path", golden_files("vae"))
+def test_vae_predict_path_vs_reference(path):
+    """``VAE.train_step`` -> ``predict_head`` (DiffPool on the pathway graph at either placement, or the conv head):
+    outputs, DiffPool losses and every parameter gradient against the reference's own class."""
+    f = load_golden(path)
+    model = _vae_from_fixture(f)
+    batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "gene_pca_match",
+                                                          "raw_indice", "age")}))
+    pred, feat, link, ent, gene = model.train_step(batch)
+    assert_close(gene, f["gene_feature"], TOL, "gene_feature")
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
+    assert_close(pred, f["pred"], TOL, "pred")
+    assert_close(link, f["link"], TOL, "link")
+    assert_close(ent, f["ent"], TOL, "ent")
+    ((pred * f["cot"].to(DEV)).sum() + 0.7 * link + 0.3 * ent).backward()
+    _check_param_grads(model, f["grad_pred"])
+    ev = model.eval_step(batch)
+    assert_close(ev[0], f["pred"], TOL, "eval_step pred")
+
+
+@pytest.mark.parametrize("path", golden_files("vae"))
+def test_vae_reconstruction_path_vs_reference(path):
+    """Encoder statistics and losses, the per-pathway decoders on a given latent (batched form for the uniform
+    'foreach' decoder, block loop for 'foreach_diffhidden'), KL and reconstruction terms and their gradients."""
+    f = load_golden(path)
+    model = _vae_from_fixture(f)
+    batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "gene_pca_match",
+                                                          "raw_indice", "age")}))
+    q_z, h, losses, _ = model.encoder(batch)
+    assert_close(h, f["embedding"], TOL, "embedding")
+    assert_close(losses[0], f["loss_std"], TOL, "loss_std")
+    assert_close(losses[2], f["loss_corr"], TOL, "loss_corr")
+    z = q_z.loc + 0.5 * q_z.scale
+    assert_close(z, f["z"], TOL, "z")
+    recon = model.foreach_decoder(z)
+    assert_close(recon, f["recon"], TOL, "recon")
+    kld = torch.distributions.kl_divergence(q_z, torch.distributions.Normal(0, 1.)).sum(-1).mean()
+    rec = torch.nn.functional.mse_loss(recon, f["target"].to(DEV))
+    assert_close(kld, f["kld"], TOL, "kld")
+    assert_close(rec, f["rec"], TOL, "reconstruction loss")
+    (rec + 0.1 * kld + losses[0] + losses[2]).backward()
+    _check_param_grads(model, f["grad_rec"])
+    out = model(batch)                                   # forward(): a random latent draw, shapes and finiteness
+    assert out["pred_x"].shape == recon.shape and bool(torch.isfinite(out["pred_x"]).all())
+    terms = model.vae_loss(out["pred_x"], f["target"].to(DEV), out["z"], out["q_z"])
+    assert all(bool(torch.isfinite(v)) for v in terms.values())
+
+
 @pytest.mark.parametrize("path", golden_files("diffpool"))
 def test_diffpool_vs_reference(path):
     from models import DiffPool

@@ -133,6 +133,37 @@ def test_multilevel_seq_matches_reference(path):
     _check_grads((pred * f["cot"]).sum() + fl, {"sd." + k: v for k, v in sd.items()}, f["grad"])
 
 
+@pytest.mark.parametrize("path", golden_files("vae"))
+def test_vae_matches_reference(path):
+    """VAE (vae.py): encoder statistics and losses, per-pathway decoders on a given latent, train_step ->
+    predict_head with DiffPool at either placement or the conv / max-pool head; values and parameter gradients."""
+    f = load_golden(path)
+    args = make_args(**literal(f["over"]))
+    sd = _sd_leaves(f["sd"])
+    named = {"sd." + k: v for k, v in sd.items()}
+    adj = (f["similarity"] + torch.eye(146, dtype=f["similarity"].dtype)).to(torch.float32)
+    pred, feat, link, ent, gene = M.vae_train_step(args, sd, _batch(f), int(f["node_num"]), adj)
+    assert_close(gene, f["gene_feature"], TOL, "gene_feature")
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
+    assert_close(pred, f["pred"], TOL, "pred")
+    assert_close(link, f["link"], TOL, "link")
+    assert_close(ent, f["ent"], TOL, "ent")
+    _check_grads((pred * f["cot"]).sum() + 0.7 * link + 0.3 * ent, named, f["grad_pred"])
+    mu, sigma, losses, _ = M.vae_encoder(args, sd, _batch(f), int(f["node_num"]))
+    assert_close(torch.cat([mu, sigma], -1), f["embedding"], TOL, "embedding")
+    assert_close(losses[0], f["loss_std"], TOL, "loss_std")
+    assert_close(losses[2], f["loss_corr"], TOL, "loss_corr")
+    recon = M.vae_foreach_decoder(sd, mu + 0.5 * (sigma + 1e-7))
+    assert_close(mu + 0.5 * (sigma + 1e-7), f["z"], TOL, "z")
+    assert_close(recon, f["recon"], TOL, "recon")
+    q_z = torch.distributions.Normal(mu, sigma + 1e-7)
+    kld = torch.distributions.kl_divergence(q_z, torch.distributions.Normal(0, 1.)).sum(-1).mean()
+    rec = torch.nn.functional.mse_loss(recon, f["target"])
+    assert_close(kld, f["kld"], TOL, "kld")
+    assert_close(rec, f["rec"], TOL, "reconstruction loss")
+    _check_grads(rec + 0.1 * kld + losses[0] + losses[2], named, f["grad_rec"])
+
+
 @pytest.mark.parametrize("path", golden_files("diffpool"))
 def test_diffpool_matches_reference(path):
     f = load_golden(path)

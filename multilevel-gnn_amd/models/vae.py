@@ -1,4 +1,5 @@
-"""VAE on the HIP kernels (interface of the reference's ``models/vae.py``: class ``VAE(MultilevelGNN)`` :39,
+"""VAE, VQ_VAE and AutoEncoder on the HIP kernels (interfaces of the reference's ``models/vae.py``,
+``models/vq_vae.py`` :36-434 and ``models/autoencoder.py`` :23-151).  ``models/vae.py``: class ``VAE(MultilevelGNN)`` :39,
 ``encoder`` :128-208, ``train_step`` / ``eval_step`` :90-117, ``forward`` :119-126, decoders :210-222,
 ``predict_head`` :233-265 -- the caller of ``DiffPool`` --, ``reconstruct_head`` :267-299,
 ``set_pathway_similarity_matrix`` :305, ``vae_loss`` :334-357 and the MMD kernels :376-446).
@@ -36,13 +37,16 @@ def _head(in_dim, hidden):
     return nn.Sequential(nn.Linear(in_dim, hidden), nn.ReLU(), nn.Dropout(0.5), nn.Linear(hidden, 2), nn.Softmax(dim=1))
 
 
-class VAE(MultilevelGNN):
+class _PretrainBase(MultilevelGNN):
+    """What the reference's three pre-training models (autoencoder.py, vae.py, vq_vae.py) repeat verbatim: the decoder
+    construction, the encoder front (GraphConv stack -> gather by gene_pca_match -> projection pooling) and the two
+    decoders."""
 
     def __init__(self, args, pca_params=None, pathway_indexs=None):
         super().__init__(args, pca_params, pathway_indexs)
         if args.dense_gnn or args.repeat_mask:
-            # the reference's encoder reads `feature_list` / `mask_x`, which it never defines (NameError)
-            raise NotImplementedError("dense_gnn / repeat_mask are not usable with the VAE encoder")
+            # the reference's encoders read `feature_list` / `mask_x`, which they never define (NameError)
+            raise NotImplementedError("dense_gnn / repeat_mask are not usable with the pre-training encoders")
         self.node_num = 5135
         self.pca_prelinear = False
         self.decoder_dim = args.decoder_dim
@@ -63,19 +67,16 @@ class VAE(MultilevelGNN):
             self.register_buffer("_out_block", torch.repeat_interleave(torch.arange(len(counts)), counts),
                                  persistent=False)
 
+    def _build_diff_pooling(self, args):
         if args.reorder_type == "diff_pooling":
             feat = {"pathway": args.final_channels, "head": args.conv_channel_list[-1]}.get(args.diff_pooling_location)
             if feat is not None:
                 self.diff_pooling = DiffPool(feat, 2, args.pathway_num, args.diff_pooling_layer,
                                              args.diff_pooling_hidden_dim, args.diff_pooling_output_dim, args)
-        H = C * k
-        self.enc_mu = nn.Linear(H, H)
-        self.enc_log_sigma = nn.Linear(H, H)
-        self.init_weight()
 
-    # ------------------------------------------------------------------ encoder / decoders
-    def encoder(self, input_batch):
-        """-> ``(q_z, cat([mu, sigma], -1), [loss_std, 0, loss_corr], gene_feature [B,G,C])``."""
+    def _project(self, input_batch, strict_mask=False):
+        """-> ``(pooled [B,C,438,k] -- [B,C,146,3k] for the flatten decoder --, gene_feature [B,G,C])``.
+        ``strict_mask``: the AutoEncoder's ``match > 0`` instead of ``match >= 0`` (autoencoder.py:106)."""
         args = self.args
         if args.reduction_method != "linear_projection":
             raise NotImplementedError("reduction_method=%r (CPU SVD branch) is outside the accelerated path"
@@ -93,7 +94,8 @@ class VAE(MultilevelGNN):
         idx = match + torch.arange(B, device=x.device)[:, None] * nodes_per_graph
         gene_feature = x[idx]
         if args.pca_match_mask:
-            gene_feature = gene_feature * (match >= 0).to(x.dtype)[:, :, None]
+            live = (match > 0) if strict_mask else (match >= 0)
+            gene_feature = gene_feature * live.to(x.dtype)[:, :, None]
         # projection pooling over the gathered rows themselves (so that a caller's gene_feature.retain_grad() sees
         # the gradient, as get_vae_sim_loss's grad_weight option expects): identity membership, G rows per graph
         ident = torch.arange(G, device=x.device)[None, :].expand(B, G)
@@ -102,26 +104,7 @@ class VAE(MultilevelGNN):
                                  match_mask=False)                                          # [B, C, 438, k]
         if self.decoder_type == "flatten":
             pooled = pooled.reshape(B, pooled.shape[1], N_PATHWAYS, self.pca_dim * N_OMICS)
-        x = pooled.permute(0, 2, 1, 3).flatten(2)
-
-        mu = self.enc_mu(x)
-        sigma = torch.exp(self.enc_log_sigma(x))
-        loss_std = -mu.flatten(1).permute(1, 0).std(1).mean()
-        loss_corr = self._mean_abs_offdiag_corr(mu)
-        return (torch.distributions.Normal(loc=mu, scale=sigma + 1e-7), torch.cat([mu, sigma], dim=-1),
-                [loss_std, 0, loss_corr], gene_feature)
-
-    @staticmethod
-    def _mean_abs_offdiag_corr(mu):
-        """mean over pathways p and feature pairs (i, j) of |corrcoef(mu[:, p, :].T)[i, j]| with the diagonal zeroed
-        (:205-206), as one batched covariance instead of a corrcoef call per pathway."""
-        m = mu.permute(1, 2, 0)                                  # [P, H, B]: variables x observations
-        m = m - m.mean(dim=2, keepdim=True)
-        cov = m @ m.transpose(1, 2) / (m.shape[2] - 1)
-        d = torch.sqrt(torch.diagonal(cov, dim1=1, dim2=2))
-        corr = (cov / d[:, :, None] / d[:, None, :]).clamp(-1, 1)     # torch.corrcoef clips too
-        eye = torch.eye(corr.shape[-1], device=mu.device, dtype=mu.dtype)
-        return (corr * (1 - eye)).abs().mean()
+        return pooled, gene_feature
 
     def flatten_decoder(self, h):
         x = h.flatten(1)
@@ -142,6 +125,41 @@ class VAE(MultilevelGNN):
         rows = hid.index_select(0, self._out_block)                  # [n_genes, B, D]: the hidden row each gene reads
         return (rows * w2[:, None, :]).sum(-1).t() + b2
 
+
+class VAE(_PretrainBase):
+
+    def __init__(self, args, pca_params=None, pathway_indexs=None):
+        super().__init__(args, pca_params, pathway_indexs)
+        self._build_diff_pooling(args)
+        H = args.final_channels * args.pca_dim
+        self.enc_mu = nn.Linear(H, H)
+        self.enc_log_sigma = nn.Linear(H, H)
+        self.init_weight()
+
+    # ------------------------------------------------------------------ encoder / decoders
+    def encoder(self, input_batch):
+        """-> ``(q_z, cat([mu, sigma], -1), [loss_std, 0, loss_corr], gene_feature [B,G,C])``."""
+        pooled, gene_feature = self._project(input_batch)
+        x = pooled.permute(0, 2, 1, 3).flatten(2)
+        mu = self.enc_mu(x)
+        sigma = torch.exp(self.enc_log_sigma(x))
+        loss_std = -mu.flatten(1).permute(1, 0).std(1).mean()
+        loss_corr = self._mean_abs_offdiag_corr(mu)
+        return (torch.distributions.Normal(loc=mu, scale=sigma + 1e-7), torch.cat([mu, sigma], dim=-1),
+                [loss_std, 0, loss_corr], gene_feature)
+
+    @staticmethod
+    def _mean_abs_offdiag_corr(mu):
+        """mean over pathways p and feature pairs (i, j) of |corrcoef(mu[:, p, :].T)[i, j]| with the diagonal zeroed
+        (:205-206), as one batched covariance instead of a corrcoef call per pathway."""
+        m = mu.permute(1, 2, 0)                                  # [P, H, B]: variables x observations
+        m = m - m.mean(dim=2, keepdim=True)
+        cov = m @ m.transpose(1, 2) / (m.shape[2] - 1)
+        d = torch.sqrt(torch.diagonal(cov, dim1=1, dim2=2))
+        corr = (cov / d[:, :, None] / d[:, None, :]).clamp(-1, 1)     # torch.corrcoef clips too
+        eye = torch.eye(corr.shape[-1], device=mu.device, dtype=mu.dtype)
+        return (corr * (1 - eye)).abs().mean()
+
     def forward(self, input_batch, x=None, gene_pca_match=None, raw_indice=None, age=None):
         q_z, h, loss, _ = self.encoder(input_batch)
         z = q_z.rsample()
@@ -149,12 +167,15 @@ class VAE(MultilevelGNN):
         return {"pred_x": output, "embedding": h, "q_z": q_z, "z": z, "loss": loss}
 
     # ------------------------------------------------------------------ prediction path
-    def _latent_image(self, h):
+    def _latent_image(self, h, keep=None):
+        """[B, 438, c] -> [B, 1, 146, 3 c'] (``channel_one``) or [B, c', 146, 3]; c' = the mean half (c // 2) of the
+        VAE's cat([mu, sigma]) unless ``keep`` says otherwise."""
         b, _, c = h.shape
+        keep = c // 2 if keep is None else keep
         if self.args.channel_one:
-            h = h[:, :, :c // 2].reshape(b, 1, N_PATHWAYS, -1)
+            h = h[:, :, :keep].reshape(b, 1, N_PATHWAYS, -1)
         else:
-            h = h[:, :, :c // 2].permute(0, 2, 1).reshape(b, c // 2, N_PATHWAYS, N_OMICS)
+            h = h[:, :, :keep].permute(0, 2, 1).reshape(b, keep, N_PATHWAYS, N_OMICS)
         if self.args.reorder_pathway and self.reorder_idxs is not None:
             h = h[:, :, self.reorder_idxs, :]
         return h
@@ -276,3 +297,82 @@ class VAE(MultilevelGNN):
         prior = torch.randn_like(z)
         return self.compute_kernel(prior, prior).mean() + self.compute_kernel(z, z).mean() - \
             2 * self.compute_kernel(prior, z).mean()
+
+
+class VectorQuantizer(nn.Module):
+    """Nearest-code-word quantiser with commitment + embedding loss and a straight-through gradient (reference
+    vq_vae.py:36-82, after the sonnet VQ-VAE).  The code vector is gathered by index instead of multiplying a one-hot
+    matrix by the codebook."""
+
+    def __init__(self, num_embeddings, embedding_dim, beta=0.25):
+        super().__init__()
+        self.K, self.D, self.beta = num_embeddings, embedding_dim, beta
+        self.embedding = nn.Embedding(self.K, self.D)
+        self.embedding.weight.data.uniform_(-1, 1)
+
+    def forward(self, latents):
+        flat = latents.reshape(-1, self.D)
+        w = self.embedding.weight
+        dist = (flat ** 2).sum(1, keepdim=True) + (w ** 2).sum(1) - 2 * flat @ w.t()
+        q = self.embedding(torch.argmin(dist, dim=1)).view(latents.shape)
+        vq_loss = F.mse_loss(q.detach(), latents) * self.beta + F.mse_loss(q, latents.detach())
+        return latents + (q - latents).detach(), vq_loss
+
+
+class VQ_VAE(VAE):
+    """Reference ``models/vq_vae.py``: the VAE's surface with a vector-quantised latent -- ``encoder`` returns the
+    pooled latent itself, ``forward`` quantises it before the decoders, ``train_step`` / ``eval_step`` feed the
+    un-quantised latent to ``predict_head``.  (``enc_mu`` / ``enc_log_sigma`` exist, unused, as in the reference.)"""
+
+    def __init__(self, args, pca_params=None, pathway_indexs=None):
+        super().__init__(args, pca_params, pathway_indexs)
+        if args.vae_generate_train_sample:
+            raise NotImplementedError("vae_generate_train_sample reads an undefined q_z in the reference's VQ_VAE")
+        self.vq_layer = VectorQuantizer(args.vqvae_num_embeddings, args.final_channels * args.pca_dim, args.vqvae_beta)
+        self.init_weight()
+
+    def encoder(self, input_batch):
+        pooled, _ = self._project(input_batch)
+        return pooled.permute(0, 2, 1, 3).contiguous().flatten(2)
+
+    def train_step(self, input_batch, require_grad=True):
+        with torch.enable_grad() if require_grad else torch.no_grad():
+            h = self.encoder(input_batch)
+            h = self._latent_image(h, keep=h.shape[-1])
+        return self.predict_head(h, input_batch.age)
+
+    eval_step = train_step
+
+    def forward(self, input_batch, x=None, gene_pca_match=None, raw_indice=None, age=None):
+        z = self.encoder(input_batch)
+        quantized_z, vq_loss = self.vq_layer(z)
+        output = self.flatten_decoder(quantized_z) if self.decoder_type == "flatten" else self.foreach_decoder(quantized_z)
+        return {"pred_x": output, "embedding": quantized_z, "z": z, "vq_loss": vq_loss}
+
+    def vae_loss(self, x_predict, x, vq_loss):
+        recons_loss = F.mse_loss(x_predict, x)
+        return {'loss': self.args.mmd_beta * recons_loss + vq_loss, 'Reconstruction_Loss': recons_loss,
+                'vq_loss': vq_loss}
+
+
+class AutoEncoder(_PretrainBase):
+    """Reference ``models/autoencoder.py``: ``forward(batch) -> (reconstruction [B, n_genes], latent, None)``; the
+    encoder masks ``match <= 0`` (:106) and hands the 4-D pooled tensor to the decoders."""
+
+    def __init__(self, args, pca_params=None, pathway_indexs=None):
+        super().__init__(args, pca_params, pathway_indexs)
+        if not args.mutual_info_mask and args.final_channels == 1:
+            # the reference's un-masked single-channel branch (:122) builds a 3-D tensor and fails at :124
+            raise NotImplementedError("AutoEncoder without mutual_info_mask needs final_channels != 1")
+        self.init_weight()
+
+    def encoder(self, input_batch):
+        return self._project(input_batch, strict_mask=True)[0]
+
+    def foreach_decoder(self, h):
+        return super().foreach_decoder(h.permute(0, 2, 1, 3).flatten(2))
+
+    def forward(self, input_batch, x=None, gene_pca_match=None, raw_indice=None, age=None):
+        h = self.encoder(input_batch)
+        output = self.flatten_decoder(h) if self.decoder_type == "flatten" else self.foreach_decoder(h)
+        return output, h, None

@@ -38,7 +38,7 @@ DEFAULTS = dict(
     gnn_encoder="linear", pca_only=False, no_inter_drop=False, no_inter_norm=False, head_init=False, all_init=True,
     pre_readout_drop=False, pre_concat_age=False, global_edge="onehot", init_emb=False, feature_drop=False,
     dropout=0.5, mul_attr=False, pathway_global_node=False, pathway_num=146, use_column=None, pathway_edge_num=8,
-    resgnn=False, pca_match_mask=False, final_channels=1, final_head=1, used_omics="012", only_mrna_pred=False, channel_one=False, vae_generate_train_sample=False, decoder_dim=4096, decoder_type='flatten', pathway_similarity='correlation', diff_pooling_location='pathway', diff_pooling_layer=2, diff_pooling_hidden_dim=32, diff_pooling_output_dim=64, after_pooling_layer=1, pooling_type='correlation', std_weight=False, grad_weight=False, mmd_kernel_type='imq', mmd_alpha=-9.0, mmd_beta=10.5, kld_weight=0.2, mmd_reg_weight=110, z_var=2, std_weight_coef=1, grad_weight_coef=1, load_autoencoder_epoch=None, autoencoder_ckpt_path=None,
+    resgnn=False, pca_match_mask=False, final_channels=1, final_head=1, used_omics="012", only_mrna_pred=False, vqvae_num_embeddings=512, channel_one=False, vae_generate_train_sample=False, decoder_dim=4096, decoder_type='flatten', pathway_similarity='correlation', diff_pooling_location='pathway', diff_pooling_layer=2, diff_pooling_hidden_dim=32, diff_pooling_output_dim=64, after_pooling_layer=1, pooling_type='correlation', std_weight=False, grad_weight=False, mmd_kernel_type='imq', mmd_alpha=-9.0, mmd_beta=10.5, kld_weight=0.2, mmd_reg_weight=110, z_var=2, std_weight_coef=1, grad_weight_coef=1, load_autoencoder_epoch=None, autoencoder_ckpt_path=None,
     pca_compare=False,
     pca_prelinear=False, learnable_pca=False, pca_loss=False, pca_loss_coef=1.0, pca_indep_loss=False,
     pca_init_type=None, pca_dim=2, pca_pool_dim=2, mutual_info_mask=False, mutual_info_threshold=None,

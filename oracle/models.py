@@ -313,12 +313,13 @@ def diffpool_cluster_sizes(max_num_nodes, num_layers):
 # ----------------------------------------------------------------------------
 # models/vae.py  (VAE(MultilevelGNN): encoder, decoders, predict_head with DiffPool)
 # ----------------------------------------------------------------------------
-def vae_encoder(args, sd, batch, node_num, decoder_type="foreach", n_pathways=146):
-    """``VAE.encoder`` (vae.py:128-208), ``reduction_method='linear_projection'``.  Differences from
-    ``MultilevelGNN.forward`` that are reproduced: the edge attributes are always passed, there is no value mask,
-    the projection weights are always ``learnable_pca_params * info_mask``.  (``dense_gnn`` / ``repeat_mask`` read
-    names the reference never defines there -- they raise ``NameError`` -- and are rejected.)
-    Returns ``(mu, sigma, [loss_std, 0, loss_corr], gene_feature)``; ``q_z = Normal(mu, sigma + 1e-7)``."""
+def _latent_projection(args, sd, batch, node_num, decoder_type="foreach", n_pathways=146, strict_mask=False):
+    """Shared front of the three pre-training models' ``encoder`` (vae.py:128-183, vq_vae.py:177-229,
+    autoencoder.py:70-127), ``reduction_method='linear_projection'``: GraphConv stack (edge attributes always passed,
+    no value mask), gather by ``gene_pca_match`` (masked where ``match < 0``; the AutoEncoder masks ``match <= 0``,
+    ``strict_mask``), projection with ``learnable_pca_params * info_mask``, segment sum.  ``dense_gnn`` /
+    ``repeat_mask`` read names the reference never defines there (NameError) and are rejected.
+    Returns ``(pooled [B,C,438,k] or [B,C,146,3k] for the flatten decoder, gene_feature [B,G,C])``."""
     if args.reduction_method != "linear_projection" or args.dense_gnn or args.repeat_mask:
         raise NotImplementedError
     NN = node_num * 3
@@ -339,7 +340,8 @@ def vae_encoder(args, sd, batch, node_num, decoder_type="foreach", n_pathways=14
     idx = match + torch.arange(B)[:, None] * NN
     gene_feature = x[idx]
     if args.pca_match_mask:
-        gene_feature = gene_feature * torch.where(match >= 0, 1, 0)[:, :, None]
+        live = (match > 0) if strict_mask else (match >= 0)
+        gene_feature = gene_feature * torch.where(live, 1, 0)[:, :, None]
     k = sd["learnable_pca_params"].shape[1]
     C = gene_feature.shape[-1]
     w = sd["learnable_pca_params"] * sd["info_mask"]
@@ -349,6 +351,13 @@ def vae_encoder(args, sd, batch, node_num, decoder_type="foreach", n_pathways=14
     pooled = torch.zeros(B, C, n_pathways * 3, k, dtype=res.dtype).scatter_reduce(2, ridx, res, reduce="sum")
     if decoder_type == "flatten":
         pooled = pooled.reshape(-1, C, n_pathways, k * 3)
+    return pooled, gene_feature
+
+
+def vae_encoder(args, sd, batch, node_num, decoder_type="foreach", n_pathways=146):
+    """``VAE.encoder`` (vae.py:128-208).  Returns ``(mu, sigma, [loss_std, 0, loss_corr], gene_feature)``;
+    ``q_z = Normal(mu, sigma + 1e-7)``."""
+    pooled, gene_feature = _latent_projection(args, sd, batch, node_num, decoder_type, n_pathways)
     x = pooled.permute(0, 2, 1, 3).flatten(2)
     mu = F.linear(x, sd["enc_mu.weight"], sd["enc_mu.bias"])
     sigma = torch.exp(F.linear(x, sd["enc_log_sigma.weight"], sd["enc_log_sigma.bias"]))
@@ -405,6 +414,58 @@ def vae_predict_head(args, sd, x, age, adj=None, training=False):
     x = _dropout(x, 0.5, training)
     x = F.linear(x, sd["head.3.weight"], sd["head.3.bias"])
     return F.softmax(x, dim=1), pca_feature, link, ent
+
+
+def vae_flatten_decoder(sd, h):
+    """``flatten_decoder`` (vae.py:210-214): Linear, ReLU, Linear, ReLU, Linear on the flattened latent."""
+    x = h.flatten(1)
+    x = F.relu(F.linear(x, sd["decoder.0.weight"], sd["decoder.0.bias"]))
+    x = F.relu(F.linear(x, sd["decoder.2.weight"], sd["decoder.2.bias"]))
+    return F.linear(x, sd["decoder.4.weight"], sd["decoder.4.bias"])
+
+
+def vector_quantize(latents, codebook, beta):
+    """``VectorQuantizer.forward`` (vq_vae.py:53-82): nearest code word per latent row (squared L2), commitment +
+    embedding loss, straight-through estimator.  Returns ``(quantized, vq_loss)``."""
+    flat = latents.reshape(-1, codebook.shape[1])
+    dist = (flat ** 2).sum(1, keepdim=True) + (codebook ** 2).sum(1) - 2 * flat @ codebook.t()
+    q = codebook[torch.argmin(dist, dim=1)].view(latents.shape)
+    vq_loss = F.mse_loss(q.detach(), latents) * beta + F.mse_loss(q, latents.detach())
+    return latents + (q - latents).detach(), vq_loss
+
+
+def vq_vae_encoder(args, sd, batch, node_num, decoder_type="foreach"):
+    """``VQ_VAE.encoder`` (vq_vae.py:177-231) -> ``[B, 438, C k]`` (``[B, 146, 3 C k]`` for the flatten decoder)."""
+    pooled, _ = _latent_projection(args, sd, batch, node_num, decoder_type)
+    return pooled.permute(0, 2, 1, 3).contiguous().flatten(2)
+
+
+def vq_vae_train_step(args, sd, batch, node_num, adj=None, reorder_idxs=None):
+    """``VQ_VAE.train_step`` / ``eval_step`` (vq_vae.py:139-165): the un-quantised latent through ``predict_head``."""
+    h = vq_vae_encoder(args, sd, batch, node_num)
+    b, _, c = h.shape
+    h = h.reshape(b, 1, 146, -1) if args.channel_one else h.permute(0, 2, 1).reshape(b, c, 146, 3)
+    if args.reorder_pathway and reorder_idxs is not None:
+        h = h[:, :, reorder_idxs, :]
+    return vae_predict_head(args, sd, h, batch.age, adj)
+
+
+def vq_vae_forward(args, sd, batch, node_num):
+    """``VQ_VAE.forward`` (vq_vae.py:168-175) with the per-pathway decoders -> ``(pred_x, quantized_z, z, vq_loss)``."""
+    z = vq_vae_encoder(args, sd, batch, node_num)
+    qz, vq_loss = vector_quantize(z, sd["vq_layer.embedding.weight"], args.vqvae_beta)
+    return vae_foreach_decoder(sd, qz), qz, z, vq_loss
+
+
+def autoencoder_forward(args, sd, batch, node_num, decoder_type="foreach"):
+    """``AutoEncoder.forward`` (autoencoder.py:62-68, encoder :70-127, decoders :130-142) -> ``(pred_x, h)``; the
+    encoder masks ``match <= 0`` (:106) and returns the 4-D pooled tensor, which the decoders flatten themselves."""
+    if not args.mutual_info_mask and args.final_channels == 1:
+        raise NotImplementedError        # the reference's un-masked single-channel branch builds a 3-D tensor and fails
+    h, _ = _latent_projection(args, sd, batch, node_num, decoder_type, strict_mask=True)
+    if decoder_type == "flatten":
+        return vae_flatten_decoder(sd, h), h
+    return vae_foreach_decoder(sd, h.permute(0, 2, 1, 3).flatten(2)), h
 
 
 def vae_train_step(args, sd, batch, node_num, adj=None, reorder_idxs=None, decoder_type="foreach"):

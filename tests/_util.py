@@ -52,7 +52,7 @@ OPT_DEFAULTS = dict(
     feature_drop=False, dropout=0.5, mul_attr=False, pathway_global_node=False, pathway_num=146,
     use_column=None, pathway_edge_num=8,
     # MultilevelGNN
-    resgnn=False, pca_match_mask=False, final_channels=1, final_head=1, used_omics="012", only_mrna_pred=False, channel_one=False, vae_generate_train_sample=False, decoder_dim=4096, decoder_type='flatten', pathway_similarity='correlation', std_weight=False, grad_weight=False, mmd_kernel_type='imq', mmd_alpha=-9.0, mmd_beta=10.5, kld_weight=0.2, mmd_reg_weight=110, z_var=2, std_weight_coef=1, grad_weight_coef=1, load_autoencoder_epoch=None, autoencoder_ckpt_path=None,
+    resgnn=False, pca_match_mask=False, final_channels=1, final_head=1, used_omics="012", only_mrna_pred=False, vqvae_num_embeddings=512, channel_one=False, vae_generate_train_sample=False, decoder_dim=4096, decoder_type='flatten', pathway_similarity='correlation', std_weight=False, grad_weight=False, mmd_kernel_type='imq', mmd_alpha=-9.0, mmd_beta=10.5, kld_weight=0.2, mmd_reg_weight=110, z_var=2, std_weight_coef=1, grad_weight_coef=1, load_autoencoder_epoch=None, autoencoder_ckpt_path=None,
     pca_compare=False,
     pca_prelinear=False, learnable_pca=False, pca_loss=False, pca_loss_coef=1.0, pca_indep_loss=False,
     pca_init_type=None, pca_dim=2, pca_pool_dim=2, mutual_info_mask=False, mutual_info_threshold=None,

@@ -156,9 +156,10 @@ def _reference():
     sys.path.insert(0, REF)
     import opt as ref_opt  # noqa
     from models.gcn_lib.sparse import torch_message, torch_vertex  # noqa
-    from models import deepergcn, multilevel_gnn, multilevel_gnn_seq, diff_pooling, vae  # noqa
+    from models import deepergcn, multilevel_gnn, multilevel_gnn_seq, diff_pooling, vae, vq_vae, autoencoder  # noqa
     return SimpleNamespace(opt=ref_opt, msg=torch_message, vertex=torch_vertex, deepergcn=deepergcn,
-                           mlg=multilevel_gnn, mlgseq=multilevel_gnn_seq, diffpool=diff_pooling, vae=vae)
+                           mlg=multilevel_gnn, mlgseq=multilevel_gnn_seq, diffpool=diff_pooling, vae=vae,
+                           vqvae=vq_vae, ae=autoencoder)
 
 
 # ----------------------------------------------------------------------------
@@ -492,6 +493,94 @@ def fx_vae(ref):
              sd=dict(model.state_dict()), grad_pred=g_pred, grad_rec=g_rec)
 
 
+def _pretrain_model(ref, cls, kw, ci, gen, seed):
+    """Shared set-up of the pre-training models' fixtures (VQ_VAE, AutoEncoder): small node_num, masked projection with
+    one live matched gene per pathway segment, a 3-graph batch."""
+    node_num, B, G, S = 40, 3, 900, 438
+    a = default_args(ref, **kw)
+    seg = torch.randint(0, S, (G,), generator=gen)
+    seg[:S] = torch.arange(S)
+    seg = torch.sort(seg)[0]
+    torch.manual_seed(seed + ci)
+    model = cls(a, None, seg)
+    NN = node_num * 3
+    model.node_num = node_num
+    model.node_embedding = nn.Parameter(torch.randn(NN, a.node_embedding_dim, generator=gen) * 0.3)
+    mask = (torch.rand(G, generator=gen) > 0.2).to(torch.float32)
+    first = torch.searchsorted(seg, torch.arange(S))
+    mask[first] = 1.0
+    model.set_pca_params(torch.randn(int(mask.sum()), a.pca_dim + 1, generator=gen) * 0.2, mask)
+    model.set_info_mask(mask[:, None].clone())
+    model.set_pathway_indexs(seg.clone())
+    model.eval()
+    ei, ea, _ = small_graph(gen, B, NN, 400, weights=True)
+    match = torch.randint(0, NN, (B, G), generator=gen)
+    match[:, ::11] = -1
+    match[:, 5::13] = 0                                       # node 0: kept by the VAEs, masked by the AutoEncoder
+    match[:, first] = torch.randint(1, NN, (B, S), generator=gen)
+    batch = SimpleNamespace(x=torch.rand(B * NN, 1, generator=gen), edge_index=ei, edge_attr=ea,
+                            gene_pca_match=match, raw_indice=seg[None, :].repeat(B, 1),
+                            age=torch.rand(B, generator=gen))
+    common = dict(over=np.array(repr(sorted(kw.items()))), node_num=node_num, x=batch.x, edge_index=ei, edge_attr=ea,
+                  gene_pca_match=match, raw_indice=batch.raw_indice, age=batch.age, pathway_indexs=seg)
+    return a, model, batch, common
+
+
+PRETRAIN_KW = dict(num_layers=2, hidden_channels=16, final_channels=4, final_head=2, node_embedding=True,
+                   node_embedding_dim=16, gnn_name="sage", head_dim=8, use_age=True, weighted_edge=True,
+                   pca_match_mask=True, mutual_info_mask=True, pca_dim=2, feature_drop=False, dropout=0.0,
+                   conv_channel_list=[8, 8], conv_kernel_list=[1, 1], decoder_type="foreach", decoder_dim=4,
+                   diff_pooling_layer=2, diff_pooling_hidden_dim=8, diff_pooling_output_dim=6, pathway_num=146,
+                   after_pooling_layer=1)
+
+
+def fx_vqvae(ref):
+    """``VQ_VAE`` (models/vq_vae.py): encoder, ``VectorQuantizer``, decoders, ``train_step`` -> ``predict_head``.
+    ``vqvae_beta`` is read by the constructor but has no ``opt.py`` entry: the fixture supplies 0.25 (the quantiser's
+    own default)."""
+    gen = torch.Generator().manual_seed(1010)
+    for ci, over in enumerate([dict(reorder_type="diff_pooling", diff_pooling_location="pathway"),
+                               dict(reorder_type="pca", channel_one=True, final_channels=1, final_head=1,
+                                    gnn_name="rsage", resgnn=False, use_age=False)]):
+        kw = dict(PRETRAIN_KW, model="vq_vae", vqvae_num_embeddings=32, vqvae_beta=0.25)
+        kw.update(over)
+        a, model, batch, common = _pretrain_model(ref, ref.vqvae.VQ_VAE, kw, ci, gen, 1050)
+        sim = np.abs(np.corrcoef(np.random.RandomState(10 + ci).randn(146, 20))) - np.eye(146)
+        model.set_pathway_similarity_matrix(sim)
+        model.reconstruct_head(a)
+        model.eval()
+        with torch.no_grad():                                  # code words near the latents: several get selected
+            zs = model.encoder(batch).reshape(-1, model.vq_layer.D)
+            model.vq_layer.embedding.weight.copy_(zs[torch.randperm(zs.shape[0], generator=gen)[:32]] * 1.05)
+        named = {"sd." + k: v for k, v in model.named_parameters()}
+        pred, feat, l, e = model.train_step(batch)
+        c = probe_weights(pred, gen)
+        l_t, e_t = torch.as_tensor(l, dtype=torch.float32), torch.as_tensor(e, dtype=torch.float32)
+        g_pred = grads_of((pred * c).sum() + 0.7 * l_t + 0.3 * e_t, named)
+        out = model(batch)
+        target = torch.rand(out["pred_x"].shape, generator=gen)
+        terms = model.vae_loss(out["pred_x"], target, out["vq_loss"])
+        g_rec = grads_of(terms["loss"], named)
+        save("vqvae_%d" % ci, similarity=sim.astype(np.float32), pred=pred, pca_feature=feat, link=l_t, ent=e_t, cot=c,
+             z=out["z"], quantized=out["embedding"], vq_loss=out["vq_loss"], recon=out["pred_x"], target=target,
+             loss=terms["loss"], sd=dict(model.state_dict()), grad_pred=g_pred, grad_rec=g_rec, **common)
+
+
+def fx_autoencoder(ref):
+    """``AutoEncoder`` (models/autoencoder.py): encoder (masks ``match <= 0``) + per-pathway / flatten decoders."""
+    gen = torch.Generator().manual_seed(1111)
+    for ci, over in enumerate([dict(), dict(decoder_type="flatten", gnn_name="rsage", resgnn=False, final_channels=1,
+                                            final_head=1)]):
+        kw = dict(PRETRAIN_KW, model="autoencoder")
+        kw.update(over)
+        a, model, batch, common = _pretrain_model(ref, ref.ae.AutoEncoder, kw, ci, gen, 1150)
+        named = {"sd." + k: v for k, v in model.named_parameters()}
+        recon, h, _ = model(batch)
+        c = probe_weights(recon, gen)
+        g = grads_of((recon * c).sum(), named)
+        save("autoencoder_%d" % ci, recon=recon, latent=h, cot=c, sd=dict(model.state_dict()), grad=g, **common)
+
+
 def fx_diffpool(ref):
     gen = torch.Generator().manual_seed(606)
     for ci, (Bp, C, hid, outc, nl, apl) in enumerate([(4, 8, 32, 64, 2, 1), (3, 16, 16, 16, 1, 2)]):
@@ -516,7 +605,8 @@ def main():
     torch.set_num_threads(4)
     only = set(sys.argv[1:])               # e.g. `make_golden.py deepergcn` regenerates one family
     for name, fx in [("aggregators", fx_aggregators), ("genconv", fx_genconv), ("sage", fx_sage),
-                     ("deepergcn", fx_deepergcn), ("multilevel", fx_multilevel), ("mlgseq", fx_mlgseq), ("vae", fx_vae), ("diffpool", fx_diffpool)]:
+                     ("deepergcn", fx_deepergcn), ("multilevel", fx_multilevel), ("mlgseq", fx_mlgseq), ("vae", fx_vae), ("vqvae", fx_vqvae), ("autoencoder", fx_autoencoder),
+                     ("diffpool", fx_diffpool)]:
         if not only or name in only:
             fx(ref)
 

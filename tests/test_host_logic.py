@@ -105,6 +105,18 @@ def test_vae_surface_and_head_sizing():
             assert m.head[0].in_features == args.diff_pooling_output_dim * 10 * 3 * args.pca_dim + int(args.use_age)
         m.set_pathway_similarity_matrix(np.zeros((146, 146)))
         assert torch.equal(m.get_pathway_adj(), torch.eye(146))
+    for name, prefix in (("vq_vae", "vqvae"), ("autoencoder", "autoencoder")):
+        for p in golden_files(prefix):
+            f = load_golden(p)
+            args = make_args(**literal(f["over"]))
+            m = get_model(name)(args, None, f["pathway_indexs"])
+            m.node_embedding = torch.nn.Parameter(f["sd"]["node_embedding"].clone())
+            m.set_pca_params(torch.zeros(int((f["sd"]["info_mask"] > 0).sum()), m.pca_dim), f["sd"]["info_mask"][:, 0])
+            m.set_info_mask(f["sd"]["info_mask"].clone())
+            if name == "vq_vae":
+                m.reconstruct_head(args)
+            assert sorted(m.state_dict()) == sorted(f["sd"]), name
+            m.load_state_dict(f["sd"], strict=True)
 
 
 def test_gbm_parameter_count():

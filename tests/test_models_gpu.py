@@ -155,16 +155,17 @@ def test_multilevel_seq_vs_reference(path):
     _check_param_grads(model, f["grad"])
 
 
-def _vae_from_fixture(f):
+def _vae_from_fixture(f, name="vae"):
     from models import get_model
     args = make_args(**literal(f["over"]))
-    model = get_model("vae")(args, None, f["pathway_indexs"])
+    model = get_model(name)(args, None, f["pathway_indexs"])
     model.node_num = int(f["node_num"])
     model.node_embedding = torch.nn.Parameter(f["sd"]["node_embedding"].clone())
     model.set_pca_params(torch.zeros(int((f["sd"]["info_mask"] > 0).sum()), model.pca_dim), f["sd"]["info_mask"][:, 0])
     model.set_info_mask(f["sd"]["info_mask"].clone())
-    model.set_pathway_similarity_matrix(f["similarity"].numpy())
-    model.reconstruct_head(args)
+    if name != "autoencoder":
+        model.set_pathway_similarity_matrix(f["similarity"].numpy())
+        model.reconstruct_head(args)
     model.load_state_dict(f["sd"], strict=True)
     model.set_pathway_indexs(f["pathway_indexs"].to(DEV))
     return model.to(DEV).eval()
@@ -216,6 +217,47 @@ def test_vae_reconstruction_path_vs_reference(path):
     assert out["pred_x"].shape == recon.shape and bool(torch.isfinite(out["pred_x"]).all())
     terms = model.vae_loss(out["pred_x"], f["target"].to(DEV), out["z"], out["q_z"])
     assert all(bool(torch.isfinite(v)) for v in terms.values())
+
+
+@pytest.mark.parametrize("path", golden_files("vqvae"))
+def test_vq_vae_vs_reference(path):
+    """VQ_VAE: prediction path on the un-quantised latent, then forward() -- quantisation (same code words chosen),
+    straight-through gradients, decoders, loss -- against the reference's own class."""
+    f = load_golden(path)
+    model = _vae_from_fixture(f, "vq_vae")
+    batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "gene_pca_match",
+                                                          "raw_indice", "age")}))
+    pred, feat, link, ent = model.train_step(batch)
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
+    assert_close(pred, f["pred"], TOL, "pred")
+    assert_close(link, f["link"], TOL, "link")
+    assert_close(ent, f["ent"], TOL, "ent")
+    ((pred * f["cot"].to(DEV)).sum() + 0.7 * link + 0.3 * ent).backward()
+    _check_param_grads(model, f["grad_pred"])
+    model.zero_grad()
+    out = model(batch)
+    assert_close(out["z"], f["z"], TOL, "z")
+    assert_close(out["embedding"], f["quantized"], TOL, "quantized latent")
+    assert_close(out["vq_loss"], f["vq_loss"], TOL, "vq_loss")
+    assert_close(out["pred_x"], f["recon"], TOL, "recon")
+    terms = model.vae_loss(out["pred_x"], f["target"].to(DEV), out["vq_loss"])
+    assert_close(terms["loss"], f["loss"], TOL, "loss")
+    terms["loss"].backward()
+    _check_param_grads(model, f["grad_rec"])
+
+
+@pytest.mark.parametrize("path", golden_files("autoencoder"))
+def test_autoencoder_vs_reference(path):
+    f = load_golden(path)
+    model = _vae_from_fixture(f, "autoencoder")
+    batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "gene_pca_match",
+                                                          "raw_indice", "age")}))
+    recon, h, none = model(batch)
+    assert none is None
+    assert_close(h, f["latent"], TOL, "latent")
+    assert_close(recon, f["recon"], TOL, "recon")
+    (recon * f["cot"].to(DEV)).sum().backward()
+    _check_param_grads(model, f["grad"])
 
 
 @pytest.mark.parametrize("path", golden_files("diffpool"))

@@ -164,6 +164,43 @@ def test_vae_matches_reference(path):
     _check_grads(rec + 0.1 * kld + losses[0] + losses[2], named, f["grad_rec"])
 
 
+@pytest.mark.parametrize("path", golden_files("vqvae"))
+def test_vq_vae_matches_reference(path):
+    """VQ_VAE (vq_vae.py): train_step -> predict_head on the un-quantised latent; forward = encoder, nearest-code
+    quantisation with the straight-through estimator, decoders; loss = mmd_beta * mse + vq_loss."""
+    f = load_golden(path)
+    args = make_args(**literal(f["over"]))
+    sd = _sd_leaves(f["sd"])
+    named = {"sd." + k: v for k, v in sd.items()}
+    adj = (f["similarity"] + torch.eye(146)).to(torch.float32)
+    pred, feat, link, ent = M.vq_vae_train_step(args, sd, _batch(f), int(f["node_num"]), adj)
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
+    assert_close(pred, f["pred"], TOL, "pred")
+    assert_close(link, f["link"], TOL, "link")
+    assert_close(ent, f["ent"], TOL, "ent")
+    _check_grads((pred * f["cot"]).sum() + 0.7 * link + 0.3 * ent, named, f["grad_pred"])
+    recon, qz, z, vq_loss = M.vq_vae_forward(args, sd, _batch(f), int(f["node_num"]))
+    assert_close(z, f["z"], TOL, "z")
+    assert_close(qz, f["quantized"], TOL, "quantized")
+    assert len(torch.unique(qz.reshape(-1, qz.shape[-1]), dim=0)) > 1          # more than one code word in use
+    assert_close(vq_loss, f["vq_loss"], TOL, "vq_loss")
+    assert_close(recon, f["recon"], TOL, "recon")
+    loss = args.mmd_beta * torch.nn.functional.mse_loss(recon, f["target"]) + vq_loss
+    assert_close(loss, f["loss"], TOL, "loss")
+    _check_grads(loss, named, f["grad_rec"])
+
+
+@pytest.mark.parametrize("path", golden_files("autoencoder"))
+def test_autoencoder_matches_reference(path):
+    f = load_golden(path)
+    args = make_args(**literal(f["over"]))
+    sd = _sd_leaves(f["sd"])
+    recon, h = M.autoencoder_forward(args, sd, _batch(f), int(f["node_num"]), args.decoder_type)
+    assert_close(h, f["latent"], TOL, "latent")
+    assert_close(recon, f["recon"], TOL, "recon")
+    _check_grads((recon * f["cot"]).sum(), {"sd." + k: v for k, v in sd.items()}, f["grad"])
+
+
 @pytest.mark.parametrize("path", golden_files("diffpool"))
 def test_diffpool_matches_reference(path):
     f = load_golden(path)

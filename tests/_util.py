@@ -32,6 +32,17 @@ def load_golden(path):
             nested.setdefault(head, {})[rest] = val
         else:
             top[k] = val
+    for head, d in nested.items():                       # dicts stored packed (make_golden.py::save)
+        if "__names__" in d:
+            flat, off = d["__flat__"], 0
+            un = {k: v for k, v in d.items() if not k.startswith("__")}
+            for name, shape in zip(d["__names__"].tolist(), d["__shapes__"].tolist()):
+                shape = [n for n in shape if n >= 0]
+                n = int(np.prod(shape)) if shape else 1
+                un[str(name)] = flat[off:off + n].reshape(shape).clone()
+                off += n
+            assert off == flat.numel()
+            nested[head] = un
     top.update(nested)
     return top
 

@@ -195,10 +195,26 @@ def small_graph(gen, n_graphs=2, n=64, e=256, edge_dim=1, weights=False):
     return ei, ea, batch
 
 
+PACK_ABOVE = 200          # dicts with more entries than this (438 decoder blocks x 4 tensors) are stored packed
+
+
 def save(name, **arrays):
+    """One .npz per fixture.  A dict becomes ``key/sub`` entries; a large dict is packed into three arrays
+    (``key/__names__``, ``key/__shapes__`` [n, 4] padded with -1, ``key/__flat__`` float32) -- a zip member per tiny
+    tensor costs more than the tensor.  ``tests/_util.py::load_golden`` undoes both."""
     out = {}
     for k, v in arrays.items():
-        if isinstance(v, dict):
+        if isinstance(v, dict) and len(v) > PACK_ABOVE:
+            as_np = {n: (t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)) for n, t in v.items()}
+            for n, a in as_np.items():                    # e.g. BatchNorm's int64 num_batches_tracked: stored as is
+                if a.dtype != np.float32 or a.ndim > 4:
+                    out["%s/%s" % (k, n)] = a
+            names = sorted(n for n, a in as_np.items() if a.dtype == np.float32 and a.ndim <= 4)
+            arrs = [as_np[n] for n in names]
+            out[k + "/__names__"] = np.array(names)
+            out[k + "/__shapes__"] = np.array([list(a.shape) + [-1] * (4 - a.ndim) for a in arrs], dtype=np.int64)
+            out[k + "/__flat__"] = np.concatenate([a.reshape(-1) for a in arrs]) if arrs else np.zeros(0, np.float32)
+        elif isinstance(v, dict):
             for kk, vv in v.items():
                 out["%s/%s" % (k, kk)] = vv.detach().cpu().numpy() if torch.is_tensor(vv) else np.asarray(vv)
         else:

@@ -78,6 +78,25 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
     const int arow = min(row0 + r31, p.N - 1);                  // rows past N re-read the last row, never stored
     const uint4* ap = p.a + (size_t)arow * row_u4 + h;          // k-step s: ap[2 s]
 
+    // residual words of this lane's results (two bf16 per tile pair), requested before the k-loop so that they
+    // arrive under the MFMAs instead of serialising load -> add -> store per row in the epilogue
+    // (JT = 8 has no registers left for that -- 128 accumulators + 64 of operand ring -- and reads it in the epilogue)
+    constexpr int RP = JT >= 2 ? JT / 2 : 1;
+    constexpr bool kPrefetchRes = JT <= 4;
+    uint32_t resw[kPrefetchRes ? RP : 1][16];
+    if (kPrefetchRes && p.res) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * h, p.N - 1);
+        const size_t base = (size_t)row * p.J + j0;
+#pragma unroll
+        for (int u = 0; u < RP; ++u) {
+          if constexpr (JT == 1) resw[u][r] = p.res[base + r31];
+          else if constexpr (kPrefetchRes) resw[u][r] = *reinterpret_cast<const uint32_t*>(p.res + base + 64 * u + 2 * r31);
+        }
+      }
+    }
+
     f32x16 acc[JT];
 #pragma unroll
     for (int t = 0; t < JT; ++t)
@@ -112,7 +131,7 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
       const size_t base = (size_t)row * p.J + j0;
       if constexpr (JT == 1) {
         float v = acc[0][r] + bias[0];
-        if (p.res) v += bf16_to_f32(p.res[base + r31]);
+        if (p.res) v += bf16_to_f32((uint16_t)resw[0][r]);
         p.c[base + r31] = f32_to_bf16(v);
       } else {
 #pragma unroll
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
           float v0 = acc[2 * u][r] + bias[2 * u], v1 = acc[2 * u + 1][r] + bias[2 * u + 1];
           const size_t at = base + 64 * u + 2 * r31;
           if (p.res) {
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(p.res + at);
+            const uint32_t w = kPrefetchRes ? resw[kPrefetchRes ? u : 0][r] : *reinterpret_cast<const uint32_t*>(p.res + at);
             v0 += __builtin_bit_cast(float, w << 16);
             v1 += __builtin_bit_cast(float, w & 0xffff0000u);
           }

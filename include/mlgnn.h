@@ -114,6 +114,9 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
  *   ew_t [E] / [E,edge_rank], eid_t [E]: ew / eid permuted to by-source order
  *   grad_x   [N,d]
  *   grad_efull [E0,d]  EDGE_FULL: d loss / d efull, written at eid (every row written once)
+ *   accumulate_efull  non-zero: grad_efull += instead of = (the same [E0,d] embedding feeds several layers --
+ *                   deepergcn.py:232-281 passes one edge_emb to every GENConv -- and their edge gradients are
+ *                   summed in place instead of by separate [E0,d] additions)
  *   grad_uv  [edge_rank+1,d]  EDGE_RANK1: d loss / d eu (edge_rank rows), then d loss / d ev
  *   learn_t  non-zero: SOFTMAX weights carry gradient (torch_message.py:51-52)
  *   workspace: mlgnn_csr_aggregate_bwd_workspace_floats(N,d,dtype,edge_rank,aggr,learn_t) floats
@@ -128,7 +131,7 @@ int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out
                             float* workspace, int64_t workspace_floats,
                             int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                             int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev,
-                            float eps, int add_root, void* stream);
+                            float eps, int add_root, int accumulate_efull, void* stream);
 
 /*
  * Gene -> pathway learnable-projection pooling.

@@ -16,7 +16,7 @@ struct BwdArgs {                      // go / x / out / efull / gx / ge are T; a
   const void* gt; const int* spread;                        // softmax one-row path (see softmax_shift_kernel)
   const uint8_t* slot8;                                     // max: winner's slot inside its row, 1 byte (max_slot_kernel)
   const float* t_dev; const float* p_dev;
-  int N; int d; int lpr_log2; int mean; int learn_t; int add_root;
+  int N; int d; int lpr_log2; int mean; int learn_t; int add_root; int ge_accumulate;
   float t; float p; float eps;
 };
 
@@ -186,7 +186,16 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
                 for (int q = 0; q < RK; ++q) gu[i][q] = fmaf(wa[u][q], dz[i], gu[i][q]);
               }
             }
-            if (MODE == M_GEN_FULL && valid[u] && cact) store_t<T, VEC>(GE + (size_t)e0[u] * a.d + c0, dz);
+            if (MODE == M_GEN_FULL && valid[u] && cact) {
+              T* gep = GE + (size_t)e0[u] * a.d + c0;
+              if (a.ge_accumulate) {                 // this layer's share on top of the layers that ran before it
+                float prev[VEC];
+                load_t<T, VEC>(prev, gep);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) dz[i] += prev[i];
+              }
+              store_t<T, VEC>(gep, dz);
+            }
           }
         };
 
@@ -422,7 +431,8 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                                        float* workspace, int64_t workspace_floats,
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                                        int aggr, int learn_t, float t, float p, const float* t_dev,
-                                       const float* p_dev, float eps, int add_root, void* stream) {
+                                       const float* p_dev, float eps, int add_root, int accumulate_efull,
+                                       void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
@@ -456,6 +466,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   a.gx = grad_x; a.ge = grad_efull; a.ws = workspace;
   a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN); a.learn_t = learn_t;
   a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
+  a.ge_accumulate = accumulate_efull;
   if (add_root && learn_t) return MLGNN_E_MODE;       // `out` must be the bare aggregate for d/dt
 
   const bool al = aligned16(grad_out) && aligned16(grad_x) && (!x || aligned16(x)) &&

@@ -181,6 +181,43 @@ def padded_rank(r):
     return 1 if r <= 1 else 2 if r <= 2 else 4 if r <= 4 else 8
 
 
+class _GradSink:
+    """Accumulation buffer shared by the aggregation layers that consume one dense edge embedding."""
+
+    def __init__(self):
+        self.buf = None
+
+
+class _EdgeFanout(torch.autograd.Function):
+    """Identity on a dense ``[E, d]`` edge embedding that several aggregation layers read (the reference hands the
+    same ``edge_emb`` to every GENConv, deepergcn.py:232-281).  Its consumers add their edge gradients into ONE buffer
+    inside their backward kernels (``accumulate_efull``) and report no gradient of their own; this node hands the
+    buffer on.  Autograd would otherwise sum L tensors of E*d elements with L-1 separate passes (measured at BASELINE
+    configs[1] size, 3 layers: 5 ms of a 33 ms step)."""
+
+    @staticmethod
+    def forward(ctx, e):
+        ctx.sink = _GradSink()
+        ctx.set_materialize_grads(False)
+        return e.view_as(e)
+
+    @staticmethod
+    def backward(ctx, g):
+        total, ctx.sink.buf = ctx.sink.buf, None
+        if g is not None:                       # a consumer outside the aggregation kernels contributed as well
+            total = g if total is None else total + g
+        return total
+
+
+def share_edge_gradient(e):
+    """Mark a dense edge embedding as shared by several :func:`gen_aggregate` calls (see :class:`_EdgeFanout`)."""
+    if not (torch.is_tensor(e) and e.dim() == 2 and e.requires_grad and torch.is_grad_enabled()):
+        return e
+    out = _EdgeFanout.apply(e)
+    out._mlgnn_grad_sink = out.grad_fn.sink
+    return out
+
+
 class _GenAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t, p, eps, learn_t, learn_p, add_root):
@@ -191,6 +228,7 @@ class _GenAggregate(torch.autograd.Function):
             raise ValueError("graph/feature size mismatch")
         edge_mode = EDGE_RANK1 if eu is not None else (EDGE_FULL if efull is not None else EDGE_NONE)
         ctx.uv_dtype = eu.dtype if eu is not None else None
+        ctx.grad_sink = getattr(efull, "_mlgnn_grad_sink", None) if efull is not None else None
         eu = _dev_f32(eu.float(), "eu") if eu is not None else None       # edge vectors stay fp32 in the kernel
         ev = _dev_f32(ev.float(), "ev") if ev is not None else None
         efull = _dev_act(efull, "efull", like=x)
@@ -260,7 +298,14 @@ class _GenAggregate(torch.autograd.Function):
         if aggr_id == AGGR_SOFTMAX and learn_t:
             grad_t = (go.float() * (aux2 - out.float() * out.float())).sum().reshape(1).to(t_dev.dtype)
         gx = torch.empty_like(x)
-        ge = torch.empty_like(efull) if edge_mode == EDGE_FULL else None
+        ge, ge_accumulate, sink = None, 0, ctx.grad_sink
+        if edge_mode == EDGE_FULL:
+            if sink is not None and sink.buf is not None:
+                ge, ge_accumulate = sink.buf, 1              # add this layer's share to the layers that ran before
+            else:
+                ge = torch.empty_like(efull)
+                if sink is not None:
+                    sink.buf = ge
         guv = ws = None
         ws_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_workspace_floats(N, d, dtype_id, rank, aggr_id, int(learn_t)))
         if ws_n < 0:
@@ -278,8 +323,10 @@ class _GenAggregate(torch.autograd.Function):
             _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), g.eid_t.data_ptr(),
             gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
             N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, int(learn_t), t, p,
-            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), _stream())
+            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), ge_accumulate, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
+        if sink is not None:
+            ge = None                                        # reported once, by the _EdgeFanout node
         if timer is not None:
             timer.stop("csr_aggregate_bwd/%s/%s" % (_AGGR_NAMES[aggr_id], _edge_name(edge_mode, rank)), t0,
                        algorithmic_bytes(N, g.num_edges, d, aggr_id, edge_mode, backward=True, learn_t=learn_t,
@@ -354,7 +401,7 @@ class _WeightedAggregate(torch.autograd.Function):
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
             g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, gx.data_ptr(), None, None, None, 0,
-            N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, 0, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, _stream())
+            N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, 0, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, 0, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         return gx, None, None, None
 

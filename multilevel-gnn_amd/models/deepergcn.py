@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from mlgnn import CSRGraph, LowRankEdge
+from mlgnn import share_edge_gradient
 from mlgnn.dense import linear
 from mlgnn.norm import layer_norm_act, layer_norm_act_fork
 from mlgnn.pool import global_pool
@@ -118,10 +119,15 @@ class DeeperGCN(torch.nn.Module):
         if not self.use_edge_attr:
             return None
         if self.global_edge == "onehot":
-            return self.edge_encoder(edge_attr.to(torch.long))               # [E, 1, H]
-        if edge_attr.dim() == 2 and 1 <= edge_attr.shape[1] <= LowRankEdge.MAX_RANK:
+            emb = self.edge_encoder(edge_attr.to(torch.long)).flatten(1)     # [E, 1, H] -> [E, H]
+        elif edge_attr.dim() == 2 and 1 <= edge_attr.shape[1] <= LowRankEdge.MAX_RANK:
             return LowRankEdge(edge_attr, self.edge_encoder.weight, self.edge_encoder.bias)
-        return self.edge_encoder(edge_attr)
+        else:
+            emb = self.edge_encoder(edge_attr).flatten(1)
+        # one dense embedding read by every layer: without per-layer edge encoders the layers' [E, H] edge gradients
+        # meet in one buffer inside the backward kernels instead of in L-1 separate additions
+        shared = self.num_layers > 1 and not any(getattr(g, "encode_edge", False) for g in self.gcns)
+        return share_edge_gradient(emb) if shared else emb
 
     def _pathway_rows(self, node_size):
         """Row indices of the last ``pathway_num`` nodes of every graph, [B * pathway_num]."""

@@ -54,7 +54,8 @@ class GENConv(GenMessagePassing):
                 if self.encode_edge else edge_attr
         elif edge_attr is not None:
             edge = self.edge_encoder(edge_attr) if self.encode_edge else edge_attr
-            edge = edge.flatten(1)
+            if edge.dim() != 2:                   # (a 2-D embedding is passed on as the object it is: it may carry the
+                edge = edge.flatten(1)            #  shared-gradient tag of mlgnn.share_edge_gradient)
         else:
             edge = None
         flat = x.flatten(1)

@@ -288,3 +288,37 @@ def test_max_backward_winner_slots_and_their_fallback(deg, d):
     got = torch.autograd.grad((out * cot.to(dev)).sum(), [xd, ud, vd])
     for name, g, r in zip(("x", "u", "v"), got, ref_g):
         assert_close(g, r, TOL, "max grad %s (deg %d)" % (name, deg))
+
+
+@pytest.mark.parametrize("aggr", ["softmax", "max", "mean"])
+def test_shared_edge_embedding_gradient_is_accumulated_in_the_kernels(aggr):
+    """Three aggregation layers reading ONE dense [E, d] edge embedding (the reference's default DeeperGCN wiring):
+    with ``share_edge_gradient`` the layers add their edge gradients into one buffer inside the backward kernels;
+    the result must equal autograd's own sum of the three tensors (up to the order of the four additions), and a
+    consumer outside the kernels must still be counted."""
+    from mlgnn import CSRGraph, gen_aggregate, share_edge_gradient
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(17)
+    N, E, d = 500, 7000, 64
+    ei = _graph(gen, N, E, hub=True).to(dev)
+    g = CSRGraph(ei, N)
+    x0 = torch.randn(N, d, generator=gen).to(dev)
+    e0 = (torch.randn(E, d, generator=gen) * 0.5).to(dev)
+    cot = torch.randn(N, d, generator=gen).to(dev)
+
+    def run(shared):
+        x = x0.clone().requires_grad_(True)
+        e = e0.clone().requires_grad_(True)
+        ee = share_edge_gradient(e * 1.0) if shared else e * 1.0
+        h = x
+        for _ in range(3):
+            h = gen_aggregate(h, g, ee, aggr=aggr) * 0.5
+        loss = (h * cot).sum() + (ee * 0.25).sum()           # the last term: a plain autograd consumer of the tag
+        gx, ge = torch.autograd.grad(loss, [x, e])
+        return h.detach(), gx, ge
+
+    ref, got = run(False), run(True)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    assert_close(got[2], ref[2], 1e-6, "grad edge embedding")
+    again = run(True)                                        # the sink is emptied by the backward: reusable
+    assert torch.equal(again[2], got[2])

@@ -336,6 +336,16 @@ int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const vo
                       const float* row_max, int ln_mode, const float* gamma, const float* beta, float ln_eps,
                       float* rstd_out, float* row_max_out, void* c, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
 
+/*
+ * Gradient of an embedding lookup e = table[idx] for a dense cotangent:
+ *   grad_table[t,:] = sum_{e: idx[e] = t} grad_e[e,:]       (grad_e [E,d], grad_table [T,d], fp32, d % 4 == 0)
+ * Replaces: the autograd of DeeperGCN's edge-type embedding, nn.Embedding(pathway_edge_num, hidden) applied to every
+ * edge (models/deepergcn.py:103-104,189-190,213).  perm [E] int32: the edge ids sorted (stably) by idx;
+ * rowptr [T+1] int32: row t owns perm[rowptr[t] .. rowptr[t+1]).  Deterministic (fixed summation order per row).
+ */
+int mlgnn_embedding_bwd(const float* grad_e, const int32_t* perm, const int32_t* rowptr, float* grad_table,
+                        int64_t T, int64_t d, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

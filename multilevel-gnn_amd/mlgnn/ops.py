@@ -181,6 +181,42 @@ def padded_rank(r):
     return 1 if r <= 1 else 2 if r <= 2 else 4 if r <= 4 else 8
 
 
+class _EdgeTypeEmbedding(torch.autograd.Function):
+    """``table[idx]`` for the per-edge type embedding of DeeperGCN (deepergcn.py:103-104,213) with the gradient
+    ``grad_table[t] = sum_{e: idx[e] = t} grad_e[e]`` on ``csrc/embedding.hip``: the edge ids are sorted by type once
+    (stable), then every table row gathers and sums its cotangent rows in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = table.shape[0]
+        return table.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, ge):
+        (idx,) = ctx.saved_tensors
+        T, d = ctx.rows, ge.shape[1]
+        ge = ge.contiguous()
+        order = torch.sort(idx, stable=True)[1].to(torch.int32)
+        rowptr = torch.zeros(T + 1, dtype=torch.int64, device=idx.device)
+        torch.cumsum(torch.bincount(idx, minlength=T), 0, out=rowptr[1:])
+        rowptr = rowptr.to(torch.int32)
+        out = torch.empty((T, d), dtype=torch.float32, device=ge.device)
+        rc = _lib.lib.mlgnn_embedding_bwd(ge.data_ptr(), order.data_ptr(), rowptr.data_ptr(), out.data_ptr(), T, d,
+                                          DTYPE_F32, _stream())
+        _lib.check(rc, "mlgnn_embedding_bwd")
+        return out, None
+
+
+def edge_type_embedding(table, idx):
+    """``nn.Embedding`` forward for a 1-D long ``idx`` with a deterministic, gather-speed backward; ATen's
+    ``F.embedding`` for anything the kernel does not cover (non-fp32, d % 4 != 0, CPU tensors)."""
+    if (table.is_cuda and table.dtype == torch.float32 and table.dim() == 2 and table.shape[1] % 4 == 0
+            and idx.dim() == 1 and idx.dtype == torch.long and idx.numel() < 2 ** 31):
+        return _EdgeTypeEmbedding.apply(table, idx)
+    return torch.nn.functional.embedding(idx, table)
+
+
 class _GradSink:
     """Accumulation buffer shared by the aggregation layers that consume one dense edge embedding."""
 

@@ -114,6 +114,10 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
  *   ew_t [E] / [E,edge_rank], eid_t [E]: ew / eid permuted to by-source order
  *   grad_x   [N,d]
  *   grad_efull [E0,d]  EDGE_FULL: d loss / d efull, written at eid (every row written once)
+ *   geid_t [E] or NULL  row of grad_efull each edge writes when it differs from the row of efull it reads: efull may be
+ *                   a TABLE read through eid (several edges per row, e.g. one row per edge type, deepergcn.py:103-104)
+ *                   while the gradient is still produced per edge ([E,d], geid_t = the edge's own id) and reduced to
+ *                   the table afterwards (mlgnn_embedding_bwd); NULL: geid_t = eid_t
  *   accumulate_efull  non-zero: grad_efull += instead of = (the same [E0,d] embedding feeds several layers --
  *                   deepergcn.py:232-281 passes one edge_emb to every GENConv -- and their edge gradients are
  *                   summed in place instead of by separate [E0,d] additions)
@@ -126,7 +130,7 @@ int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out
                             const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
                             const int32_t* rowptr,
                             const float* ew_t, const float* eu, const float* ev,
-                            const void* efull, const int32_t* eid_t,
+                            const void* efull, const int32_t* eid_t, const int32_t* geid_t,
                             void* grad_x, void* grad_efull, float* grad_uv,
                             float* workspace, int64_t workspace_floats,
                             int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,

@@ -12,6 +12,7 @@ struct BwdArgs {                      // go / x / out / efull / gx / ge are T; a
   const void* go; const void* x; const void* out; const float* aux; const int* argmax;
   const int* rowptr_t; const int* col_t; const int* pos_t; const int* rowptr;
   const float* ew_t; const float* eu; const float* ev; const void* efull; const int* eid_t;
+  const int* geid_t;                                        // row of grad_efull per edge (NULL: eid_t)
   void* gx; void* ge; float* ws;
   const void* gt; const int* spread;                        // softmax one-row path (see softmax_shift_kernel)
   const uint8_t* slot8;                                     // max: winner's slot inside its row, 1 byte (max_slot_kernel)
@@ -102,7 +103,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
       for (int base = beg; base < end; base += kWave) {
         const int cnt = min(kWave, end - base);
         uint32_t my_off = 0;
-        int my_pos = 0, my_eid = 0;
+        int my_pos = 0, my_eid = 0, my_gid = 0;
         float my_ew[ESA], my_inv = 1.f;
 #pragma unroll
         for (int k = 0; k < ESA; ++k) my_ew[k] = 0.f;
@@ -113,7 +114,10 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
           if constexpr (ES > 0) {
             load_edge_scalars<ES>(my_ew, a.ew_t, (size_t)(base + lane));
           }
-          if (MODE == M_GEN_FULL) my_eid = a.eid_t[base + lane];
+          if (MODE == M_GEN_FULL) {
+            my_eid = a.eid_t[base + lane];
+            my_gid = a.geid_t ? a.geid_t[base + lane] : my_eid;
+          }
           if (AGGR == A_SUM && a.mean)
             my_inv = __builtin_amdgcn_rcpf((float)max(a.rowptr[dst + 1] - a.rowptr[dst], 1));
         }
@@ -123,7 +127,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
           float ga[kUnroll][VEC], gb[kUnroll][VEC], gc[kUnroll][VEC], ef[kUnroll][VEC];
           int ai[kUnroll][VEC];
           float wa[kUnroll][ESA], inv[kUnroll];
-          int pos[kUnroll], e0[kUnroll];
+          int pos[kUnroll], e0[kUnroll], g0[kUnroll];
           bool valid[kUnroll];
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) {
@@ -136,6 +140,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
             inv[u] = (AGGR == A_SUM) ? __shfl(my_inv, src) : 1.f;
             pos[u] = (AGGR == A_MAX) ? __shfl(my_pos, src) : 0;
             e0[u] = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
+            g0[u] = (MODE == M_GEN_FULL) ? __shfl(my_gid, src) : 0;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { ga[u][i] = 0.f; gb[u][i] = 0.f; gc[u][i] = 0.f; ef[u][i] = 0.f; ai[u][i] = -2; }
             if (FULL || valid[u]) {
@@ -187,7 +192,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
               }
             }
             if (MODE == M_GEN_FULL && valid[u] && cact) {
-              T* gep = GE + (size_t)e0[u] * a.d + c0;
+              T* gep = GE + (size_t)g0[u] * a.d + c0;
               if (a.ge_accumulate) {                 // this layer's share on top of the layers that ran before it
                 float prev[VEC];
                 load_t<T, VEC>(prev, gep);
@@ -426,7 +431,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                                        const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
                                        const int32_t* rowptr,
                                        const float* ew_t, const float* eu, const float* ev,
-                                       const void* efull, const int32_t* eid_t,
+                                       const void* efull, const int32_t* eid_t, const int32_t* geid_t,
                                        void* grad_x, void* grad_efull, float* grad_uv,
                                        float* workspace, int64_t workspace_floats,
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
@@ -462,7 +467,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   BwdArgs a;
   a.go = grad_out; a.x = x; a.out = out; a.aux = aux;
   a.argmax = argmax; a.rowptr_t = rowptr_t; a.col_t = col_t; a.pos_t = pos_t; a.rowptr = rowptr;
-  a.ew_t = ew_t; a.eu = eu; a.ev = ev; a.efull = efull; a.eid_t = eid_t;
+  a.ew_t = ew_t; a.eu = eu; a.ev = ev; a.efull = efull; a.eid_t = eid_t; a.geid_t = geid_t;
   a.gx = grad_x; a.ge = grad_efull; a.ws = workspace;
   a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN); a.learn_t = learn_t;
   a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;

@@ -16,7 +16,7 @@ SIGNATURES = {
     "mlgnn_csr_aggregate_bwd_workspace_floats": (_I64, [_I64, _I64, _INT, _INT, _INT, _INT]),
     "mlgnn_csr_aggregate_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                        _I64, _I64, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _P]),
-    "mlgnn_csr_aggregate_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "mlgnn_csr_aggregate_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                        _P, _P, _P, _P, _I64,
                                        _I64, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _INT, _P]),
     "mlgnn_embedding_bwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _INT, _P]),

@@ -245,6 +245,78 @@ class _EdgeFanout(torch.autograd.Function):
         return total
 
 
+class _TableFanout(torch.autograd.Function):
+    """Identity on the ``[T, d]`` table of a :class:`TableEdge`.  The aggregation layers that read it produce their
+    edge gradient per EDGE (``[E, d]``, accumulated across layers in ``sink.buf`` inside the backward kernels); this
+    node reduces it to the table once, ``grad_table[t] = sum_{e: idx[e] = t}`` (``csrc/embedding.hip``)."""
+
+    @staticmethod
+    def forward(ctx, table, owner):
+        ctx.sink, ctx.owner = _GradSink(), owner
+        ctx.set_materialize_grads(False)
+        return table.view_as(table)
+
+    @staticmethod
+    def backward(ctx, g):
+        per_edge, ctx.sink.buf = ctx.sink.buf, None
+        total = None
+        if per_edge is not None:
+            order, rowptr = ctx.owner.sorted_by_type()
+            T, d = ctx.owner.table_rows, per_edge.shape[1]
+            total = torch.empty((T, d), dtype=torch.float32, device=per_edge.device)
+            rc = _lib.lib.mlgnn_embedding_bwd(per_edge.data_ptr(), order.data_ptr(), rowptr.data_ptr(),
+                                              total.data_ptr(), T, d, DTYPE_F32, _stream())
+            _lib.check(rc, "mlgnn_embedding_bwd")
+        if g is not None:
+            total = g if total is None else total + g
+        return total, None
+
+
+class TableEdge:
+    """Edge embedding read through a table: ``e_ij = table[idx_ij]`` -- ``table`` ``[T, d]``, ``idx`` ``[E]`` long in
+    COO order.  This is DeeperGCN's default edge term (``global_edge='onehot'``: ``nn.Embedding(pathway_edge_num, H)``
+    applied to every edge, deepergcn.py:103-104,189-190,213): the ``[E, H]`` embedding is never materialised, the
+    aggregation kernels read the (cache-resident) table row of every edge, and the per-edge gradient the backward
+    kernels produce is reduced to the table once for all layers that share it.  ``through_linear`` composes with a
+    per-layer ``Linear(H, d)`` edge encoder (torch_vertex.py:68,77) as a ``[T, H] x [H, d]`` product."""
+
+    def __init__(self, table, idx):
+        if table.dim() != 2 or idx.dim() != 1 or idx.dtype != torch.long:
+            raise ValueError("TableEdge takes table [T, d] and idx [E] (long)")
+        self.idx = idx
+        self.table_rows = table.shape[0]
+        self.sink = None
+        if table.requires_grad and torch.is_grad_enabled() and table.is_cuda and table.dtype == torch.float32:
+            table = _TableFanout.apply(table, self)
+            self.sink = table.grad_fn.sink
+        self.table = table
+        self._by_graph = {}
+        self._sorted = None
+
+    def through_linear(self, W, b):
+        return TableEdge(torch.nn.functional.linear(self.table, W, b), self.idx)
+
+    def dense(self):
+        return self.table.index_select(0, self.idx)
+
+    def rows_for(self, graph):
+        """Table row per edge in by-destination and by-source order (int32), cached per graph."""
+        key = id(graph)
+        if key not in self._by_graph:
+            i32 = self.idx.to(torch.int32)
+            self._by_graph[key] = (i32[graph.eid.long()].contiguous(), i32[graph.eid_t.long()].contiguous())
+        return self._by_graph[key]
+
+    def sorted_by_type(self):
+        """Edge ids sorted (stably) by table row, and the row pointer over them (int32); once per batch."""
+        if self._sorted is None:
+            order = torch.sort(self.idx, stable=True)[1].to(torch.int32)
+            rowptr = torch.zeros(self.table_rows + 1, dtype=torch.int64, device=self.idx.device)
+            torch.cumsum(torch.bincount(self.idx, minlength=self.table_rows), 0, out=rowptr[1:])
+            self._sorted = (order, rowptr.to(torch.int32))
+        return self._sorted
+
+
 def share_edge_gradient(e):
     """Mark a dense edge embedding as shared by several :func:`gen_aggregate` calls (see :class:`_EdgeFanout`)."""
     if not (torch.is_tensor(e) and e.dim() == 2 and e.requires_grad and torch.is_grad_enabled()):
@@ -256,7 +328,8 @@ def share_edge_gradient(e):
 
 class _GenAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t, p, eps, learn_t, learn_p, add_root):
+    def forward(ctx, x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t, p, eps, learn_t, learn_p, add_root,
+                table_edge=None):
         x = _dev_act(x, "x")
         dtype_id = _DTYPE_IDS[x.dtype]
         N, d = x.shape
@@ -265,11 +338,18 @@ class _GenAggregate(torch.autograd.Function):
         edge_mode = EDGE_RANK1 if eu is not None else (EDGE_FULL if efull is not None else EDGE_NONE)
         ctx.uv_dtype = eu.dtype if eu is not None else None
         ctx.grad_sink = getattr(efull, "_mlgnn_grad_sink", None) if efull is not None else None
+        ctx.table_edge = table_edge
+        eid_fwd = graph.eid
+        if table_edge is not None:                      # efull is the table; every edge names its row
+            eid_fwd = table_edge.rows_for(graph)[0]
+            ctx.grad_sink = table_edge.sink
         eu = _dev_f32(eu.float(), "eu") if eu is not None else None       # edge vectors stay fp32 in the kernel
         ev = _dev_f32(ev.float(), "ev") if ev is not None else None
         efull = _dev_act(efull, "efull", like=x)
-        if efull is not None and tuple(efull.shape) != (graph.num_edges, d):
+        if efull is not None and table_edge is None and tuple(efull.shape) != (graph.num_edges, d):
             raise ValueError("edge embedding must be [E, d]")
+        if table_edge is not None and (efull.shape[1] != d or table_edge.idx.numel() != graph.num_edges):
+            raise ValueError("table edge term must be table [T, d] with one row index per edge")
         rank = 0
         if eu is not None:
             if eu.dim() != 2 or eu.shape[1] != d or ev.numel() != d:
@@ -298,7 +378,7 @@ class _GenAggregate(torch.autograd.Function):
         rowmax = torch.empty(N, **f32) if (x.dtype == torch.float32 and d in (4, 8, 16, 32, 64, 128, 256)) else None
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), _lib.ptr(eu), _lib.ptr(ev),
-            _lib.ptr(efull), graph.eid.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),
+            _lib.ptr(efull), eid_fwd.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),
             _lib.ptr(argmax), _lib.ptr(rowmax), N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, float(t), float(p),
             _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), int(add_root), _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
@@ -334,14 +414,20 @@ class _GenAggregate(torch.autograd.Function):
         if aggr_id == AGGR_SOFTMAX and learn_t:
             grad_t = (go.float() * (aux2 - out.float() * out.float())).sum().reshape(1).to(t_dev.dtype)
         gx = torch.empty_like(x)
-        ge, ge_accumulate, sink = None, 0, ctx.grad_sink
-        if edge_mode == EDGE_FULL:
+        ge, ge_accumulate, sink, te = None, 0, ctx.grad_sink, ctx.table_edge
+        eid_t, geid_t = g.eid_t, None
+        if te is not None:                                   # read the table row, write the edge's own gradient row
+            eid_t, geid_t = te.rows_for(g)[1], g.eid_t
+        if edge_mode == EDGE_FULL and (te is None or sink is not None):
             if sink is not None and sink.buf is not None:
                 ge, ge_accumulate = sink.buf, 1              # add this layer's share to the layers that ran before
             else:
-                ge = torch.empty_like(efull)
+                ge = torch.empty_like(efull) if te is None else torch.empty((g.num_edges, d), dtype=efull.dtype,
+                                                                            device=efull.device)
                 if sink is not None:
                     sink.buf = ge
+        elif edge_mode == EDGE_FULL:                         # a table without gradient: scratch row space
+            ge = torch.empty((g.num_edges, d), dtype=efull.dtype, device=efull.device)
         guv = ws = None
         ws_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_workspace_floats(N, d, dtype_id, rank, aggr_id, int(learn_t)))
         if ws_n < 0:
@@ -356,20 +442,20 @@ class _GenAggregate(torch.autograd.Function):
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go_k.data_ptr(), x.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(argmax),
             g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(), g.rowptr.data_ptr(),
-            _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), g.eid_t.data_ptr(),
+            _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), eid_t.data_ptr(), _lib.ptr(geid_t),
             gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
             N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, int(learn_t), t, p,
             _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), ge_accumulate, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
-        if sink is not None:
-            ge = None                                        # reported once, by the _EdgeFanout node
+        if sink is not None or te is not None:
+            ge = None                                        # reported once, by the fan-out node of the shared term
         if timer is not None:
             timer.stop("csr_aggregate_bwd/%s/%s" % (_AGGR_NAMES[aggr_id], _edge_name(edge_mode, rank)), t0,
                        algorithmic_bytes(N, g.num_edges, d, aggr_id, edge_mode, backward=True, learn_t=learn_t,
                                          s=x.element_size(), rank=max(rank, 1)))
         geu = guv[:ctx.uv_rows].to(ctx.uv_dtype) if guv is not None else None
         gev = guv[rank].to(ctx.uv_dtype) if guv is not None else None
-        return gx, geu, gev, ge, grad_t, grad_p, None, None, None, None, None, None, None, None, None
+        return gx, geu, gev, ge, grad_t, grad_p, None, None, None, None, None, None, None, None, None, None
 
 
 def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, learn_t=False, learn_p=False,
@@ -377,7 +463,8 @@ def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, l
     """``aggregate(relu(x_j + e_ij) + eps)`` over incoming edges -- GENConv.message + aggregate
     (torch_vertex.py:94-101, torch_message.py:44-85) in one kernel.
 
-    ``edge``: ``None`` | :class:`LowRankEdge` / :class:`RankOneEdge` (already composed to width d) | ``[E, d]`` tensor (COO order).
+    ``edge``: ``None`` | :class:`LowRankEdge` / :class:`RankOneEdge` (already composed to width d) |
+    :class:`TableEdge` (a row of a ``[T, d]`` table per edge) | ``[E, d]`` tensor (COO order).
     ``t``/``p``: float, or the 1-element parameter when ``learn_t``/``learn_p``.
     ``*_sum`` variants return the un-scaled value; the caller applies ``deg ** sigmoid(y)``.
     ``add_root``: return ``x + aggregate`` from the same pass (GENConv's ``h = x + m``); ignored
@@ -386,13 +473,19 @@ def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, l
     if not isinstance(graph, CSRGraph):
         raise TypeError("graph must be a CSRGraph")
     aggr_id = AGGR_IDS[aggr]
-    eu = ev = efull = ew_pair = None
+    eu = ev = efull = ew_pair = table_edge = None
+    if isinstance(edge, TableEdge):
+        if not (x.is_cuda and edge.table.dtype == x.dtype == torch.float32):
+            edge = edge.dense()                          # (bf16 / CPU: the materialised embedding)
+        else:
+            table_edge, efull = edge, edge.table
+            edge = None
     if isinstance(edge, LowRankEdge):
         if edge.weight.shape[0] != x.shape[1]:
             raise ValueError("factored edge term has width %d, features have %d" % (edge.weight.shape[0], x.shape[1]))
         eu, ev = edge.weight.t(), edge.bias                           # [r, d], [d]
         ew_pair = graph.edge_table(edge.a, padded_rank(edge.rank))
-    elif edge is not None:
+    elif edge is not None and table_edge is None:
         efull = edge
     t_par = t if torch.is_tensor(t) else None
     p_par = p if torch.is_tensor(p) else None
@@ -401,7 +494,7 @@ def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, l
     lt, lp = bool(learn_t) and t_par is not None, bool(learn_p) and p_par is not None
     fuse_root = bool(add_root) and not lt and not lp and aggr_id != AGGR_POWER
     out = _GenAggregate.apply(x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t_val, p_val, eps,
-                              lt, lp, fuse_root)
+                              lt, lp, fuse_root, table_edge)
     if add_root and not fuse_root:
         return out + x
     rm = getattr(out.grad_fn, "rowmax", None) if out.grad_fn is not None else None
@@ -436,7 +529,7 @@ class _WeightedAggregate(torch.autograd.Function):
         ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
-            g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, gx.data_ptr(), None, None, None, 0,
+            g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, None, gx.data_ptr(), None, None, None, 0,
             N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, 0, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, 0, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         return gx, None, None, None

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from mlgnn import CSRGraph, LowRankEdge
-from mlgnn import edge_type_embedding, share_edge_gradient
+from mlgnn import TableEdge, share_edge_gradient
 from mlgnn.dense import linear
 from mlgnn.norm import layer_norm_act, layer_norm_act_fork
 from mlgnn.pool import global_pool
@@ -120,11 +120,12 @@ class DeeperGCN(torch.nn.Module):
             return None
         if self.global_edge == "onehot":
             idx = edge_attr.to(torch.long)
-            if idx.dim() == 2 and idx.shape[1] == 1 and self.edge_encoder.padding_idx is None \
-                    and self.edge_encoder.max_norm is None:
-                emb = edge_type_embedding(self.edge_encoder.weight, idx[:, 0])       # [E, H] (= [E, 1, H] flattened)
-            else:
-                emb = self.edge_encoder(idx).flatten(1)
+            enc = self.edge_encoder
+            if (idx.dim() == 2 and idx.shape[1] == 1 and enc.padding_idx is None and enc.max_norm is None
+                    and enc.weight.is_cuda and enc.weight.dtype == torch.float32):
+                # [E, 1, H] flattened = table[idx]: kept as (table, row per edge); the kernels read the table rows
+                return TableEdge(enc.weight, idx[:, 0])
+            emb = enc(idx).flatten(1)
         elif edge_attr.dim() == 2 and 1 <= edge_attr.shape[1] <= LowRankEdge.MAX_RANK:
             return LowRankEdge(edge_attr, self.edge_encoder.weight, self.edge_encoder.bias)
         else:

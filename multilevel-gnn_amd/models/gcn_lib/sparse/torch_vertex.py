@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from mlgnn import LowRankEdge, as_graph, weighted_mean_aggregate
+from mlgnn import LowRankEdge, TableEdge, as_graph, weighted_mean_aggregate
 from mlgnn.dense import linear
 from mlgnn.graph import sage_graph
 from mlgnn.norm import msg_norm_add
@@ -44,12 +44,13 @@ class GENConv(GenMessagePassing):
     def forward(self, x, edge_index, edge_attr=None, residual=None):
         """``edge_index``: COO ``[2, E]`` or a prebuilt :class:`mlgnn.CSRGraph`.
         ``residual``: added to the result inside the last Linear's epilogue (the caller's ``conv(...) + h``).
-        ``edge_attr``: ``[E, d_e]`` tensor, or a :class:`mlgnn.LowRankEdge` (raw attributes
-        kept factored through the Linear encoders: no ``[E, d]`` tensor, no edge GEMM)."""
+        ``edge_attr``: ``[E, d_e]`` tensor, a :class:`mlgnn.LowRankEdge` (raw attributes kept factored
+        through the Linear encoders: no ``[E, d]`` tensor, no edge GEMM) or a :class:`mlgnn.TableEdge`
+        (one row of a small table per edge: the edge-type embedding)."""
         if self.pca_only:
             return self.feature_encoder(x)
         graph = as_graph(edge_index, x.shape[0])
-        if isinstance(edge_attr, LowRankEdge):
+        if isinstance(edge_attr, (LowRankEdge, TableEdge)):
             edge = edge_attr.through_linear(self.edge_encoder.weight, self.edge_encoder.bias) \
                 if self.encode_edge else edge_attr
         elif edge_attr is not None:

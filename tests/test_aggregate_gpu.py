@@ -344,3 +344,48 @@ def test_edge_type_embedding_backward(E, T, d):
     assert_close(g1, tr.grad, TOL, "embedding grad")
     g2, = torch.autograd.grad((edge_type_embedding(td, idx.cuda()) * cot.cuda()).sum(), td)
     assert torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("aggr", ["softmax", "max", "mean", "power"])
+@pytest.mark.parametrize("layers,encode", [(1, False), (3, False), (2, True)])
+def test_table_edge_matches_the_materialised_embedding(aggr, layers, encode):
+    """``TableEdge(table, idx)`` (the edge-type embedding kept as table + row index) against the same layers fed with
+    the materialised ``table[idx]`` through the CPU oracle: outputs, grad x, grad table (reduced once for all layers
+    that share the table) and, with a per-layer Linear on the table, its weight gradients."""
+    from mlgnn import CSRGraph, TableEdge, gen_aggregate
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(layers * 7 + len(aggr))
+    N, E, d, T = 400, 6000, 64, 50
+    ei = _graph(gen, N, E, hub=True)
+    x0 = torch.randn(N, d, generator=gen)
+    table0 = torch.randn(T, d, generator=gen) * 0.5
+    idx = torch.randint(0, T - 3, (E,), generator=gen)                 # the last three table rows: no edge at all
+    Ws = [torch.randn(d, d, generator=gen) * d ** -0.5 for _ in range(layers)]
+    cot = torch.randn(N, d, generator=gen)
+
+    x, table = x0.clone().requires_grad_(True), table0.clone().requires_grad_(True)
+    Wr = [w.clone().requires_grad_(True) for w in Ws]
+    h = x
+    for l in range(layers):
+        tl = table @ Wr[l].t() if encode else table
+        msg = torch.relu(h[ei[0]] + tl[idx]) + 1e-7
+        h = G.gen_aggregate(msg, ei[1], N, aggr, t=1.0, p=2.0) * 0.5
+    ref_g = torch.autograd.grad((h * cot).sum(), [x, table] + (Wr if encode else []))
+    ref = h.detach()
+
+    xd, td = x0.to(dev).requires_grad_(True), table0.to(dev).requires_grad_(True)
+    Wd = [w.to(dev).requires_grad_(True) for w in Ws]
+    graph = CSRGraph(ei.to(dev), N)
+    te = TableEdge(td, idx.to(dev))
+    hd = xd
+    for l in range(layers):
+        hd = gen_aggregate(hd, graph, te.through_linear(Wd[l], None) if encode else te, aggr=aggr, t=1.0, p=2.0) * 0.5
+    assert_close(hd, ref, TOL, "table edge fwd")
+    got = torch.autograd.grad((hd * cot.to(dev)).sum(), [xd, td] + (Wd if encode else []))
+    for name, a, b in zip(["x", "table"] + ["W%d" % l for l in range(layers)], got, ref_g):
+        assert_close(a, b, TOL, "table edge grad " + name)
+    assert not bool(got[1][T - 3:].any())
+    with torch.no_grad():                                              # no gradient wanted: plain table, no fan-out
+        out = gen_aggregate(xd, graph, TableEdge(td.detach(), idx.to(dev)), aggr=aggr, t=1.0, p=2.0)
+    first = G.gen_aggregate(torch.relu(x0[ei[0]] + table0[idx]) + 1e-7, ei[1], N, aggr, t=1.0, p=2.0)
+    assert_close(out, first, TOL, "table edge, inference")

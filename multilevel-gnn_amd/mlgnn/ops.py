@@ -222,6 +222,7 @@ class _GradSink:
 
     def __init__(self):
         self.buf = None
+        self.graph = None          # TableEdge: the graph whose by-source edge order the rows of buf follow
 
 
 class _EdgeFanout(torch.autograd.Function):
@@ -261,7 +262,7 @@ class _TableFanout(torch.autograd.Function):
         per_edge, ctx.sink.buf = ctx.sink.buf, None
         total = None
         if per_edge is not None:
-            order, rowptr = ctx.owner.sorted_by_type()
+            order, rowptr = ctx.owner.sorted_by_type(ctx.sink.graph)
             T, d = ctx.owner.table_rows, per_edge.shape[1]
             total = torch.empty((T, d), dtype=torch.float32, device=per_edge.device)
             rc = _lib.lib.mlgnn_embedding_bwd(per_edge.data_ptr(), order.data_ptr(), rowptr.data_ptr(),
@@ -300,21 +301,26 @@ class TableEdge:
         return self.table.index_select(0, self.idx)
 
     def rows_for(self, graph):
-        """Table row per edge in by-destination and by-source order (int32), cached per graph."""
+        """``(table row per edge in by-destination order, in by-source order, arange(E))`` (int32), cached per graph.
+        The per-edge gradient is laid out in BY-SOURCE order -- the order the backward kernel walks the edges in -- so
+        that it is written (and, from the second layer on, re-read) as a stream instead of as scattered rows."""
         key = id(graph)
         if key not in self._by_graph:
             i32 = self.idx.to(torch.int32)
-            self._by_graph[key] = (i32[graph.eid.long()].contiguous(), i32[graph.eid_t.long()].contiguous())
+            self._by_graph[key] = (i32[graph.eid.long()].contiguous(), i32[graph.eid_t.long()].contiguous(),
+                                   torch.arange(self.idx.numel(), dtype=torch.int32, device=self.idx.device))
         return self._by_graph[key]
 
-    def sorted_by_type(self):
-        """Edge ids sorted (stably) by table row, and the row pointer over them (int32); once per batch."""
-        if self._sorted is None:
-            order = torch.sort(self.idx, stable=True)[1].to(torch.int32)
+    def sorted_by_type(self, graph):
+        """By-source edge positions sorted (stably) by table row, and the row pointer over them (int32)."""
+        key = id(graph)
+        if self._sorted is None or self._sorted[0] != key:
+            by_src = self.rows_for(graph)[1].long()
+            order = torch.sort(by_src, stable=True)[1].to(torch.int32)
             rowptr = torch.zeros(self.table_rows + 1, dtype=torch.int64, device=self.idx.device)
-            torch.cumsum(torch.bincount(self.idx, minlength=self.table_rows), 0, out=rowptr[1:])
-            self._sorted = (order, rowptr.to(torch.int32))
-        return self._sorted
+            torch.cumsum(torch.bincount(by_src, minlength=self.table_rows), 0, out=rowptr[1:])
+            self._sorted = (key, order, rowptr.to(torch.int32))
+        return self._sorted[1], self._sorted[2]
 
 
 def share_edge_gradient(e):
@@ -417,7 +423,11 @@ class _GenAggregate(torch.autograd.Function):
         ge, ge_accumulate, sink, te = None, 0, ctx.grad_sink, ctx.table_edge
         eid_t, geid_t = g.eid_t, None
         if te is not None:                                   # read the table row, write the edge's own gradient row
-            eid_t, geid_t = te.rows_for(g)[1], g.eid_t
+            _, eid_t, geid_t = te.rows_for(g)                # (gradient rows in by-source order: a streamed write)
+            if sink is not None:
+                if sink.graph is not None and sink.graph is not g:
+                    raise RuntimeError("a TableEdge is tied to one graph (one batch)")
+                sink.graph = g
         if edge_mode == EDGE_FULL and (te is None or sink is not None):
             if sink is not None and sink.buf is not None:
                 ge, ge_accumulate = sink.buf, 1              # add this layer's share to the layers that ran before

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Development tool: randomised sweep of the aggregation kernels against the CPU oracle (tests/test_aggregate_gpu.py's
+case runner) over odd sizes -- widths with and without the vector path, tiny and hub-heavy graphs, every aggregator
+and edge term.  `python tools/fuzz_aggregate.py [cases] [seed]`; prints the first failing configuration."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multilevel-gnn_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import test_aggregate_gpu as T
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    aggrs = ["add", "mean", "max", "softmax", "softmax_sg", "power"]
+    kinds = ["none", "rank1", "rank2", "rank3", "rank7", "rank8", "full"]
+    for i in range(n_cases):
+        N = rng.choice([1, 2, 3, 5, 17, 64, 65, 130, 257, 600, 1500])
+        E = rng.choice([1, 7, 33, 64, 65, 300, 1000, 4097, 9000]) if N > 2 else rng.choice([1, 5])   # (E = 0: tests/test_aggregate_gpu.py)
+        d = rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 31, 32, 36, 64, 100, 128, 132, 200, 256, 260])
+        aggr, kind = rng.choice(aggrs), rng.choice(kinds)
+        learn = rng.random() < 0.2 and aggr in ("softmax", "power") and kind in ("none", "rank1", "full")
+        hub = rng.random() < 0.5 and E > 300 and N > 2
+        t = rng.choice([1.0, 0.5, 2.0, -1.0])
+        cfg = dict(N=N, E=E, d=d, aggr=aggr, edge_kind=kind, t=t, p=rng.choice([1.0, 2.0, 3.0]), learn=learn, hub=hub,
+                   seed=i)
+        try:
+            T._run_case(**cfg)
+        except Exception as exc:              # noqa: BLE001 -- report the configuration, then fail
+            print("FAILED case %d: %r\n%s: %s" % (i, cfg, type(exc).__name__, exc))
+            raise SystemExit(1)
+        if (i + 1) % 25 == 0:
+            print("%d cases ok" % (i + 1), flush=True)
+    print("all %d cases ok" % n_cases)
+
+
+if __name__ == "__main__":
+    main()

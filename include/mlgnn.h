@@ -169,7 +169,7 @@ int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
                               int dtype, void* stream);
 
 /*
- * Fused LayerNorm (+ ReLU) over [rows, d]: fp32 (d <= 256, d % 4 == 0) or bf16 storage with fp32 statistics and
+ * Fused LayerNorm (+ ReLU) over [rows, d]: fp32 (d <= 256 with d % 4 == 0, or d <= 512 with d % 8 == 0) or bf16 storage with fp32 statistics and
  * arithmetic (MLGNN_DTYPE_BF16: x, out, grad_out, grad_extra, grad_x are bf16, d <= 512, d % 8 == 0; gamma, beta,
  * mean, rstd and the parameter gradients stay fp32).
  * Replaces: norm_layer('layer') followed by act_layer('relu') as chained by MLP

@@ -1,5 +1,5 @@
-// Fused LayerNorm (+ ReLU) forward / backward over [rows, d]: fp32 (d <= 256, d % 4 == 0) or bf16 storage with
-// fp32 arithmetic (d <= 512, d % 8 == 0).
+// Fused LayerNorm (+ ReLU) forward / backward over [rows, d]: fp32 (d <= 256 with d % 4 == 0, or d <= 512 with
+// d % 8 == 0) or bf16 storage with fp32 arithmetic (d <= 512, d % 8 == 0).
 //
 // Reference: norm_layer('layer') + act_layer('relu') as chained by MLP
 // (models/gcn_lib/sparse/torch_nn.py:27-38,54-75) and by the res+ block
@@ -198,11 +198,12 @@ static int ln_grid(int64_t rows, int lpr_log2) {
 }
 
 static bool ln_ok(int64_t d) { return d > 0 && d <= 256 && d % 4 == 0; }
-static int ln_vec(int dtype) { return dtype == MLGNN_DTYPE_BF16 ? 8 : 4; }
-// fp32: d <= 256, d % 4 == 0; bf16: d <= 512, d % 8 == 0 (one row per wave at most, 16 bytes per lane)
+// channels per lane: bf16 8 (16 bytes); fp32 4 (16 bytes) up to d = 256, 8 (two 16-byte loads) for 256 < d <= 512
+static int ln_vec(int dtype, int64_t d) { return (dtype == MLGNN_DTYPE_BF16 || d > 256) ? 8 : 4; }
+// one row per wave at most: fp32 d <= 512 (d % 4 == 0 up to 256, d % 8 == 0 beyond); bf16 d <= 512, d % 8 == 0
 static bool ln_ok_t(int64_t d, int dtype) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return false;
-  const int v = ln_vec(dtype);
+  const int v = ln_vec(dtype, d);
   return d > 0 && d <= 64 * v && d % v == 0;
 }
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -235,7 +236,7 @@ using namespace mlgnn;
 
 extern "C" int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d, int dtype) {
   if (rows < 0 || !ln_ok_t(d, dtype)) return MLGNN_E_SHAPE;
-  return (int64_t)ln_grid(rows, lanes_per_row_log2(d, ln_vec(dtype))) * 2 * d;
+  return (int64_t)ln_grid(rows, lanes_per_row_log2(d, ln_vec(dtype, d))) * 2 * d;
 }
 
 extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
@@ -250,9 +251,11 @@ extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const 
   a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.mean = mean; a.rstd = rstd;
   a.rowmax = row_max;
   a.rows = (int)rows; a.d = (int)d; a.eps = eps; a.relu = relu;
-  const int lpr = lanes_per_row_log2(d, ln_vec(dtype));
+  const int lpr = lanes_per_row_log2(d, ln_vec(dtype, d));
   const dim3 grid(ln_grid(rows, lpr)), block(kBlock);
-  if (dtype == MLGNN_DTYPE_F32) {
+  if (dtype == MLGNN_DTYPE_F32 && d > 256) {
+    MLGNN_LNT_LAUNCH(layernorm_act_fwd_kernel, float, 8, lpr, grid, block, 0, (hipStream_t)stream, a)
+  } else if (dtype == MLGNN_DTYPE_F32) {
     MLGNN_LNT_LAUNCH(layernorm_act_fwd_kernel, float, 4, lpr, grid, block, 0, (hipStream_t)stream, a)
   } else {
     MLGNN_LNT_LAUNCH(layernorm_act_fwd_kernel, bf16_t, 8, lpr, grid, block, 0, (hipStream_t)stream, a)
@@ -268,7 +271,7 @@ extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, cons
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (rows < 0 || rows > INT32_MAX || !ln_ok_t(d, dtype)) return MLGNN_E_SHAPE;
   if (!grad_gamma_beta || !workspace) return MLGNN_E_NULL;
-  const int lpr = lanes_per_row_log2(d, ln_vec(dtype));
+  const int lpr = lanes_per_row_log2(d, ln_vec(dtype, d));
   const int nblk = ln_grid(rows, lpr);
   if (workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
   if (rows > 0 && (!grad_out || !x || !gamma || !beta || !rstd || !grad_x)) return MLGNN_E_NULL;
@@ -280,7 +283,9 @@ extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, cons
   a.rows = (int)rows; a.d = (int)d; a.relu = relu;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(nblk), block(kBlock);
-  if (dtype == MLGNN_DTYPE_F32) {
+  if (dtype == MLGNN_DTYPE_F32 && d > 256) {
+    MLGNN_LNT_LAUNCH(layernorm_act_bwd_kernel, float, 8, lpr, grid, block, 0, s, a)
+  } else if (dtype == MLGNN_DTYPE_F32) {
     MLGNN_LNT_LAUNCH(layernorm_act_bwd_kernel, float, 4, lpr, grid, block, 0, s, a)
   } else {
     MLGNN_LNT_LAUNCH(layernorm_act_bwd_kernel, bf16_t, 8, lpr, grid, block, 0, s, a)

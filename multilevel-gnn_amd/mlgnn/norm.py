@@ -9,11 +9,12 @@ from .ops import _DTYPE_IDS, DTYPE_F32, _stream, tag_row_max
 
 
 def fused_supported(x):
-    """fp32: d <= 256, d % 4 == 0; bf16 storage (fp32 arithmetic): d <= 512, d % 8 == 0."""
+    """fp32: d <= 256 with d % 4 == 0, or d <= 512 with d % 8 == 0; bf16 storage (fp32 arithmetic): d <= 512, d % 8 == 0."""
     if not (x.is_cuda and x.dim() == 2):
         return False
     if x.dtype == torch.float32:
-        return 0 < x.shape[1] <= 256 and x.shape[1] % 4 == 0
+        d = x.shape[1]
+        return (0 < d <= 256 and d % 4 == 0) or (256 < d <= 512 and d % 8 == 0)
     return x.dtype == torch.bfloat16 and 0 < x.shape[1] <= 512 and x.shape[1] % 8 == 0
 
 

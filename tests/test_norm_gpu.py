@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("rows,d", [(1, 4), (7, 8), (1000, 32), (513, 64), (2049, 100), (4097, 128), (3000, 256),
-                                    (70000, 128)])
+                                    (70000, 128), (2000, 264), (3001, 384), (5000, 512)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_layer_norm_act(rows, d, relu):
     from mlgnn.norm import layer_norm_act
@@ -32,9 +32,10 @@ def test_layer_norm_act(rows, d, relu):
 
 def test_unsupported_width_uses_aten_on_device():
     from mlgnn.norm import layer_norm_act
-    x = torch.randn(10, 258, device="cuda:0")
-    w, b = torch.ones(258, device="cuda:0"), torch.zeros(258, device="cuda:0")
-    assert_close(layer_norm_act(x, w, b, 1e-5, True), F.relu(F.layer_norm(x, (258,), w, b)), 1e-6)
+    for d in (258, 260, 520):                                   # not a multiple of 4 / of 8 beyond 256 / too wide
+        x = torch.randn(10, d, device="cuda:0")
+        w, b = torch.ones(d, device="cuda:0"), torch.zeros(d, device="cuda:0")
+        assert_close(layer_norm_act(x, w, b, 1e-5, True), F.relu(F.layer_norm(x, (d,), w, b)), 1e-6)
 
 
 @pytest.mark.parametrize("rows,d", [(1, 4), (1000, 32), (777, 100), (5000, 128), (3000, 256)])

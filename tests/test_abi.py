@@ -65,3 +65,42 @@ def test_ops_refuse_cpu_tensors():
     g = CSRGraph(torch.tensor([[0, 1], [1, 0]]), 2)
     with pytest.raises(RuntimeError, match="no CPU path"):
         gen_aggregate(torch.zeros(2, 4), g, None, aggr="add")
+
+
+def test_argument_errors_of_the_dense_and_embedding_entry_points():
+    """Shape / dtype / mode / NULL errors are reported before anything is launched (no GPU needed): the bf16 variants
+    of the tall GEMM, weight gradient and LayerNorm, and the embedding gradient."""
+    from mlgnn import _lib
+    lib = _lib.lib
+    F32, BF16 = 0, 1
+    # tall GEMM: supported shapes per storage type, workspace sizes
+    assert lib.mlgnn_tallgemm_supported(1000, 128, 256, F32) == 1
+    assert lib.mlgnn_tallgemm_supported(1000, 512, 256, F32) == 0          # fp32 image beyond LDS
+    assert lib.mlgnn_tallgemm_supported(1000, 512, 256, BF16) == 1         # bf16: column slices
+    assert lib.mlgnn_tallgemm_supported(1000, 40, 64, BF16) == 0 and lib.mlgnn_tallgemm_supported(1000, 64, 48, BF16) == 0
+    assert lib.mlgnn_tallgemm_supported(1000, 64, 64, 5) == 0
+    assert lib.mlgnn_tallgemm_workspace_bytes(256, 512, BF16) == 256 * 512 * 2
+    assert lib.mlgnn_tallgemm_workspace_bytes(128, 256, F32) == 128 * 256 * 4 + 64
+    tg = lambda dtype, ln, N=64, R=64, J=64: lib.mlgnn_tallgemm_nt(None, None, None, None, None, ln, None, None, 0.0,
+                                                                    None, None, None, None, 1 << 20, N, R, J, dtype, None)
+    assert tg(BF16, 1) == -3                                               # LayerNorm modes are fp32-only
+    assert tg(BF16, 0) == -1 and tg(F32, 0) == -1                          # NULL operands
+    assert tg(BF16, 0, R=40) == -2 and tg(7, 0) == -4
+    assert tg(BF16, 0, N=0) == 0
+    # weight gradient
+    assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 512, 256, BF16) > 0
+    assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 512, 200, BF16) == -2       # K % 128 != 0
+    assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 100, 256, BF16) == -2       # M % 64 != 0
+    assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 256, 256, F32) == -2        # fp32: 64 tiles > 32
+    assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 128, 128, 9) == -4
+    wg = lambda dtype, M, K, ws=1 << 30: lib.mlgnn_linear_wgrad(None, None, None, None, None, None, ws, 1000, M, K, dtype, None)
+    assert wg(BF16, 512, 256) == -1 and wg(BF16, 512, 200) == -2 and wg(3, 128, 128) == -4
+    # LayerNorm: widths per storage type
+    assert lib.mlgnn_layernorm_bwd_workspace_floats(1000, 512, F32) > 0 and lib.mlgnn_layernorm_bwd_workspace_floats(1000, 512, BF16) > 0
+    assert lib.mlgnn_layernorm_bwd_workspace_floats(1000, 260, F32) == -2             # beyond 256 needs d % 8 == 0
+    assert lib.mlgnn_layernorm_bwd_workspace_floats(1000, 516, BF16) == -2 and lib.mlgnn_layernorm_bwd_workspace_floats(1000, 520, F32) == -2
+    ln = lambda dtype, d: lib.mlgnn_layernorm_act_fwd(None, None, None, None, None, None, None, 10, d, 1e-5, 1, dtype, None)
+    assert ln(F32, 128) == -1 and ln(BF16, 100) == -2 and ln(4, 128) == -4
+    # embedding gradient
+    emb = lambda T, d, dtype=F32: lib.mlgnn_embedding_bwd(None, None, None, None, T, d, dtype, None)
+    assert emb(0, 128) == 0 and emb(10, 128) == -1 and emb(10, 130) == -2 and emb(10, 128, BF16) == -4

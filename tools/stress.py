@@ -92,26 +92,39 @@ def main():
                                 "algorithmic_GB": round(d["bytes"] / 1e9, 3), "GBps": round(gbs, 1),
                                 "frac_of_8TBps": round(gbs / 8000.0, 3)}
 
-    # DiffPool at the stress size: library GEMM path (N=4096 > 160)
+    # DiffPool at the stress size (pooled graph of 4096 nodes, 1024 clusters): beyond the fused small-graph kernel, a
+    # chain of plain large GEMMs -> library (hipBLASLt) in the run's storage type; MFMA utilisation = achieved / dense peak
     P, K, C = 4096, 1024, a.hidden
-    z = torch.randn(1, P, C, device=dev, requires_grad=True)
-    s = torch.randn(1, P, K, device=dev, requires_grad=True)
-    adj = torch.rand(P, P, device=dev)
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    peak = 2500.0 if a.dtype == "bf16" else 157.3                 # TFLOP/s dense: bf16 MFMA / fp32 matrix (MI355X_MICROARCH.md)
+    z = torch.randn(1, P, C, device=dev).to(dt).requires_grad_(True)
+    s = torch.randn(1, P, K, device=dev).to(dt).requires_grad_(True)
+    adj = torch.rand(P, P, device=dev).to(dt)
+
+    def pool_fwd():
+        return dense_diff_pool(z, adj, s)
 
     def pool():
-        x, aa, l, e = dense_diff_pool(z, adj, s)
-        (x.sum() + aa.sum() + l + e).backward()
+        x, aa, l, e = pool_fwd()
+        (x.float().sum() + aa.float().sum() + l.float() + e.float()).backward()
 
-    pool()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        pool()
-    torch.cuda.synchronize()
-    dtp = (time.perf_counter() - t0) / 5
+    def timed(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    with torch.no_grad():
+        dtf = timed(pool_fwd)
+    dtp = timed(pool)
     flop_fwd = 2 * K * P * C + 2 * K * P * P + 2 * K * K * P + 2 * P * P * K
-    res["diffpool_4096_1024"] = {"fwd_bwd_ms": dtp * 1e3, "fwd_GFLOP": flop_fwd / 1e9,
-                                 "approx_TFLOPs_fwd_bwd": 3 * flop_fwd / dtp / 1e12, "path": "library GEMMs (fp32)"}
+    res["diffpool_4096_1024"] = {"dtype": a.dtype, "fwd_ms": dtf * 1e3, "fwd_bwd_ms": dtp * 1e3, "fwd_GFLOP": flop_fwd / 1e9,
+                                 "fwd_TFLOPs": flop_fwd / dtf / 1e12, "fwd_MFMA_utilisation": flop_fwd / dtf / 1e12 / peak,
+                                 "approx_TFLOPs_fwd_bwd": 3 * flop_fwd / dtp / 1e12,
+                                 "dense_peak_TFLOPs": peak, "path": "library GEMMs (%s)" % a.dtype}
     print(json.dumps(res, indent=1))
 
 

@@ -178,9 +178,10 @@ def main():
             batch.csr = g
             if not last:
                 build_topology(i + 1)
-        bucket.zero()
+        bucket.release()
         loss = W.training_loss(model, batch)
         loss.backward()
+        bucket.collect()
         bucket.all_reduce_mean()
         opt.step()
         return loss

@@ -21,10 +21,33 @@ class FlatGradBucket:
         self.flat = torch.zeros(total, dtype=dt, device=dev)
         self.group = process_group
         off = 0
+        self.views = []
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(p.grad)
             off += n
+
+    # Two ways to fill the bucket.  (a) zero() before backward: autograd accumulates into the views in place -- one
+    # small add kernel per parameter.  (b) release() before backward, collect() after it: autograd hands over fresh
+    # gradient tensors and ONE multi-tensor copy moves them into the bucket (60 launches fewer per step for the
+    # benchmark model); the views are the parameters' .grad again afterwards, for the optimizer.
+    def release(self):
+        for p in self.params:
+            p.grad = None
+
+    def collect(self):
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()                          # parameter not reached by this backward
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def zero(self):
         """Use instead of ``optimizer.zero_grad()`` (which would drop the views)."""

@@ -83,7 +83,7 @@ def train_epoch(model, device, loader, optimizer, criterion, criterion_weight, a
         model.step = step
         pred, pca_feature = model(batch)
         loss_feature = model.get_feature_loss(pca_feature)
-        bucket.zero()
+        bucket.release()
         target = batch.y.reshape(-1, 2).to(torch.float32)
         if args.weighted_loss or args.batch_weighted_loss:
             w = criterion_weight[torch.arange(target.shape[0]), (target[:, 1] == 1).to(int)][:, None].to(device)
@@ -93,6 +93,7 @@ def train_epoch(model, device, loader, optimizer, criterion, criterion_weight, a
             loss = criterion(pred.to(torch.float32), target)
         loss = loss + loss_feature
         loss.backward()
+        bucket.collect()
         bucket.all_reduce_mean()
         if args.clip_grad:
             torch.nn.utils.clip_grad_norm_(parameters=model.parameters(), max_norm=20, norm_type=2)

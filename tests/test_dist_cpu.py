@@ -42,9 +42,15 @@ def _worker(rank, world, port, q):
     bucket = FlatGradBucket(model)
     x, y = _data()
     shard = slice(rank * 4, rank * 4 + 4)
-    for _ in range(2):                                  # second round: views survive zero()
-        bucket.zero()
-        torch.nn.functional.mse_loss(model(x[shard]), y[shard]).backward()
+    for it in range(3):                                 # rounds 2, 3: views survive zero() and release()/collect()
+        if it < 2:
+            bucket.zero()                               # autograd accumulates into the views
+            torch.nn.functional.mse_loss(model(x[shard]), y[shard]).backward()
+        else:
+            bucket.release()                            # fresh gradient tensors, one multi-tensor copy into the bucket
+            torch.nn.functional.mse_loss(model(x[shard]), y[shard]).backward()
+            assert all(p.grad is not None and not bucket.check_views() for p in model.parameters())
+            bucket.collect()
         assert bucket.check_views()
         bucket.all_reduce_mean()
     q.put((rank, bucket.flat.clone(), torch.cat([p.detach().reshape(-1) for p in model.parameters()])))

@@ -180,18 +180,22 @@ int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
  * grad_gamma_beta [2,d]; workspace: mlgnn_layernorm_bwd_workspace_floats(rows, d, dtype) floats.
  * grad_extra [rows,d] or NULL: a gradient that reaches x on another branch (the identity branch of the
  * res+ block, deepergcn.py:241), added into grad_x in the same pass.
+ * keep_mask [rows,d] bytes or NULL: the dropout that follows norm + activation in the res+ block (deepergcn.py:239-240,
+ * 246-247) in the same pass -- out = act(norm(x)) * (keep ? keep_scale : 0); the backward scales grad_out alike.
  * row_max [rows] or NULL (both directions): max |.| per row of out / grad_x, handed to the Linear that
  * consumes it (mlgnn_tallgemm_nt) so that it does not have to read its operand twice.
  */
 int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d, int dtype);
 int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
-                            float* mean, float* rstd, float* row_max, int64_t rows, int64_t d, float eps,
+                            float* mean, float* rstd, float* row_max, const uint8_t* keep_mask, float keep_scale,
+                            int64_t rows, int64_t d, float eps,
                             int relu, int dtype, void* stream);
 int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* gamma,
                             const float* beta, const float* mean, const float* rstd,
                             const void* grad_extra, void* grad_x, float* row_max, float* grad_gamma_beta,
                             float* workspace,
-                            int64_t workspace_floats, int64_t rows, int64_t d, int relu,
+                            int64_t workspace_floats, const uint8_t* keep_mask, float keep_scale,
+                            int64_t rows, int64_t d, int relu,
                             int dtype, void* stream);
 
 /*

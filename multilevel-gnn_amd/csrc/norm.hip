@@ -33,8 +33,26 @@ constexpr int kLnRows = 4;            // row groups in flight per wave
 struct LnArgs {
   const void* x; const void* go; const float* gamma; const float* beta; const void* gextra;
   void* out; float* mean; float* rstd; void* gx; float* ws; float* rowmax;
+  const uint8_t* keep; float keep_scale;        // dropout behind the activation: out *= keep ? keep_scale : 0
   int rows; int d; float eps; int relu;
 };
+
+// VEC one-byte keep flags -> multipliers (0 or scale)
+template <int VEC>
+__device__ __forceinline__ void load_keep(float (&m)[VEC], const uint8_t* p, float scale) {
+  if constexpr (VEC == 4) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = ((w >> (8 * i)) & 0xffu) ? scale : 0.f;
+  } else {
+    const uint2 w = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m[i] = ((w.x >> (8 * i)) & 0xffu) ? scale : 0.f;
+      m[4 + i] = ((w.y >> (8 * i)) & 0xffu) ? scale : 0.f;
+    }
+  }
+}
 
 // T = float (VEC 4) or bf16_t (VEC 8): 16 bytes per lane either way; statistics and arithmetic in fp32
 template <typename T, int VEC, int LPR_LOG2>
@@ -83,8 +101,15 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_fwd_kernel(const LnArgs 
         for (int i = 0; i < VEC; ++i) {
           const float y = fmaf((v[u][i] - mu) * rs, g[i], b[i]);
           o[i] = a.relu ? fmaxf(y, 0.f) : y;
-          om = fmaxf(om, fabsf(o[i]));
         }
+        if (a.keep) {
+          float km[VEC];
+          load_keep<VEC>(km, a.keep + (size_t)r * a.d + c0, a.keep_scale);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] *= km[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) om = fmaxf(om, fabsf(o[i]));
         store_t<T, VEC>(out + (size_t)r * a.d + c0, o);
         if (cl == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
       }
@@ -128,6 +153,12 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_bwd_kernel(const LnArgs 
       if (ok[u]) {
         load_t<T, VEC>(v[u], x + (size_t)r * a.d + c0);
         load_t<T, VEC>(go[u], gout + (size_t)r * a.d + c0);
+        if (a.keep) {
+          float km[VEC];
+          load_keep<VEC>(km, a.keep + (size_t)r * a.d + c0, a.keep_scale);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) go[u][i] *= km[i];
+        }
         mu[u] = a.mean ? a.mean[r] : 0.f; rs[u] = a.rstd[r]; nsc[u] = a.mean ? rs[u] : 1.0f;
       }
     }
@@ -240,7 +271,8 @@ extern "C" int64_t mlgnn_layernorm_bwd_workspace_floats(int64_t rows, int64_t d,
 }
 
 extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const float* beta, void* out,
-                                       float* mean, float* rstd, float* row_max, int64_t rows, int64_t d, float eps,
+                                       float* mean, float* rstd, float* row_max, const uint8_t* keep_mask,
+                                       float keep_scale, int64_t rows, int64_t d, float eps,
                                        int relu, int dtype, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (rows < 0 || rows > INT32_MAX || !ln_ok_t(d, dtype)) return MLGNN_E_SHAPE;
@@ -249,7 +281,8 @@ extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const 
   if (!a16(x) || !a16(out) || !a16(gamma) || !a16(beta)) return MLGNN_E_ALIGN;
   LnArgs a{};
   a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.mean = mean; a.rstd = rstd;
-  a.rowmax = row_max;
+  a.rowmax = row_max; a.keep = keep_mask; a.keep_scale = keep_scale;
+  if (keep_mask && d % ln_vec(dtype, d) != 0) return MLGNN_E_SHAPE;
   a.rows = (int)rows; a.d = (int)d; a.eps = eps; a.relu = relu;
   const int lpr = lanes_per_row_log2(d, ln_vec(dtype, d));
   const dim3 grid(ln_grid(rows, lpr)), block(kBlock);
@@ -266,7 +299,8 @@ extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const 
 extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* gamma,
                                        const float* beta, const float* mean, const float* rstd,
                                        const void* grad_extra, void* grad_x, float* row_max, float* grad_gamma_beta, float* workspace,
-                                       int64_t workspace_floats, int64_t rows, int64_t d, int relu,
+                                       int64_t workspace_floats, const uint8_t* keep_mask, float keep_scale,
+                                       int64_t rows, int64_t d, int relu,
                                        int dtype, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (rows < 0 || rows > INT32_MAX || !ln_ok_t(d, dtype)) return MLGNN_E_SHAPE;
@@ -278,7 +312,7 @@ extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, cons
   if (!a16(x) || !a16(grad_out) || !a16(grad_x) || !a16(gamma) || !a16(beta) || !a16(grad_extra)) return MLGNN_E_ALIGN;
   LnArgs a{};
   a.x = x; a.go = grad_out; a.gamma = gamma; a.beta = beta;
-  a.gextra = grad_extra;
+  a.gextra = grad_extra; a.keep = keep_mask; a.keep_scale = keep_scale;
   a.mean = (float*)mean; a.rstd = (float*)rstd; a.gx = grad_x; a.ws = workspace; a.rowmax = row_max;
   a.rows = (int)rows; a.d = (int)d; a.relu = relu;
   hipStream_t s = (hipStream_t)stream;

@@ -23,9 +23,18 @@ def _f32_params(weight, bias):
     return weight.float().contiguous(), bias.float().contiguous()
 
 
+def _keep_mask(x, p):
+    """Dropout keep flags (one byte per element) and the 1/(1-p) scale; ``(None, 1.0)`` for p == 0."""
+    if not p:
+        return None, 1.0
+    if p >= 1.0:
+        return torch.zeros(x.shape, dtype=torch.uint8, device=x.device), 0.0
+    return torch.empty(x.shape, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - p), 1.0 / (1.0 - p)
+
+
 class _LayerNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu):
+    def forward(ctx, x, weight, bias, eps, relu, keep=None, keep_scale=1.0):
         x = x.contiguous()
         rows, d = x.shape
         out = torch.empty_like(x)
@@ -35,18 +44,22 @@ class _LayerNormAct(torch.autograd.Function):
         weight, bias = _f32_params(weight, bias)
         # max |row| rides along for the fp32 split-precision GEMM that consumes the result; bf16 has no use for it
         ctx.row_max = torch.empty(rows, dtype=torch.float32, device=x.device) if x.dtype == torch.float32 else None
+        if keep is not None and (keep.shape != x.shape or keep.dtype != torch.uint8 or not keep.is_contiguous()):
+            raise ValueError("dropout keep mask must be a contiguous uint8 tensor of the input's shape")
         rc = _lib.lib.mlgnn_layernorm_act_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                                              mean.data_ptr(), rstd.data_ptr(), _lib.ptr(ctx.row_max), rows, d,
+                                              mean.data_ptr(), rstd.data_ptr(), _lib.ptr(ctx.row_max), _lib.ptr(keep),
+                                              float(keep_scale), rows, d,
                                               float(eps), int(relu), _DTYPE_IDS[x.dtype], _stream())
         _lib.check(rc, "mlgnn_layernorm_act_fwd")
         ctx.relu = bool(relu)
+        ctx.keep, ctx.keep_scale = keep, float(keep_scale)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         return out
 
     @staticmethod
     def backward(ctx, go):
         gx, ggb = _ln_backward(ctx, go, None)
-        return gx, ggb[0], ggb[1], None, None
+        return gx, ggb[0], ggb[1], None, None, None, None
 
 
 def _ln_backward(ctx, go, extra):
@@ -63,7 +76,8 @@ def _ln_backward(ctx, go, extra):
     row_max = torch.empty(rows, dtype=torch.float32, device=x.device) if x.dtype == torch.float32 else None
     rc = _lib.lib.mlgnn_layernorm_act_bwd(go.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                                           mean.data_ptr(), rstd.data_ptr(), _lib.ptr(extra), gx.data_ptr(),
-                                          _lib.ptr(row_max), ggb.data_ptr(), ws.data_ptr(), n, rows, d,
+                                          _lib.ptr(row_max), ggb.data_ptr(), ws.data_ptr(), n, _lib.ptr(ctx.keep),
+                                          ctx.keep_scale, rows, d,
                                           int(ctx.relu), dt, _stream())
     _lib.check(rc, "mlgnn_layernorm_act_bwd")
     if row_max is not None:
@@ -84,7 +98,8 @@ def ln_backward_normalised(go, xhat, weight, bias, rstd, relu=True):
     weight, bias = weight.contiguous(), bias.contiguous()
     rc = _lib.lib.mlgnn_layernorm_act_bwd(go.data_ptr(), xhat.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                                           None, rstd.data_ptr(), None, gx.data_ptr(), row_max.data_ptr(),
-                                          ggb.data_ptr(), ws.data_ptr(), n, rows, d, int(relu), DTYPE_F32, _stream())
+                                          ggb.data_ptr(), ws.data_ptr(), n, None, 1.0, rows, d, int(relu), DTYPE_F32,
+                                          _stream())
     _lib.check(rc, "mlgnn_layernorm_act_bwd")
     return gx, ggb[0], ggb[1], row_max
 
@@ -95,23 +110,29 @@ class _LayerNormActFork(torch.autograd.Function):
     the LayerNorm gradient inside ONE backward pass instead of a separate accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu):
-        out = _LayerNormAct.forward(ctx, x, weight, bias, eps, relu)
+    def forward(ctx, x, weight, bias, eps, relu, keep=None, keep_scale=1.0):
+        out = _LayerNormAct.forward(ctx, x, weight, bias, eps, relu, keep, keep_scale)
         return out, x.view_as(x)
 
     @staticmethod
     def backward(ctx, go, g_identity):
         gx, ggb = _ln_backward(ctx, go, g_identity)
-        return gx, ggb[0], ggb[1], None, None
+        return gx, ggb[0], ggb[1], None, None, None, None
 
 
-def layer_norm_act(x, weight, bias, eps=1e-5, relu=False):
-    """``relu?(LayerNorm(x))`` over the last dimension of a 2-D tensor.  Shapes the fused kernel
-    does not cover (see :func:`fused_supported`) take ATen's LayerNorm on the same device."""
+def layer_norm_act(x, weight, bias, eps=1e-5, relu=False, dropout_p=0.0, dropout_mask=None):
+    """``dropout?(relu?(LayerNorm(x)))`` over the last dimension of a 2-D tensor -- norm, activation and the dropout
+    the res+ block puts behind them (deepergcn.py:239-240,246-247) in one pass.  ``dropout_p``: probability (the
+    caller passes 0 outside training); ``dropout_mask``: explicit uint8 keep flags instead of a fresh draw (tests).
+    Shapes the fused kernel does not cover (see :func:`fused_supported`) take ATen on the same device."""
     if weight is not None and bias is not None and fused_supported(x):
-        return _tag_from_node(_LayerNormAct.apply(x, weight, bias, eps, relu))
+        keep, scale = (dropout_mask, 1.0 / (1.0 - dropout_p)) if dropout_mask is not None else _keep_mask(x, dropout_p)
+        return _tag_from_node(_LayerNormAct.apply(x, weight, bias, eps, relu, keep, scale))
     y = F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
-    return F.relu(y) if relu else y
+    y = F.relu(y) if relu else y
+    if dropout_mask is not None:
+        return y * dropout_mask.to(y.dtype) / (1.0 - dropout_p)
+    return F.dropout(y, dropout_p, True) if dropout_p else y
 
 
 def _tag_from_node(y):
@@ -119,13 +140,14 @@ def _tag_from_node(y):
     return tag_row_max(y, rm) if rm is not None else y
 
 
-def layer_norm_act_fork(x, weight, bias, eps=1e-5, relu=False):
+def layer_norm_act_fork(x, weight, bias, eps=1e-5, relu=False, dropout_p=0.0, dropout_mask=None):
     """``(layer_norm_act(x), x)`` for a residual block: use the second value as the identity branch
     (``h = f(y) + x``) so that its gradient is added inside the LayerNorm backward kernel."""
     if weight is not None and bias is not None and fused_supported(x) and x.is_contiguous():
-        y, identity = _LayerNormActFork.apply(x, weight, bias, eps, relu)
+        keep, scale = (dropout_mask, 1.0 / (1.0 - dropout_p)) if dropout_mask is not None else _keep_mask(x, dropout_p)
+        y, identity = _LayerNormActFork.apply(x, weight, bias, eps, relu, keep, scale)
         return _tag_from_node(y), identity
-    return layer_norm_act(x, weight, bias, eps, relu), x
+    return layer_norm_act(x, weight, bias, eps, relu, dropout_p, dropout_mask), x
 
 
 class _MsgNormAdd(torch.autograd.Function):

@@ -144,13 +144,16 @@ class DeeperGCN(torch.nn.Module):
     def _drop(self, h):
         return F.dropout(h, p=self.dropout, training=self.training)
 
-    def _norm(self, layer, h, relu=False):
-        """``norms[layer](h)`` (+ ReLU): one fused HIP pass for LayerNorm, the module otherwise."""
+    def _norm(self, layer, h, relu=False, drop=False):
+        """``norms[layer](h)`` (+ ReLU) (+ the dropout behind it): one fused HIP pass for LayerNorm, the modules
+        otherwise."""
         m = self.norms[layer]
+        p = self.dropout if (drop and self.training) else 0.0
         if isinstance(m, nn.LayerNorm):
-            return layer_norm_act(h, m.weight, m.bias, m.eps, relu)
+            return layer_norm_act(h, m.weight, m.bias, m.eps, relu, dropout_p=p)
         h = m(h)
-        return F.relu(h) if relu else h
+        h = F.relu(h) if relu else h
+        return self._drop(h) if drop else h
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_batch):
@@ -182,19 +185,20 @@ class DeeperGCN(torch.nn.Module):
             h = self.gcns[0](h, graph, edge_emb)
             for layer in range(1, L):
                 m = self.norms[layer - 1]
+                drop = not self.no_inter_drop
                 if not self.no_inter_norm and isinstance(m, nn.LayerNorm) and h.dim() == 2:
                     # the residual add runs in the conv's last GEMM epilogue and its gradient inside the
-                    # LayerNorm backward kernel (same values, two elementwise passes fewer)
-                    h2, identity = layer_norm_act_fork(h, m.weight, m.bias, m.eps, relu=True)
+                    # LayerNorm backward kernel (same values, two elementwise passes fewer); the dropout behind
+                    # norm + ReLU is applied by the same kernels
+                    h2, identity = layer_norm_act_fork(h, m.weight, m.bias, m.eps, relu=True,
+                                                       dropout_p=self.dropout if (drop and self.training) else 0.0)
                 else:
                     h2 = F.relu(h) if self.no_inter_norm else self._norm(layer - 1, h, relu=True)
                     identity = h
-                if not self.no_inter_drop:
-                    h2 = self._drop(h2)
+                    if drop:
+                        h2 = self._drop(h2)
                 h = self.gcns[layer](h2, graph, edge_emb, residual=identity)
-            h = self._norm(L - 1, h)
-            if not self.no_inter_drop:
-                h = self._drop(h)
+            h = self._norm(L - 1, h, drop=not self.no_inter_drop)
         elif self.block == 'res':
             h = self._drop(self._norm(0, self.gcns[0](h, graph, edge_emb), relu=True))
             for layer in range(1, L):

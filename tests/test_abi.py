@@ -99,7 +99,8 @@ def test_argument_errors_of_the_dense_and_embedding_entry_points():
     assert lib.mlgnn_layernorm_bwd_workspace_floats(1000, 512, F32) > 0 and lib.mlgnn_layernorm_bwd_workspace_floats(1000, 512, BF16) > 0
     assert lib.mlgnn_layernorm_bwd_workspace_floats(1000, 260, F32) == -2             # beyond 256 needs d % 8 == 0
     assert lib.mlgnn_layernorm_bwd_workspace_floats(1000, 516, BF16) == -2 and lib.mlgnn_layernorm_bwd_workspace_floats(1000, 520, F32) == -2
-    ln = lambda dtype, d: lib.mlgnn_layernorm_act_fwd(None, None, None, None, None, None, None, 10, d, 1e-5, 1, dtype, None)
+    ln = lambda dtype, d: lib.mlgnn_layernorm_act_fwd(None, None, None, None, None, None, None, None, 1.0, 10, d, 1e-5, 1,
+                                                      dtype, None)
     assert ln(F32, 128) == -1 and ln(BF16, 100) == -2 and ln(4, 128) == -4
     # embedding gradient
     emb = lambda T, d, dtype=F32: lib.mlgnn_embedding_bwd(None, None, None, None, T, d, dtype, None)

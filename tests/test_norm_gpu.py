@@ -30,6 +30,47 @@ def test_layer_norm_act(rows, d, relu):
         assert_close(g, r, 1e-4, "ln grad " + name)
 
 
+@pytest.mark.parametrize("rows,d,dtype", [(1000, 128, torch.float32), (4097, 256, torch.float32), (513, 36, torch.float32),
+                                          (3000, 512, torch.float32), (2000, 256, torch.bfloat16)])
+@pytest.mark.parametrize("fork", [False, True])
+def test_layer_norm_act_with_fused_dropout(rows, d, dtype, fork):
+    """norm -> ReLU -> dropout in one pass each way: with an explicit keep mask the result must equal the composition
+    ``relu(LN(x)) * mask / (1 - p)`` and its gradients; with a drawn mask the kept fraction must be 1 - p."""
+    from mlgnn.norm import layer_norm_act, layer_norm_act_fork
+    gen = torch.Generator().manual_seed(rows + d)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    rb = (lambda t: t) if dtype == torch.float32 else (lambda t: t.to(torch.bfloat16).float())
+    p = 0.3
+    x = rb(torch.randn(rows, d, generator=gen) * 2 + 0.5).requires_grad_(True)
+    w = rb(torch.rand(d, generator=gen) + 0.5).requires_grad_(True)
+    b = rb(torch.randn(d, generator=gen) * 0.3).requires_grad_(True)
+    cot, cot2 = rb(torch.randn(rows, d, generator=gen)), rb(torch.randn(rows, d, generator=gen))
+    mask = (torch.rand(rows, d, generator=gen) > p).to(torch.uint8)
+    pre = F.layer_norm(x, (d,), w, b, 1e-5)
+    ref = F.relu(pre) * mask / (1 - p)
+    gr = torch.autograd.grad((ref * cot).sum() + ((x * cot2).sum() if fork else 0), [x, w, b])
+    keep = pre.detach().abs() > 1e-4                         # (ReLU mask ties, see the bf16 LayerNorm test)
+    dev = "cuda:0"
+    xd, wd, bd = (t.detach().to(dev).to(dtype).requires_grad_(True) for t in (x, w, b))
+    if fork:
+        out, ident = layer_norm_act_fork(xd, wd, bd, 1e-5, True, dropout_p=p, dropout_mask=mask.to(dev))
+        loss = (out.float() * cot.to(dev)).sum() + (ident.float() * cot2.to(dev)).sum()
+    else:
+        out = layer_norm_act(xd, wd, bd, 1e-5, True, dropout_p=p, dropout_mask=mask.to(dev))
+        loss = (out.float() * cot.to(dev)).sum()
+    assert_close(out.float(), ref, tol, "ln + dropout fwd")
+    assert bool((out[(mask == 0).to(dev)] == 0).all())
+    got = torch.autograd.grad(loss, [xd, wd, bd])
+    assert_close(got[0].float().cpu() * keep, gr[0] * keep, tol, "grad x")
+    assert_close(got[1].float(), gr[1], tol * 2, "grad gamma")
+    assert_close(got[2].float(), gr[2], tol * 2, "grad beta")
+    drawn = layer_norm_act(torch.ones(rows, d, device=dev, dtype=dtype) + xd.detach(), wd.detach() * 0, bd.detach() * 0 + 1,
+                           1e-5, False, dropout_p=p)                        # LN output == beta == 1 everywhere
+    frac = float((drawn != 0).float().mean())
+    assert abs(frac - (1 - p)) < 0.02 and abs(float(drawn.float().max()) - 1 / (1 - p)) < 2e-2
+    assert torch.equal(layer_norm_act(xd, wd, bd, 1e-5, True, dropout_p=0.0), layer_norm_act(xd, wd, bd, 1e-5, True))
+
+
 def test_unsupported_width_uses_aten_on_device():
     from mlgnn.norm import layer_norm_act
     for d in (258, 260, 520):                                   # not a multiple of 4 / of 8 beyond 256 / too wide

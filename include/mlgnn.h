@@ -333,6 +333,8 @@ int mlgnn_segment_pool_fwd(const void* x, const int32_t* ptr, void* out, int32_t
  *   2: a is such an xhat: relu(gamma[k] a + beta[k]) is applied as it is loaded (gamma, beta [R]; pass the
  *      producer's row_max_out as row_max);
  *   0: neither (gamma, beta, rstd_out, row_max_out ignored).
+ * bt_transposed non-zero (fp32 only): bt is stored [R,J] -- a Linear's own weight used for its input gradient -- and is
+ * read with swapped indices while the weight image is built, instead of being copied first.
  * workspace: mlgnn_tallgemm_workspace_bytes(R, J, dtype) bytes (weight image in MFMA fragment order).
  * MLGNN_DTYPE_BF16 (BASELINE configs[4]): a, bt, residual, c are bf16 (bias stays fp32), one bf16 MFMA per product
  * with fp32 accumulation and a single rounding at the store; R % 16 == 0, J % 32 == 0 (R <= 1024, J <= 4096, the
@@ -340,7 +342,7 @@ int mlgnn_segment_pool_fwd(const void* x, const int32_t* ptr, void* out, int32_t
  */
 int mlgnn_tallgemm_supported(int64_t N, int64_t R, int64_t J, int dtype);
 int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J, int dtype);
-int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual,
+int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transposed, const float* bias, const void* residual,
                       const float* row_max, int ln_mode, const float* gamma, const float* beta, float ln_eps,
                       float* rstd_out, float* row_max_out, void* c, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
 

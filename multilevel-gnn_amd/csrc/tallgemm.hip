@@ -44,8 +44,11 @@ __device__ __forceinline__ void pow2_scale(float max_abs, float& s, float& inv) 
 // Bt[32 t + (l & 31)][16 s + 8 (l >> 5) + j] * scale, j = 0..7  (B operand of v_mfma_f32_32x32x16_f16).
 // Every workgroup first reduces max |Bt| over the whole (<= 128 KB, L2 resident) weight itself -- cheaper
 // than a separate one-workgroup launch in front -- and workgroup 0 records 1/scale in the header.
+// transposed: the operand is stored [R, J] (a Linear's own weight, used for its input gradient) and read with
+// swapped indices here instead of being copied into [J, R] first.
 __global__ __launch_bounds__(kBlock) void tallgemm_split_weight_kernel(const float* __restrict__ bt,
-                                                                       f16x8* __restrict__ image, int J, int R) {
+                                                                       f16x8* __restrict__ image, int J, int R,
+                                                                       int transposed) {
   __shared__ float red[kWavesPerBlock];
   const int n4 = J * R / 4;                                     // R % 16 == 0
   float m = 0.f;
@@ -68,11 +71,11 @@ __global__ __launch_bounds__(kBlock) void tallgemm_split_weight_kernel(const flo
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (kstep, tile, lane)
   if (idx >= ksteps * tiles * 64) return;
   const int lane = idx & 63, t = (idx >> 6) % tiles, s = (idx >> 6) / tiles;
-  const float* src = bt + (size_t)(32 * t + (lane & 31)) * R + 16 * s + 8 * (lane >> 5);
+  const int row = 32 * t + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
   f16x8 hi, lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float v = src[j] * scale;
+    const float v = (transposed ? bt[(size_t)(k0 + j) * J + row] : bt[(size_t)row * R + k0 + j]) * scale;
     const _Float16 h = (_Float16)v;
     hi[j] = h;
     lo[j] = (_Float16)(v - (float)h);
@@ -287,7 +290,7 @@ extern "C" int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J, int dtyp
   return R * J * 4 + kTgHeader * 16;
 }
 
-extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bias, const void* residual,
+extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transposed, const float* bias, const void* residual,
                                  const float* row_max, int ln_mode, const float* gamma, const float* beta,
                                  float ln_eps, float* rstd_out, float* row_max_out, void* c, void* workspace,
                                  int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype,
@@ -296,7 +299,7 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
   if (N < 0 || N > INT32_MAX) return MLGNN_E_SHAPE;
   if (N == 0) return 0;
   if (dtype == MLGNN_DTYPE_BF16) {                          // plain product (+ bias, + residual) only
-    if (ln_mode != 0) return MLGNN_E_MODE;
+    if (ln_mode != 0 || bt_transposed) return MLGNN_E_MODE;
     if (tb_tiles_per_slice(R, J) == 0) return MLGNN_E_SHAPE;
     if (!a || !bt || !c || !workspace) return MLGNN_E_NULL;
     if (workspace_bytes < R * J * 2) return MLGNN_E_WORKSPACE;
@@ -318,7 +321,7 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, const float* bia
   hipStream_t s = (hipStream_t)stream;
   const int n_frag_lanes = (int)(R / 16) * (int)(J / 32) * 64;
   hipLaunchKernelGGL(tallgemm_split_weight_kernel, dim3((n_frag_lanes + 255) / 256), dim3(256), 0, s,
-                     (const float*)bt, (f16x8*)workspace, (int)J, (int)R);
+                     (const float*)bt, (f16x8*)workspace, (int)J, (int)R, bt_transposed);
   int err = (int)hipGetLastError();
   if (err) return err;
   TgArgs p;

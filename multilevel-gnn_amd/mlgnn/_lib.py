@@ -46,7 +46,7 @@ SIGNATURES = {
     "mlgnn_segment_pool_fwd": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P]),
     "mlgnn_tallgemm_supported": (_INT, [_I64, _I64, _I64, _INT]),
     "mlgnn_tallgemm_workspace_bytes": (_I64, [_I64, _I64, _INT]),
-    "mlgnn_tallgemm_nt": (_INT, [_P, _P, _P, _P, _P, _INT, _P, _P, _F, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
+    "mlgnn_tallgemm_nt": (_INT, [_P, _P, _INT, _P, _P, _P, _INT, _P, _P, _F, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
 }
 
 ERRORS = {-1: "MLGNN_E_NULL", -2: "MLGNN_E_SHAPE", -3: "MLGNN_E_MODE", -4: "MLGNN_E_DTYPE",

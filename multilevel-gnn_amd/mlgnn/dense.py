@@ -11,7 +11,7 @@ WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bot
 ROW_MAX_STATS = {"given": 0, "computed": 0}      # tall GEMMs whose operand came with / without its row maxima
 
 
-def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None):
+def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None, bt_transposed=False):
     """``a [N,R] @ bt[J,R]^T (+ bias) (+ residual [N,J])`` through the scaled split-precision fp16-MFMA kernel
     (``csrc/tallgemm.hip``).  The caller checks :func:`tall_matmul_supported` first.  ``row_max`` [N]: ``max |a[i]|``
     when the producer of ``a`` supplied it (see :func:`mlgnn.ops.tag_row_max`).
@@ -19,7 +19,9 @@ def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None):
     the affine map, its 1/sigma and ``max relu(gamma xhat + beta)`` per row.  ``ln = ("in", gamma, beta)``: ``a`` is
     such an ``xhat``; ``relu(gamma a + beta)`` is applied as it is loaded."""
     N, R = a.shape
-    J = bt.shape[0]
+    if bt_transposed and a.dtype != torch.float32:           # (the bf16 kernel packs a [J, R] operand)
+        bt, bt_transposed = bt.t(), False
+    J = bt.shape[1] if bt_transposed else bt.shape[0]        # bt_transposed: bt is [R, J], read with swapped indices
     a, bt = a.contiguous(), bt.contiguous()
     dt = _DTYPE_IDS[a.dtype]
     out = torch.empty((N, J), dtype=a.dtype, device=a.device)
@@ -39,7 +41,8 @@ def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None):
             eps = float(ln[3])
             rstd = torch.empty(N, dtype=torch.float32, device=a.device)
             rmax = torch.empty(N, dtype=torch.float32, device=a.device)
-    rc = _lib.lib.mlgnn_tallgemm_nt(a.data_ptr(), bt.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(row_max),
+    rc = _lib.lib.mlgnn_tallgemm_nt(a.data_ptr(), bt.data_ptr(), int(bt_transposed), _lib.ptr(bias), _lib.ptr(residual),
+                                    _lib.ptr(row_max),
                                     mode, _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.ptr(rstd), _lib.ptr(rmax),
                                     out.data_ptr(), ws.data_ptr(), nbytes, N, R, J, dt,
                                     torch.cuda.current_stream().cuda_stream)
@@ -95,7 +98,7 @@ class _TallLinear(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             if tall_matmul_supported(N, M, K, go.dtype):
-                gx = tall_matmul_nt(go, weight.t().contiguous(), row_max=row_max_of(go))   # go [N,M] @ (W^T)[K,M]^T
+                gx = tall_matmul_nt(go, weight, row_max=row_max_of(go), bt_transposed=True)     # go [N,M] @ W [M,K]
             else:
                 gx = go.matmul(weight)
         gw = gb = None
@@ -138,10 +141,10 @@ class _FusedMLP2(torch.autograd.Function):
         has_b1, has_b2 = ctx.flags
         go = go.contiguous()
         gw2, gb2 = _wgrad(go, xhat, gamma.contiguous(), beta.contiguous())          # go^T relu(gamma xhat + beta)
-        gy = tall_matmul_nt(go, w2.t().contiguous(), row_max=_rm(go))
+        gy = tall_matmul_nt(go, w2, row_max=_rm(go), bt_transposed=True)
         gh, ggamma, gbeta, gh_max = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
         gw1, gb1 = _wgrad(gh, x)
-        gx = tall_matmul_nt(gh, w1.t().contiguous(), row_max=gh_max) if ctx.needs_input_grad[0] else None
+        gx = tall_matmul_nt(gh, w1, row_max=gh_max, bt_transposed=True) if ctx.needs_input_grad[0] else None
         return (gx, gw1, gb1 if has_b1 else None, ggamma, gbeta, gw2, gb2 if has_b2 else None,
                 go if ctx.needs_input_grad[7] else None, None)
 

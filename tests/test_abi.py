@@ -81,12 +81,13 @@ def test_argument_errors_of_the_dense_and_embedding_entry_points():
     assert lib.mlgnn_tallgemm_supported(1000, 64, 64, 5) == 0
     assert lib.mlgnn_tallgemm_workspace_bytes(256, 512, BF16) == 256 * 512 * 2
     assert lib.mlgnn_tallgemm_workspace_bytes(128, 256, F32) == 128 * 256 * 4 + 64
-    tg = lambda dtype, ln, N=64, R=64, J=64: lib.mlgnn_tallgemm_nt(None, None, None, None, None, ln, None, None, 0.0,
-                                                                    None, None, None, None, 1 << 20, N, R, J, dtype, None)
+    tg = lambda dtype, ln, N=64, R=64, J=64, tr=0: lib.mlgnn_tallgemm_nt(None, None, tr, None, None, None, ln, None, None,
+                                                                          0.0, None, None, None, None, 1 << 20, N, R, J,
+                                                                          dtype, None)
     assert tg(BF16, 1) == -3                                               # LayerNorm modes are fp32-only
     assert tg(BF16, 0) == -1 and tg(F32, 0) == -1                          # NULL operands
     assert tg(BF16, 0, R=40) == -2 and tg(7, 0) == -4
-    assert tg(BF16, 0, N=0) == 0
+    assert tg(BF16, 0, N=0) == 0 and tg(BF16, 0, tr=1) == -3             # transposed operand: fp32 only
     # weight gradient
     assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 512, 256, BF16) > 0
     assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 512, 200, BF16) == -2       # K % 128 != 0

@@ -53,6 +53,19 @@ def test_split_precision_error(scale):
     assert err < 2e-6 and rms < 1e-6
 
 
+@pytest.mark.parametrize("N,R,J", [(1000, 128, 256), (4097, 256, 128), (777, 16, 32), (3000, 64, 64)])
+def test_transposed_operand_is_read_in_place(N, R, J):
+    """bt_transposed: the [R, J] matrix (a Linear's own weight in its input gradient) gives bit-identical results to
+    the product with its contiguous transpose."""
+    from mlgnn.dense import tall_matmul_nt
+    gen = torch.Generator().manual_seed(R + J)
+    a = torch.randn(N, R, generator=gen).cuda()
+    w = (torch.randn(R, J, generator=gen) * 0.1).cuda()               # [R, J]
+    ref = tall_matmul_nt(a, w.t().contiguous())
+    out = tall_matmul_nt(a, w, bt_transposed=True)
+    assert torch.equal(out, ref)
+
+
 def test_unsupported_shapes_are_reported():
     from mlgnn.dense import tall_matmul_supported
     assert not tall_matmul_supported(1000, 128, 96)          # J not a power-of-two multiple of 32

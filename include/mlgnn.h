@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 7
+#define MLGNN_ABI_VERSION 8
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -355,6 +355,32 @@ int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transposed, const fl
  */
 int mlgnn_embedding_bwd(const float* grad_e, const int32_t* perm, const int32_t* rowptr, float* grad_table,
                         int64_t T, int64_t d, int dtype, void* stream);
+
+/*
+ * Large bf16 GEMM with fp32 accumulation on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), both operands with the
+ * contraction index contiguous:
+ *     C[M,N] = sum_{s < nseg} A_s[M,K_s] * B_s[N,K_s]^T  (+ alpha * aux[M,N])
+ * Replaces: the dense products of torch_geometric's dense_diff_pool (s^T x, s^T adj s, s s^T) as called from
+ * DiffPoolLayer.forward (models/diff_pooling.py:59-65) at sizes past the fused small-graph kernel (BASELINE
+ * configs[4]: 4096 pooled nodes, 1024 clusters), and their gradients.
+ *   a[s], b[s]   device pointers to bf16 matrices, leading dimensions lda[s], ldb[s] (elements, multiples of 8,
+ *                pointers 16-byte aligned); k[s] % 64 == 0; 1 <= nseg <= 4;  M % 128 == 0, N % 128 == 0
+ *   splits       1: the epilogue below runs in the kernel.  > 1: the contraction range is cut into `splits` parts
+ *                whose fp32 results go to slab [splits][M][N] (nothing else is written); sum them in a fixed order
+ *                afterwards -- there are no atomics anywhere
+ *   c            [M,N] result, leading dimension ldc, c_dtype MLGNN_DTYPE_BF16 or MLGNN_DTYPE_F32 (nullable)
+ *   ct           [N,M] bf16 transposed copy of the result, leading dimension ldct (nullable)
+ *   aux, alpha   optional [M,N] term added before the stores (aux_dtype as c_dtype)
+ *   dot          optional [M,N] bf16: dot_partial[w] = sum over workgroup w's tile of dot[i][j] * (fp32 result, before
+ *                alpha * aux); dot_partial has mlgnn_gemm_bf16_nt_workgroups(M, N, 1) entries
+ * One workgroup per 128 x 128 tile (and split): mlgnn_gemm_bf16_nt_workgroups(M, N, splits) in all (0: bad shape).
+ */
+int mlgnn_gemm_bf16_nt_workgroups(int64_t M, int64_t N, int splits);
+int mlgnn_gemm_bf16_nt(const void* const* a, const void* const* b, const int64_t* lda, const int64_t* ldb,
+                       const int64_t* k, int nseg, int64_t M, int64_t N, int splits, float* slab,
+                       void* c, int64_t ldc, int c_dtype, void* ct, int64_t ldct,
+                       const void* aux, int64_t ldaux, int aux_dtype, float alpha,
+                       const void* dot, int64_t lddot, float* dot_partial, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 8
+#define MLGNN_ABI_VERSION 9
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -365,9 +365,9 @@ int mlgnn_embedding_bwd(const float* grad_e, const int32_t* perm, const int32_t*
  * configs[4]: 4096 pooled nodes, 1024 clusters), and their gradients.
  *   a[s], b[s]   device pointers to bf16 matrices, leading dimensions lda[s], ldb[s] (elements, multiples of 8,
  *                pointers 16-byte aligned); k[s] % 64 == 0; 1 <= nseg <= 4;  M % 128 == 0, N % 128 == 0
- *   splits       1: the epilogue below runs in the kernel.  > 1: the contraction range is cut into `splits` parts
- *                whose fp32 results go to slab [splits][M][N] (nothing else is written); sum them in a fixed order
- *                afterwards -- there are no atomics anywhere
+ *   splits, slab slab = NULL (splits must be 1): the epilogue below runs in the kernel.  slab != NULL: the contraction
+ *                range is cut into `splits` >= 1 parts whose fp32 results go to slab [splits][M][N] (nothing else is
+ *                written); sum them in a fixed order afterwards -- there are no atomics anywhere
  *   c            [M,N] result, leading dimension ldc, c_dtype MLGNN_DTYPE_BF16 or MLGNN_DTYPE_F32 (nullable)
  *   ct           [N,M] bf16 transposed copy of the result, leading dimension ldct (nullable)
  *   aux, alpha   optional [M,N] term added before the stores (aux_dtype as c_dtype)
@@ -381,6 +381,40 @@ int mlgnn_gemm_bf16_nt(const void* const* a, const void* const* b, const int64_t
                        void* c, int64_t ldc, int c_dtype, void* ct, int64_t ldct,
                        const void* aux, int64_t ldaux, int aux_dtype, float alpha,
                        const void* dot, int64_t lddot, float* dot_partial, void* stream);
+
+/*
+ * dense_diff_pool for LARGE pooled graphs on the bf16 matrix cores (BASELINE configs[4]: N = 4096 nodes, K = 1024
+ * clusters, C = 256 channels), one pooled graph per call.
+ * Replaces: torch_geometric.nn.dense_diff_pool as called from DiffPoolLayer.forward (models/diff_pooling.py:59-65):
+ *   S = softmax(s_logits, -1);  x_out = S^T z;  adj_out = S^T adj S;
+ *   stats[0] = ||adj - S S^T||_F / numel(adj);  stats[1] = mean_n(sum_k -S log(S + 1e-15));  stats[2] = ||adj - S S^T||_F
+ * z [N,C], adj [N,N] bf16; s_logits [N,K] fp32 or bf16 (logits_dtype); s_out [N,K] bf16 = the rounded softmax every
+ * product uses (saved for the backward); x_out [K,C], adj_out [K,K] in out_dtype; stats float[3] (device).
+ * N, K, C multiples of 128 (mlgnn_diffpool_large_supported).  The link term is evaluated as
+ * ||adj||^2 - 2 <S, adj S> + ||S^T S||^2 (exact identity, fp32 partial sums in a fixed order; csrc/diffpool_large.hip).
+ * workspace: mlgnn_diffpool_large_workspace_bytes(N, K, C) bytes, 256-byte aligned; its first
+ * mlgnn_diffpool_large_saved_bytes(N, K, C) bytes (T = adj S, its transpose, S^T, z^T, S^T S) must reach the backward
+ * unchanged (`saved`).
+ *
+ * Backward: grad_x [K,C], grad_adj_out [K,K] (grad_dtype) = cotangents of x_out / adj_out;
+ * coef (device, float[2]) = { grad_link / (numel(adj) * stats[2]),  grad_ent / N };
+ * outputs grad_z [N,C], grad_logits [N,K] in logits_dtype.  adj is treated as a constant (no adjacency gradient);
+ * adj_symmetric non-zero promises adj = adj^T and saves the product adj^T S (one third of the backward).
+ * workspace: mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, adj_symmetric) bytes.
+ */
+int mlgnn_diffpool_large_supported(int64_t N, int64_t K, int64_t C);
+int64_t mlgnn_diffpool_large_workspace_bytes(int64_t N, int64_t K, int64_t C);
+int64_t mlgnn_diffpool_large_saved_bytes(int64_t N, int64_t K, int64_t C);
+int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
+                             void* s_out, void* x_out, void* adj_out, int out_dtype, float* stats,
+                             void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int64_t C,
+                             void* stream);
+int64_t mlgnn_diffpool_large_bwd_workspace_bytes(int64_t N, int64_t K, int64_t C, int adj_symmetric);
+int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
+                             const void* s_soft, const void* saved, const void* grad_x,
+                             const void* grad_adj_out, int grad_dtype, const float* coef, void* grad_z,
+                             void* grad_logits, int adj_symmetric, void* workspace, int64_t workspace_bytes,
+                             int64_t N, int64_t K, int64_t C, void* stream);
 
 #ifdef __cplusplus
 }

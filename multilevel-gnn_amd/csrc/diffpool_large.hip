@@ -1,0 +1,458 @@
+// DiffPool soft-assignment contraction for LARGE pooled graphs (BASELINE configs[4]: 4096 nodes, 1024 clusters, 256
+// channels, bf16 storage / fp32 accumulation): the chain of big dense products on the bf16 matrix cores
+// (csrc/gemm_nt.hip) with everything around them fused into producers / epilogues.
+//
+// Reference: torch_geometric.nn.dense_diff_pool as called from DiffPoolLayer.forward (models/diff_pooling.py:59-65):
+//     S = softmax(s, -1);  X' = S^T Z;  A' = S^T A S;  link = ||A - S S^T||_F / numel(A);
+//     ent = mean_n( sum_k -S log(S + 1e-15) )
+//
+// What is computed (one pooled graph; all big operands bf16, every sum in fp32):
+//   * S~ = bf16(softmax(logits)) [N,K] and its transpose; entropy from the fp32 softmax in the same pass.
+//   * T = A S~ [N,K] (34 GFLOP at configs[4]) -- written as T and as T^T by the product's epilogue, which also
+//     accumulates <S~, T> from the fp32 accumulators.
+//   * [A' | G] = S~^T [T | S~]  (G = S~^T S~, [K,K]) as ONE split-K product, X' = S~^T Z as another.
+//   * The link term never forms the [N,N] matrix S S^T (another 34 GFLOP):
+//         ||A - S S^T||_F^2 = ||A||_F^2 - 2 <A, S S^T> + ||S S^T||_F^2 = ||A||_F^2 - 2 <S, A S> + ||S^T S||_F^2
+//     (exact identities; <A, S S^T> = sum_ik S_ik (A S)_ik needs no symmetry of A).  All three terms are sums of
+//     fp32 partials in a fixed order.  The subtraction cancels when S S^T ~ A: the relative error of link^2 is
+//     ~1e-6 * ||A||_F^2 / ||A - S S^T||_F^2 -- negligible unless the assignment reproduces the adjacency to
+//     better than 1 %, where link (a regulariser) is ~0 anyway.  Its gradient is formed the same way:
+//         d link / dS = c (-(A + A^T) S + 2 S G),   c = grad_link / (numel(A) * ||A - S S^T||_F)
+//   * backward:  dS = Z dX'^T + T (dA' - cI)^T... all four terms summed by ONE multi-term product
+//         dS = [Z | T | T2 | S~] [dX' | dA' - cI | dA'^T - cI | 2c G]^T,      T2 = A^T S~
+//     then the softmax backward (with the entropy term) as one streaming pass; dZ = S~ dX'.
+// No atomics; every reduction is a fixed-order sum of per-workgroup partials: bitwise reproducible.
+#include "common.h"
+#include "gemm_nt.h"
+#include "mlgnn.h"
+
+namespace mlgnn {
+
+int slab_reduce_launch(const float* slab, int splits, int M, int N, int n_a, void* ca, int64_t lda, int ca_f32,
+                       uint16_t* cb, int64_t ldb, float* sq_partial, int blocks, hipStream_t s);
+
+constexpr float kDplEps = 1e-15f;
+constexpr int kDplPartials = 1024;       // workgroups of the streaming reductions (= partial sums each)
+
+// ---- row softmax: logits [N,K] (fp32 or bf16) -> S~ bf16 [N,K]; per-workgroup entropy partial ------------------
+template <typename T>
+__device__ __forceinline__ float dpl_load(const T* p, size_t i) {
+  if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(p)[i];
+  else return bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dpl_softmax_kernel(const T* __restrict__ logits, uint16_t* __restrict__ s_out,
+                                                          float* __restrict__ ent_partial, int N, int K) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ent = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
+    const T* lr = logits + (size_t)row * K;
+    float mx = -3.0e38f;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, dpl_load(lr, k));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int k = lane; k < K; k += 64) sum += __expf(dpl_load(lr, k) - mx);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int k = lane; k < K; k += 64) {
+      const float s = __expf(dpl_load(lr, k) - mx) * inv;
+      ent -= s * __logf(s + kDplEps);
+      s_out[(size_t)row * K + k] = f32_to_bf16(s);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ent += __shfl_xor(ent, o);
+  if (lane == 0) wsum[wave] = ent;
+  __syncthreads();
+  if (threadIdx.x == 0) ent_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// dlogits = S (ds - <ds, S>),  ds = dS + c_ent * d/dS(-S log(S + eps)),   S recomputed in fp32 from the logits
+template <typename T>
+__global__ __launch_bounds__(256) void dpl_softmax_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ ds_in,
+                                                              const float* __restrict__ coef, T* __restrict__ dlogits,
+                                                              int N, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float c_ent = coef[1];
+  for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
+    const T* lr = logits + (size_t)row * K;
+    const float* dr = ds_in + (size_t)row * K;
+    float mx = -3.0e38f;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, dpl_load(lr, k));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int k = lane; k < K; k += 64) sum += __expf(dpl_load(lr, k) - mx);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    float dot = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float s = __expf(dpl_load(lr, k) - mx) * inv;
+      const float g = dr[k] - c_ent * (__logf(s + kDplEps) + s / (s + kDplEps));
+      dot += g * s;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+    for (int k = lane; k < K; k += 64) {
+      const float s = __expf(dpl_load(lr, k) - mx) * inv;
+      const float g = dr[k] - c_ent * (__logf(s + kDplEps) + s / (s + kDplEps));
+      const float v = s * (g - dot);
+      if constexpr (sizeof(T) == 4) reinterpret_cast<float*>(dlogits)[(size_t)row * K + k] = v;
+      else reinterpret_cast<uint16_t*>(dlogits)[(size_t)row * K + k] = f32_to_bf16(v);
+    }
+  }
+}
+
+// ---- bf16 transpose through LDS: in [R,C] (leading dimension ld_in) -> out [C,R] (ld_out); R, C % 64 == 0 -------
+__global__ __launch_bounds__(256) void dpl_transpose_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                            int64_t ld_in, int64_t ld_out, int tiles_c) {
+  __shared__ uint16_t tile[64][66];
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  // 64 rows x 128 B: 8 lanes per row, 16 bytes each; 256 threads = 32 rows per pass
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = pass * 32 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(in + (size_t)(r0 + r) * ld_in + c0 + ch * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tile[r][ch * 8 + 2 * i] = (uint16_t)(w[i] & 0xffff);
+      tile[r][ch * 8 + 2 * i + 1] = (uint16_t)(w[i] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = pass * 32 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)tile[ch * 8 + 2 * i][c] | ((uint32_t)tile[ch * 8 + 2 * i + 1][c] << 16);
+    *reinterpret_cast<uint4*>(out + (size_t)(c0 + c) * ld_out + r0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// ---- sum of squares of a bf16 matrix (contiguous, n % 8 == 0) -> one partial per workgroup ------------------------
+__global__ __launch_bounds__(256) void dpl_sumsq_kernel(const uint4* __restrict__ x, int64_t n8, float* __restrict__ partial) {
+  __shared__ float wsum[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = x[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = __builtin_bit_cast(float, w[j] << 16), b = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+      acc += a * a + b * b;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// ---- forward scalars: stats = {link, ent, ||A - S S^T||_F} from the partial sums, fixed order ---------------------
+struct DplFinalArgs {
+  const float* a2; int n_a2;          // ||A||_F^2 partials
+  const float* dot; int n_dot;        // <S, A S> partials
+  const float* g2; int n_g2;          // ||S^T S||_F^2 partials
+  const float* ent; int n_ent;        // entropy partials
+  float* stats; float inv_numel; float inv_rows;
+};
+
+__device__ float dpl_block_sum(const float* p, int n, float* sh) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += p[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void dpl_final_kernel(const DplFinalArgs p) {
+  __shared__ float sh[4];
+  const float a2 = dpl_block_sum(p.a2, p.n_a2, sh);
+  const float dot = dpl_block_sum(p.dot, p.n_dot, sh);
+  const float g2 = dpl_block_sum(p.g2, p.n_g2, sh);
+  const float ent = dpl_block_sum(p.ent, p.n_ent, sh);
+  if (threadIdx.x == 0) {
+    const float sq = fmaxf(a2 - 2.f * dot + g2, 0.f);
+    const float norm = sqrtf(sq);
+    p.stats[0] = norm * p.inv_numel;
+    p.stats[1] = ent * p.inv_rows;
+    p.stats[2] = norm;
+  }
+}
+
+// ---- backward operand preparation ----------------------------------------------------------------------------------
+// ga [K,K] (fp32 or bf16), G [K,K] bf16, coef[0] = c  ->  b1 = ga - cI,  b2 = ga^T - cI,  b3 = 2c G   (bf16 [K,K])
+template <typename T>
+__global__ __launch_bounds__(256) void dpl_prep_ga_kernel(const T* __restrict__ ga, const uint16_t* __restrict__ G,
+                                                          const float* __restrict__ coef, uint16_t* __restrict__ b1,
+                                                          uint16_t* __restrict__ b2, uint16_t* __restrict__ b3, int K) {
+  const float c = coef[0];
+  const int64_t n = (int64_t)K * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / K), q = (int)(i % K);
+    const float d = r == q ? c : 0.f;
+    b1[i] = f32_to_bf16(dpl_load(ga, i) - d);
+    b2[i] = f32_to_bf16(dpl_load(ga, (size_t)q * K + r) - d);
+    b3[i] = f32_to_bf16(2.f * c * bf16_to_f32(G[i]));
+  }
+}
+
+// gx [K,C] (fp32 or bf16) -> bf16 copy
+template <typename T>
+__global__ __launch_bounds__(256) void dpl_to_bf16_kernel(const T* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = f32_to_bf16(dpl_load(x, i));
+}
+
+int dpl_transpose(const uint16_t* in, uint16_t* out, int R, int C, int64_t ld_in, int64_t ld_out, hipStream_t s) {
+  if (R % 64 || C % 64) return MLGNN_E_SHAPE;
+  hipLaunchKernelGGL(dpl_transpose_kernel, dim3((R / 64) * (C / 64)), dim3(256), 0, s, in, out, ld_in, ld_out, C / 64);
+  return (int)hipGetLastError();
+}
+
+inline size_t dpl_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// split factor that brings a product with `tiles` output tiles to about one workgroup per CU
+inline int dpl_splits(int tiles, int ktiles) {
+  int s = 256 / tiles;
+  if (s < 1) s = 1;
+  if (s > ktiles) s = ktiles;
+  return s;
+}
+
+struct DplLayout {       // byte offsets into the forward workspace (kept for the backward) and scratch
+  size_t stack, T, G, scratch, total;      // stack [2K + C, N]: T^T, S~^T, Z^T;  T [N,K];  G [K,K]
+  size_t slab, part_a2, part_dot, part_g2, part_ent;
+  int splits_ag, splits_x;
+};
+
+DplLayout dpl_layout(int64_t N, int64_t K, int64_t C) {
+  DplLayout L;
+  size_t o = 0;
+  L.stack = o; o += dpl_align((size_t)(2 * K + C) * N * 2);
+  L.T = o; o += dpl_align((size_t)N * K * 2);
+  L.G = o; o += dpl_align((size_t)K * K * 2);
+  L.scratch = o;
+  const int tiles_ag = (int)((K / kGemmTile) * (2 * K / kGemmTile)), tiles_x = (int)((K / kGemmTile) * (C / kGemmTile));
+  L.splits_ag = dpl_splits(tiles_ag, (int)(N / kGemmBK));
+  L.splits_x = dpl_splits(tiles_x, (int)(N / kGemmBK));
+  const size_t slab_ag = (size_t)L.splits_ag * K * 2 * K * 4, slab_x = (size_t)L.splits_x * K * C * 4;
+  L.slab = o; o += dpl_align(slab_ag > slab_x ? slab_ag : slab_x);
+  L.part_a2 = o; o += dpl_align(kDplPartials * 4);
+  L.part_dot = o; o += dpl_align((size_t)(N / kGemmTile) * (K / kGemmTile) * 4);
+  L.part_g2 = o; o += dpl_align(kDplPartials * 4);
+  L.part_ent = o; o += dpl_align(kDplPartials * 4);
+  L.total = o;
+  return L;
+}
+
+bool dpl_supported(int64_t N, int64_t K, int64_t C) {
+  return N >= kGemmTile && K >= kGemmTile && C >= kGemmTile && N % kGemmTile == 0 && K % kGemmTile == 0 &&
+         C % kGemmTile == 0 && N <= 32768 && K <= 8192 && C <= 8192;
+}
+
+}  // namespace mlgnn
+
+using namespace mlgnn;
+
+#define DPL_CHECK(expr)       \
+  do {                        \
+    const int rc_ = (expr);   \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+extern "C" int mlgnn_diffpool_large_supported(int64_t N, int64_t K, int64_t C) { return dpl_supported(N, K, C) ? 1 : 0; }
+
+extern "C" int64_t mlgnn_diffpool_large_workspace_bytes(int64_t N, int64_t K, int64_t C) {
+  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+  return (int64_t)dpl_layout(N, K, C).total;
+}
+
+extern "C" int64_t mlgnn_diffpool_large_saved_bytes(int64_t N, int64_t K, int64_t C) {
+  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+  return (int64_t)dpl_layout(N, K, C).scratch;
+}
+
+extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
+                                        void* s_out, void* x_out, void* adj_out, int out_dtype, float* stats,
+                                        void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int64_t C,
+                                        void* stream) {
+  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+  if (!z || !adj || !s_logits || !s_out || !x_out || !adj_out || !stats || !workspace) return MLGNN_E_NULL;
+  if ((logits_dtype != MLGNN_DTYPE_F32 && logits_dtype != MLGNN_DTYPE_BF16) ||
+      (out_dtype != MLGNN_DTYPE_F32 && out_dtype != MLGNN_DTYPE_BF16)) return MLGNN_E_DTYPE;
+  const DplLayout L = dpl_layout(N, K, C);
+  if (workspace_bytes < (int64_t)L.total) return MLGNN_E_WORKSPACE;
+  if (((uintptr_t)z | (uintptr_t)adj | (uintptr_t)s_out | (uintptr_t)workspace) & 15) return MLGNN_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  uint16_t* stack = (uint16_t*)(ws + L.stack);
+  uint16_t* Tt = stack;                               // [K,N]
+  uint16_t* St = stack + (size_t)K * N;               // [K,N]
+  uint16_t* Zt = stack + (size_t)2 * K * N;           // [C,N]
+  uint16_t* T = (uint16_t*)(ws + L.T);
+  uint16_t* G = (uint16_t*)(ws + L.G);
+  float* slab = (float*)(ws + L.slab);
+  float* p_a2 = (float*)(ws + L.part_a2);
+  float* p_dot = (float*)(ws + L.part_dot);
+  float* p_g2 = (float*)(ws + L.part_g2);
+  float* p_ent = (float*)(ws + L.part_ent);
+  uint16_t* S = (uint16_t*)s_out;
+  const int n = (int)N, k = (int)K, c = (int)C;
+
+  // 1. S~ = softmax(logits), entropy partials; S~^T and Z^T into the stacked operand
+  const int sm_blocks = (int)((N + 3) / 4 < kDplPartials ? (N + 3) / 4 : kDplPartials);
+  if (logits_dtype == MLGNN_DTYPE_F32)
+    hipLaunchKernelGGL(dpl_softmax_kernel<float>, dim3(sm_blocks), dim3(256), 0, st, (const float*)s_logits, S, p_ent, n, k);
+  else
+    hipLaunchKernelGGL(dpl_softmax_kernel<bf16_t>, dim3(sm_blocks), dim3(256), 0, st, (const bf16_t*)s_logits, S, p_ent, n, k);
+  DPL_CHECK(dpl_transpose(S, St, n, k, K, N, st));
+  DPL_CHECK(dpl_transpose((const uint16_t*)z, Zt, n, c, C, N, st));
+  // 2. ||A||_F^2
+  hipLaunchKernelGGL(dpl_sumsq_kernel, dim3(kDplPartials), dim3(256), 0, st, (const uint4*)adj, (int64_t)N * N / 8, p_a2);
+  // 3. T = A S~ (and T^T, <S~, T>)
+  {
+    GemmDesc d{};
+    d.nseg = 1;
+    d.seg[0] = GemmSeg{(const uint16_t*)adj, St, N, N, n};
+    d.M = n; d.N = k; d.splits = 1;
+    d.c = T; d.ldc = K; d.c_f32 = 0;
+    d.ct = Tt; d.ldct = N;
+    d.dot = S; d.lddot = K; d.dot_partial = p_dot;
+    DPL_CHECK(gemm_nt_launch(d, st));
+  }
+  // 4. [A' | G] = S~^T [T | S~]
+  {
+    GemmDesc d{};
+    d.nseg = 1;
+    d.seg[0] = GemmSeg{St, Tt, N, N, n};               // B operand: rows 0 .. 2K of the stack (T^T then S~^T)
+    d.M = k; d.N = 2 * k; d.splits = L.splits_ag; d.slab = slab;
+    DPL_CHECK(gemm_nt_launch(d, st));
+    DPL_CHECK(slab_reduce_launch(slab, L.splits_ag, k, 2 * k, k, adj_out, K, out_dtype == MLGNN_DTYPE_F32, G, K, p_g2,
+                                 kDplPartials, st));
+  }
+  // 5. X' = S~^T Z
+  {
+    GemmDesc d{};
+    d.nseg = 1;
+    d.seg[0] = GemmSeg{St, Zt, N, N, n};
+    d.M = k; d.N = c; d.splits = L.splits_x; d.slab = slab;
+    DPL_CHECK(gemm_nt_launch(d, st));
+    DPL_CHECK(slab_reduce_launch(slab, L.splits_x, k, c, c, x_out, C, out_dtype == MLGNN_DTYPE_F32, nullptr, 0, nullptr,
+                                 kDplPartials, st));
+  }
+  // 6. link / entropy
+  DplFinalArgs f{p_a2, kDplPartials, p_dot, (int)((N / kGemmTile) * (K / kGemmTile)), p_g2, kDplPartials, p_ent, sm_blocks,
+                 stats, (float)(1.0 / ((double)N * (double)N)), (float)(1.0 / (double)N)};
+  hipLaunchKernelGGL(dpl_final_kernel, dim3(1), dim3(256), 0, st, f);
+  return (int)hipGetLastError();
+}
+
+extern "C" int64_t mlgnn_diffpool_large_bwd_workspace_bytes(int64_t N, int64_t K, int64_t C, int adj_symmetric) {
+  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+  size_t o = 0;
+  o += 3 * dpl_align((size_t)K * K * 2);                        // b1, b2, b3
+  o += 2 * dpl_align((size_t)K * C * 2);                        // gx bf16, its transpose
+  o += dpl_align((size_t)N * K * 4);                            // dS fp32
+  const int tiles_z = (int)((N / kGemmTile) * (C / kGemmTile));
+  o += dpl_align((size_t)dpl_splits(tiles_z, (int)(K / kGemmBK)) * N * C * 4);   // dZ slabs
+  if (!adj_symmetric) o += dpl_align((size_t)N * N * 2) + dpl_align((size_t)N * K * 2);   // A^T, T2
+  return (int64_t)o;
+}
+
+extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
+                                        const void* s_soft, const void* saved, const void* grad_x,
+                                        const void* grad_adj_out, int grad_dtype, const float* coef, void* grad_z,
+                                        void* grad_logits, int adj_symmetric, void* workspace, int64_t workspace_bytes,
+                                        int64_t N, int64_t K, int64_t C, void* stream) {
+  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+  if (!z || !adj || !s_logits || !s_soft || !saved || !grad_x || !grad_adj_out || !coef || !grad_z || !grad_logits ||
+      !workspace) return MLGNN_E_NULL;
+  if ((logits_dtype != MLGNN_DTYPE_F32 && logits_dtype != MLGNN_DTYPE_BF16) ||
+      (grad_dtype != MLGNN_DTYPE_F32 && grad_dtype != MLGNN_DTYPE_BF16)) return MLGNN_E_DTYPE;
+  if (workspace_bytes < mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, adj_symmetric)) return MLGNN_E_WORKSPACE;
+  const DplLayout L = dpl_layout(N, K, C);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned char* sv = (const unsigned char*)saved;
+  const uint16_t* stack = (const uint16_t*)(sv + L.stack);
+  const uint16_t* St = stack + (size_t)K * N;
+  const uint16_t* T = (const uint16_t*)(sv + L.T);
+  const uint16_t* G = (const uint16_t*)(sv + L.G);
+  const uint16_t* S = (const uint16_t*)s_soft;
+  const int n = (int)N, k = (int)K, c = (int)C;
+  unsigned char* ws = (unsigned char*)workspace;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { unsigned char* p = ws + o; o += dpl_align(bytes); return p; };
+  uint16_t* b1 = (uint16_t*)take((size_t)K * K * 2);
+  uint16_t* b2 = (uint16_t*)take((size_t)K * K * 2);
+  uint16_t* b3 = (uint16_t*)take((size_t)K * K * 2);
+  uint16_t* gxb = (uint16_t*)take((size_t)K * C * 2);
+  uint16_t* gxt = (uint16_t*)take((size_t)K * C * 2);
+  float* dS = (float*)take((size_t)N * K * 4);
+  const int splits_z = dpl_splits((int)((N / kGemmTile) * (C / kGemmTile)), (int)(K / kGemmBK));
+  float* slab = (float*)take((size_t)splits_z * N * C * 4);
+  const uint16_t* T2 = T;
+  if (!adj_symmetric) {
+    uint16_t* At = (uint16_t*)take((size_t)N * N * 2);
+    uint16_t* t2 = (uint16_t*)take((size_t)N * K * 2);
+    DPL_CHECK(dpl_transpose((const uint16_t*)adj, At, n, n, N, N, st));
+    GemmDesc d{};
+    d.nseg = 1;
+    d.seg[0] = GemmSeg{At, St, N, N, n};
+    d.M = n; d.N = k; d.splits = 1;
+    d.c = t2; d.ldc = K; d.c_f32 = 0;
+    DPL_CHECK(gemm_nt_launch(d, st));
+    T2 = t2;
+  }
+  // operands derived from the incoming gradients
+  if (grad_dtype == MLGNN_DTYPE_F32) {
+    hipLaunchKernelGGL(dpl_prep_ga_kernel<float>, dim3(1024), dim3(256), 0, st, (const float*)grad_adj_out, G, coef, b1, b2, b3, k);
+    hipLaunchKernelGGL(dpl_to_bf16_kernel<float>, dim3(256), dim3(256), 0, st, (const float*)grad_x, gxb, (int64_t)K * C);
+  } else {
+    hipLaunchKernelGGL(dpl_prep_ga_kernel<bf16_t>, dim3(1024), dim3(256), 0, st, (const bf16_t*)grad_adj_out, G, coef, b1, b2, b3, k);
+    hipLaunchKernelGGL(dpl_to_bf16_kernel<bf16_t>, dim3(256), dim3(256), 0, st, (const bf16_t*)grad_x, gxb, (int64_t)K * C);
+  }
+  DPL_CHECK(dpl_transpose(gxb, gxt, k, c, C, K, st));
+  // dS = Z gx^T + T (ga - cI)^T + T2 (ga^T - cI)^T + S~ (2cG)^T    (one product over the concatenated contraction range)
+  {
+    GemmDesc d{};
+    d.nseg = 4;
+    d.seg[0] = GemmSeg{(const uint16_t*)z, gxb, C, C, c};
+    d.seg[1] = GemmSeg{T, b1, K, K, k};
+    d.seg[2] = GemmSeg{T2, b2, K, K, k};
+    d.seg[3] = GemmSeg{S, b3, K, K, k};
+    d.M = n; d.N = k; d.splits = 1;
+    d.c = dS; d.ldc = K; d.c_f32 = 1;
+    DPL_CHECK(gemm_nt_launch(d, st));
+  }
+  const int sm_blocks = (int)((N + 3) / 4 < kDplPartials ? (N + 3) / 4 : kDplPartials);
+  if (logits_dtype == MLGNN_DTYPE_F32)
+    hipLaunchKernelGGL(dpl_softmax_bwd_kernel<float>, dim3(sm_blocks), dim3(256), 0, st, (const float*)s_logits, dS, coef,
+                       (float*)grad_logits, n, k);
+  else
+    hipLaunchKernelGGL(dpl_softmax_bwd_kernel<bf16_t>, dim3(sm_blocks), dim3(256), 0, st, (const bf16_t*)s_logits, dS, coef,
+                       (bf16_t*)grad_logits, n, k);
+  // dZ = S~ gx
+  {
+    GemmDesc d{};
+    d.nseg = 1;
+    d.seg[0] = GemmSeg{S, gxt, K, K, k};
+    d.M = n; d.N = c; d.splits = splits_z; d.slab = slab;
+    DPL_CHECK(gemm_nt_launch(d, st));
+    // dZ takes the dtype of z = the dtype of the logits
+    DPL_CHECK(slab_reduce_launch(slab, splits_z, n, c, c, grad_z, C, logits_dtype == MLGNN_DTYPE_F32, nullptr, 0, nullptr,
+                                 kDplPartials, st));
+  }
+  return (int)hipGetLastError();
+}

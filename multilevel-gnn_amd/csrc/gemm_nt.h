@@ -21,8 +21,8 @@ struct GemmDesc {
   GemmSeg seg[kGemmMaxSeg];
   int nseg;
   int M, N;                  // multiples of 128
-  int splits;                // split-K factor: > 1 writes fp32 slabs [splits][M][N] to `slab` and nothing else
-  float* slab;
+  int splits;                // split-K factor (> 1 needs `slab`)
+  float* slab;               // non-NULL: fp32 partial results [splits][M][N] and nothing else
   // outputs of the un-split product (any may be NULL)
   void* c; int64_t ldc; int c_f32;                    // C [M,N], bf16 or fp32
   uint16_t* ct; int64_t ldct;                         // C^T [N,M], bf16

@@ -26,6 +26,7 @@
 //     cannot be scheduled above them.
 //   * workgroup -> tile: XCD-aware (workgroups b and b+8 share an XCD's L2): every XCD owns a contiguous range of
 //     tiles, ordered in groups of 4 tile rows so that the range is a compact block of the output.
+#include <stdlib.h>
 #include "gemm_nt.h"
 #include "mlgnn.h"
 
@@ -37,10 +38,10 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-constexpr int kGThreads = 512;
-constexpr int kGStages = 4;
+constexpr int kGConsumers = 4;                                 // MFMA waves (1 per SIMD)
+constexpr int kGLoaders = 4;                                   // LDS-DMA waves (1 per SIMD)
+constexpr int kGThreads = (kGConsumers + kGLoaders) * kWave;
 constexpr int kGStageBytes = 2 * kGemmTile * kGemmBK * 2;      // 32 KB: A tile then B tile
-constexpr int kGLds = kGStages * kGStageBytes;                 // 128 KB
 constexpr int kGGroupRows = 4;                                 // tile rows per ordering group
 constexpr int kGCtPitch = (kGemmTile + 8) * 2;                 // bytes per row of the transposed staging image
 
@@ -60,12 +61,23 @@ __device__ __forceinline__ i32x4 lds_read16_hi(uint32_t addr) {          // + 32
   return v;
 }
 
+template <int N>
+__device__ __forceinline__ void wait_dma_tiles() {              // all but the N youngest tiles (8 DMAs each) have landed
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+}
+
+// STAGES LDS stages of 32 KB; the loader waves keep STAGES - 2 K-steps in flight behind the one being multiplied
+// (whose last fragment reads may still be outstanding at the barrier) and the one about to be read.
+template <int STAGES, int ABL = 0>
 __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
+  constexpr int DEPTH = STAGES - 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
-  const int r31 = lane & 31, h = lane >> 5;
 
   // ---- which tile / K range -----------------------------------------------------------------------------------
   const int tiles = p.tiles_m * p.tiles_n;
@@ -89,45 +101,83 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
   const int t_end = (int)((int64_t)p.ktiles * (split + 1) / p.d.splits);
   const int T = t_end - t_begin;
 
-  // ---- DMA source addresses: per stage this wave moves pieces (1 KB = 8 rows) wave and wave + 8 of each operand
-  const int row_a0 = 8 * wave + (lane >> 3), row_a1 = row_a0 + 64;
-  const int chunk0 = (lane & 7) ^ ((row_a0 >> 1) & 7);           // (row_a1 >> 1) & 7 is the same: 64 rows further
-  int seg = 0, seg_left = 0;
-  const uint16_t *pa0, *pa1, *pb0, *pb1;
-  auto enter_segment = [&](int s, int k_tile) {
-    const GemmSeg& g = p.d.seg[s];
-    const uint16_t* a = g.a + (int64_t)k_tile * kGemmBK + chunk0 * 8;
-    const uint16_t* b = g.b + (int64_t)k_tile * kGemmBK + chunk0 * 8;
-    pa0 = a + (int64_t)(m0 + row_a0) * g.lda;
-    pa1 = a + (int64_t)(m0 + row_a1) * g.lda;
-    pb0 = b + (int64_t)(n0 + row_a0) * g.ldb;
-    pb1 = b + (int64_t)(n0 + row_a1) * g.ldb;
-    seg_left = g.K / kGemmBK - k_tile;
-  };
-  {
-    int t = t_begin;
-    while (t >= p.d.seg[seg].K / kGemmBK) t -= p.d.seg[seg++].K / kGemmBK;
-    enter_segment(seg, t);
-  }
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  auto issue = [&](int stage) {
-    unsigned char* dst = smem + stage * kGStageBytes + wave * 1024;
-    __builtin_amdgcn_global_load_lds((glb_void_t*)pa0, (lds_void_t*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)pa1, (lds_void_t*)(dst + 8192), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)pb0, (lds_void_t*)(dst + 16384), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)pb1, (lds_void_t*)(dst + 24576), 16, 0, 0);
-    if (--seg_left == 0 && seg + 1 < p.d.nseg) {
-      enter_segment(++seg, 0);
-    } else {
-      pa0 += kGemmBK; pa1 += kGemmBK; pb0 += kGemmBK; pb1 += kGemmBK;
+  if (wave >= kGConsumers) {
+    if (ABL >= 3) return;
+    // ================= loader waves: nothing but LDS-DMA issue, so that a full memory queue never holds up an MFMA
+    // wave lw moves pieces (1 KB = 8 rows of a stage) lw, lw + 4, ..., lw + 28 of each operand
+    const int lw = wave - kGConsumers;
+    const int row0 = 8 * lw + (lane >> 3);                        // + 32 i for piece i; (row >> 1) & 7 is the same for all
+    const int chunk0 = (lane & 7) ^ ((row0 >> 1) & 7);
+    int seg = 0, seg_left = 0;
+    const uint16_t *pa, *pb;
+    int64_t step_a, step_b;                                       // 32 rows
+    auto enter_segment = [&](int s, int k_tile) {
+      const GemmSeg& g = p.d.seg[s];
+      pa = g.a + (int64_t)(m0 + row0) * g.lda + (int64_t)k_tile * kGemmBK + chunk0 * 8;
+      pb = g.b + (int64_t)(n0 + row0) * g.ldb + (int64_t)k_tile * kGemmBK + chunk0 * 8;
+      step_a = 32 * g.lda;
+      step_b = 32 * g.ldb;
+      seg_left = g.K / kGemmBK - k_tile;
+    };
+    {
+      int t = t_begin;
+      while (t >= p.d.seg[seg].K / kGemmBK) t -= p.d.seg[seg++].K / kGemmBK;
+      enter_segment(seg, t);
     }
-  };
+    auto issue = [&](int stage) {
+      unsigned char* dst = smem + stage * kGStageBytes + lw * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + i * step_a), (lds_void_t*)(dst + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + i * step_b), (lds_void_t*)(dst + 16384 + i * 4096), 16, 0, 0);
+      }
+      if (--seg_left == 0 && seg + 1 < p.d.nseg) {
+        enter_segment(++seg, 0);
+      } else {
+        pa += kGemmBK;
+        pb += kGemmBK;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+      if (i < T) issue(i);
+    int stage_in = DEPTH % STAGES;
+    for (int t = 0; t < T; ++t) {
+      const int ahead = min(DEPTH - 1, T - 1 - t);                // tiles issued behind tile t
+      if (ahead >= 4) wait_dma_tiles<4>();
+      else if (ahead == 3) wait_dma_tiles<3>();
+      else if (ahead == 2) wait_dma_tiles<2>();
+      else if (ahead == 1) wait_dma_tiles<1>();
+      else wait_dma_tiles<0>();
+      __builtin_amdgcn_s_barrier();                               // tile t may be read; tile t - 1 is in registers
+      if (t + DEPTH < T && ABL != 1) {
+        issue(stage_in);                                          // into the stage that held tile t - 2
+        stage_in = stage_in + 1 == STAGES ? 0 : stage_in + 1;
+      }
+    }
+    // the workgroup barriers of the epilogue below
+    if (p.d.slab) return;
+    if (p.d.dot || p.d.ct) __syncthreads();
+    if (p.d.dot) __syncthreads();
+    if (p.d.ct) __syncthreads();
+    return;
+  }
 
-  // ---- fragment read addresses (bytes inside a stage) -----------------------------------------------------------
+  // ================= MFMA waves: one per SIMD, a 64 x 64 quadrant each ==========================================
+  // Fragments of K-step t + 1 are read (into the other register set) while the MFMAs of K-step t run.
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r31 = lane & 31, h = lane >> 5;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const int sw = (r31 >> 1) & 7;
-  const uint32_t c0 = (uint32_t)(((4 * kh + h) ^ sw) << 4), c1 = (uint32_t)(((4 * kh + 2 + h) ^ sw) << 4);
   const uint32_t a_row = lds0 + (uint32_t)(64 * wm + r31) * 128;
   const uint32_t b_row = lds0 + 16384 + (uint32_t)(64 * wn + r31) * 128;
+  uint32_t a_at[4], b_at[4];                                     // k-step s of a stage: 16-byte chunk 2 s + h, swizzled
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const uint32_t c = (uint32_t)(((2 * s4 + h) ^ sw) << 4);
+    a_at[s4] = a_row + c;
+    b_at[s4] = b_row + c;
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -137,135 +187,143 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (T > 0) issue(0);
-  if (T > 1) issue(1);
-  for (int t = 0; t < T; ++t) {
-    if (t + 2 < T) {
-      issue((t + 2) & (kGStages - 1));
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (t + 1 < T) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    const uint32_t st = (uint32_t)(t & (kGStages - 1)) * kGStageBytes;
-    i32x4 a00 = lds_read16(a_row + st + c0), a10 = lds_read16_hi(a_row + st + c0);
-    i32x4 b00 = lds_read16(b_row + st + c0), b10 = lds_read16_hi(b_row + st + c0);
-    i32x4 a01 = lds_read16(a_row + st + c1), a11 = lds_read16_hi(a_row + st + c1);
-    i32x4 b01 = lds_read16(b_row + st + c1), b11 = lds_read16_hi(b_row + st + c1);
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a00), "+v"(a10), "+v"(b00), "+v"(b10)::"memory");
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a00), __builtin_bit_cast(bf16x8, b00), acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a00), __builtin_bit_cast(bf16x8, b10), acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a10), __builtin_bit_cast(bf16x8, b00), acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a10), __builtin_bit_cast(bf16x8, b10), acc[1][1], 0, 0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11), "+v"(b01), "+v"(b11)::"memory");
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a01), __builtin_bit_cast(bf16x8, b01), acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a01), __builtin_bit_cast(bf16x8, b11), acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a11), __builtin_bit_cast(bf16x8, b01), acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a11), __builtin_bit_cast(bf16x8, b11), acc[1][1], 0, 0, 0);
+  // Fragment registers: set s holds k-step s of the current K-step's stage (4 x 16 bytes: A rows +0 / +32, B rows
+  // +0 / +32).  A set is refilled, with the same k-step of the NEXT stage or of this one, two MFMA groups before it
+  // is used: the reads of g + 3 are issued behind the MFMAs of g, so that at most 12 LDS reads are outstanding.
+  i32x4 fa0[4], fa1[4], fb0[4], fb1[4];
+#define MLGNN_READ(SET, ST)                          \
+  do {                                               \
+    if (ABL == 3) break;                             \
+    fa0[SET] = lds_read16(a_at[SET] + (ST));         \
+    fa1[SET] = lds_read16_hi(a_at[SET] + (ST));      \
+    fb0[SET] = lds_read16(b_at[SET] + (ST));         \
+    fb1[SET] = lds_read16_hi(b_at[SET] + (ST));      \
+  } while (0)
+#define MLGNN_LANDED(SET, CNT) \
+  asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa0[SET]), "+v"(fa1[SET]), "+v"(fb0[SET]), "+v"(fb1[SET])::"memory")
+#define MLGNN_MFMA(SET)                                                                                                   \
+  do {                                                                                                                    \
+    if (ABL != 2) {                                                                                                       \
+      const bf16x8 xa0 = __builtin_bit_cast(bf16x8, fa0[SET]), xa1 = __builtin_bit_cast(bf16x8, fa1[SET]);                \
+      const bf16x8 xb0 = __builtin_bit_cast(bf16x8, fb0[SET]), xb1 = __builtin_bit_cast(bf16x8, fb1[SET]);                \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb0, acc[0][0], 0, 0, 0);                                  \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb1, acc[0][1], 0, 0, 0);                                  \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb0, acc[1][0], 0, 0, 0);                                  \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb1, acc[1][1], 0, 0, 0);                                  \
+    }                                                                                                                     \
+  } while (0)
+
+  // sched_barrier: the compiler may not move anything across (it would otherwise collect the MFMAs behind the reads)
+#define MLGNN_PIN() __builtin_amdgcn_sched_barrier(0)
+  if (ABL == 3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa0[i] = fa1[i] = fb0[i] = fb1[i] = i32x4{(int)threadIdx.x, 0x3f803f80, i, 0x40004000};
+  }
+  if (ABL < 3) __builtin_amdgcn_s_barrier();                      // K-step 0 has landed
+  uint32_t st = 0;                                               // byte offset of the stage being multiplied
+  MLGNN_READ(0, st);
+  MLGNN_READ(1, st);
+  MLGNN_READ(2, st);
+  MLGNN_PIN();
+  for (int t = 0; t + 1 < T; ++t) {
+    const uint32_t st_next = st + kGStageBytes == STAGES * kGStageBytes ? 0 : st + kGStageBytes;
+    MLGNN_LANDED(0, 8);
+    MLGNN_MFMA(0);
+    MLGNN_PIN();
+    MLGNN_READ(3, st);
+    MLGNN_LANDED(1, 8);
+    MLGNN_MFMA(1);
+    MLGNN_PIN();
+    if (ABL < 3) __builtin_amdgcn_s_barrier();                    // K-step t + 1 has landed
+    MLGNN_READ(0, st_next);
+    MLGNN_LANDED(2, 8);
+    MLGNN_MFMA(2);
+    MLGNN_PIN();
+    MLGNN_READ(1, st_next);
+    MLGNN_LANDED(3, 8);
+    MLGNN_MFMA(3);
+    MLGNN_PIN();
+    MLGNN_READ(2, st_next);
+    MLGNN_PIN();
+    st = st_next;
+  }
+  MLGNN_LANDED(0, 8);
+  MLGNN_MFMA(0);
+  MLGNN_PIN();
+  MLGNN_READ(3, st);
+  MLGNN_LANDED(1, 8);
+  MLGNN_MFMA(1);
+  MLGNN_LANDED(2, 4);
+  MLGNN_MFMA(2);
+  MLGNN_LANDED(3, 0);
+  MLGNN_MFMA(3);
+#undef MLGNN_PIN
+#undef MLGNN_READ
+#undef MLGNN_LANDED
+#undef MLGNN_MFMA
+
+  // this wave owns rows  m0 + 64 wm + 32 mi + (r & 3) + 8 (r >> 2) + 4 h,  columns  n0 + 64 wn + 32 ni + r31
+  const int row_base = m0 + 64 * wm + 4 * h;
+  const int col_base = n0 + 64 * wn + r31;
+#define MLGNN_FOR_ACC(BODY)                                                              \
+  _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                   \
+    const int row = row_base + 32 * mi + (r & 3) + 8 * (r >> 2), col = col_base + 32 * ni;             \
+    BODY                                                                                 \
   }
 
-  // ---- sum the two k halves: every wave hands the 32-row half it does not finish to its SIMD partner ----------
-  __syncthreads();                                               // all fragment reads of the last stages are done
-  float4* xch = reinterpret_cast<float4*>(smem);                 // [wave][ni][4 register groups][lane]
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 v;
-      v.x = kh ? acc[0][ni][4 * g] : acc[1][ni][4 * g];
-      v.y = kh ? acc[0][ni][4 * g + 1] : acc[1][ni][4 * g + 1];
-      v.z = kh ? acc[0][ni][4 * g + 2] : acc[1][ni][4 * g + 2];
-      v.w = kh ? acc[0][ni][4 * g + 3] : acc[1][ni][4 * g + 3];
-      xch[((wave * 2 + ni) * 4 + g) * 64 + lane] = v;
-    }
-  __syncthreads();
-  float fin[2][16];
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 v = xch[(((wave ^ 4) * 2 + ni) * 4 + g) * 64 + lane];
-      fin[ni][4 * g] = (kh ? acc[1][ni][4 * g] : acc[0][ni][4 * g]) + v.x;
-      fin[ni][4 * g + 1] = (kh ? acc[1][ni][4 * g + 1] : acc[0][ni][4 * g + 1]) + v.y;
-      fin[ni][4 * g + 2] = (kh ? acc[1][ni][4 * g + 2] : acc[0][ni][4 * g + 2]) + v.z;
-      fin[ni][4 * g + 3] = (kh ? acc[1][ni][4 * g + 3] : acc[0][ni][4 * g + 3]) + v.w;
-    }
-  // this wave now owns rows  m0 + 64 wm + 32 kh + (r & 3) + 8 (r >> 2) + 4 h,  columns  n0 + 64 wn + 32 ni + r31
-  const int row_base = m0 + 64 * wm + 32 * kh + 4 * h;
-  const int col_base = n0 + 64 * wn + r31;
-
-  if (p.d.splits > 1) {
+  if (p.d.slab) {
     float* slab = p.d.slab + (size_t)split * p.d.M * p.d.N;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        slab[(size_t)(row_base + (r & 3) + 8 * (r >> 2)) * p.d.N + col_base + 32 * ni] = fin[ni][r];
+    MLGNN_FOR_ACC(slab[(size_t)row * p.d.N + col] = acc[mi][ni][r];)
     return;
   }
-
+  if (p.d.dot || p.d.ct) __syncthreads();                         // every wave has read its last fragments: LDS is free
   if (p.d.dot) {
     float part = 0.f;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        part += fin[ni][r] * bf16_to_f32(p.d.dot[(size_t)(row_base + (r & 3) + 8 * (r >> 2)) * p.d.lddot + col_base + 32 * ni]);
+    MLGNN_FOR_ACC(part += acc[mi][ni][r] * bf16_to_f32(p.d.dot[(size_t)row * p.d.lddot + col]);)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-    float* wsum = reinterpret_cast<float*>(smem + 65536 + 40960);          // past both staging regions
+    float* wsum = reinterpret_cast<float*>(smem + 40960);        // behind the transposed staging image
     if (lane == 0) wsum[wave] = part;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float tot = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) tot += wsum[w];
-      p.d.dot_partial[blockIdx.x] = tot;
-    }
+    if (threadIdx.x == 0) p.d.dot_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
   }
   if (p.d.aux) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const size_t at = (size_t)(row_base + (r & 3) + 8 * (r >> 2)) * p.d.ldaux + col_base + 32 * ni;
-        const float x = p.d.aux_f32 ? reinterpret_cast<const float*>(p.d.aux)[at]
-                                    : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.d.aux)[at]);
-        fin[ni][r] += p.d.alpha * x;
-      }
+    MLGNN_FOR_ACC(
+        const size_t at = (size_t)row * p.d.ldaux + col;
+        acc[mi][ni][r] += p.d.alpha * (p.d.aux_f32 ? reinterpret_cast<const float*>(p.d.aux)[at]
+                                                   : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.d.aux)[at]));)
   }
   if (p.d.c) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const size_t at = (size_t)(row_base + (r & 3) + 8 * (r >> 2)) * p.d.ldc + col_base + 32 * ni;
-        if (p.d.c_f32) reinterpret_cast<float*>(p.d.c)[at] = fin[ni][r];
-        else reinterpret_cast<uint16_t*>(p.d.c)[at] = f32_to_bf16(fin[ni][r]);
-      }
+    if (p.d.c_f32) {
+      MLGNN_FOR_ACC(reinterpret_cast<float*>(p.d.c)[(size_t)row * p.d.ldc + col] = acc[mi][ni][r];)
+    } else {
+      MLGNN_FOR_ACC(reinterpret_cast<uint16_t*>(p.d.c)[(size_t)row * p.d.ldc + col] = f32_to_bf16(acc[mi][ni][r]);)
+    }
   }
   if (p.d.ct) {
     // transposed copy through LDS: image[n][m] bf16 (pitch 272 B), a lane's 4 consecutive rows = one 8-byte write
-    unsigned char* img = smem + 65536;
+    unsigned char* img = smem;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 w;
-        w.x = (uint32_t)f32_to_bf16(fin[ni][4 * g]) | ((uint32_t)f32_to_bf16(fin[ni][4 * g + 1]) << 16);
-        w.y = (uint32_t)f32_to_bf16(fin[ni][4 * g + 2]) | ((uint32_t)f32_to_bf16(fin[ni][4 * g + 3]) << 16);
-        *reinterpret_cast<uint2*>(img + (64 * wn + 32 * ni + r31) * kGCtPitch + (64 * wm + 32 * kh + 8 * g + 4 * h) * 2) = w;
-      }
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 w;
+          w.x = (uint32_t)f32_to_bf16(acc[mi][ni][4 * g]) | ((uint32_t)f32_to_bf16(acc[mi][ni][4 * g + 1]) << 16);
+          w.y = (uint32_t)f32_to_bf16(acc[mi][ni][4 * g + 2]) | ((uint32_t)f32_to_bf16(acc[mi][ni][4 * g + 3]) << 16);
+          *reinterpret_cast<uint2*>(img + (64 * wn + 32 * ni + r31) * kGCtPitch + (64 * wm + 32 * mi + 8 * g + 4 * h) * 2) = w;
+        }
     __syncthreads();
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int n = pass * 32 + (threadIdx.x >> 4), ch = threadIdx.x & 15;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int n = pass * 16 + (threadIdx.x >> 4), ch = threadIdx.x & 15;
       const uint4 v = *reinterpret_cast<const uint4*>(img + n * kGCtPitch + ch * 16);
       *reinterpret_cast<uint4*>(p.d.ct + (size_t)(n0 + n) * p.d.ldct + m0 + ch * 8) = v;
     }
   }
+#undef MLGNN_FOR_ACC
 }
 
 // out[i] = sum_z slab[z][i]  in a fixed order; columns [0, n_a) of every row go to `ca` (bf16 or fp32, leading
@@ -332,15 +390,33 @@ int gemm_nt_launch(const GemmDesc& d, hipStream_t s) {
   }
   if (d.splits > p.ktiles) return MLGNN_E_SHAPE;
   if (d.splits > 1 && !d.slab) return MLGNN_E_NULL;
+  if (!d.slab && !d.c && !d.ct && !d.dot) return MLGNN_E_NULL;
   if (d.ct && (d.ldct % 8 || ((uintptr_t)d.ct & 15))) return MLGNN_E_ALIGN;
   p.tiles_m = d.M / kGemmTile;
   p.tiles_n = d.N / kGemmTile;
-  static bool attr_set = false;      // idempotent: a race only repeats the call
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
-    attr_set = true;
+  static const int variant = getenv("MLGNN_GEMM_VARIANT") ? atoi(getenv("MLGNN_GEMM_VARIANT")) : 0;   // tuning aid
+#define MLGNN_GEMM_CASE(ID, STAGES, ABL)                                                                             \
+  case ID: {                                                                                                         \
+    auto kern = &gemm_nt_kernel<STAGES, ABL>;                                                                        \
+    constexpr int lds = STAGES * kGStageBytes;                                                                       \
+    static bool attr_set = false; /* idempotent: a race only repeats the call */                                     \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kern, dim3(gemm_nt_workgroups(d)), dim3(kGThreads), lds, s, p);                               \
+    break;                                                                                                           \
   }
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3(gemm_nt_workgroups(d)), dim3(kGThreads), kGLds, s, p);
+  switch (variant) {
+    MLGNN_GEMM_CASE(0, 4, 0)
+    MLGNN_GEMM_CASE(1, 5, 0)
+    MLGNN_GEMM_CASE(11, 4, 1)
+    MLGNN_GEMM_CASE(12, 4, 2)
+    MLGNN_GEMM_CASE(13, 4, 3)
+    MLGNN_GEMM_CASE(14, 4, 4)
+    default: return MLGNN_E_MODE;
+  }
+#undef MLGNN_GEMM_CASE
   return (int)hipGetLastError();
 }
 
@@ -368,7 +444,7 @@ extern "C" int mlgnn_gemm_bf16_nt(const void* const* a, const void* const* b, co
                                   const void* dot, int64_t lddot, float* dot_partial, void* stream) {
   if (!a || !b || !lda || !ldb || !k) return MLGNN_E_NULL;
   if (nseg < 1 || nseg > kGemmMaxSeg || M > INT32_MAX || N > INT32_MAX) return MLGNN_E_SHAPE;
-  if ((dot && !dot_partial) || (splits == 1 && !c && !ct && !dot)) return MLGNN_E_NULL;
+  if ((dot && !dot_partial) || (!slab && !c && !ct && !dot)) return MLGNN_E_NULL;
   GemmDesc d{};
   d.nseg = nseg;
   for (int i = 0; i < nseg; ++i) {

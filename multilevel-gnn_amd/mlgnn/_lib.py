@@ -51,6 +51,13 @@ SIGNATURES = {
     "mlgnn_gemm_bf16_nt": (_INT, [_c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64),
                                   _INT, _I64, _I64, _INT, _P, _P, _I64, _INT, _P, _I64, _P, _I64, _INT, _F,
                                   _P, _I64, _P, _P]),
+    "mlgnn_diffpool_large_supported": (_INT, [_I64, _I64, _I64]),
+    "mlgnn_diffpool_large_workspace_bytes": (_I64, [_I64, _I64, _I64]),
+    "mlgnn_diffpool_large_saved_bytes": (_I64, [_I64, _I64, _I64]),
+    "mlgnn_diffpool_large_fwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_diffpool_large_bwd_workspace_bytes": (_I64, [_I64, _I64, _I64, _INT]),
+    "mlgnn_diffpool_large_bwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _I64,
+                                        _I64, _I64, _I64, _P]),
 }
 
 ERRORS = {-1: "MLGNN_E_NULL", -2: "MLGNN_E_SHAPE", -3: "MLGNN_E_MODE", -4: "MLGNN_E_DTYPE",

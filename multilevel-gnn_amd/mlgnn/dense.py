@@ -294,6 +294,83 @@ class _DiffPoolFused(torch.autograd.Function):
         return gz, gadj, gs
 
 
+class _DiffPoolLarge(torch.autograd.Function):
+    """One pooled graph past the fused small-graph kernel (BASELINE configs[4]: 4096 nodes, 1024 clusters): the chain of
+    large bf16 products on the matrix cores, ``mlgnn_diffpool_large_fwd`` / ``_bwd`` (csrc/diffpool_large.hip)."""
+
+    @staticmethod
+    def forward(ctx, z, adj, s, adj_symmetric):
+        N, C = z.shape
+        K = s.shape[1]
+        dev = z.device
+        zb = z.contiguous() if z.dtype == torch.bfloat16 else z.to(torch.bfloat16).contiguous()
+        ab = adj.contiguous() if adj.dtype == torch.bfloat16 else adj.to(torch.bfloat16).contiguous()
+        s = s.contiguous()
+        out_dtype = z.dtype
+        S = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
+        x_out = torch.empty((K, C), dtype=out_dtype, device=dev)
+        a_out = torch.empty((K, K), dtype=out_dtype, device=dev)
+        stats = torch.empty(3, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(_lib.lib.mlgnn_diffpool_large_workspace_bytes(N, K, C)), dtype=torch.uint8, device=dev)
+        rc = _lib.lib.mlgnn_diffpool_large_fwd(zb.data_ptr(), ab.data_ptr(), s.data_ptr(), _dt(s), S.data_ptr(),
+                                               x_out.data_ptr(), a_out.data_ptr(), _dt(x_out), stats.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), N, K, C, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_diffpool_large_fwd")
+        ctx.save_for_backward(zb, ab, s, S, ws, stats)
+        ctx.cfg = (bool(adj_symmetric), z.dtype, adj.numel())
+        return x_out, a_out, stats[0].to(out_dtype), stats[1].to(out_dtype)
+
+    @staticmethod
+    def backward(ctx, gx, ga, g_link, g_ent):
+        zb, ab, s, S, ws, stats = ctx.saved_tensors
+        sym, z_dtype, numel = ctx.cfg
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("the large DiffPool path treats the adjacency as a constant (no gradient)")
+        N, C = zb.shape
+        K = S.shape[1]
+        dev = zb.device
+        gdt = torch.float32 if gx.dtype == torch.float32 else torch.bfloat16
+        gx, ga = gx.to(gdt).contiguous(), ga.to(gdt).contiguous()
+        coef = torch.stack([g_link.float() / (numel * stats[2]), g_ent.float() / N]).contiguous()
+        gz = torch.empty((N, C), dtype=s.dtype, device=dev)
+        gs = torch.empty((N, K), dtype=s.dtype, device=dev)
+        wb = torch.empty(int(_lib.lib.mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, int(sym))), dtype=torch.uint8, device=dev)
+        rc = _lib.lib.mlgnn_diffpool_large_bwd(zb.data_ptr(), ab.data_ptr(), s.data_ptr(), _dt(s), S.data_ptr(), ws.data_ptr(),
+                                               gx.data_ptr(), ga.data_ptr(), _dt(gx), coef.data_ptr(), gz.data_ptr(),
+                                               gs.data_ptr(), int(sym), wb.data_ptr(), wb.numel(), N, K, C,
+                                               torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_diffpool_large_bwd")
+        return gz.to(z_dtype), None, gs, None
+
+
+def _dt(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def diff_pool_large_supported(z, adj, s):
+    B, N, C = z.shape
+    return (z.is_cuda and z.dtype == torch.bfloat16 and s.dtype == torch.bfloat16 and adj.dtype == torch.bfloat16
+            and not adj.requires_grad and bool(_lib.lib.mlgnn_diffpool_large_supported(N, s.shape[2], C)))
+
+
+def _diff_pool_large(z, adj, s, adj_symmetric=False):
+    """Batch loop around the one-graph product chain; losses are combined as the reference does
+    (one Frobenius norm over the whole batch, entropy averaged over all nodes)."""
+    B = z.shape[0]
+    xs, as_, l2, es = [], [], [], []
+    for b in range(B):
+        a_b = adj[b if adj.shape[0] == B and B > 1 else 0]
+        x, a, link, ent = _DiffPoolLarge.apply(z[b], a_b, s[b], adj_symmetric)
+        xs.append(x)
+        as_.append(a)
+        l2.append((link.float() * a_b.numel()) ** 2)
+        es.append(ent.float())
+    if B == 1:
+        return xs[0].unsqueeze(0), as_[0].unsqueeze(0), link, ent
+    link = torch.sqrt(torch.stack(l2).sum()) / adj.numel()
+    return torch.stack(xs), torch.stack(as_), link.to(z.dtype), torch.stack(es).mean().to(z.dtype)
+
+
 def _diff_pool_library(z, adj, s):
     s = torch.softmax(s, dim=-1)
     st = s.transpose(1, 2)
@@ -304,10 +381,12 @@ def _diff_pool_library(z, adj, s):
     return out, out_adj, link, ent
 
 
-def dense_diff_pool(z, adj, s):
+def dense_diff_pool(z, adj, s, adj_symmetric=False):
     """``S = softmax(s)``; returns ``(S^T Z, S^T A S, ||A - S S^T||_F / numel(A), mean entropy)``.
     Pooled graphs of up to 160 nodes / 48 clusters / 64 channels (the reference's 146 -> 37 -> 10)
-    run as one fused fp32-MFMA launch; larger ones as batched library GEMMs."""
+    run as one fused fp32-MFMA launch; bf16 graphs whose sizes are multiples of 128 (BASELINE configs[4]:
+    4096 nodes, 1024 clusters) as the matrix-core product chain of csrc/diffpool_large.hip; anything else as
+    batched library GEMMs.  ``adj_symmetric`` promises ``adj == adj^T`` (saves a third of the large backward)."""
     z = z.unsqueeze(0) if z.dim() == 2 else z
     adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
     s = s.unsqueeze(0) if s.dim() == 2 else s
@@ -316,4 +395,6 @@ def dense_diff_pool(z, adj, s):
     if (z.is_cuda and z.dtype == torch.float32 and adj.shape[0] in (1, B)
             and _lib.lib.mlgnn_diffpool_fwd_supported(N, K, C)):
         return _DiffPoolFused.apply(z, adj, s)
+    if adj.shape[0] in (1, B) and diff_pool_large_supported(z, adj, s):
+        return _diff_pool_large(z, adj, s, adj_symmetric)
     return _diff_pool_library(z, adj, s)

@@ -1,0 +1,174 @@
+"""DiffPool contraction for large pooled graphs (csrc/diffpool_large.hip, csrc/gemm_nt.hip; BASELINE configs[4]:
+4096 nodes, 1024 clusters, 256 channels, bf16) against the fp64 oracle ``oracle.primitives.dense_diff_pool``
+(reference: torch_geometric dense_diff_pool as called from models/diff_pooling.py:59-65).
+
+Two levels.  (i) Kernel arithmetic: given the bf16-rounded softmax S~ the kernel itself produced, every product must
+equal the fp64 product of the same rounded operands up to fp32 summation error (1e-5 of the absolute-value bound) --
+bf16 operands multiply exactly in fp32.  (ii) End to end against the oracle on unrounded fp64 arithmetic with the bf16
+bound: each of the chain's three roundings (S~, T = A S~, the output) is 2^-9 relative, worst case they add, so
+|err| <= 2^-7 * (product of absolute values)."""
+import math
+
+import pytest
+import torch
+
+from oracle import primitives as OP
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(256, 128, 128), (512, 256, 128), (1024, 384, 256)]
+
+
+def _inputs(N, K, C, seed, symmetric=False):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(N, C, generator=g).bfloat16()
+    a = torch.rand(N, N, generator=g)
+    if symmetric:
+        a = 0.5 * (a + a.t())
+    a = (a + torch.eye(N)).bfloat16()
+    s = (torch.randn(N, K, generator=g) * 2.0).bfloat16()
+    return z, a, s
+
+
+def _align(x):
+    return (x + 255) // 256 * 256
+
+
+def _raw_forward(z, a, s, out_dtype=torch.float32):
+    """The C entry point with fp32 outputs (the module surface ties the output dtype to the input's)."""
+    from mlgnn import _lib
+    N, C = z.shape
+    K = s.shape[1]
+    dev = z.device
+    S = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
+    x = torch.empty((K, C), dtype=out_dtype, device=dev)
+    ao = torch.empty((K, K), dtype=out_dtype, device=dev)
+    stats = torch.empty(3, device=dev)
+    ws = torch.empty(int(_lib.lib.mlgnn_diffpool_large_workspace_bytes(N, K, C)), dtype=torch.uint8, device=dev)
+    rc = _lib.lib.mlgnn_diffpool_large_fwd(z.data_ptr(), a.data_ptr(), s.data_ptr(), 1, S.data_ptr(), x.data_ptr(),
+                                           ao.data_ptr(), 0 if out_dtype == torch.float32 else 1, stats.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), N, K, C, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mlgnn_diffpool_large_fwd")
+    off_t = _align((2 * K + C) * N * 2)
+    stack = ws[:(2 * K + C) * N * 2].view(torch.bfloat16).view(2 * K + C, N)
+    T = ws[off_t:off_t + N * K * 2].view(torch.bfloat16).view(N, K)
+    G = ws[off_t + _align(N * K * 2):off_t + _align(N * K * 2) + K * K * 2].view(torch.bfloat16).view(K, K)
+    return S, x, ao, stats, stack, T, G
+
+
+@pytest.mark.parametrize("N,K,C", SIZES)
+def test_kernel_arithmetic_given_rounded_softmax(N, K, C):
+    z, a, s = (t.cuda() for t in _inputs(N, K, C, 1))
+    S, x, ao, stats, stack, T, G = _raw_forward(z, a, s)
+    soft = torch.softmax(s.double(), -1)
+    # S~ is the correctly rounded softmax (fast exp: 2 ulp of fp32 before rounding -> at most one bf16 ulp apart)
+    assert ((S.double() - soft).abs() <= 2.0 ** -8 * soft + 1e-30).all()
+    Sd, zd, ad = S.double(), z.double(), a.double()
+    # stacked transposes
+    assert torch.equal(stack[K:2 * K], S.t())
+    assert torch.equal(stack[2 * K:], z.t())
+    # T = A S~ (fp32 accumulation, one rounding) and its transposed copy
+    Tref = ad @ Sd
+    assert ((T.double() - Tref).abs() <= 2.0 ** -8 * Tref.abs() + 1e-5 * (ad.abs() @ Sd.abs())).all()
+    assert torch.equal(stack[:K], T.t())
+    Td = T.double()
+    assert ((x.double() - Sd.t() @ zd).abs() <= 1e-5 * (Sd.t() @ zd.abs())).all()
+    assert ((ao.double() - Sd.t() @ Td).abs() <= 1e-5 * (Sd.t() @ Td.abs())).all()
+    Gref = Sd.t() @ Sd
+    assert ((G.double() - Gref).abs() <= 2.0 ** -8 * Gref).all()
+    # link from the identity ||A||^2 - 2 <S, A S> + ||S^T S||^2 vs the direct Frobenius norm of the same rounded S
+    direct = float(torch.linalg.norm(ad - Sd @ Sd.t()))
+    assert abs(float(stats[2]) - direct) <= 1e-4 * direct
+    assert abs(float(stats[0]) - direct / (N * N)) <= 1e-4 * direct / (N * N)
+    ent = float((-soft * torch.log(soft + 1e-15)).sum(-1).mean())
+    assert abs(float(stats[1]) - ent) <= 1e-4 * abs(ent)
+
+
+@pytest.mark.parametrize("N,K,C", SIZES)
+def test_forward_backward_vs_oracle(N, K, C):
+    from mlgnn.dense import dense_diff_pool
+    z, a, s = _inputs(N, K, C, 2)
+    zd, ad, sd = z.double().requires_grad_(True), a.double(), s.double().requires_grad_(True)
+    rx, ra, rl, re = OP.dense_diff_pool(zd, ad, sd)
+    g = torch.Generator().manual_seed(3)
+    wx, wa = torch.randn(K, C, generator=g).double(), torch.randn(K, K, generator=g).double() / K
+    (rx[0] * wx).sum().add((ra[0] * wa).sum()).add(rl * 3e4).add(re * 2.0).backward()
+
+    zc, sc = z.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+    x, ao, link, ent = dense_diff_pool(zc, a.cuda(), sc)
+    assert x.dtype == torch.bfloat16 and x.shape == (1, K, C) and ao.shape == (1, K, K)
+    soft = torch.softmax(sd.detach(), -1)
+    bound_x = soft.t() @ zd.detach().abs()
+    bound_a = soft.t() @ ad.abs() @ soft
+    tol = 2.0 ** -7                                       # three bf16 roundings, worst case
+    assert ((x[0].double().cpu() - rx[0].detach()).abs() <= tol * bound_x).all()
+    assert ((ao[0].double().cpu() - ra[0].detach()).abs() <= tol * bound_a).all()
+    assert abs(float(link) - float(rl)) <= 2.0 ** -7 * float(rl)
+    assert abs(float(ent) - float(re)) <= 2.0 ** -7 * abs(float(re))
+    ((x[0].float() * wx.float().cuda()).sum() + (ao[0].float() * wa.float().cuda()).sum() + link.float() * 3e4
+     + ent.float() * 2.0).backward()
+    for got, ref, name in ((zc.grad, zd.grad, "grad z"), (sc.grad, sd.grad, "grad logits")):
+        err = float(torch.linalg.norm(got.double().cpu() - ref)) / float(torch.linalg.norm(ref))
+        assert err <= 2.0 ** -6, (name, err)             # bf16 operands and bf16 gradient storage: norm-wise 1.6 %
+
+
+def test_symmetric_adjacency_shortcut_is_bitwise_identical():
+    from mlgnn.dense import dense_diff_pool
+    N, K, C = 512, 256, 128
+    z, a, s = _inputs(N, K, C, 4, symmetric=True)
+    assert torch.equal(a, a.t())
+    outs = []
+    for sym in (False, True):
+        zc, sc = z.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+        x, ao, link, ent = dense_diff_pool(zc, a.cuda(), sc, adj_symmetric=sym)
+        (x.float().sum() + (ao.float() ** 2).sum() + 1e4 * link.float() + ent.float()).backward()
+        outs.append((x, ao, link, ent, zc.grad, sc.grad))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+
+
+def test_batched_and_reproducible():
+    from mlgnn.dense import dense_diff_pool
+    N, K, C = 256, 128, 128
+    zs, ss = [], []
+    for b in range(2):
+        z, a, s = _inputs(N, K, C, 10 + b)
+        zs.append(z)
+        ss.append(s)
+    z, s, a = torch.stack(zs).cuda(), torch.stack(ss).cuda(), a.cuda()
+    x1, a1, l1, e1 = dense_diff_pool(z, a, s)
+    x2, a2, l2, e2 = dense_diff_pool(z, a, s)
+    assert torch.equal(x1, x2) and torch.equal(a1, a2) and torch.equal(l1, l2) and torch.equal(e1, e2)
+    rx, ra, rl, re = OP.dense_diff_pool(z.double().cpu(), a.double().cpu(), s.double().cpu())
+    assert x1.shape == rx.shape and a1.shape == ra.shape
+    assert abs(float(l1) - float(rl)) <= 2.0 ** -7 * float(rl)
+    assert abs(float(e1) - float(re)) <= 2.0 ** -7 * abs(float(re))
+    assert float((x1.double().cpu() - rx).abs().max()) <= 2.0 ** -6 * float(rx.abs().max())
+
+
+def test_configs4_size_properties():
+    """BASELINE configs[4] size (4096 nodes, 1024 clusters, 256 channels): too large for the fp64 oracle in seconds on
+    all outputs, so the size-independent properties: column sums (S^T Z summed over clusters = column sums of Z since
+    softmax rows sum to 1), total edge mass (sum A' = sum_ij A_ij up to rounding), a sampled block of A' against fp64."""
+    from mlgnn.dense import dense_diff_pool
+    N, K, C = 4096, 1024, 256
+    z, a, s = (t.cuda() for t in _inputs(N, K, C, 5))
+    zc, sc = z.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    x, ao, link, ent = dense_diff_pool(zc, a, sc)
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all() and torch.isfinite(ao).all()
+    col = x[0].double().sum(0)
+    want = z.double().sum(0)
+    assert ((col - want).abs() <= 2.0 ** -7 * z.double().abs().sum(0)).all()
+    mass, want_mass = float(ao[0].double().sum()), float(a.double().sum())
+    assert abs(mass - want_mass) <= 2.0 ** -7 * want_mass
+    soft = torch.softmax(s.double(), -1)
+    blk = soft[:, :64].t() @ (a.double() @ soft[:, 64:128])
+    assert ((ao[0, :64, 64:128].double() - blk).abs() <= 2.0 ** -7 * blk.abs()).all()
+    direct = float(torch.linalg.norm(a.double() - soft @ soft.t())) / (N * N)
+    assert abs(float(link) - direct) <= 2.0 ** -7 * direct
+    assert 0.0 < float(ent) <= math.log(K) + 1e-3
+    (x.float().sum() + ao.float().sum() + link.float() + ent.float()).backward()
+    assert torch.isfinite(zc.grad).all() and torch.isfinite(sc.grad).all()
+    # d/dz of sum(S^T z) is the row sum of S = 1 for every entry
+    assert ((zc.grad.float() - 1.0).abs() <= 2.0 ** -6).all()

@@ -23,7 +23,7 @@ def _bound(segments):
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (256, 384, 192, 1), (1024, 256, 4096, 1), (512, 512, 1024, 4),
-                                          (128, 256, 128, 2), (384, 128, 320, 5)])
+                                          (128, 256, 128, 2), (384, 128, 320, 5), (128, 128, 64, 1)])
 def test_gemm_nt_matches_fp64(M, N, K, splits):
     from mlgnn.gemm import gemm_bf16_nt
     g = torch.Generator().manual_seed(M + N + K)

@@ -389,15 +389,16 @@ int mlgnn_gemm_bf16_nt(const void* const* a, const void* const* b, const int64_t
  *   S = softmax(s_logits, -1);  x_out = S^T z;  adj_out = S^T adj S;
  *   stats[0] = ||adj - S S^T||_F / numel(adj);  stats[1] = mean_n(sum_k -S log(S + 1e-15));  stats[2] = ||adj - S S^T||_F
  * z [N,C], adj [N,N] bf16; s_logits [N,K] fp32 or bf16 (logits_dtype); s_out [N,K] bf16 = the rounded softmax every
- * product uses (saved for the backward); x_out [K,C], adj_out [K,K] in out_dtype; stats float[3] (device).
+ * product uses (saved for the backward); x_out [K,C], adj_out [K,K], scal_out [2] = {stats[0], stats[1]} in out_dtype;
+ * stats float[3] (device).
  * N, K, C multiples of 128 (mlgnn_diffpool_large_supported).  The link term is evaluated as
  * ||adj||^2 - 2 <S, adj S> + ||S^T S||^2 (exact identity, fp32 partial sums in a fixed order; csrc/diffpool_large.hip).
  * workspace: mlgnn_diffpool_large_workspace_bytes(N, K, C) bytes, 256-byte aligned; its first
  * mlgnn_diffpool_large_saved_bytes(N, K, C) bytes (T = adj S, its transpose, S^T, z^T, S^T S) must reach the backward
  * unchanged (`saved`).
  *
- * Backward: grad_x [K,C], grad_adj_out [K,K] (grad_dtype) = cotangents of x_out / adj_out;
- * coef (device, float[2]) = { grad_link / (numel(adj) * stats[2]),  grad_ent / N };
+ * Backward: grad_x [K,C], grad_adj_out [K,K] (grad_dtype) = cotangents of x_out / adj_out; grad_link, grad_ent = the
+ * scalar cotangents of stats[0] / stats[1] ON THE DEVICE (scalar_dtype; no host sync); stats = the forward's;
  * outputs grad_z [N,C], grad_logits [N,K] in logits_dtype.  adj is treated as a constant (no adjacency gradient);
  * adj_symmetric non-zero promises adj = adj^T and saves the product adj^T S (one third of the backward).
  * workspace: mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, adj_symmetric) bytes.
@@ -406,13 +407,14 @@ int mlgnn_diffpool_large_supported(int64_t N, int64_t K, int64_t C);
 int64_t mlgnn_diffpool_large_workspace_bytes(int64_t N, int64_t K, int64_t C);
 int64_t mlgnn_diffpool_large_saved_bytes(int64_t N, int64_t K, int64_t C);
 int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
-                             void* s_out, void* x_out, void* adj_out, int out_dtype, float* stats,
-                             void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int64_t C,
-                             void* stream);
+                             void* s_out, void* x_out, void* adj_out, void* scal_out, int out_dtype,
+                             float* stats, void* workspace, int64_t workspace_bytes, int64_t N, int64_t K,
+                             int64_t C, void* stream);
 int64_t mlgnn_diffpool_large_bwd_workspace_bytes(int64_t N, int64_t K, int64_t C, int adj_symmetric);
 int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
                              const void* s_soft, const void* saved, const void* grad_x,
-                             const void* grad_adj_out, int grad_dtype, const float* coef, void* grad_z,
+                             const void* grad_adj_out, int grad_dtype, const void* grad_link,
+                             const void* grad_ent, int scalar_dtype, const float* stats, void* grad_z,
                              void* grad_logits, int adj_symmetric, void* workspace, int64_t workspace_bytes,
                              int64_t N, int64_t K, int64_t C, void* stream);
 

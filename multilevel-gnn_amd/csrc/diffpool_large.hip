@@ -71,6 +71,53 @@ __global__ __launch_bounds__(256) void dpl_softmax_kernel(const T* __restrict__ 
   if (threadIdx.x == 0) ent_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
+// K = 512 * CH: 16-byte loads, the row stays in registers (CH x 8 values per lane), 16-byte stores
+template <int CH>
+__global__ __launch_bounds__(256) void dpl_softmax_vec_kernel(const uint16_t* __restrict__ logits, uint16_t* __restrict__ s_out,
+                                                              float* __restrict__ ent_partial, int N) {
+  __shared__ float wsum[4];
+  constexpr int K = 512 * CH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ent = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
+    float v[CH][8];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      load_t<bf16_t, 8>(v[c], reinterpret_cast<const bf16_t*>(logits + (size_t)row * K + c * 512 + lane * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[c][j]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] = __expf(v[c][j] - mx);
+        sum += v[c][j];
+      }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] *= inv;
+        ent -= v[c][j] * __logf(v[c][j] + kDplEps);
+      }
+      store_t<bf16_t, 8>(reinterpret_cast<bf16_t*>(s_out + (size_t)row * K + c * 512 + lane * 8), v[c]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ent += __shfl_xor(ent, o);
+  if (lane == 0) wsum[wave] = ent;
+  __syncthreads();
+  if (threadIdx.x == 0) ent_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 // dlogits = S (ds - <ds, S>),  ds = dS + c_ent * d/dS(-S log(S + eps)),   S recomputed in fp32 from the logits
 template <typename T>
 __global__ __launch_bounds__(256) void dpl_softmax_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ ds_in,
@@ -163,7 +210,7 @@ struct DplFinalArgs {
   const float* dot; int n_dot;        // <S, A S> partials
   const float* g2; int n_g2;          // ||S^T S||_F^2 partials
   const float* ent; int n_ent;        // entropy partials
-  float* stats; float inv_numel; float inv_rows;
+  float* stats; void* scal_out; int scal_f32; float inv_numel; float inv_rows;
 };
 
 __device__ float dpl_block_sum(const float* p, int n, float* sh) {
@@ -189,11 +236,25 @@ __global__ __launch_bounds__(256) void dpl_final_kernel(const DplFinalArgs p) {
     p.stats[0] = norm * p.inv_numel;
     p.stats[1] = ent * p.inv_rows;
     p.stats[2] = norm;
+    if (p.scal_f32) {
+      reinterpret_cast<float*>(p.scal_out)[0] = p.stats[0];
+      reinterpret_cast<float*>(p.scal_out)[1] = p.stats[1];
+    } else {
+      reinterpret_cast<uint16_t*>(p.scal_out)[0] = f32_to_bf16(p.stats[0]);
+      reinterpret_cast<uint16_t*>(p.scal_out)[1] = f32_to_bf16(p.stats[1]);
+    }
   }
 }
 
 // ---- backward operand preparation ----------------------------------------------------------------------------------
 // ga [K,K] (fp32 or bf16), G [K,K] bf16, coef[0] = c  ->  b1 = ga - cI,  b2 = ga^T - cI,  b3 = 2c G   (bf16 [K,K])
+// coef = { grad_link / (numel(adj) * ||adj - S S^T||_F),  grad_ent / N }  from the scalar cotangents (device)
+template <typename T>
+__global__ void dpl_coef_kernel(const T* g_link, const T* g_ent, const float* stats, float* coef, float inv_numel, float inv_rows) {
+  coef[0] = dpl_load(g_link, 0) * inv_numel / stats[2];
+  coef[1] = dpl_load(g_ent, 0) * inv_rows;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dpl_prep_ga_kernel(const T* __restrict__ ga, const uint16_t* __restrict__ G,
                                                           const float* __restrict__ coef, uint16_t* __restrict__ b1,
@@ -285,11 +346,11 @@ extern "C" int64_t mlgnn_diffpool_large_saved_bytes(int64_t N, int64_t K, int64_
 }
 
 extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
-                                        void* s_out, void* x_out, void* adj_out, int out_dtype, float* stats,
-                                        void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int64_t C,
+                                        void* s_out, void* x_out, void* adj_out, void* scal_out, int out_dtype,
+                                        float* stats, void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int64_t C,
                                         void* stream) {
   if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
-  if (!z || !adj || !s_logits || !s_out || !x_out || !adj_out || !stats || !workspace) return MLGNN_E_NULL;
+  if (!z || !adj || !s_logits || !s_out || !x_out || !adj_out || !scal_out || !stats || !workspace) return MLGNN_E_NULL;
   if ((logits_dtype != MLGNN_DTYPE_F32 && logits_dtype != MLGNN_DTYPE_BF16) ||
       (out_dtype != MLGNN_DTYPE_F32 && out_dtype != MLGNN_DTYPE_BF16)) return MLGNN_E_DTYPE;
   const DplLayout L = dpl_layout(N, K, C);
@@ -313,8 +374,15 @@ extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const vo
 
   // 1. S~ = softmax(logits), entropy partials; S~^T and Z^T into the stacked operand
   const int sm_blocks = (int)((N + 3) / 4 < kDplPartials ? (N + 3) / 4 : kDplPartials);
+  const bool vec = logits_dtype == MLGNN_DTYPE_BF16 && ((uintptr_t)s_logits & 15) == 0;
   if (logits_dtype == MLGNN_DTYPE_F32)
     hipLaunchKernelGGL(dpl_softmax_kernel<float>, dim3(sm_blocks), dim3(256), 0, st, (const float*)s_logits, S, p_ent, n, k);
+  else if (vec && k == 512)
+    hipLaunchKernelGGL(dpl_softmax_vec_kernel<1>, dim3(sm_blocks), dim3(256), 0, st, (const uint16_t*)s_logits, S, p_ent, n);
+  else if (vec && k == 1024)
+    hipLaunchKernelGGL(dpl_softmax_vec_kernel<2>, dim3(sm_blocks), dim3(256), 0, st, (const uint16_t*)s_logits, S, p_ent, n);
+  else if (vec && k == 2048)
+    hipLaunchKernelGGL(dpl_softmax_vec_kernel<4>, dim3(sm_blocks), dim3(256), 0, st, (const uint16_t*)s_logits, S, p_ent, n);
   else
     hipLaunchKernelGGL(dpl_softmax_kernel<bf16_t>, dim3(sm_blocks), dim3(256), 0, st, (const bf16_t*)s_logits, S, p_ent, n, k);
   DPL_CHECK(dpl_transpose(S, St, n, k, K, N, st));
@@ -354,7 +422,7 @@ extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const vo
   }
   // 6. link / entropy
   DplFinalArgs f{p_a2, kDplPartials, p_dot, (int)((N / kGemmTile) * (K / kGemmTile)), p_g2, kDplPartials, p_ent, sm_blocks,
-                 stats, (float)(1.0 / ((double)N * (double)N)), (float)(1.0 / (double)N)};
+                 stats, scal_out, out_dtype == MLGNN_DTYPE_F32, (float)(1.0 / ((double)N * (double)N)), (float)(1.0 / (double)N)};
   hipLaunchKernelGGL(dpl_final_kernel, dim3(1), dim3(256), 0, st, f);
   return (int)hipGetLastError();
 }
@@ -362,6 +430,7 @@ extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const vo
 extern "C" int64_t mlgnn_diffpool_large_bwd_workspace_bytes(int64_t N, int64_t K, int64_t C, int adj_symmetric) {
   if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
   size_t o = 0;
+  o += dpl_align(16);                                           // coef
   o += 3 * dpl_align((size_t)K * K * 2);                        // b1, b2, b3
   o += 2 * dpl_align((size_t)K * C * 2);                        // gx bf16, its transpose
   o += dpl_align((size_t)N * K * 4);                            // dS fp32
@@ -373,12 +442,14 @@ extern "C" int64_t mlgnn_diffpool_large_bwd_workspace_bytes(int64_t N, int64_t K
 
 extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
                                         const void* s_soft, const void* saved, const void* grad_x,
-                                        const void* grad_adj_out, int grad_dtype, const float* coef, void* grad_z,
+                                        const void* grad_adj_out, int grad_dtype, const void* grad_link,
+                                        const void* grad_ent, int scalar_dtype, const float* stats, void* grad_z,
                                         void* grad_logits, int adj_symmetric, void* workspace, int64_t workspace_bytes,
                                         int64_t N, int64_t K, int64_t C, void* stream) {
   if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
-  if (!z || !adj || !s_logits || !s_soft || !saved || !grad_x || !grad_adj_out || !coef || !grad_z || !grad_logits ||
-      !workspace) return MLGNN_E_NULL;
+  if (!z || !adj || !s_logits || !s_soft || !saved || !grad_x || !grad_adj_out || !grad_link || !grad_ent || !stats ||
+      !grad_z || !grad_logits || !workspace) return MLGNN_E_NULL;
+  if (scalar_dtype != MLGNN_DTYPE_F32 && scalar_dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if ((logits_dtype != MLGNN_DTYPE_F32 && logits_dtype != MLGNN_DTYPE_BF16) ||
       (grad_dtype != MLGNN_DTYPE_F32 && grad_dtype != MLGNN_DTYPE_BF16)) return MLGNN_E_DTYPE;
   if (workspace_bytes < mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, adj_symmetric)) return MLGNN_E_WORKSPACE;
@@ -394,6 +465,14 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
   unsigned char* ws = (unsigned char*)workspace;
   size_t o = 0;
   auto take = [&](size_t bytes) { unsigned char* p = ws + o; o += dpl_align(bytes); return p; };
+  float* coef = (float*)take(16);
+  {
+    const float inv_numel = (float)(1.0 / ((double)N * (double)N)), inv_rows = (float)(1.0 / (double)N);
+    if (scalar_dtype == MLGNN_DTYPE_F32)
+      hipLaunchKernelGGL(dpl_coef_kernel<float>, dim3(1), dim3(1), 0, st, (const float*)grad_link, (const float*)grad_ent, stats, coef, inv_numel, inv_rows);
+    else
+      hipLaunchKernelGGL(dpl_coef_kernel<bf16_t>, dim3(1), dim3(1), 0, st, (const bf16_t*)grad_link, (const bf16_t*)grad_ent, stats, coef, inv_numel, inv_rows);
+  }
   uint16_t* b1 = (uint16_t*)take((size_t)K * K * 2);
   uint16_t* b2 = (uint16_t*)take((size_t)K * K * 2);
   uint16_t* b3 = (uint16_t*)take((size_t)K * K * 2);

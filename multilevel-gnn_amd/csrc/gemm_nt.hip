@@ -9,24 +9,29 @@
 // Several (A_s, B_s) terms may be summed into one result: the contraction simply runs over the concatenated K range,
 // which is how the backward forms  dS = Z dX'^T + T (dA'^T - cI) + T2 (dA' - cI) + S (2c G)  in ONE launch.
 //
-// Structure (one workgroup per CU, 8 waves = 2 per SIMD):
+// Structure (one workgroup per CU, 8 waves: on every SIMD one MFMA wave and one loader wave):
 //   * 128 x 128 output tile, K-step 64.  A 4096 x 1024 result has 256 tiles: one per CU, no split needed; smaller
 //     results are split along K into fp32 slabs (fixed-order reduce afterwards: bitwise reproducible, no atomics).
-//   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no registers), four 32 KB stages, loads two
-//     K-steps ahead of their use and left in flight across the barrier (counted vmcnt + raw s_barrier): ONE barrier
-//     per K-step.
+//   * loader waves (4) do nothing but issue LDS-DMA (global_load_lds_dwordx4: global -> LDS without registers) two
+//     K-steps ahead of the MFMAs, four 32 KB stages.  A CU takes in about 70 GB/s from L2 this way (measured: 28 us for
+//     the 2 MB a workgroup of the 4096 x 1024 x 4096 product streams), which at this tile size is about as long as
+//     the MFMAs themselves (30 us): when the same waves issued DMA and MFMA, a full memory queue held up the MFMAs
+//     behind it (48 us); with the issue on its own waves the two overlap (39 us).
+//   * MFMA waves (4) own a 64 x 64 quadrant each: 16 x v_mfma_f32_32x32x16_bf16 per K-step, fragments in four register
+//     sets (one per 16-deep k-step) that are refilled two MFMA groups before their use, across the K-step boundary.
+//   * ONE barrier per K-step joins loaders ("K-step t + 1 has landed": counted vmcnt, the later K-steps stay in
+//     flight across the barrier) and MFMA waves ("K-step t - 1 is in registers, its stage may be refilled").
 //   * LDS image of a stage: [128 rows][64 k] bf16 per operand, 128-byte rows, 16-byte chunks XOR-swizzled by
 //     (row >> 1) & 7 -- the DMA destination is linear, so the swizzle is applied to the per-lane SOURCE address
 //     and again to the fragment read address; ds_read_b128 is then conflict-free.
-//   * waves are arranged 2 (k halves) x 2 x 2: the two waves that share a SIMD take the two 32-deep halves of
-//     every K-step of the same 64 x 64 quadrant (one LDS fragment read per MFMA instead of 1.5 for 64 x 32 wave
-//     tiles); the halves are summed once, through LDS, in the epilogue.
 //   * fragment reads are inline asm (the compiler would otherwise drain every in-flight DMA before each ds_read of
 //     the array the DMA writes); their waits are tied to the fragment registers by "+v" operands so that the MFMAs
-//     cannot be scheduled above them.
+//     cannot be scheduled above them, and sched_barriers keep the read / MFMA interleave as written.
 //   * workgroup -> tile: XCD-aware (workgroups b and b+8 share an XCD's L2): every XCD owns a contiguous range of
 //     tiles, ordered in groups of 4 tile rows so that the range is a compact block of the output.
-#include <stdlib.h>
+// Measured (MI355X, random data): 4096 x 1024 x 4096 in 39 us = 880 TFLOP/s (35 % of the 2.5 PFLOP/s dense bf16 peak;
+// SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) = 0.35); the MFMA stream alone (no LDS traffic) runs
+// at 1.58 PFLOP/s in this kernel, with its fragment reads at 1.13.
 #include "gemm_nt.h"
 #include "mlgnn.h"
 
@@ -72,7 +77,7 @@ __device__ __forceinline__ void wait_dma_tiles() {              // all but the N
 
 // STAGES LDS stages of 32 KB; the loader waves keep STAGES - 2 K-steps in flight behind the one being multiplied
 // (whose last fragment reads may still be outstanding at the barrier) and the one about to be read.
-template <int STAGES, int ABL = 0>
+template <int STAGES>
 __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
   constexpr int DEPTH = STAGES - 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -102,7 +107,6 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
   const int T = t_end - t_begin;
 
   if (wave >= kGConsumers) {
-    if (ABL >= 3) return;
     // ================= loader waves: nothing but LDS-DMA issue, so that a full memory queue never holds up an MFMA
     // wave lw moves pieces (1 KB = 8 rows of a stage) lw, lw + 4, ..., lw + 28 of each operand
     const int lw = wave - kGConsumers;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
       else if (ahead == 1) wait_dma_tiles<1>();
       else wait_dma_tiles<0>();
       __builtin_amdgcn_s_barrier();                               // tile t may be read; tile t - 1 is in registers
-      if (t + DEPTH < T && ABL != 1) {
+      if (t + DEPTH < T) {
         issue(stage_in);                                          // into the stage that held tile t - 2
         stage_in = stage_in + 1 == STAGES ? 0 : stage_in + 1;
       }
@@ -193,7 +197,6 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
   i32x4 fa0[4], fa1[4], fb0[4], fb1[4];
 #define MLGNN_READ(SET, ST)                          \
   do {                                               \
-    if (ABL == 3) break;                             \
     fa0[SET] = lds_read16(a_at[SET] + (ST));         \
     fa1[SET] = lds_read16_hi(a_at[SET] + (ST));      \
     fb0[SET] = lds_read16(b_at[SET] + (ST));         \
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
   asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa0[SET]), "+v"(fa1[SET]), "+v"(fb0[SET]), "+v"(fb1[SET])::"memory")
 #define MLGNN_MFMA(SET)                                                                                                   \
   do {                                                                                                                    \
-    if (ABL != 2) {                                                                                                       \
+    {                                                                                                                     \
       const bf16x8 xa0 = __builtin_bit_cast(bf16x8, fa0[SET]), xa1 = __builtin_bit_cast(bf16x8, fa1[SET]);                \
       const bf16x8 xb0 = __builtin_bit_cast(bf16x8, fb0[SET]), xb1 = __builtin_bit_cast(bf16x8, fb1[SET]);                \
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb0, acc[0][0], 0, 0, 0);                                  \
@@ -215,11 +218,7 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
 
   // sched_barrier: the compiler may not move anything across (it would otherwise collect the MFMAs behind the reads)
 #define MLGNN_PIN() __builtin_amdgcn_sched_barrier(0)
-  if (ABL == 3) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa0[i] = fa1[i] = fb0[i] = fb1[i] = i32x4{(int)threadIdx.x, 0x3f803f80, i, 0x40004000};
-  }
-  if (ABL < 3) __builtin_amdgcn_s_barrier();                      // K-step 0 has landed
+  __builtin_amdgcn_s_barrier();                                   // K-step 0 has landed
   uint32_t st = 0;                                               // byte offset of the stage being multiplied
   MLGNN_READ(0, st);
   MLGNN_READ(1, st);
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
     MLGNN_LANDED(1, 8);
     MLGNN_MFMA(1);
     MLGNN_PIN();
-    if (ABL < 3) __builtin_amdgcn_s_barrier();                    // K-step t + 1 has landed
+    __builtin_amdgcn_s_barrier();                                 // K-step t + 1 has landed
     MLGNN_READ(0, st_next);
     MLGNN_LANDED(2, 8);
     MLGNN_MFMA(2);
@@ -394,29 +393,14 @@ int gemm_nt_launch(const GemmDesc& d, hipStream_t s) {
   if (d.ct && (d.ldct % 8 || ((uintptr_t)d.ct & 15))) return MLGNN_E_ALIGN;
   p.tiles_m = d.M / kGemmTile;
   p.tiles_n = d.N / kGemmTile;
-  static const int variant = getenv("MLGNN_GEMM_VARIANT") ? atoi(getenv("MLGNN_GEMM_VARIANT")) : 0;   // tuning aid
-#define MLGNN_GEMM_CASE(ID, STAGES, ABL)                                                                             \
-  case ID: {                                                                                                         \
-    auto kern = &gemm_nt_kernel<STAGES, ABL>;                                                                        \
-    constexpr int lds = STAGES * kGStageBytes;                                                                       \
-    static bool attr_set = false; /* idempotent: a race only repeats the call */                                     \
-    if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-      attr_set = true;                                                                                               \
-    }                                                                                                                \
-    hipLaunchKernelGGL(kern, dim3(gemm_nt_workgroups(d)), dim3(kGThreads), lds, s, p);                               \
-    break;                                                                                                           \
+  constexpr int kStages = 4;                   // 5 (three K-steps in flight, all 160 KB of LDS) measured the same
+  constexpr int lds = kStages * kGStageBytes;
+  static bool attr_set = false;                // idempotent: a race only repeats the call
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<kStages>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
   }
-  switch (variant) {
-    MLGNN_GEMM_CASE(0, 4, 0)
-    MLGNN_GEMM_CASE(1, 5, 0)
-    MLGNN_GEMM_CASE(11, 4, 1)
-    MLGNN_GEMM_CASE(12, 4, 2)
-    MLGNN_GEMM_CASE(13, 4, 3)
-    MLGNN_GEMM_CASE(14, 4, 4)
-    default: return MLGNN_E_MODE;
-  }
-#undef MLGNN_GEMM_CASE
+  hipLaunchKernelGGL(gemm_nt_kernel<kStages>, dim3(gemm_nt_workgroups(d)), dim3(kGThreads), lds, s, p);
   return (int)hipGetLastError();
 }
 

@@ -54,9 +54,9 @@ SIGNATURES = {
     "mlgnn_diffpool_large_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_diffpool_large_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "mlgnn_diffpool_large_saved_bytes": (_I64, [_I64, _I64, _I64]),
-    "mlgnn_diffpool_large_fwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_diffpool_large_fwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "mlgnn_diffpool_large_bwd_workspace_bytes": (_I64, [_I64, _I64, _I64, _INT]),
-    "mlgnn_diffpool_large_bwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _I64,
+    "mlgnn_diffpool_large_bwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _INT, _P, _P, _P, _INT, _P, _I64,
                                         _I64, _I64, _I64, _P]),
 }
 

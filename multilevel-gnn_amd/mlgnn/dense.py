@@ -311,19 +311,21 @@ class _DiffPoolLarge(torch.autograd.Function):
         x_out = torch.empty((K, C), dtype=out_dtype, device=dev)
         a_out = torch.empty((K, K), dtype=out_dtype, device=dev)
         stats = torch.empty(3, dtype=torch.float32, device=dev)
+        scal = torch.empty(2, dtype=out_dtype, device=dev)
         ws = torch.empty(int(_lib.lib.mlgnn_diffpool_large_workspace_bytes(N, K, C)), dtype=torch.uint8, device=dev)
         rc = _lib.lib.mlgnn_diffpool_large_fwd(zb.data_ptr(), ab.data_ptr(), s.data_ptr(), _dt(s), S.data_ptr(),
-                                               x_out.data_ptr(), a_out.data_ptr(), _dt(x_out), stats.data_ptr(),
-                                               ws.data_ptr(), ws.numel(), N, K, C, torch.cuda.current_stream().cuda_stream)
+                                               x_out.data_ptr(), a_out.data_ptr(), scal.data_ptr(), _dt(x_out),
+                                               stats.data_ptr(), ws.data_ptr(), ws.numel(), N, K, C,
+                                               torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_diffpool_large_fwd")
         ctx.save_for_backward(zb, ab, s, S, ws, stats)
-        ctx.cfg = (bool(adj_symmetric), z.dtype, adj.numel())
-        return x_out, a_out, stats[0].to(out_dtype), stats[1].to(out_dtype)
+        ctx.cfg = (bool(adj_symmetric), z.dtype)
+        return x_out, a_out, scal[0], scal[1]
 
     @staticmethod
     def backward(ctx, gx, ga, g_link, g_ent):
         zb, ab, s, S, ws, stats = ctx.saved_tensors
-        sym, z_dtype, numel = ctx.cfg
+        sym, z_dtype = ctx.cfg
         if ctx.needs_input_grad[1]:
             raise NotImplementedError("the large DiffPool path treats the adjacency as a constant (no gradient)")
         N, C = zb.shape
@@ -331,13 +333,14 @@ class _DiffPoolLarge(torch.autograd.Function):
         dev = zb.device
         gdt = torch.float32 if gx.dtype == torch.float32 else torch.bfloat16
         gx, ga = gx.to(gdt).contiguous(), ga.to(gdt).contiguous()
-        coef = torch.stack([g_link.float() / (numel * stats[2]), g_ent.float() / N]).contiguous()
+        if g_link.dtype != g_ent.dtype or g_link.dtype not in (torch.float32, torch.bfloat16):
+            g_link, g_ent = g_link.float(), g_ent.float()
         gz = torch.empty((N, C), dtype=s.dtype, device=dev)
         gs = torch.empty((N, K), dtype=s.dtype, device=dev)
         wb = torch.empty(int(_lib.lib.mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, int(sym))), dtype=torch.uint8, device=dev)
         rc = _lib.lib.mlgnn_diffpool_large_bwd(zb.data_ptr(), ab.data_ptr(), s.data_ptr(), _dt(s), S.data_ptr(), ws.data_ptr(),
-                                               gx.data_ptr(), ga.data_ptr(), _dt(gx), coef.data_ptr(), gz.data_ptr(),
-                                               gs.data_ptr(), int(sym), wb.data_ptr(), wb.numel(), N, K, C,
+                                               gx.data_ptr(), ga.data_ptr(), _dt(gx), g_link.data_ptr(), g_ent.data_ptr(),
+                                               _dt(g_link), stats.data_ptr(), gz.data_ptr(), gs.data_ptr(), int(sym), wb.data_ptr(), wb.numel(), N, K, C,
                                                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_diffpool_large_bwd")
         return gz.to(z_dtype), None, gs, None

@@ -44,9 +44,10 @@ def _raw_forward(z, a, s, out_dtype=torch.float32):
     x = torch.empty((K, C), dtype=out_dtype, device=dev)
     ao = torch.empty((K, K), dtype=out_dtype, device=dev)
     stats = torch.empty(3, device=dev)
+    scal = torch.empty(2, dtype=out_dtype, device=dev)
     ws = torch.empty(int(_lib.lib.mlgnn_diffpool_large_workspace_bytes(N, K, C)), dtype=torch.uint8, device=dev)
     rc = _lib.lib.mlgnn_diffpool_large_fwd(z.data_ptr(), a.data_ptr(), s.data_ptr(), 1, S.data_ptr(), x.data_ptr(),
-                                           ao.data_ptr(), 0 if out_dtype == torch.float32 else 1, stats.data_ptr(),
+                                           ao.data_ptr(), scal.data_ptr(), 0 if out_dtype == torch.float32 else 1, stats.data_ptr(),
                                            ws.data_ptr(), ws.numel(), N, K, C, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_diffpool_large_fwd")
     off_t = _align((2 * K + C) * N * 2)

@@ -92,8 +92,8 @@ def main():
                                 "algorithmic_GB": round(d["bytes"] / 1e9, 3), "GBps": round(gbs, 1),
                                 "frac_of_8TBps": round(gbs / 8000.0, 3)}
 
-    # DiffPool at the stress size (pooled graph of 4096 nodes, 1024 clusters): beyond the fused small-graph kernel, a
-    # chain of plain large GEMMs -> library (hipBLASLt) in the run's storage type; MFMA utilisation = achieved / dense peak
+    # DiffPool at the stress size (pooled graph of 4096 nodes, 1024 clusters): bf16 -> the matrix-core product chain of
+    # csrc/diffpool_large.hip (tools/bench_diffpool.py has the full report); fp32 -> library GEMMs
     P, K, C = 4096, 1024, a.hidden
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     peak = 2500.0 if a.dtype == "bf16" else 157.3                 # TFLOP/s dense: bf16 MFMA / fp32 matrix (MI355X_MICROARCH.md)
@@ -124,7 +124,10 @@ def main():
     res["diffpool_4096_1024"] = {"dtype": a.dtype, "fwd_ms": dtf * 1e3, "fwd_bwd_ms": dtp * 1e3, "fwd_GFLOP": flop_fwd / 1e9,
                                  "fwd_TFLOPs": flop_fwd / dtf / 1e12, "fwd_MFMA_utilisation": flop_fwd / dtf / 1e12 / peak,
                                  "approx_TFLOPs_fwd_bwd": 3 * flop_fwd / dtp / 1e12,
-                                 "dense_peak_TFLOPs": peak, "path": "library GEMMs (%s)" % a.dtype}
+                                 "dense_peak_TFLOPs": peak,
+                                 "path": "csrc/diffpool_large.hip + gemm_nt.hip (bf16 MFMA)" if a.dtype == "bf16"
+                                 else "library GEMMs (fp32)",
+                                 "note": "FLOP counted in the reference's formulation (incl. S S^T); see tools/bench_diffpool.py"}
     print(json.dumps(res, indent=1))
 
 

@@ -97,6 +97,15 @@ __device__ __forceinline__ float pre_act(float xj, const float* a, const float* 
   else return xj;
 }
 
+// Non-finite inputs.  relu / max / the power clamp are v_max / v_min here, which return the OTHER operand when one is
+// NaN: a NaN (or Inf) in x_j or in the edge term would silently vanish from the aggregate, where the reference carries
+// it to the loss (relu(NaN) = NaN, torch_vertex.py:94-101).  Every GEN message therefore also feeds a per-channel
+// tracker  nb = fma(z, 0, nb)  (0 for finite z, NaN for NaN / +-Inf) that is added to the row's result.  Inline asm:
+// this translation unit is built with -fno-honor-nans, under which the compiler may fold z * 0.
+__device__ __forceinline__ void track_nonfinite(float& nb, float z) {
+  asm("v_fma_f32 %0, %1, 0, %0" : "+v"(nb) : "v"(z));
+}
+
 template <int MODE, bool ADD_EPS>
 __device__ __forceinline__ float message(float xj, const float* a, const float* u, float v, float ef, float eps) {
   if constexpr (MODE == M_IDENTITY) return xj;

@@ -38,6 +38,9 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
   // eps is added once per row instead of once per edge: softmax weights are shift invariant,
   // max and sum commute with the shift (power needs the clamp of m itself and keeps it per edge)
   constexpr bool kLateEps = is_gen<MODE>() && AGGR != A_POWER;
+  // non-finite messages are carried to the result (aggregate_common.h) -- except for max: torch_scatter's scatter_max
+  // compares (`new > current`), so a NaN message never wins there either; +Inf wins by itself
+  constexpr bool kTrack = is_gen<MODE>() && AGGR != A_MAX;
 
   for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
     // lanes past the last channel (d/VEC not a power of two) re-read the last valid chunk and are
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
       const int deg = end - beg;
 
       // accumulators: SUM/POWER use acc; MAX uses acc (best) + bpos; SOFTMAX uses mx, acc (S), w1, w2
-      float acc[VEC], mx[VEC], w1[VEC], w2[VEC];
+      float acc[VEC], mx[VEC], w1[VEC], w2[VEC], nb[VEC];    // nb: non-finite tracker (aggregate_common.h)
       int bpos[VEC];
       // FAST (softmax only): no running maximum -- weights 2^(t m) against the fixed reference 0.  Messages are
       // relu outputs of normalised features, so t m stays far inside fp32's exponent range and the per-batch
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         acc[i] = (AGGR == A_MAX) ? kNegBig : 0.f;
-        mx[i] = FAST ? 0.f : kNegBig; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1;
+        mx[i] = FAST ? 0.f : kNegBig; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1; nb[i] = 0.f;
       }
 
       for (int base = beg; base < end; base += kWave) {
@@ -128,8 +131,15 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
-              for (int i = 0; i < VEC; ++i)
-                m[u][i] = message<MODE, !kLateEps>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i], a.eps);
+              for (int i = 0; i < VEC; ++i) {
+                if constexpr (kTrack) {
+                  const float z = pre_act<MODE>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i]);
+                  track_nonfinite(nb[i], z);
+                  m[u][i] = kLateEps ? fmaxf(z, 0.0f) : fmaxf(z, 0.0f) + a.eps;
+                } else {
+                  m[u][i] = message<MODE, !kLateEps>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i], a.eps);
+                }
+              }
           }
 
           if constexpr (AGGR == A_SUM) {
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
       for (int off = lpr; off < kWave; off <<= 1) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
+          if constexpr (kTrack) nb[i] += __shfl_xor(nb[i], off);
           if constexpr (AGGR == A_SUM) {
             acc[i] += __shfl_xor(acc[i], off);
           } else if constexpr (AGGR == A_POWER) {
@@ -277,6 +288,10 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
             ax[i] = mu;
             ax2[i] = w2[i] * inv;
           }
+        }
+        if constexpr (kTrack) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] += nb[i];           // + 0, or NaN when a message of this row was not finite
         }
         const size_t off = (size_t)r * a.d + c0;
         if (a.add_root) {            // h = x_i + m_i (GENConv.forward, torch_vertex.py:89) in the same pass

@@ -125,6 +125,9 @@ __device__ __forceinline__ float half_max(float v) {
   return fmaxf(v, __shfl_xor(v, 16));
 }
 
+// relu that carries a NaN through like torch's (fmaxf / v_max_f32 return the non-NaN operand)
+__device__ __forceinline__ float relu_keep_nan(float y) { return (y < 0.f) ? 0.f : y; }
+
 // exp2 / log2 on the transcendental unit (v_exp_f32 / v_log_f32, ~1 ulp)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_fwd_kernel(const LnArgs 
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           const float y = fmaf((v[u][i] - mu) * rs, g[i], b[i]);
-          o[i] = a.relu ? fmaxf(y, 0.f) : y;
+          o[i] = a.relu ? relu_keep_nan(y) : y;
         }
         if (a.keep) {
           float km[VEC];

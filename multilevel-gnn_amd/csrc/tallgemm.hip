@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
     if constexpr (LN == 2) {
       const float* g = kg + 16 * s + 8 * h;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = fmaxf(fmaf(e[j], g[j], g[R + j]), 0.f);
+      for (int j = 0; j < 8; ++j) e[j] = relu_keep_nan(fmaf(e[j], g[j], g[R + j]));
     }
   };
 

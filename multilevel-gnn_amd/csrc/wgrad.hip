@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
                         bool act) {
     if (act) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) st[j] = fmaxf(fmaf(st[j], g, b), 0.f);
+      for (int j = 0; j < 8; ++j) st[j] = relu_keep_nan(fmaf(st[j], g, b));
     }
     if constexpr (MASKED) {
 #pragma unroll

@@ -29,8 +29,8 @@ class CSRGraph:
         else:
             self._build_host(edge_index)
         self._deg = None
-        self._scalar_cache = {}
-        self._table_cache = {}
+        self._scalar_cache = None
+        self._table_cache = None
 
     def _build_device(self, edge_index):
         """Two stable radix sorts on the GPU (``mlgnn_coo_to_csr``), enqueued on the current stream."""
@@ -81,7 +81,7 @@ class CSRGraph:
         for name in ("rowptr", "col", "eid", "rowptr_t", "col_t", "pos_t", "eid_t"):
             setattr(self, name, getattr(self, name).to(device))
         self.device = torch.device(device)
-        self._deg, self._scalar_cache, self._table_cache = None, {}, {}
+        self._deg, self._scalar_cache, self._table_cache = None, None, None
         return self
 
     @staticmethod
@@ -99,25 +99,28 @@ class CSRGraph:
         return self._deg
 
     def edge_scalar(self, a):
-        """Per-edge scalar [E] (COO order) -> (by-destination order, by-source order); cached per tensor."""
-        key = (a.data_ptr(), a._version, a.numel())
-        hit = self._scalar_cache.get(key)
-        if hit is None:
-            flat = a.reshape(-1).to(torch.float32)
-            by_dst = flat[self.eid.long()].contiguous()
-            hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
-            self._scalar_cache = {key: hit}
+        """Per-edge scalar [E] (COO order) -> (by-destination order, by-source order).  The last result is kept:
+        the entry holds the source tensor itself (identity + version checked), so its storage cannot be freed and
+        handed to a different tensor with the same address under the cache."""
+        ent = self._scalar_cache
+        if ent is not None and ent[0] is a and ent[1] == a._version:
+            return ent[2]
+        flat = a.reshape(-1).to(torch.float32)
+        by_dst = flat[self.eid.long()].contiguous()
+        hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
+        self._scalar_cache = (a, a._version, hit)
         return hit
 
     def edge_table(self, a, width):
         """Per-edge attribute rows [E, r] (COO order) zero padded to ``width`` columns ->
         (by-destination order, by-source order), both [E, width] fp32; cached per tensor."""
+        src = a
         if a.dim() == 1:
             a = a[:, None]
         if a.shape[0] != self.num_edges or a.shape[1] > width:
             raise ValueError("edge attributes must be [E=%d, <=%d], got %s" % (self.num_edges, width, tuple(a.shape)))
-        key = (a.data_ptr(), a._version, tuple(a.shape), a.stride(), width)
-        hit = self._table_cache.get(key)
+        ent = self._table_cache
+        hit = ent[3] if (ent is not None and ent[0] is src and ent[1] == src._version and ent[2] == width) else None
         if hit is None:
             if a.is_cuda and self.eid.is_cuda:
                 from . import _lib
@@ -138,7 +141,7 @@ class CSRGraph:
                     rows = torch.nn.functional.pad(rows, (0, width - rows.shape[1]))
                 by_dst = rows[self.eid.long()].contiguous()
                 hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
-            self._table_cache = {key: hit}
+            self._table_cache = (src, src._version, width, hit)      # holds `src`: see edge_scalar
         return hit
 
 

@@ -52,7 +52,9 @@ def scatter_max(src, index, dim_size):
       ``arg`` with ``src.size(dim)`` and masks ``out`` to 0 there);
     * the first element (lowest edge position) attaining the maximum wins
       (the CPU loop updates only on a strict ``>``);
-    * the gradient flows to that single element.
+    * the gradient flows to that single element;
+    * a NaN element never wins: the CPU loop starts from ``numeric_limits::lowest()`` and updates on
+      ``new > current``, which is false for NaN (a group of NaNs only keeps its fill value and comes out as 0).
 
     Call sites: PyG ``MaxAggregation`` from ``torch_message.py:47``;
     ``global_max_pool`` (``deepergcn.py:153``); inside ``scatter_softmax``.
@@ -61,7 +63,8 @@ def scatter_max(src, index, dim_size):
     idx = _expand_index(index, src)
     with torch.no_grad():
         init = src.new_full((dim_size,) + tuple(src.shape[1:]), float("-inf"))
-        vmax = init.scatter_reduce(0, idx, src, reduce="amax", include_self=True)
+        comparable = torch.where(torch.isnan(src), torch.full_like(src, float("-inf")), src)
+        vmax = init.scatter_reduce(0, idx, comparable, reduce="amax", include_self=True)
         pos = torch.arange(E, device=src.device).view([-1] + [1] * (src.dim() - 1)).expand_as(src)
         is_max = src == vmax.gather(0, idx)
         cand = torch.where(is_max, pos, torch.full_like(pos, E))

@@ -85,12 +85,24 @@ def make_args(**over):
     return SimpleNamespace(**d)
 
 
-def assert_close(a, b, tol=1e-4, what=""):
-    """|a-b| <= tol * max(1, |b|_inf): absolute for O(1) values, relative for large ones."""
+def assert_close(a, b, tol=1e-4, what="", elementwise=False):
+    """Default (parameter gradients, scalars): the norm form |a-b| <= tol * max(1, |b|_inf).
+    ``elementwise=True`` (forward outputs, gradients w.r.t. the inputs): every entry on its own,
+    |a-b| <= tol * |b| + 0.1 * tol * max(1, |b|_inf) -- relative ``tol`` per element with an absolute floor of a
+    tenth of the norm form's allowance, so an entry of size 1e-3 next to one of size 300 is still held to ~3e-3
+    absolute instead of 3e-2."""
     a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     assert a.shape == b.shape, "%s: shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
     if a.numel() == 0:
         return
+    assert bool(torch.isfinite(a).all()) == bool(torch.isfinite(b).all()), "%s: non-finite entries differ" % what
     scale = max(1.0, float(b.abs().max()))
+    if elementwise:
+        bound = tol * b.abs() + 0.1 * tol * scale
+        over = (a - b).abs() - bound
+        worst = int(over.argmax())
+        assert float(over.max()) <= 0.0, "%s: entry %d: |%.6e - %.6e| > %.3e (elementwise, tol %.1e)" % (
+            what, worst, float(a.flatten()[worst]), float(b.flatten()[worst]), float(bound.flatten()[worst]), tol)
+        return
     err = float((a - b).abs().max())
     assert err <= tol * scale, "%s: max|diff|=%.3e > %.1e*%.3g" % (what, err, tol, scale)

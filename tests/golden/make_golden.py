@@ -277,7 +277,12 @@ def fx_genconv(ref):
             dict(d=32, aggr="max", norm="layer"),
             dict(d=16, aggr="mean", norm="batch"),
             dict(d=16, aggr="power", p=2.0, norm="layer"),
-            dict(d=32, aggr="softmax_sg", t=1.5, norm="layer", edge_dim_full=True)]
+            dict(d=32, aggr="softmax_sg", t=1.5, norm="layer", edge_dim_full=True),
+            # degree-scaled aggregators (torch_message.py:60-63,77-80), y learnable / fixed (appended: the
+            # generator state of the fixtures above is unchanged)
+            dict(d=16, aggr="softmax_sum", t=0.8, learn_t=True, y=0.3, learn_y=True, norm="layer"),
+            dict(d=32, aggr="power_sum", p=2.0, y=-0.4, learn_y=False, norm="layer"),
+            dict(d=16, aggr="power_sum", p=1.5, learn_p=True, y=0.2, learn_y=True, msg_norm=True, norm="layer")]
     for ci, cfg in enumerate(cfgs):
         cfg = dict(cfg)
         d = cfg.pop("d")
@@ -332,7 +337,10 @@ def fx_deepergcn(ref):
              dict(gcn_aggr="softmax", global_edge="onehot", pathway_edge_num=5),
              # use_column None: the 7-column edge attribute through Linear(7, hidden) (deepergcn.py:90)
              dict(gcn_aggr="softmax", use_column=None),
-             dict(gcn_aggr="max", use_column=None, block="res", msg_norm=True, learn_msg_scale=True)]
+             dict(gcn_aggr="max", use_column=None, block="res", msg_norm=True, learn_msg_scale=True),
+             # degree-scaled aggregators through the whole model (appended)
+             dict(gcn_aggr="softmax_sum", learn_t=True, t=0.7, y=0.25, learn_y=True),
+             dict(gcn_aggr="power_sum", p=2.0, y=-0.3, learn_y=True, block="res")]
     for ci, over in enumerate(cases):
         a = default_args(ref, **dict(base, **over))
         ei, ea, bvec = small_graph(gen, 2, 64, 256, edge_dim=7 if a.use_column is None else 1)
@@ -359,7 +367,15 @@ def fx_multilevel(ref):
     gen = torch.Generator().manual_seed(505)
     node_num, B, G, S = 40, 2, 900, 438
     for ci, over in enumerate([dict(gnn_name="sage"), dict(gnn_name="rsage", resgnn=False, pca_dim=3, pca_pool_dim=1,
-                                                          pathway_pool_dim=1, use_age=False, node_embedding_dim=32)]):
+                                                          pathway_pool_dim=1, use_age=False, node_embedding_dim=32),
+                               # GNN-loop wirings of multilevel_gnn.py:188-199 (appended): dense concatenation,
+                               # residual layers, the input mask re-applied between layers (+ row normalisation)
+                               dict(gnn_name="sage", dense_gnn=True, num_layers=3),
+                               dict(gnn_name="sage", resgnn=True, num_layers=3, hidden_channels=16, final_channels=16,
+                                    final_head=1),
+                               dict(gnn_name="rsage", repeat_mask=True, repeat_cyclic=1, num_layers=3),
+                               dict(gnn_name="sage", repeat_mask=True, repeat_cyclic=2, repeat_norm=True, num_layers=4,
+                                    resgnn=True, hidden_channels=16, final_channels=16, final_head=1)]):
         kw = dict(model="multilevel_gnn", num_layers=2, hidden_channels=16, final_channels=8, final_head=4,
                   node_embedding=True, node_embedding_dim=16, gnn_name="sage", head_dim=4, use_age=True,
                   weighted_edge=True, value_att_mask=True, pca_match_mask=True, mutual_info_mask=True,

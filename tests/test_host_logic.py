@@ -135,3 +135,26 @@ def test_gbm_parameter_count():
             "head.0.weight", "head.3.bias"} <= keys
     assert tuple(m.state_dict()["head.0.weight"].shape) == (256, 6913)
     assert tuple(m.state_dict()["gnn_model.1.gconv.nn.0.weight"].shape) == (32, 96)
+
+
+def test_edge_cache_is_keyed_on_the_tensor_not_its_address():
+    """A freed edge-weight tensor's storage is usually handed to the next tensor of the same size (same data_ptr,
+    version 0): the per-graph cache must not return the old weights for it."""
+    from mlgnn import CSRGraph
+    ei = torch.tensor([[0, 1, 2, 3, 0], [1, 2, 3, 0, 2]])
+    g = CSRGraph(ei, 4)
+    a = torch.arange(5, dtype=torch.float32)
+    first = g.edge_scalar(a)[0].clone()
+    assert g.edge_scalar(a)[0] is g.edge_scalar(a)[0]                # same tensor: cached
+    ptr = a.data_ptr()
+    b = a                                                            # the cache entry keeps the old tensor alive,
+    del a                                                            # so a new tensor cannot reuse its address
+    c = torch.full((5,), 7.0)
+    assert c.data_ptr() != ptr or c is b
+    assert torch.equal(g.edge_scalar(c)[0], torch.full((5,), 7.0))
+    assert not torch.equal(first, g.edge_scalar(c)[0])
+    t = torch.arange(10, dtype=torch.float32).view(5, 2)
+    by_dst, by_src = g.edge_table(t, 2)
+    assert g.edge_table(t, 2)[0] is by_dst
+    t.add_(1.0)                                                      # in-place update bumps the version
+    assert torch.equal(g.edge_table(t, 2)[0], by_dst + 1.0)

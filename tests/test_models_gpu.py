@@ -40,9 +40,9 @@ def test_genconv_vs_reference(path):
     x = f["x"].to(DEV).requires_grad_(True)
     ea = f["edge_attr"].to(DEV).requires_grad_(True)
     out = conv(x, f["edge_index"].to(DEV), ea)
-    assert_close(out, f["out"], TOL, "genconv out")
+    assert_close(out, f["out"], TOL, "genconv out", elementwise=True)
     (out * f["cot"].to(DEV)).sum().backward()
-    assert_close(x.grad, f["grad"]["x"], TOL, "grad x")
+    assert_close(x.grad, f["grad"]["x"], TOL, "grad x", elementwise=True)
     assert_close(ea.grad, f["grad"]["edge_attr"], TOL, "grad edge_attr")
     _check_param_grads(conv, f["grad"])
 
@@ -65,9 +65,9 @@ def test_genconv_rank_one_edge_path(path):
     one = torch.ones(1, device=DEV)
     zero = torch.zeros(1, device=DEV)
     out = conv(x, f["edge_index"].to(DEV), RankOneEdge(f["edge_attr"][:, 0].to(DEV), one, zero))
-    assert_close(out, f["out"], TOL, "genconv out (rank-1)")
+    assert_close(out, f["out"], TOL, "genconv out (rank-1)", elementwise=True)
     (out * f["cot"].to(DEV)).sum().backward()
-    assert_close(x.grad, f["grad"]["x"], TOL, "grad x")
+    assert_close(x.grad, f["grad"]["x"], TOL, "grad x", elementwise=True)
     _check_param_grads(conv, f["grad"])
 
 
@@ -81,9 +81,9 @@ def test_sage_vs_reference(path):
     conv.to(DEV)
     x = f["x"].to(DEV).requires_grad_(True)
     out = conv(x, f["edge_index"].to(DEV), f["edge_attr"].to(DEV))
-    assert_close(out, f["out"], TOL, "sage out")
+    assert_close(out, f["out"], TOL, "sage out", elementwise=True)
     (out * f["cot"].to(DEV)).sum().backward()
-    assert_close(x.grad, f["grad"]["x"], TOL, "grad x")
+    assert_close(x.grad, f["grad"]["x"], TOL, "grad x", elementwise=True)
     _check_param_grads(conv, f["grad"])
 
 
@@ -103,7 +103,7 @@ def test_deepergcn_vs_reference(path):
     batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "batch", "age",
                                                           "pathway_node_attr", "node_size")}))
     out = model(batch)
-    assert_close(out, f["out"], TOL, "deepergcn out")
+    assert_close(out, f["out"], TOL, "deepergcn out", elementwise=True)
     (out * f["cot"].to(DEV)).sum().backward()
     _check_param_grads(model, f["grad"])
 
@@ -123,8 +123,8 @@ def test_multilevel_vs_reference(path):
     batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "gene_pca_match",
                                                           "raw_indice", "age")}))
     pred, feat = model(batch)
-    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
-    assert_close(pred, f["pred"], TOL, "pred")
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature", elementwise=True)
+    assert_close(pred, f["pred"], TOL, "pred", elementwise=True)
     fl = model.get_feature_loss(feat)
     assert_close(fl, f["feature_loss"], TOL, "feature loss")
     ((pred * f["cot"].to(DEV)).sum() + fl).backward()
@@ -147,8 +147,8 @@ def test_multilevel_seq_vs_reference(path):
     batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "gene_pca_match",
                                                           "raw_indice", "age")}))
     pred, feat = model(batch)
-    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
-    assert_close(pred, f["pred"], TOL, "pred")
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature", elementwise=True)
+    assert_close(pred, f["pred"], TOL, "pred", elementwise=True)
     fl = model.get_feature_loss(feat)
     assert_close(fl, f["feature_loss"], TOL, "feature loss")
     ((pred * f["cot"].to(DEV)).sum() + fl).backward()
@@ -181,8 +181,8 @@ def test_vae_predict_path_vs_reference(path):
                                                           "raw_indice", "age")}))
     pred, feat, link, ent, gene = model.train_step(batch)
     assert_close(gene, f["gene_feature"], TOL, "gene_feature")
-    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
-    assert_close(pred, f["pred"], TOL, "pred")
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature", elementwise=True)
+    assert_close(pred, f["pred"], TOL, "pred", elementwise=True)
     assert_close(link, f["link"], TOL, "link")
     assert_close(ent, f["ent"], TOL, "ent")
     ((pred * f["cot"].to(DEV)).sum() + 0.7 * link + 0.3 * ent).backward()
@@ -228,8 +228,8 @@ def test_vq_vae_vs_reference(path):
     batch = _to_dev(SimpleNamespace(**{k: f[k] for k in ("x", "edge_index", "edge_attr", "gene_pca_match",
                                                           "raw_indice", "age")}))
     pred, feat, link, ent = model.train_step(batch)
-    assert_close(feat, f["pca_feature"], TOL, "pca_feature")
-    assert_close(pred, f["pred"], TOL, "pred")
+    assert_close(feat, f["pca_feature"], TOL, "pca_feature", elementwise=True)
+    assert_close(pred, f["pred"], TOL, "pred", elementwise=True)
     assert_close(link, f["link"], TOL, "link")
     assert_close(ent, f["ent"], TOL, "ent")
     ((pred * f["cot"].to(DEV)).sum() + 0.7 * link + 0.3 * ent).backward()
@@ -274,5 +274,5 @@ def test_diffpool_vs_reference(path):
     assert_close(link, f["link"], TOL, "link")
     assert_close(ent, f["ent"], TOL, "ent")
     ((out * f["cot"].to(DEV)).sum() + 0.7 * link + 0.3 * ent).backward()
-    assert_close(x.grad, f["grad"]["x"], TOL, "grad x")
+    assert_close(x.grad, f["grad"]["x"], TOL, "grad x", elementwise=True)
     _check_param_grads(dp, f["grad"])

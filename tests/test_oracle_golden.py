@@ -63,7 +63,8 @@ def test_genconv_matches_reference(path):
     sd = _sd_leaves(f["sd"])
     x, ea = _leaf(f["x"]), _leaf(f["edge_attr"])
     out = G.genconv(x, f["edge_index"], ea, sd, "", aggr=cfg["aggr"], t=cfg.get("t", 1.0),
-                    learn_t=cfg.get("learn_t", False), p=cfg.get("p", 1.0), msg_norm_on=cfg.get("msg_norm", False),
+                    learn_t=cfg.get("learn_t", False), p=cfg.get("p", 1.0), learn_p=cfg.get("learn_p", False),
+                    msg_norm_on=cfg.get("msg_norm", False),
                     encode_edge=True, norm_kind=cfg["norm"], mlp_layers=2, training=True)
     assert_close(out, f["out"], TOL, "genconv out")
     named = {"x": x, "edge_attr": ea}

@@ -75,3 +75,13 @@ def test_dense_diff_pool_formula():
     # A - S S^T = 1 - 0.5 = 0.5 each; ||.||_F = 1.0; /numel(adj unsqueezed)=4
     assert_close(link, 0.25, 1e-6)
     assert_close(ent, math.log(2.0), 1e-6)
+
+
+def test_scatter_max_ignores_nan_like_the_comparison_loop():
+    """torch_scatter's CPU scatter_max updates on ``new > current`` from ``lowest()``: NaN never wins."""
+    nan = float("nan")
+    src = torch.tensor([[1.0, nan], [nan, nan], [3.0, 2.0], [nan, 5.0]])
+    index = torch.tensor([0, 0, 0, 1])
+    out, arg = P.scatter_max(src, index, 3)
+    assert torch.equal(out, torch.tensor([[3.0, 2.0], [0.0, 5.0], [0.0, 0.0]]))     # all-NaN group -> fill -> 0
+    assert torch.equal(arg, torch.tensor([[2, 2], [4, 3], [4, 4]]))

@@ -124,16 +124,14 @@ def main():
 
     from mlgnn import ops
     from mlgnn import workload as W
-    from mlgnn.dist import FlatGradBucket, broadcast_parameters
+    from mlgnn.dist import broadcast_parameters
+    from mlgnn.optim import FlatAdam
 
     torch.manual_seed(1234)
     model = W.ThreeLevelGNN(hidden=args.hidden, num_layers=3, aggr=args.aggr, n_members=args.members).to(dev)
     broadcast_parameters(model)
-    bucket = FlatGradBucket(model)
-    try:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
-    except (RuntimeError, TypeError):
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = FlatAdam(model, lr=1e-3)            # Adam over the flat parameter / gradient buffers: one launch per step
+    bucket = opt.bucket
 
     strong = args.global_batch > 0
     if strong and args.global_batch % world != 0:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 9
+#define MLGNN_ABI_VERSION 10
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -417,6 +417,27 @@ int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logit
                              const void* grad_ent, int scalar_dtype, const float* stats, void* grad_z,
                              void* grad_logits, int adj_symmetric, void* workspace, int64_t workspace_bytes,
                              int64_t N, int64_t K, int64_t C, void* stream);
+
+/*
+ * Optimizer step on one flat fp32 buffer: global-norm gradient clipping + Adam with L2 weight decay, two launches.
+ * Replaces: train.py:63-66,112-114 -- clip_grad_norm_(parameters, max_norm=20, norm_type=2) (when --clip_grad) and
+ * torch.optim.Adam(lr, betas, weight_decay).step(); torch's single-tensor formula, element by element:
+ *   g' = clip g (+ weight_decay p);  m += (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= step_size m / (sqrt(v) / bias2_sqrt + eps),     clip = min(1, max_norm / (||g||_2 + 1e-6))
+ * params, grads, exp_avg, exp_avg_sq: [n] fp32 (the module's tensors laid out contiguously, mlgnn.optim.FlatAdam);
+ * step_size = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t) for step count t (host doubles, like torch);
+ * max_norm <= 0: no clipping (grads untouched); otherwise the clipped gradients are written back like
+ * clip_grad_norm_ does and workspace[256] receives ||g||_2.
+ * live_ranges (device, int64 [n_ranges][3] = first element, length, elements in the ranges before): the elements
+ * whose parameter received a gradient this step, n_live in all, n_ranges <= 64; everything else is left untouched
+ * (torch skips parameters whose .grad is None).  The norm is taken over all n gradients: the caller keeps the
+ * gradients of unreached parameters at zero.  workspace: mlgnn_adam_workspace_floats() floats.
+ */
+int64_t mlgnn_adam_workspace_floats(void);
+int mlgnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    const int64_t* live_ranges, int n_ranges, int64_t n_live, float max_norm, float beta1,
+                    float beta2, float eps, float weight_decay, float step_size, float bias2_sqrt,
+                    float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

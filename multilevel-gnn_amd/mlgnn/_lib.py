@@ -58,6 +58,8 @@ SIGNATURES = {
     "mlgnn_diffpool_large_bwd_workspace_bytes": (_I64, [_I64, _I64, _I64, _INT]),
     "mlgnn_diffpool_large_bwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _INT, _P, _P, _P, _INT, _P, _I64,
                                         _I64, _I64, _I64, _P]),
+    "mlgnn_adam_workspace_floats": (_I64, []),
+    "mlgnn_adam_step": (_INT, [_P, _P, _P, _P, _I64, _P, _INT, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
 }
 
 ERRORS = {-1: "MLGNN_E_NULL", -2: "MLGNN_E_SHAPE", -3: "MLGNN_E_MODE", -4: "MLGNN_E_DTYPE",

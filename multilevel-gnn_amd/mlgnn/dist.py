@@ -22,6 +22,7 @@ class FlatGradBucket:
         self.group = process_group
         off = 0
         self.views = []
+        self.reached = [True] * len(self.params)       # which parameters the last collected backward reached
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
@@ -38,9 +39,10 @@ class FlatGradBucket:
 
     def collect(self):
         src, dst = [], []
-        for p, v in zip(self.params, self.views):
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            self.reached[i] = p.grad is not None
             if p.grad is None:
-                v.zero_()                          # parameter not reached by this backward
+                v.zero_()                          # parameter not reached by this backward: zero in the flat buffer
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
@@ -48,6 +50,9 @@ class FlatGradBucket:
             torch._foreach_copy_(dst, src)
         for p, v in zip(self.params, self.views):
             p.grad = v
+        # (torch.optim optimizers then see a zero gradient for an unreached parameter where the reference's
+        # zero_grad(set_to_none) would make them skip it: with weight decay that parameter decays.
+        # mlgnn.optim.FlatAdam reads `reached` and skips it like torch does.)
 
     def zero(self):
         """Use instead of ``optimizer.zero_grad()`` (which would drop the views)."""

@@ -1,0 +1,123 @@
+"""Optimizer step of the reference's training loop on one flat buffer (``mlgnn_adam_step``).
+
+Reference: ``train.py:112-114`` -- ``torch.optim.Adam(model.parameters(), lr, betas, weight_decay=wd)`` and
+``StepLR(step_size, gamma)`` -- and ``:63-66`` -- ``loss.backward(); clip_grad_norm_(..., 20); optimizer.step()``.
+:class:`FlatAdam` lays parameters, gradients and both moments out contiguously (the gradient side is
+:class:`mlgnn.dist.FlatGradBucket`, so the data-parallel all-reduce and the optimizer share one buffer) and runs
+clipping + Adam for the whole model as two kernel launches; :class:`StepLR` is the host-side schedule.
+"""
+import math
+
+import torch
+
+from . import _lib
+from .dist import FlatGradBucket
+
+MAX_RANGES = 64
+
+
+def live_ranges(sizes, reached):
+    """Element ranges ``[(first, length, elements before)]`` of the parameters that received a gradient, adjacent
+    parameters merged.  ``sizes``: numel per parameter in bucket order; ``reached``: bool per parameter."""
+    out, off, before = [], 0, 0
+    for n, ok in zip(sizes, reached):
+        if ok and n:
+            if out and out[-1][0] + out[-1][1] == off:
+                out[-1][1] += n
+            else:
+                out.append([off, n, before])
+            before += n
+        off += n
+    return [tuple(r) for r in out]
+
+
+class FlatAdam:
+    """``torch.optim.Adam`` (L2 ``weight_decay``, no amsgrad) + optional ``clip_grad_norm_(max_norm)`` over a module
+    whose parameters are re-laid into one flat fp32 buffer (``p.data`` become views of it; ``state_dict`` is
+    unaffected).  Usage per step::
+
+        bucket.release(); loss.backward(); bucket.collect(); bucket.all_reduce_mean(); opt.step()
+
+    with ``bucket = opt.bucket``.  Parameters the backward did not reach are skipped like ``grad is None`` in torch.
+    One global step count: a parameter that is reached only in some steps uses it too (torch counts per parameter);
+    the shipped models reach a parameter either always or never."""
+
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=None,
+                 process_group=None):
+        self.bucket = FlatGradBucket(module, process_group)
+        params = self.bucket.params
+        dev = params[0].device
+        if not all(p.dtype == torch.float32 and p.device == dev for p in params):
+            raise TypeError("FlatAdam wants fp32 parameters on one device")
+        self.sizes = [p.numel() for p in params]
+        self.flat_p = torch.empty(sum(self.sizes), dtype=torch.float32, device=dev)
+        off = 0
+        for p, n in zip(params, self.sizes):
+            view = self.flat_p[off:off + n].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            off += n
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.param_groups = [dict(lr=lr, initial_lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.clip = float(clip_grad_norm) if clip_grad_norm else 0.0
+        self.step_count = 0
+        self._ws = torch.zeros(int(_lib.lib.mlgnn_adam_workspace_floats()), dtype=torch.float32, device=dev) \
+            if dev.type == "cuda" else None
+        self._ranges_key, self._ranges_dev, self._n_live, self._n_ranges = None, None, 0, 0
+
+    @property
+    def grad_norm(self):
+        """Total gradient norm of the last clipped step (device scalar; what ``clip_grad_norm_`` returns)."""
+        return self._ws[256]
+
+    def zero_grad(self, set_to_none=True):
+        self.bucket.release()
+
+    def _ranges(self):
+        key = tuple(self.bucket.reached)
+        if key != self._ranges_key:
+            rg = live_ranges(self.sizes, key)
+            if len(rg) > MAX_RANGES:
+                raise RuntimeError("more than %d separate live parameter ranges" % MAX_RANGES)
+            self._ranges_dev = torch.tensor(rg if rg else [(0, 0, 0)], dtype=torch.int64, device=self.flat_p.device)
+            self._n_live = sum(r[1] for r in rg)
+            self._n_ranges = len(rg)
+            self._ranges_key = key
+        return self._ranges_dev
+
+    def step(self):
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        self.step_count += 1
+        t = self.step_count
+        step_size = g["lr"] / (1.0 - b1 ** t)
+        bias2_sqrt = math.sqrt(1.0 - b2 ** t)
+        rg = self._ranges()
+        rc = _lib.lib.mlgnn_adam_step(self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                      self.exp_avg_sq.data_ptr(), self.flat_p.numel(), rg.data_ptr(), self._n_ranges,
+                                      self._n_live, self.clip, b1, b2, g["eps"], g["weight_decay"], step_size, bias2_sqrt,
+                                      self._ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_adam_step")
+        # the kernel wrote parameters, moments and (when clipping) gradients behind torch's back: bump the version
+        # counters (shared by every view of the flat buffers) so that version-keyed caches and autograd's
+        # saved-tensor checks see the update
+        torch.autograd.graph.increment_version(self.flat_p)
+        if self.clip > 0:
+            torch.autograd.graph.increment_version(self.bucket.flat)
+
+
+class StepLR:
+    """``torch.optim.lr_scheduler.StepLR``: ``lr = initial_lr * gamma ** (epoch // step_size)`` after ``epoch`` calls of
+    :meth:`step` (``train.py:114,205``)."""
+
+    def __init__(self, optimizer, step_size, gamma=0.1):
+        self.optimizer, self.step_size, self.gamma, self.last_epoch = optimizer, int(step_size), gamma, 0
+
+    def step(self):
+        self.last_epoch += 1
+        for g in self.optimizer.param_groups:
+            g["lr"] = g["initial_lr"] * self.gamma ** (self.last_epoch // self.step_size)
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]

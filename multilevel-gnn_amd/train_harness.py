@@ -23,7 +23,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 from mlgnn.data import DataLoader, SyntheticTCGA  # noqa: E402
-from mlgnn.dist import FlatGradBucket, broadcast_parameters  # noqa: E402
+from mlgnn.dist import broadcast_parameters  # noqa: E402
+from mlgnn.optim import FlatAdam, StepLR  # noqa: E402
 from models import get_model  # noqa: E402
 
 # defaults of the reference's opt.py for the flags the models and the loop read
@@ -95,9 +96,7 @@ def train_epoch(model, device, loader, optimizer, criterion, criterion_weight, a
         loss.backward()
         bucket.collect()
         bucket.all_reduce_mean()
-        if args.clip_grad:
-            torch.nn.utils.clip_grad_norm_(parameters=model.parameters(), max_norm=20, norm_type=2)
-        optimizer.step()
+        optimizer.step()            # clip_grad_norm_(20) (when --clip_grad) + Adam: two launches over the flat buffer
         losses.append(loss.detach())
     return float(torch.stack(losses).mean()) if losses else float("nan")       # ONE host sync per epoch
 
@@ -155,9 +154,11 @@ def run(args):
         model.set_pathway_indexs(data.raw_indice.to(device))
     model.to(device)
     broadcast_parameters(model)
-    bucket = FlatGradBucket(model)
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, betas=(args.beta1, args.beta2), weight_decay=args.wd)
-    scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=args.step, gamma=args.gamma) if args.step > 0 else None
+    # train.py:112-114 (Adam + StepLR) and :63-66 (clip_grad_norm_(20) + step) as ONE fused update of the flat buffer
+    optimizer = FlatAdam(model, lr=args.lr, betas=(args.beta1, args.beta2), weight_decay=args.wd,
+                         clip_grad_norm=20.0 if args.clip_grad else None)
+    bucket = optimizer.bucket
+    scheduler = StepLR(optimizer, step_size=args.step, gamma=args.gamma) if args.step > 0 else None
     cw = data.get_weight_balance(train_idx, args.batch_size, args.weight_power)
     if args.weight_balance:
         criterion = torch.nn.BCELoss(weight=cw.to(device))

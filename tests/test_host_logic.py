@@ -158,3 +158,23 @@ def test_edge_cache_is_keyed_on_the_tensor_not_its_address():
     assert g.edge_table(t, 2)[0] is by_dst
     t.add_(1.0)                                                      # in-place update bumps the version
     assert torch.equal(g.edge_table(t, 2)[0], by_dst + 1.0)
+
+
+def test_live_ranges_and_step_lr():
+    from mlgnn.optim import StepLR, live_ranges
+    assert live_ranges([4, 6, 2, 5], [True, True, False, True]) == [(0, 10, 0), (12, 5, 10)]
+    assert live_ranges([4, 6], [False, False]) == []
+    assert live_ranges([3, 0, 2], [True, True, True]) == [(0, 5, 0)]
+
+    class _Opt:
+        param_groups = [dict(lr=0.1, initial_lr=0.1)]
+    o = _Opt()
+    sched = StepLR(o, step_size=3, gamma=0.25)
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.SGD([p], lr=0.1)
+    tsched = torch.optim.lr_scheduler.StepLR(topt, step_size=3, gamma=0.25)
+    for _ in range(10):
+        topt.step()
+        tsched.step()
+        sched.step()
+        assert abs(sched.get_last_lr()[0] - tsched.get_last_lr()[0]) < 1e-12

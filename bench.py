@@ -52,9 +52,20 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, model_sd):
-    """Oracle fwd+bwd on a bounded sample of the SAME workload, host cores of this box."""
-    from types import SimpleNamespace
+    """Oracle forward and backward, timed separately (median of 5 after one warm-up: BASELINE.md section 3 protocol), on
+    a bounded sample of the SAME workload, host cores of this box."""
+    import statistics
     from mlgnn import workload as W
     from oracle import workload as OW
     # the GPU box gives one GPU's job a 16-core share; more torch threads than that only thrash
@@ -66,22 +77,46 @@ def cpu_baseline(args, model_sd):
     sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and k != "pathway_adj")
           for k, v in model_sd.items()}
     params = [v for v in sd.values() if v.requires_grad]
-
-    def step():
+    fwd, bwd = [], []
+    for it in range(6):
+        t0 = time.perf_counter()
         loss = OW.training_loss(sd, batch, aggr=args.aggr)
+        t1 = time.perf_counter()
         torch.autograd.grad(loss, params, allow_unused=True)
+        t2 = time.perf_counter()
+        if it:                               # iteration 0 = warm-up (allocator, thread pool)
+            fwd.append(t1 - t0)
+            bwd.append(t2 - t1)
+    f, b = statistics.median(fwd), statistics.median(bwd)
+    return {"value": nb / (f + b), "unit": "graphs/s", "cores": threads, "kind": "port", "cpu_model": _cpu_model(),
+            "fwd_s_median": f, "bwd_s_median": b, "timed_iterations": len(fwd),
+            "sample": "%d graphs of the same synthetic workload, forward and backward timed separately, median of %d "
+                      "after 1 warm-up (oracle: materialised [E,d] gather -> elementwise -> scatter, no optimizer "
+                      "step)" % (nb, len(fwd))}
 
-    step()                                   # warm-up (allocator, thread pool)
-    t0, n = time.perf_counter(), 0
-    while True:
-        step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > 12.0 or n >= 5:
-            break
-    return {"value": nb * n / el, "unit": "graphs/s", "cores": threads, "kind": "port",
-            "sample": "%d graphs x %d timed fwd+bwd iterations of the same synthetic workload "
-                      "(oracle: materialised [E,d] gather -> elementwise -> scatter, no optimizer step)" % (nb, n)}
+
+def load_traffic():
+    """profiles/traffic.json (HBM bytes per launch from the PMC passes of tools/profile_round.sh) -- only if it was
+    measured on THESE kernel sources; a stale file is reported loudly and not used."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, {"file": "profiles/traffic.json", "stale": True, "reason": "missing"}
+    try:
+        blob = json.load(open(path))
+    except Exception as e:  # noqa: BLE001
+        return None, {"file": "profiles/traffic.json", "stale": True, "reason": "unreadable: %s" % e}
+    src = dict(blob.get("_source", {}))
+    src["file"] = "profiles/traffic.json"
+    import build_native
+    have = build_native.sources_digest()
+    if src.get("kernel_sources_sha256") != have:
+        src.update(stale=True, reason="kernel sources changed since the counters were collected (re-run "
+                                      "tools/profile_round.sh)", kernel_sources_now=have)
+        print("bench.py: profiles/traffic.json is STALE for these kernel sources -- roofline.traffic left null",
+              file=sys.stderr, flush=True)
+        return None, src
+    src["stale"] = False
+    return blob, src
 
 
 def stream_copy_ceiling(dev, mib=1024, reps=10):
@@ -180,9 +215,18 @@ def main():
         loss = W.training_loss(model, batch)
         loss.backward()
         bucket.collect()
-        bucket.all_reduce_mean()
+        if ar_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.all_reduce_mean()
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            bucket.all_reduce_mean()
         opt.step()
         return loss
+
+    ar_events = None
 
     def fence():
         if world > 1:
@@ -194,6 +238,7 @@ def main():
     timer = None if args.no_kernel_timer else ops.KernelTimer()
     ops.KERNEL_TIMER = timer
     fence()
+    ar_events = [] if world > 1 else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i, last=(i == args.steps - 1))
@@ -221,6 +266,9 @@ def main():
                                                                       "" if args.no_overlap else " (of the next batch, on a second stream)"),
                        "graphs_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "collective_backend": backend if world > 1 else None,
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "allreduce_ms": (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)) if ar_events else None,
+                       "allreduce_bytes": bucket.flat.numel() * 4,
                        "final_loss": final_loss},
         }
         if timer is not None:
@@ -232,17 +280,36 @@ def main():
                                  "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
             # dominant = the hand-written kernel with the largest total time in the timed region
             dom = max(summ, key=lambda n: summ[n]["total_ms"])
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(dom.split("/")[0])
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"],
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac"],
-                               "traffic": traffic, "avg_launch_ms": kernels[dom]["avg_ms"],
-                               "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"]}
+            blob, tsrc = load_traffic()
+            N_all, E_all = B * args.nodes, B * args.edges
+
+            def view(name):
+                """algorithmic (edge-gather, no cache credit: the contract figure), counter-measured and compulsory
+                bytes of one launch, each as a rate and a fraction of the 8 TB/s peak."""
+                k = kernels[name]
+                secs = k["avg_ms"] * 1e-3
+                traffic = blob.get(name.split("/")[0]) if blob else None
+                # perfect reuse: every node row read once and written once, indices and edge scalars once
+                backward = name.startswith("csr_aggregate_bwd")
+                comp = (3 if backward else 2) * N_all * args.hidden * 4 + E_all * 8 + (N_all + 1) * 4
+                return {"kernel": name, "avg_launch_ms": k["avg_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
+                        "achieved": k["achieved_GBps"], "frac": k["frac"], "traffic": traffic,
+                        "frac_hbm_counter": (traffic / secs / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                        "compulsory_bytes": comp, "frac_compulsory": comp / secs / 1e9 / HBM_PEAK_GBS}
+            v = view(dom)
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": v["achieved"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": v["frac"], "traffic": v["traffic"],
+                               "frac_hbm_counter": v["frac_hbm_counter"], "compulsory_bytes": v["compulsory_bytes"],
+                               "frac_compulsory": v["frac_compulsory"], "traffic_source": tsrc,
+                               "avg_launch_ms": v["avg_launch_ms"],
+                               "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"],
+                               "note": "frac = algorithmic bytes (one gathered row per edge, no cache credit: SURVEY 8d) "
+                                       "/ time / peak and can exceed the physical HBM fraction because a graph's rows "
+                                       "are re-used out of L2 / Infinity Cache; frac_hbm_counter = PMC bytes / time / "
+                                       "peak is the physical one"}
+            other = [n for n in summ if n.startswith("csr_aggregate_") and n != dom]
+            if other:
+                out["roofline"]["also"] = [view(n) for n in sorted(other)]
             if world == 1:
                 ceil = stream_copy_ceiling(dev)
                 out["roofline"]["stream_copy_GBps"] = ceil

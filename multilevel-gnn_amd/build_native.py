@@ -18,6 +18,19 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def sources_digest():
+    """sha256 over everything libmlgnn.so is built from (kernel sources, headers, this file's flags): what a set of
+    profiler numbers under profiles/ is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    files += [os.path.join(ROOT, "include", "mlgnn.h"), os.path.abspath(__file__)]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

@@ -13,6 +13,10 @@ import os
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys_path = os.path.join(ROOT, "multilevel-gnn_amd")
+import sys  # noqa: E402
+if sys_path not in sys.path:
+    sys.path.insert(0, sys_path)
 
 
 def find(pattern):
@@ -40,6 +44,8 @@ def main():
     ap.add_argument("--stats", required=True)
     ap.add_argument("--tag", required=True)
     ap.add_argument("--cmd", default="")
+    ap.add_argument("--pmc-cmd", default="")
+    ap.add_argument("--commit", default="")
     ap.add_argument("--pmc-fetch")
     ap.add_argument("--pmc-write")
     ap.add_argument("--top", type=int, default=30)
@@ -79,7 +85,14 @@ def main():
         # so its traffic entry is the sum of the two launches
         if "softmax_shift" in traffic and "csr_aggregate_bwd" in traffic:
             traffic["csr_aggregate_bwd"] += traffic["softmax_shift"]
-        json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+        # provenance travels with the numbers: bench.py refuses them when the kernel sources have changed since
+        import build_native
+        blob = {"_source": {"tag": a.tag, "commit": a.commit or os.environ.get("MLGNN_COMMIT", "unknown"),
+                            "command": a.pmc_cmd or a.cmd, "kernel_sources_sha256": build_native.sources_digest(),
+                            "counters": "2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes "
+                                        "(MI355X_MICROARCH.md, HBM: FETCH_SIZE reports half of a 16 B/lane stream on gfx950)"}}
+        blob.update(traffic)
+        json.dump(blob, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
         json.dump(detail, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % a.tag), "w"), indent=1)
         print("wrote profiles/traffic.json", traffic)
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 10
+#define MLGNN_ABI_VERSION 11
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -61,6 +61,30 @@ extern "C" {
 
 int mlgnn_version(void);
 
+/*
+ * Long rows ("hub" nodes: a transcription factor's cross-omics edges, dataloader/multiloader.py:664-671).  One
+ * wavefront owns one row in the aggregation kernels; rows with more than `cap` edges are cut into chunks of `cap`
+ * that run as rows of their own and are combined in chunk order (no atomics; csrc/hub.hip).  mlgnn_hub_rows builds
+ * the chunk tables of ONE direction on the device from a row pointer (rowptr for the forward, rowptr_t for the
+ * backward): vrows [capacity][3] = {real row, first edge, one past the last edge} of every chunk behind a row's first
+ * `cap` edges, hubs [capacity][3] = {row, first chunk, number of chunks} per split row, counts[2] = their numbers.
+ * capacity = mlgnn_hub_capacity(E, cap); tmp: mlgnn_hub_scratch_bytes(capacity, d) bytes of scratch for the chunks'
+ * partial results, private to one call.  Pass the struct to mlgnn_csr_aggregate_fwd / _bwd (NULL or cap = 0: off).
+ */
+typedef struct mlgnn_hub {
+  int32_t cap;
+  int32_t capacity;
+  const int32_t* vrows;
+  const int32_t* hubs;
+  const int32_t* counts;
+  void* tmp;
+  int64_t tmp_bytes;
+} mlgnn_hub_t;
+int64_t mlgnn_hub_capacity(int64_t E, int cap);
+int64_t mlgnn_hub_scratch_bytes(int64_t capacity, int64_t d);
+int mlgnn_hub_rows(const int32_t* rowptr, int64_t N, int cap, int64_t capacity, int32_t* vrows, int32_t* hubs,
+                   int32_t* counts, void* stream);
+
 /* Number of float elements of workspace mlgnn_csr_aggregate_bwd needs: per-workgroup partials of a
  * factored edge term of edge_rank attributes (0 when the edge mode is not EDGE_RANK1) plus, for
  * AGGR_SOFTMAX without learn_t, the rescaled cotangent [N,d] of the one-row gather path, or, for AGGR_MAX with
@@ -93,6 +117,8 @@ int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int dtype
  *                   read from that device address instead (learnable parameters: no host sync)
  *   add_root        non-zero: out = x + aggregate (GENConv's h = x + m, torch_vertex.py:89, same pass);
  *                   the backward then adds grad_out to grad_x.  Not combinable with learn_t.
+ *   hub             long-row tables of the by-destination CSR (mlgnn_hub_rows over rowptr), or NULL; with
+ *                   SOFTMAX / POWER it needs aux (the chunks are combined through it)
  */
 int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t* col,
                             const float* ew, const float* eu, const float* ev,
@@ -100,7 +126,7 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
                             void* out, float* aux, float* aux2, int32_t* argmax, float* row_max,
                             int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                             int aggr, float t, float p, const float* t_dev, const float* p_dev,
-                            float eps, int add_root, void* stream);
+                            float eps, int add_root, const mlgnn_hub_t* hub, void* stream);
 
 /*
  * Backward of the above with respect to x (and the edge term), atomic-free, on the
@@ -135,7 +161,7 @@ int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out
                             float* workspace, int64_t workspace_floats,
                             int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                             int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev,
-                            float eps, int add_root, int accumulate_efull, void* stream);
+                            float eps, int add_root, int accumulate_efull, const mlgnn_hub_t* hub, void* stream);
 
 /*
  * Gene -> pathway learnable-projection pooling.

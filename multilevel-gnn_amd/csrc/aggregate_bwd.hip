@@ -19,6 +19,7 @@ struct BwdArgs {                      // go / x / out / efull / gx / ge are T; a
   const float* t_dev; const float* p_dev;
   int N; int d; int lpr_log2; int mean; int learn_t; int add_root; int ge_accumulate;
   float t; float p; float eps;
+  int cap; const int* vrows; const int* vcount;             // long source rows, as in FwdArgs (csrc/hub.hip)
 };
 
 // VEC one-byte winner slots -> ints
@@ -43,7 +44,7 @@ __device__ __forceinline__ void load_slots(int (&r)[VEC], const uint8_t* p) {
 // edge gathers ONE row (gt) instead of two (go, lse): half the gather traffic, and no per-edge scalar either.
 // SHIFT with max: the winning edge of (i, c) is looked up as a 1-byte slot inside row i (max_slot_kernel) instead of
 // the 4-byte by-destination position the forward wrote -- the second gathered row shrinks from 4 d to d bytes.
-template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool SHIFT>
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool SHIFT, bool VIRT>
 __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (*red)[kWave * VEC]) {
   constexpr int RK = rank_of<MODE>();
   constexpr int ES = edge_scalars<MODE>();
@@ -62,7 +63,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
   const int groups = kWave >> a.lpr_log2;
   const int sub = lane >> a.lpr_log2;
   const int cl = lane & (lpr - 1);
-  const RowWalk walk = make_row_walk(a.N);
+  const RowWalk walk = make_row_walk(VIRT ? *a.vcount : a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
   const float t_eps = sc.t_log2e * a.eps;
   const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
@@ -90,12 +91,14 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
     }
 
     for (int r = walk.first; r < walk.r_end; r += walk.stride) {
-      const int beg = a.rowptr_t[r];
-      const int end = a.rowptr_t[r + 1];
+      // xr: the source node whose features this row of edges belongs to (VIRT: a chunk of a long row, csrc/hub.hip)
+      const int xr = VIRT ? a.vrows[3 * r] : r;
+      const int beg = VIRT ? a.vrows[3 * r + 1] : a.rowptr_t[r];
+      const int end = VIRT ? a.vrows[3 * r + 2] : min(a.rowptr_t[r + 1], beg + a.cap);
       float xj[VEC], gx[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { xj[i] = 0.f; gx[i] = 0.f; }
-      if (is_gen<MODE>() && end > beg) load_t<T, VEC>(xj, X + (size_t)r * a.d + c0);
+      if (is_gen<MODE>() && end > beg) load_t<T, VEC>(xj, X + (size_t)xr * a.d + c0);
       float xjv[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) xjv[i] = xj[i] + ev[i];
@@ -217,13 +220,14 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
 #pragma unroll
         for (int i = 0; i < VEC; ++i) gx[i] += __shfl_xor(gx[i], off);
       if (sub == 0 && cact) {
-        if (a.add_root) {            // identity branch of h = x + m
+        if (a.add_root && !VIRT) {    // identity branch of h = x + m (once per real row: the main launch)
           float gr[VEC];
           load_t<T, VEC>(gr, GO + (size_t)r * a.d + c0);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) gx[i] += gr[i];
         }
-        store_t<T, VEC>(GX + (size_t)r * a.d + c0, gx);
+        if constexpr (VIRT) store_vec<VEC>(reinterpret_cast<float*>(a.gx) + (size_t)r * a.d + c0, gx);   // chunk partial: fp32
+        else store_t<T, VEC>(GX + (size_t)r * a.d + c0, gx);
       }
     }
 
@@ -260,22 +264,22 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
 // fp32 more than 60 binades on either side for the cotangent itself
 constexpr float kMaxLse = 60.0f;
 
-template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T>
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool VIRT = false>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
   __shared__ float red[kWavesPerBlock][kWave * VEC];
   if constexpr (AGGR == A_SOFTMAX && !LEARN_T) {
     // *a.spread != 0: softmax_shift_kernel met a node with |lse| > kMaxLse in some channel; the two-row path
     // stays as the fallback for such inputs (never seen in practice: lse = log2 sum_e 2^(t m_e))
     const bool shift_ok = a.gt != nullptr && *a.spread == 0;
-    if (shift_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true>(a, red);
-    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false>(a, red);
+    if (shift_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT>(a, red);
+    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT>(a, red);
   } else if constexpr (AGGR == A_MAX) {
     // *a.spread != 0: some node has more than 254 incoming edges, its slots do not fit a byte
     const bool slots_ok = a.slot8 != nullptr && *a.spread == 0;
-    if (slots_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true>(a, red);
-    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false>(a, red);
+    if (slots_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT>(a, red);
+    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT>(a, red);
   } else {
-    csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false>(a, red);
+    csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT>(a, red);
   }
 }
 
@@ -437,7 +441,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                                        int aggr, int learn_t, float t, float p, const float* t_dev,
                                        const float* p_dev, float eps, int add_root, int accumulate_efull,
-                                       void* stream) {
+                                       const mlgnn_hub_t* hub, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
@@ -457,8 +461,14 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   if (mode == M_GEN_FULL && col_t && (!efull || !eid_t || !grad_efull)) return MLGNN_E_NULL;
   const int nblk = grid_for_rows(N);
   const bool bf16 = dtype == MLGNN_DTYPE_BF16;
-  // workspace = [edge-term partials: nblk * (rk+1) * d][softmax one-row path: flag (4 floats), gt [N*d] of T]
-  const int64_t part_floats = rk > 0 ? (int64_t)nblk * (rk + 1) * d : 0;
+  const bool split = hub && hub->cap > 0 && col_t;
+  if (split) {
+    if (!hub->vrows || !hub->hubs || !hub->counts || !hub->tmp) return MLGNN_E_NULL;
+    if (hub->capacity < 1 || hub->tmp_bytes < mlgnn_hub_scratch_bytes(hub->capacity, d)) return MLGNN_E_WORKSPACE;
+    if ((int64_t)hub->capacity * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
+  }
+  // workspace = [edge-term partials: (nblk + kHubBlocks) * (rk+1) * d][softmax one-row path: flag (4 floats), gt [N*d] of T]
+  const int64_t part_floats = rk > 0 ? (int64_t)(nblk + kHubBlocks) * (rk + 1) * d : 0;
   const bool want_shift = ag == A_SOFTMAX && !learn_t;
   const bool want_slots = ag == A_MAX && d % 4 == 0;
   const int64_t shift_floats = want_shift ? 4 + (N * d * (bf16 ? 2 : 4) + 3) / 4 : (want_slots ? 4 + (N * d + 3) / 4 : 0);
@@ -472,6 +482,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN); a.learn_t = learn_t;
   a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
   a.ge_accumulate = accumulate_efull;
+  a.cap = split ? hub->cap : kNoCap; a.vrows = nullptr; a.vcount = nullptr;
   if (add_root && learn_t) return MLGNN_E_MODE;       // `out` must be the bare aggregate for d/dt
 
   const bool al = aligned16(grad_out) && aligned16(grad_x) && (!x || aligned16(x)) &&
@@ -522,36 +533,59 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
     }
   }
   const bool lt = learn_t != 0 && ag == A_SOFTMAX;
-  for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
-    constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
-    constexpr bool kCanLearn = (AGGR == A_SOFTMAX);
-    auto launch = [&](auto t_c, auto vec_c) {
-      using T = typename decltype(t_c)::type;
-      constexpr int VEC = decltype(vec_c)::value;
-      auto go = [&](auto kernel) {
-        // The strided walk is one pass over the rows only while every workgroup is resident (otherwise each
-        // generation of workgroups sweeps all graphs again, through a cold L2): size the grid to the occupancy of
-        // this instantiation.
-        static int per_cu = 0;                                  // one static per instantiation
-        if (per_cu == 0) {
-          int n = 0;
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, 0) != hipSuccess || n < 1) n = 2;
-          per_cu = n;
-        }
-        int g = per_cu * num_cus() / kXcds * kXcds;
-        launched_blocks = g < nblk ? (g < kXcds ? kXcds : g) : nblk;
-        hipLaunchKernelGGL(kernel, dim3(launched_blocks), block, 0, s, a);
+  // fixed_grid > 0: the launch over the extra chunks of long rows (csrc/hub.hip)
+  auto run = [&](const BwdArgs& args, int fixed_grid, auto virt_c) {
+    constexpr bool VIRT = decltype(virt_c)::value;
+    for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
+      constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
+      constexpr bool kCanLearn = (AGGR == A_SOFTMAX);
+      auto launch = [&](auto t_c, auto vec_c) {
+        using T = typename decltype(t_c)::type;
+        constexpr int VEC = decltype(vec_c)::value;
+        auto go = [&](auto kernel, auto learn_c) {
+          // The strided walk is one pass over the rows only while every workgroup is resident (otherwise each
+          // generation of workgroups sweeps all graphs again, through a cold L2): size the grid to the occupancy of
+          // this instantiation.  (`learn_c` makes the two variants of one (T, VEC, MODE, AGGR) distinct
+          // instantiations of this lambda: their kernels have the same function type, and would share the static.)
+          static int per_cu = 0;
+          (void)learn_c;
+          if (per_cu == 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, 0) != hipSuccess || n < 1) n = 2;
+            per_cu = n;
+          }
+          int g = per_cu * num_cus() / kXcds * kXcds;
+          g = g < nblk ? (g < kXcds ? kXcds : g) : nblk;
+          if (fixed_grid > 0) g = fixed_grid; else launched_blocks = g;
+          hipLaunchKernelGGL(kernel, dim3(g), block, 0, s, args);
+        };
+        if (kCanLearn && lt) go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, kCanLearn, VIRT>, BC<true>{});
+        else go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false, VIRT>, BC<false>{});
       };
-      if (kCanLearn && lt) go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, kCanLearn>);
-      else go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false>);
-    };
-    if (bf16) { if (vec == 8) launch(TypeTag<bf16_t>{}, IC<8>{}); else launch(TypeTag<bf16_t>{}, IC<1>{}); }
-    else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
-  });
+      if (bf16) { if (vec == 8) launch(TypeTag<bf16_t>{}, IC<8>{}); else launch(TypeTag<bf16_t>{}, IC<1>{}); }
+      else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
+    });
+  };
+  run(a, 0, BC<false>{});
+  int total_blocks = launched_blocks;
+  if (split) {
+    int err1 = (int)hipGetLastError();
+    if (err1) return err1;
+    BwdArgs b = a;
+    b.cap = kNoCap; b.vrows = hub->vrows; b.vcount = hub->counts;
+    b.gx = hub->tmp;                                            // one partial grad_x row per extra chunk
+    b.ws = rk > 0 ? workspace + (int64_t)launched_blocks * (rk + 1) * d : nullptr;
+    run(b, kHubBlocks, BC<true>{});
+    total_blocks += kHubBlocks;
+    err1 = (int)hipGetLastError();
+    if (err1) return err1;
+    err1 = hub_combine_bwd(hub->hubs, hub->counts, grad_x, hub->tmp, (int)d, bf16, s);
+    if (err1) return err1;
+  }
   int err = (int)hipGetLastError();
   if (err) return err;
   if (rk > 0) {
-    launch_reduce_partials(workspace, grad_uv, launched_blocks, (rk + 1) * (int)d, s);
+    launch_reduce_partials(workspace, grad_uv, total_blocks, (rk + 1) * (int)d, s);
     err = (int)hipGetLastError();
   }
   return err;

@@ -12,6 +12,8 @@ constexpr int kUnroll = 4;                 // neighbour rows in flight per lane 
 // persistent walk: 0.73 / 0.51 ms).  The backward keeps the strided walk: it is bound
 // by per-edge instruction issue, and one edge-term partial per workgroup favours few, long-lived workgroups.
 constexpr int kFwdRowsPerWave = 4;
+constexpr int kNoCap = 0x3fffffff;
+constexpr int kHubBlocks = 256;             // workgroups of the backward launch over the extra chunks of long rows
 constexpr float kPowLo = 1e-7f, kPowHi = 1e1f;   // torch_message.py:69
 constexpr float kNegBig = -3.0e38f;
 
@@ -43,6 +45,10 @@ struct FwdArgs {                      // x / efull / out are T (fp32 or bf16); e
   const float* t_dev; const float* p_dev;
   int N; int d; int lpr_log2; int mean; int add_root;
   float t; float p; float eps;
+  // long rows (csrc/hub.hip): every row is clamped to its first `cap` edges (kNoCap: off; a clamped row's result is
+  // a partial: no root term).  The VIRT instantiation of the kernel walks the extra chunks instead:
+  // vrows[r] = {real row, first edge, one past the last edge}, *vcount of them, results to scratch row r (fp32)
+  int cap; const int* vrows; const int* vcount;
 };
 
 // t / p either immediate or read from device memory (learnable parameters: no host sync)
@@ -99,11 +105,13 @@ __device__ __forceinline__ float pre_act(float xj, const float* a, const float* 
 
 // Non-finite inputs.  relu / max / the power clamp are v_max / v_min here, which return the OTHER operand when one is
 // NaN: a NaN (or Inf) in x_j or in the edge term would silently vanish from the aggregate, where the reference carries
-// it to the loss (relu(NaN) = NaN, torch_vertex.py:94-101).  Every GEN message therefore also feeds a per-channel
-// tracker  nb = fma(z, 0, nb)  (0 for finite z, NaN for NaN / +-Inf) that is added to the row's result.  Inline asm:
-// this translation unit is built with -fno-honor-nans, under which the compiler may fold z * 0.
-__device__ __forceinline__ void track_nonfinite(float& nb, float z) {
-  asm("v_fma_f32 %0, %1, 0, %0" : "+v"(nb) : "v"(z));
+// it to the loss (relu(NaN) = NaN, torch_vertex.py:94-101).  Every GEN message is therefore re-poisoned after its
+// relu:  m = fma(z, 0, m)  leaves m unchanged for finite z (z * 0 = +-0) and makes it NaN for NaN / +-Inf, from
+// where the sums / exponentials carry it to the row's result by themselves.  One VALU op per gathered element and no
+// extra register (a per-channel accumulator cost the softmax forward an occupancy step: 78 -> 82 VGPRs).  Inline
+// asm: this translation unit is built with -fno-honor-nans, under which the compiler may fold z * 0.
+__device__ __forceinline__ void keep_nonfinite(float& m, float z) {
+  asm("v_fma_f32 %0, %1, 0, %0" : "+v"(m) : "v"(z));
 }
 
 template <int MODE, bool ADD_EPS>
@@ -113,6 +121,17 @@ __device__ __forceinline__ float message(float xj, const float* a, const float* 
   else if constexpr (ADD_EPS) return fmaxf(pre_act<MODE>(xj, a, u, v, ef), 0.0f) + eps;
   else return fmaxf(pre_act<MODE>(xj, a, u, v, ef), 0.0f);
 }
+
+// csrc/hub.hip
+struct HubFwdArgs {
+  const int* hubs; const int* vrows; const int* counts; const int* rowptr;
+  void* out; float* aux; float* aux2; int* argmax; float* rowmax; const void* x;      // real rows
+  const void* out_v; const float* aux_v; const float* aux2_v; const int* argmax_v;    // extra chunks
+  const float* p_dev; float p;
+  int d; int cap; int aggr; int mean; int add_root; int second;
+};
+int hub_combine_fwd(const HubFwdArgs& a, bool bf16, hipStream_t s);
+int hub_combine_bwd(const int* hubs, const int* counts, void* gx, const void* gx_v, int d, bool bf16, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // host-side dispatch

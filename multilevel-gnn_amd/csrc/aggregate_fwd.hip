@@ -18,7 +18,7 @@
 
 namespace mlgnn {
 
-template <typename T, int VEC, int MODE, int AGGR, bool SECOND>
+template <typename T, int VEC, int MODE, int AGGR, bool SECOND, bool VIRT = false>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs a) {
   const T* X = static_cast<const T*>(a.x);
   const T* EF = static_cast<const T*>(a.efull);
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
   const int groups = kWave >> a.lpr_log2;
   const int sub = lane >> a.lpr_log2;
   const int cl = lane & (lpr - 1);
-  const RowWalk walk = make_chunk_walk(a.N);
+  const RowWalk walk = make_chunk_walk(VIRT ? *a.vcount : a.N);
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
   const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
   constexpr int RK = rank_of<MODE>();                    // rank of the factored edge term (0: none)
@@ -71,12 +71,15 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
     auto rows = [&](auto tpos_c) {
     constexpr bool TPOS = decltype(tpos_c)::value;
     for (int r = walk.first; r < walk.r_end; r += walk.stride) {
-      const int beg = a.rowptr[r];
-      const int end = a.rowptr[r + 1];
+      // a chunk of a long row (csrc/hub.hip) is a partial result: no root term, combined by hub_combine_fwd_kernel
+      const int beg = VIRT ? a.vrows[3 * r + 1] : a.rowptr[r];
+      const int row_end = VIRT ? a.vrows[3 * r + 2] : a.rowptr[r + 1];
+      const int end = VIRT ? row_end : min(row_end, beg + a.cap);
+      const bool partial = VIRT || end != row_end;
       const int deg = end - beg;
 
       // accumulators: SUM/POWER use acc; MAX uses acc (best) + bpos; SOFTMAX uses mx, acc (S), w1, w2
-      float acc[VEC], mx[VEC], w1[VEC], w2[VEC], nb[VEC];    // nb: non-finite tracker (aggregate_common.h)
+      float acc[VEC], mx[VEC], w1[VEC], w2[VEC];
       int bpos[VEC];
       // FAST (softmax only): no running maximum -- weights 2^(t m) against the fixed reference 0.  Messages are
       // relu outputs of normalised features, so t m stays far inside fp32's exponent range and the per-batch
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         acc[i] = (AGGR == A_MAX) ? kNegBig : 0.f;
-        mx[i] = FAST ? 0.f : kNegBig; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1; nb[i] = 0.f;
+        mx[i] = FAST ? 0.f : kNegBig; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1;
       }
 
       for (int base = beg; base < end; base += kWave) {
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
               for (int i = 0; i < VEC; ++i) {
                 if constexpr (kTrack) {
                   const float z = pre_act<MODE>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i]);
-                  track_nonfinite(nb[i], z);
                   m[u][i] = kLateEps ? fmaxf(z, 0.0f) : fmaxf(z, 0.0f) + a.eps;
+                  keep_nonfinite(m[u][i], z);
                 } else {
                   m[u][i] = message<MODE, !kLateEps>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i], a.eps);
                 }
@@ -198,7 +201,8 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
             for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
               for (int i = 0; i < VEC; ++i) {
-                const float mc = fminf(fmaxf(m[u][i], kPowLo), kPowHi);
+                float mc = fminf(fmaxf(m[u][i], kPowLo), kPowHi);
+                keep_nonfinite(mc, m[u][i]);            // torch.clamp carries a NaN message; v_min / v_max drop it
                 const float l2 = fast_log2(mc);
                 const float pw = fast_exp2(sc.p * l2);
                 acc[i] += (FULL || valid[u]) ? pw : 0.f;
@@ -217,7 +221,6 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
       for (int off = lpr; off < kWave; off <<= 1) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          if constexpr (kTrack) nb[i] += __shfl_xor(nb[i], off);
           if constexpr (AGGR == A_SUM) {
             acc[i] += __shfl_xor(acc[i], off);
           } else if constexpr (AGGR == A_POWER) {
@@ -283,24 +286,22 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
             } else { o[i] = 0.f; }
           } else {  // POWER
             const float mu = acc[i] * inv;
-            const float muc = fminf(fmaxf(mu, kPowLo), kPowHi);
+            float muc = fminf(fmaxf(mu, kPowLo), kPowHi);
+            keep_nonfinite(muc, mu);                             // the outer clamp carries NaN too (torch_message.py:72)
             o[i] = fast_exp2(fast_log2(muc) * __builtin_amdgcn_rcpf(sc.p));
             ax[i] = mu;
             ax2[i] = w2[i] * inv;
           }
         }
-        if constexpr (kTrack) {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) o[i] += nb[i];           // + 0, or NaN when a message of this row was not finite
-        }
         const size_t off = (size_t)r * a.d + c0;
-        if (a.add_root) {            // h = x_i + m_i (GENConv.forward, torch_vertex.py:89) in the same pass
+        if (a.add_root && !partial) { // h = x_i + m_i (GENConv.forward, torch_vertex.py:89) in the same pass
           float xr[VEC];
           load_t<T, VEC>(xr, X + off);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) o[i] += xr[i];
         }
-        store_t<T, VEC>(OUT + off, o);
+        if constexpr (VIRT) store_vec<VEC>(reinterpret_cast<float*>(a.out) + off, o);   // chunk partials stay fp32 (hub.hip)
+        else store_t<T, VEC>(OUT + off, o);
         if (AGGR == A_MAX && a.argmax) store_vec<VEC>(a.argmax + off, am);
         if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_vec<VEC>(a.aux + off, ax);
         if (SECOND && a.aux2) store_vec<VEC>(a.aux2 + off, ax2);
@@ -334,7 +335,7 @@ extern "C" int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d
   if (N < 0 || d < 0 || edge_rank < 0 || edge_rank > 8) return MLGNN_E_SHAPE;
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   // per-workgroup partials of the factored edge term + the softmax shift / max winner-slot buffers (aggregate_bwd.hip)
-  int64_t n = edge_rank > 0 ? (int64_t)grid_for_rows(N) * (edge_rank + 1) * d : 0;
+  int64_t n = edge_rank > 0 ? (int64_t)(grid_for_rows(N) + kHubBlocks) * (edge_rank + 1) * d : 0;
   if (aggr == MLGNN_AGGR_SOFTMAX && !learn_t)
     n += 4 + (N * d * (dtype == MLGNN_DTYPE_BF16 ? 2 : 4) + 3) / 4;
   if (aggr == MLGNN_AGGR_MAX && d % 4 == 0) n += 4 + (N * d + 3) / 4;      // flag + one-byte winner slots
@@ -347,10 +348,15 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
                                        void* out, float* aux, float* aux2, int32_t* argmax, float* row_max,
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                                        int aggr, float t, float p, const float* t_dev, const float* p_dev,
-                                       float eps, int add_root, void* stream) {
+                                       float eps, int add_root, const mlgnn_hub_t* hub, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;      // 32-bit row offsets: [N,d] tensors < 4 GiB
+  if (hub && hub->cap > 0) {
+    if (!hub->vrows || !hub->hubs || !hub->counts || !hub->tmp) return MLGNN_E_NULL;
+    if (hub->capacity < 1 || hub->tmp_bytes < mlgnn_hub_scratch_bytes(hub->capacity, d)) return MLGNN_E_WORKSPACE;
+    if ((int64_t)hub->capacity * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
+  }
   const int mode = pick_mode(msg, edge_mode, edge_rank);
   const int ag = pick_aggr(aggr);
   if (mode < 0 || ag < 0) return MLGNN_E_MODE;
@@ -367,6 +373,8 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   a.efull = efull; a.eid = eid; a.out = out; a.aux = aux; a.aux2 = aux2;
   a.argmax = argmax; a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN);
   a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
+  const bool split = hub && hub->cap > 0 && col;
+  a.cap = split ? hub->cap : kNoCap; a.vrows = nullptr; a.vcount = nullptr;
 
   const bool al = aligned16(x) && aligned16(out) && (!efull || aligned16(efull)) &&
                   (!aux || aligned16(aux)) && (!aux2 || aligned16(aux2)) && (!argmax || aligned16(argmax)) &&
@@ -380,18 +388,47 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   a.lpr_log2 = lanes_per_row_log2(d, vec);
   a.rowmax = row_max;
   if (row_max && d != ((int64_t)vec << a.lpr_log2)) return MLGNN_E_SHAPE;    // row max: one chunk, no shadow lanes
-  for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
-    constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
-    constexpr bool kHasSecond = (AGGR == A_SOFTMAX || AGGR == A_POWER);
-    auto launch = [&](auto t_c, auto vec_c) {
-      using T = typename decltype(t_c)::type;
-      constexpr int VEC = decltype(vec_c)::value;
-      if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, kHasSecond>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, false>), grid, block, 0, s, a);
-    };
-    if (bf16) { if (vec == 8) launch(TypeTag<bf16_t>{}, IC<8>{}); else launch(TypeTag<bf16_t>{}, IC<1>{}); }
-    else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
-  });
-  return (int)hipGetLastError();
+  auto run = [&](const FwdArgs& args, const dim3 g, auto virt_c) {
+    constexpr bool VIRT = decltype(virt_c)::value;
+    for_mode_aggr(mode, ag, [&](auto mode_c, auto aggr_c) {
+      constexpr int MODE = decltype(mode_c)::value, AGGR = decltype(aggr_c)::value;
+      constexpr bool kHasSecond = (AGGR == A_SOFTMAX || AGGR == A_POWER);
+      auto launch = [&](auto t_c, auto vec_c) {
+        using T = typename decltype(t_c)::type;
+        constexpr int VEC = decltype(vec_c)::value;
+        if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, kHasSecond, VIRT>), g, block, 0, s, args);
+        else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, false, VIRT>), g, block, 0, s, args);
+      };
+      if (bf16) { if (vec == 8) launch(TypeTag<bf16_t>{}, IC<8>{}); else launch(TypeTag<bf16_t>{}, IC<1>{}); }
+      else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
+    });
+  };
+  run(a, grid, BC<false>{});
+  int err = (int)hipGetLastError();
+  if (err || !split) return err;
+
+  // long rows: the chunks behind the first `cap` edges of every row, then the fixed-order combine (csrc/hub.hip)
+  const size_t rows = (size_t)hub->capacity;
+  unsigned char* tmp = static_cast<unsigned char*>(hub->tmp);
+  auto carve = [&](size_t bytes) { unsigned char* q = tmp; tmp += (bytes + 63) & ~(size_t)63; return q; };
+  void* out_v = carve(rows * d * 4);                               // chunk partials are fp32 whatever the storage type
+  float* aux_v = reinterpret_cast<float*>(carve(rows * d * 4));
+  float* aux2_v = reinterpret_cast<float*>(carve(rows * d * 4));
+  int* arg_v = reinterpret_cast<int*>(carve(rows * d * 4));
+  FwdArgs b = a;
+  b.cap = kNoCap; b.vrows = hub->vrows; b.vcount = hub->counts;
+  b.out = out_v; b.aux = aux ? aux_v : nullptr; b.aux2 = aux2 ? aux2_v : nullptr; b.argmax = argmax ? arg_v : nullptr;
+  b.rowmax = nullptr; b.add_root = 0;
+  run(b, dim3(256), BC<true>{});
+  err = (int)hipGetLastError();
+  if (err) return err;
+  HubFwdArgs h;
+  h.hubs = hub->hubs; h.vrows = hub->vrows; h.counts = hub->counts; h.rowptr = rowptr;
+  h.out = out; h.aux = aux; h.aux2 = aux2; h.argmax = argmax; h.rowmax = row_max; h.x = x;
+  h.out_v = out_v; h.aux_v = aux_v; h.aux2_v = aux2_v; h.argmax_v = arg_v;
+  h.p_dev = p_dev; h.p = p; h.d = (int)d; h.cap = hub->cap; h.aggr = ag; h.mean = a.mean; h.add_root = add_root;
+  h.second = second ? 1 : 0;
+  if ((ag == A_SOFTMAX || ag == A_POWER) && !aux) return MLGNN_E_NULL;      // the combine needs the chunks' lse / means
+  return hub_combine_fwd(h, bf16, s);
 }
 

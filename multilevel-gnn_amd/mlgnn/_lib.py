@@ -15,10 +15,10 @@ SIGNATURES = {
     "mlgnn_version": (_INT, []),
     "mlgnn_csr_aggregate_bwd_workspace_floats": (_I64, [_I64, _I64, _INT, _INT, _INT, _INT]),
     "mlgnn_csr_aggregate_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                       _I64, _I64, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _P]),
+                                       _I64, _I64, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _P, _P]),
     "mlgnn_csr_aggregate_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                        _P, _P, _P, _P, _I64,
-                                       _I64, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _INT, _P]),
+                                       _I64, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _INT, _P, _P]),
     "mlgnn_embedding_bwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -60,7 +60,17 @@ SIGNATURES = {
                                         _I64, _I64, _I64, _P]),
     "mlgnn_adam_workspace_floats": (_I64, []),
     "mlgnn_adam_step": (_INT, [_P, _P, _P, _P, _I64, _P, _INT, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "mlgnn_hub_capacity": (_I64, [_I64, _INT]),
+    "mlgnn_hub_scratch_bytes": (_I64, [_I64, _I64]),
+    "mlgnn_hub_rows": (_INT, [_P, _I64, _INT, _I64, _P, _P, _P, _P]),
 }
+
+
+class HubStruct(_c.Structure):
+    """``mlgnn_hub_t`` (include/mlgnn.h)."""
+    _fields_ = [("cap", _c.c_int32), ("capacity", _c.c_int32), ("vrows", _P), ("hubs", _P), ("counts", _P),
+                ("tmp", _P), ("tmp_bytes", _I64)]
+
 
 ERRORS = {-1: "MLGNN_E_NULL", -2: "MLGNN_E_SHAPE", -3: "MLGNN_E_MODE", -4: "MLGNN_E_DTYPE",
           -5: "MLGNN_E_WORKSPACE", -6: "MLGNN_E_ALIGN"}

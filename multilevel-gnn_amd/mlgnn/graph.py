@@ -4,7 +4,14 @@ The reference keeps graphs as COO ``edge_index [2, E]`` int64 and lets every lay
 gather/scatter from it (``MessagePassing.propagate``).  Here the topology is sorted once per batch;
 all layers (and forward + backward) share it.
 """
+import ctypes
+import os
+
 import torch
+
+# rows (in-edges of a node for the forward, out-edges for the backward) longer than this are cut into chunks that
+# run as rows of their own and are combined in order (csrc/hub.hip); 0 disables
+HUB_CAP = int(os.environ.get("MLGNN_HUB_CAP", "256"))
 
 
 class CSRGraph:
@@ -31,6 +38,39 @@ class CSRGraph:
         self._deg = None
         self._scalar_cache = None
         self._table_cache = None
+        self._hub = {}
+
+    def hub_tables(self, direction):
+        """Chunk tables of the long rows of one direction (``"dst"``: by-destination CSR, forward; ``"src"``:
+        transposed CSR, backward), built on the device on first use: ``(vrows, hubs, counts, capacity)`` or ``None``
+        (``HUB_CAP = 0``, a host graph, or no edge)."""
+        if HUB_CAP <= 0 or not self.rowptr.is_cuda or self.num_edges == 0:
+            return None
+        hit = self._hub.get(direction)
+        if hit is None:
+            from . import _lib
+            cap_rows = int(_lib.lib.mlgnn_hub_capacity(self.num_edges, HUB_CAP))
+            i32 = dict(dtype=torch.int32, device=self.device)
+            vrows, hubs, counts = torch.empty((cap_rows, 3), **i32), torch.empty((cap_rows, 3), **i32), torch.empty(2, **i32)
+            rowptr = self.rowptr if direction == "dst" else self.rowptr_t
+            rc = _lib.lib.mlgnn_hub_rows(rowptr.data_ptr(), self.num_nodes, HUB_CAP, cap_rows, vrows.data_ptr(),
+                                         hubs.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "mlgnn_hub_rows")
+            hit = self._hub[direction] = (vrows, hubs, counts, cap_rows)
+        return hit
+
+    def hub_arg(self, direction, d):
+        """``(pointer to a mlgnn_hub_t or None, objects to keep alive until the launch is enqueued)`` for one kernel
+        call on ``[N, d]`` features: the tables above plus fresh scratch for the chunks' partial results."""
+        tabs = self.hub_tables(direction)
+        if tabs is None:
+            return None, ()
+        from . import _lib
+        vrows, hubs, counts, cap_rows = tabs
+        nbytes = int(_lib.lib.mlgnn_hub_scratch_bytes(cap_rows, d))
+        tmp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        st = _lib.HubStruct(HUB_CAP, cap_rows, vrows.data_ptr(), hubs.data_ptr(), counts.data_ptr(), tmp.data_ptr(), nbytes)
+        return ctypes.byref(st), (st, tmp)
 
     def _build_device(self, edge_index):
         """Two stable radix sorts on the GPU (``mlgnn_coo_to_csr``), enqueued on the current stream."""
@@ -81,7 +121,7 @@ class CSRGraph:
         for name in ("rowptr", "col", "eid", "rowptr_t", "col_t", "pos_t", "eid_t"):
             setattr(self, name, getattr(self, name).to(device))
         self.device = torch.device(device)
-        self._deg, self._scalar_cache, self._table_cache = None, None, None
+        self._deg, self._scalar_cache, self._table_cache, self._hub = None, None, None, {}
         return self
 
     @staticmethod

@@ -382,12 +382,16 @@ class _GenAggregate(torch.autograd.Function):
         t0 = timer.start() if timer is not None else None
         # max |row| of the result rides along for the Linear that consumes it (fp32, one channel chunk)
         rowmax = torch.empty(N, **f32) if (x.dtype == torch.float32 and d in (4, 8, 16, 32, 64, 128, 256)) else None
+        hub, hub_keep = graph.hub_arg("dst", d)
+        if hub is not None and aggr_id in (AGGR_SOFTMAX, AGGR_POWER) and aux is None:
+            aux = torch.empty((N, d), **f32)                  # the chunks of a long row are combined through their lse
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), _lib.ptr(eu), _lib.ptr(ev),
             _lib.ptr(efull), eid_fwd.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(aux2),
             _lib.ptr(argmax), _lib.ptr(rowmax), N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, float(t), float(p),
-            _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), int(add_root), _stream())
+            _lib.ptr(t_dev), _lib.ptr(p_dev), float(eps), int(add_root), hub, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
+        del hub_keep
         if timer is not None:
             timer.stop("csr_aggregate_fwd/%s/%s" % (_AGGR_NAMES[aggr_id], _edge_name(edge_mode, rank)), t0,
                        algorithmic_bytes(N, graph.num_edges, d, aggr_id, edge_mode, s=x.element_size(),
@@ -449,14 +453,16 @@ class _GenAggregate(torch.autograd.Function):
         ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
         timer = KERNEL_TIMER
         t0 = timer.start() if timer is not None else None
+        hub, hub_keep = g.hub_arg("src", d)
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go_k.data_ptr(), x.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(argmax),
             g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(), g.rowptr.data_ptr(),
             _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), eid_t.data_ptr(), _lib.ptr(geid_t),
             gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
             N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, int(learn_t), t, p,
-            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), ge_accumulate, _stream())
+            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), ge_accumulate, hub, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
+        del hub_keep
         if sink is not None or te is not None:
             ge = None                                        # reported once, by the fan-out node of the shared term
         if timer is not None:
@@ -522,10 +528,11 @@ class _WeightedAggregate(torch.autograd.Function):
         msg = MSG_WEIGHTED if ew_pair is not None else MSG_IDENTITY
         aggr_id = AGGR_MEAN if mean else AGGR_SUM
         ew = ew_pair[0] if ew_pair is not None else None
+        hub, hub_keep = graph.hub_arg("dst", d)
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), None, None, None, None,
             out.data_ptr(), None, None, None, None, N, d, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, 0, aggr_id, 1.0, 1.0, None, None,
-            0.0, 0, _stream())
+            0.0, 0, hub, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         ctx.graph, ctx.ew_pair, ctx.cfg = graph, ew_pair, (msg, aggr_id, N, d)
         return out
@@ -537,10 +544,11 @@ class _WeightedAggregate(torch.autograd.Function):
         go = _dev_act(go, "grad_out")
         gx = torch.empty_like(go)
         ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
+        hub, hub_keep = g.hub_arg("src", d)
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
             g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, None, gx.data_ptr(), None, None, None, 0,
-            N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, 0, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, 0, _stream())
+            N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, 0, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, 0, hub, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         return gx, None, None, None
 

@@ -25,9 +25,9 @@ def test_header_and_binding_agree():
 def test_version_and_error_codes():
     from mlgnn import _lib
     lib = _lib.lib
-    assert lib.mlgnn_version() == 10
-    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 1, 0, 0) == 8 * 2 * 128      # 8 workgroups minimum
-    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 8, 0, 0) == 8 * 9 * 128
+    assert lib.mlgnn_version() == 11
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 1, 0, 0) == (8 + 256) * 2 * 128      # 8 workgroups minimum + the long-row launch
+    assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 8, 0, 0) == (8 + 256) * 9 * 128
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 9, 0, 0) == -2
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(-1, 4, 0, 1, 0, 0) == -2
     # softmax: + flag (4) + rescaled cotangent (10*128 fp32 / bf16)
@@ -36,13 +36,13 @@ def test_version_and_error_codes():
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 0, 3, 1) == 0
     null = [None] * 13
     # N = 0 is a no-op, bad dtype / mode / NULL pointers are reported, nothing is launched
-    assert lib.mlgnn_csr_aggregate_fwd(*null, 0, 8, 0, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None) == 0
-    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 7, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None) == -4
-    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 0, 9, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None) == -3
-    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 0, 1, 0, 0, 2, 1.0, 1.0, None, None, 1e-7, 0, None) == -3   # weighted+max
-    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 0, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None) == -1
-    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 0, 2, 1, 3, 3, 1.0, 1.0, None, None, 1e-7, 0, None) == -3   # edge rank 3
-    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 0, 0, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None) == -2
+    assert lib.mlgnn_csr_aggregate_fwd(*null, 0, 8, 0, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None, None) == 0
+    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 7, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None, None) == -4
+    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 0, 9, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None, None) == -3
+    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 0, 1, 0, 0, 2, 1.0, 1.0, None, None, 1e-7, 0, None, None) == -3   # weighted+max
+    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 0, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None, None) == -1
+    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 8, 0, 2, 1, 3, 3, 1.0, 1.0, None, None, 1e-7, 0, None, None) == -3   # edge rank 3
+    assert lib.mlgnn_csr_aggregate_fwd(*null, 4, 0, 0, 2, 0, 0, 3, 1.0, 1.0, None, None, 1e-7, 0, None, None) == -2
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -1,0 +1,142 @@
+"""Long rows (hub nodes) of the aggregation kernels (csrc/hub.hip): rows past ``HUB_CAP`` edges are cut into chunks
+that run as rows of their own and are combined in chunk order.  Power-law graph with in- and out-degrees past 20 000
+(a transcription factor's cross-omics edges, dataloader/multiloader.py:664-671) against the CPU oracle, every
+aggregator, forward and backward; the split must also reproduce the unsplit kernels' numbers."""
+import pytest
+import torch
+
+from _util import assert_close
+from oracle import gcn_lib as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def _power_law_graph(gen, N=30000, E=400000):
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = torch.randint(0, N - 3, (E,), generator=gen)
+    dst[:25000] = 0                       # in-degree 25 000 (97 chunks of 256)
+    src[25000:47000] = 1                  # out-degree 22 000
+    dst[47000:52000] = 2                  # medium hubs: 5 000 in, 3 000 out, and one row of exactly cap + 1
+    src[52000:55000] = 3
+    dst[55000:55257] = 4                  # exactly cap + 1
+    src[56025:58000] = 0                  # the in-hub is also a source hub
+    return torch.stack([src, dst])
+
+
+def _case(aggr, edge_kind, d, learn=False, dtype=torch.float32, seed=0):
+    from mlgnn import CSRGraph, RankOneEdge, gen_aggregate
+    gen = torch.Generator().manual_seed(seed)
+    ei = _power_law_graph(gen)
+    N, E = 30000, ei.shape[1]
+    rnd = (lambda t: t.to(dtype).float())
+    x = rnd(torch.randn(N, d, generator=gen))
+    a = torch.rand(E, generator=gen)
+    u, v = torch.randn(d, generator=gen) * 0.5, torch.randn(d, generator=gen) * 0.2
+    cot = rnd(torch.randn(N, d, generator=gen))
+    # the oracle runs in fp64 here: a sequential fp32 sum over a 25 000-edge row carries more rounding error than the
+    # tolerance (the kernels sum such a row in 4 x 2 lane groups x 25 chunks, i.e. with far shorter chains)
+    leaves = {"x": x.double().requires_grad_(True)}
+    e = 0
+    if edge_kind == "rank1":
+        leaves["u"], leaves["v"] = u.double().requires_grad_(True), v.double().requires_grad_(True)
+        e = a.double()[:, None] * leaves["u"] + leaves["v"]
+    t = torch.tensor([0.8]) if learn else 0.8
+    if learn:
+        leaves["t"] = t.double().requires_grad_(True)
+    cot = cot.double()
+    z = leaves["x"][ei[0]] + e
+    msg = torch.relu(z) + 1e-7
+    # a pre-activation within fp32 rounding of the relu kink may land on either side of it (fma vs add ordering):
+    # such (source, channel) entries are left out of the gradient comparison (a handful in millions)
+    kink = torch.zeros(N, d, dtype=torch.bool).index_put_((ei[0],), z.detach().abs() < 1e-6, accumulate=True)
+    ref = G.gen_aggregate(msg, ei[1], N, aggr, t=leaves.get("t", t), learn_t=learn, p=2.0)
+    names = list(leaves)
+    ref_g = dict(zip(names, torch.autograd.grad((ref * cot).sum(), [leaves[k] for k in names])))
+
+    gl = {k: val.detach().to(DEV).to(dtype if k == "x" else torch.float32).requires_grad_(True) for k, val in leaves.items()}
+    graph = CSRGraph(ei.to(DEV), N)
+    counts = graph.hub_tables("dst")[2].cpu().tolist()
+    assert counts[0] >= 97 + 19 + 1 and counts[1] >= 3, counts          # the planted rows really are split
+    edge = RankOneEdge(a.to(DEV), gl["u"], gl["v"]) if edge_kind == "rank1" else None
+    out = gen_aggregate(gl["x"], graph, edge, aggr=aggr, t=gl.get("t", 0.8), p=2.0, learn_t=learn)
+    tol = TOL if dtype == torch.float32 else 2.0 ** -7
+    assert_close(out.float(), ref, tol, "%s/%s fwd with split rows" % (aggr, edge_kind), elementwise=True)
+    got = torch.autograd.grad((out.float() * cot.float().to(DEV)).sum(), [gl[k] for k in names])
+    assert int(kink.sum()) < 1000
+    for k, g in zip(names, got):
+        g, r = g.float().cpu(), ref_g[k]
+        if k == "x":
+            g, r = g.masked_fill(kink, 0.0), r.masked_fill(kink, 0.0)
+        assert_close(g, r, tol, "%s/%s grad %s with split rows" % (aggr, edge_kind, k), elementwise=(k == "x"))
+    return out
+
+
+@pytest.mark.parametrize("aggr", ["softmax", "max", "mean", "add", "power", "softmax_sg"])
+@pytest.mark.parametrize("edge_kind", ["rank1", "none"])
+def test_split_rows_match_oracle(aggr, edge_kind):
+    _case(aggr, edge_kind, 64)
+
+
+def test_split_rows_learnable_temperature_and_wide_rows():
+    _case("softmax", "rank1", 128, learn=True, seed=1)
+    _case("max", "rank1", 320, seed=2)                      # more than one channel chunk per row
+
+
+def test_split_rows_bf16():
+    _case("softmax", "rank1", 128, dtype=torch.bfloat16, seed=3)
+    _case("mean", "none", 64, dtype=torch.bfloat16, seed=4)
+
+
+def test_split_equals_unsplit_and_root_term_and_sage():
+    """Same graph with the split switched off: same numbers (fp32 summation order aside), incl. GENConv's fused root
+    add, the row maxima that ride along, and the SAGE weighted mean."""
+    from mlgnn import CSRGraph, RankOneEdge, gen_aggregate, graph as graph_mod, weighted_mean_aggregate
+    from mlgnn.ops import row_max_of
+    gen = torch.Generator().manual_seed(9)
+    ei = _power_law_graph(gen).to(DEV)
+    N, d = 30000, 128
+    x = torch.randn(N, d, generator=gen).to(DEV)
+    a = torch.rand(ei.shape[1], generator=gen).to(DEV)
+    u, v = (torch.randn(d, generator=gen) * 0.5).to(DEV), (torch.randn(d, generator=gen) * 0.2).to(DEV)
+    cot = torch.randn(N, d, generator=gen).to(DEV)
+    res = {}
+    for cap in (256, 0):
+        graph_mod.HUB_CAP = cap
+        try:
+            g = CSRGraph(ei, N)
+            xr = x.clone().requires_grad_(True)
+            h = gen_aggregate(xr, g, RankOneEdge(a, u, v), aggr="softmax", add_root=True)
+            rm = row_max_of(h)
+            gh, = torch.autograd.grad((h * cot).sum(), [xr])
+            xs = x.clone().requires_grad_(True)
+            s = weighted_mean_aggregate(xs, g, a)
+            gs, = torch.autograd.grad((s * cot).sum(), [xs])
+            res[cap] = (h, rm, gh, s, gs)
+        finally:
+            graph_mod.HUB_CAP = 256
+    for got, want, name in zip(res[256], res[0], ("h = x + m", "row max", "grad x", "sage mean", "sage grad")):
+        if got is None or want is None:
+            assert got is None and want is None
+            continue
+        # different fp32 summation order over up to 25 000 terms (the unsplit row is the longer chain)
+        assert_close(got, want, 1e-4, name, elementwise=True)
+    assert torch.equal(res[256][1], res[256][0].abs().amax(1))          # the hub rows' maxima were recomputed
+
+
+def test_graph_without_long_rows_is_untouched():
+    from mlgnn import CSRGraph, gen_aggregate, graph as graph_mod
+    gen = torch.Generator().manual_seed(5)
+    N, E, d = 4000, 30000, 64
+    ei = torch.randint(0, N, (2, E), generator=gen).to(DEV)
+    x = torch.randn(N, d, generator=gen).to(DEV)
+    g = CSRGraph(ei, N)
+    assert g.hub_tables("dst")[2].cpu().tolist() == [0, 0] and g.hub_tables("src")[2].cpu().tolist() == [0, 0]
+    out = gen_aggregate(x, g, None, aggr="softmax")
+    graph_mod.HUB_CAP = 0
+    try:
+        ref = gen_aggregate(x, CSRGraph(ei, N), None, aggr="softmax")
+    finally:
+        graph_mod.HUB_CAP = 256
+    assert torch.equal(out, ref)

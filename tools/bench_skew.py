@@ -35,8 +35,12 @@ def graph(B, n, e, hubs, hub_deg, dev, hub_is_source=True):
 
 
 def main():
+    import json
+    from mlgnn import graph as graph_mod
     dev = torch.device("cuda:0")
     B, n, e, d = 32, 15405, 60000, 64
+    rows = []
+    print("HUB_CAP =", graph_mod.HUB_CAP)
     for name, hubs, deg, as_src in [("ER", 0, 0, True), ("20 hubs x 1500 out-edges", 20, 1500, True),
                                     ("20 hubs x 1500 in-edges", 20, 1500, False), ("2 hubs x 15000 out", 2, 15000, True)]:
         ei = graph(B, n, e, hubs, deg, dev, as_src)
@@ -53,6 +57,13 @@ def main():
         o2 = gen_aggregate(x, g, RankOneEdge(w, u, v), aggr="softmax")
         tsb = timed(lambda: torch.autograd.grad(o2, [x], go, retain_graph=True))
         print("%-28s SAGE mean fwd %.3f ms bwd %.3f ms | GEN softmax fwd %.3f ms bwd %.3f ms" % (name, tf, tb, tsf, tsb))
+        rows.append({"graph": name, "sage_mean_fwd_ms": tf, "sage_mean_bwd_ms": tb, "gen_softmax_fwd_ms": tsf,
+                     "gen_softmax_bwd_ms": tsb})
+    er = rows[0]
+    for r in rows:
+        r["vs_ER"] = {k: round(r[k] / er[k], 2) for k in er if k.endswith("_ms")}
+    print(json.dumps({"hub_cap": graph_mod.HUB_CAP, "config": "%d graphs x %d nodes x %d edges, d=%d, fp32" % (B, n, e, d),
+                      "rows": rows}))
 
 
 if __name__ == "__main__":

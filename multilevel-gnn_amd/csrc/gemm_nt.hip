@@ -31,7 +31,11 @@
 //     tiles, ordered in groups of 4 tile rows so that the range is a compact block of the output.
 // Measured (MI355X, random data): 4096 x 1024 x 4096 in 39 us = 880 TFLOP/s (35 % of the 2.5 PFLOP/s dense bf16 peak;
 // SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) = 0.35); the MFMA stream alone (no LDS traffic) runs
-// at 1.58 PFLOP/s in this kernel, with its fragment reads at 1.13.
+// at 1.58 PFLOP/s in this kernel, with its fragment reads at 1.13.  Also measured and not kept: loader waves that
+// stage through registers (global_load_dwordx4 two K-steps ahead, ds_write_b128 one K-step later -- plain loads take in
+// more per CU than LDS-DMA): 46 us, the LDS write traffic next to the fragment reads costs more than the loads gain;
+// all eight waves doing both DMA and MFMA (48 us), a second pair of MFMA waves splitting K with an LDS reduce (42 us),
+// a fifth stage / three K-steps in flight (same), s_setprio around the MFMAs (same).
 #include "gemm_nt.h"
 #include "mlgnn.h"
 

@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--members", type=int, default=25000)
     ap.add_argument("--aggr", default="softmax")
-    ap.add_argument("--pool-batches", type=int, default=2, help="distinct pre-generated batches cycled")
+    ap.add_argument("--pool-batches", type=int, default=4, help="distinct pre-generated batches cycled")
     ap.add_argument("--cpu-baseline-graphs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="build each batch's CSR in line instead of one batch ahead on a second stream")

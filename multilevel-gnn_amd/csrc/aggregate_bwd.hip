@@ -489,6 +489,10 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                   (!out || aligned16(out)) && (!aux || aligned16(aux)) && (!argmax || aligned16(argmax)) &&
                   (!efull || aligned16(efull)) && (!grad_efull || aligned16(grad_efull)) &&
                   (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  {
+    const uintptr_t need = rk >= 4 ? 16 : 4 * (uintptr_t)(rk > 0 ? rk : 1);     // vector loads of the edge scalar table
+    if (ew_t && (reinterpret_cast<uintptr_t>(ew_t) % need) != 0) return MLGNN_E_ALIGN;
+  }
   const int vec = bf16 ? ((d % 8 == 0 && al) ? 8 : 1) : ((d % 4 == 0 && al) ? 4 : 1);
   const dim3 block(kBlock);
   int launched_blocks = nblk;

@@ -379,6 +379,12 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   const bool al = aligned16(x) && aligned16(out) && (!efull || aligned16(efull)) &&
                   (!aux || aligned16(aux)) && (!aux2 || aligned16(aux2)) && (!argmax || aligned16(argmax)) &&
                   (!eu || aligned16(eu)) && (!ev || aligned16(ev));
+  // the per-edge scalar table is read with 4 * rank byte loads (rank 2: float2, 4 / 8: float4) on every path
+  {
+    const int es = mode == M_WEIGHTED ? 1 : rank_of_mode(mode);
+    const uintptr_t need = es >= 4 ? 16 : 4 * (uintptr_t)(es > 0 ? es : 1);
+    if (ew && (reinterpret_cast<uintptr_t>(ew) % need) != 0) return MLGNN_E_ALIGN;
+  }
   const bool bf16 = dtype == MLGNN_DTYPE_BF16;
   // channels per lane: 16-byte accesses (4 x fp32 / 8 x bf16) when the width allows, scalar otherwise
   const int vec = bf16 ? ((d % 8 == 0 && al) ? 8 : 1) : ((d % 4 == 0 && al) ? 4 : 1);

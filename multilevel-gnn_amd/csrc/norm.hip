@@ -283,6 +283,7 @@ extern "C" int mlgnn_layernorm_act_fwd(const void* x, const float* gamma, const 
   a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.mean = mean; a.rstd = rstd;
   a.rowmax = row_max; a.keep = keep_mask; a.keep_scale = keep_scale;
   if (keep_mask && d % ln_vec(dtype, d) != 0) return MLGNN_E_SHAPE;
+  if (keep_mask && (reinterpret_cast<uintptr_t>(keep_mask) % 8) != 0) return MLGNN_E_ALIGN;    // read 4 / 8 flags at a time
   a.rows = (int)rows; a.d = (int)d; a.eps = eps; a.relu = relu;
   const int lpr = lanes_per_row_log2(d, ln_vec(dtype, d));
   const dim3 grid(ln_grid(rows, lpr)), block(kBlock);
@@ -310,6 +311,7 @@ extern "C" int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, cons
   if (workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
   if (rows > 0 && (!grad_out || !x || !gamma || !beta || !rstd || !grad_x)) return MLGNN_E_NULL;
   if (!a16(x) || !a16(grad_out) || !a16(grad_x) || !a16(gamma) || !a16(beta) || !a16(grad_extra)) return MLGNN_E_ALIGN;
+  if (keep_mask && (reinterpret_cast<uintptr_t>(keep_mask) % 8) != 0) return MLGNN_E_ALIGN;
   LnArgs a{};
   a.x = x; a.go = grad_out; a.gamma = gamma; a.beta = beta;
   a.gextra = grad_extra; a.keep = keep_mask; a.keep_scale = keep_scale;

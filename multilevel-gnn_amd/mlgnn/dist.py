@@ -47,7 +47,12 @@ class FlatGradBucket:
                 src.append(p.grad)
                 dst.append(v)
         if src:
-            torch._foreach_copy_(dst, src)
+            multi_copy = getattr(torch, "_foreach_copy_", None)      # one multi-tensor launch where torch has the op
+            if multi_copy is not None:
+                multi_copy(dst, src)
+            else:
+                for d, s in zip(dst, src):
+                    d.copy_(s)
         for p, v in zip(self.params, self.views):
             p.grad = v
         # (torch.optim optimizers then see a zero gradient for an unreached parameter where the reference's

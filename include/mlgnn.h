@@ -320,8 +320,9 @@ int mlgnn_edge_table_to_csr(const float* attr, int64_t row_stride, int64_t r, in
 /*
  * MsgNorm fused with GENConv's root add:  h = x + normalize(m, p=2, dim=1) * ||x||_2 * scale[0]
  * Replaces: MsgNorm.forward (models/gcn_lib/sparse/torch_message.py:175-179) + h = x + m
- * (models/gcn_lib/sparse/torch_vertex.py:86-89).  x, m, h [rows, d] fp32, d <= 256, d % 4 == 0;
- * scale: device pointer to the (learnable) scalar.  Backward returns grad_x, grad_m and
+ * (models/gcn_lib/sparse/torch_vertex.py:86-89).  x, m, h [rows, d]: MLGNN_DTYPE_F32 with d <= 256, d % 4 == 0, or
+ * MLGNN_DTYPE_BF16 storage (fp32 arithmetic) with d <= 512, d % 8 == 0; scale: device pointer to the (learnable)
+ * fp32 scalar.  Backward returns grad_x, grad_m and
  * grad_scale[1]; workspace: mlgnn_msgnorm_bwd_workspace_floats(rows, d) floats.
  */
 int64_t mlgnn_msgnorm_bwd_workspace_floats(int64_t rows, int64_t d);

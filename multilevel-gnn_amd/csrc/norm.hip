@@ -342,17 +342,20 @@ namespace mlgnn {
 
 constexpr float kNormEps = 1e-12f;
 
-struct MnArgs {
-  const float* x; const float* m; const float* gh; const float* scale;
-  float* h; float* gx; float* gm; float* ws;
+struct MnArgs {            // x / m / gh / h / gx / gm are T (fp32 or bf16); scale, ws fp32
+  const void* x; const void* m; const void* gh; const float* scale;
+  void* h; void* gx; void* gm; float* ws;
   int rows; int d;
 };
 
-template <int LPR_LOG2>
+template <typename T, int VEC, int LPR_LOG2>
 __global__ __launch_bounds__(kBlock) void msgnorm_add_fwd_kernel(const MnArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, GROUPS = kWave / LPR;
+  const T* X = static_cast<const T*>(a.x);
+  const T* M = static_cast<const T*>(a.m);
+  T* H = static_cast<T*>(a.h);
   const int lane = threadIdx.x & (kWave - 1);
-  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * 4;
+  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * VEC;
   const bool cact = c0 < a.d;
   const int wave_global = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
   const int n_waves = gridDim.x * kWavesPerBlock;
@@ -360,31 +363,38 @@ __global__ __launch_bounds__(kBlock) void msgnorm_add_fwd_kernel(const MnArgs a)
   for (int r0 = wave_global * GROUPS; r0 < a.rows; r0 += n_waves * GROUPS) {
     const int r = r0 + sub;
     const bool ok = (r < a.rows) && cact;
-    float xv[4] = {0, 0, 0, 0}, mv[4] = {0, 0, 0, 0};
-    if (ok) { load_vec<4>(xv, a.x + (size_t)r * a.d + c0); load_vec<4>(mv, a.m + (size_t)r * a.d + c0); }
+    float xv[VEC], mv[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { xv[i] = 0.f; mv[i] = 0.f; }
+    if (ok) { load_t<T, VEC>(xv, X + (size_t)r * a.d + c0); load_t<T, VEC>(mv, M + (size_t)r * a.d + c0); }
     float qx = 0.f, qm = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { qx = fmaf(xv[i], xv[i], qx); qm = fmaf(mv[i], mv[i], qm); }
+    for (int i = 0; i < VEC; ++i) { qx = fmaf(xv[i], xv[i], qx); qm = fmaf(mv[i], mv[i], qm); }
     const float nx = sqrtf(group_sum<LPR_LOG2>(qx));
     const float nm = fmaxf(sqrtf(group_sum<LPR_LOG2>(qm)), kNormEps);
     const float c = s * nx / nm;
     if (ok) {
-      float o[4];
+      float o[VEC];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = fmaf(mv[i], c, xv[i]);
-      store_vec<4>(a.h + (size_t)r * a.d + c0, o);
+      for (int i = 0; i < VEC; ++i) o[i] = fmaf(mv[i], c, xv[i]);
+      store_t<T, VEC>(H + (size_t)r * a.d + c0, o);
     }
   }
 }
 
 // gm = c*g - (c/nm^2)(g.m) m ;  gx = g + (g.m) s/(nm nx) x ;  gs = sum_rows (g.m) nx/nm   (g = grad of h)
-template <int LPR_LOG2>
+template <typename T, int VEC, int LPR_LOG2>
 __global__ __launch_bounds__(kBlock) void msgnorm_add_bwd_kernel(const MnArgs a) {
   constexpr int LPR = 1 << LPR_LOG2, GROUPS = kWave / LPR;
   __shared__ float red[kWavesPerBlock];
+  const T* X = static_cast<const T*>(a.x);
+  const T* M = static_cast<const T*>(a.m);
+  const T* GH = static_cast<const T*>(a.gh);
+  T* GX = static_cast<T*>(a.gx);
+  T* GM = static_cast<T*>(a.gm);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * 4;
+  const int sub = lane / LPR, cl = lane % LPR, c0 = cl * VEC;
   const bool cact = c0 < a.d;
   const int wave_global = blockIdx.x * kWavesPerBlock + wave;
   const int n_waves = gridDim.x * kWavesPerBlock;
@@ -393,15 +403,17 @@ __global__ __launch_bounds__(kBlock) void msgnorm_add_bwd_kernel(const MnArgs a)
   for (int r0 = wave_global * GROUPS; r0 < a.rows; r0 += n_waves * GROUPS) {
     const int r = r0 + sub;
     const bool ok = (r < a.rows) && cact;
-    float xv[4] = {0, 0, 0, 0}, mv[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+    float xv[VEC], mv[VEC], g[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { xv[i] = 0.f; mv[i] = 0.f; g[i] = 0.f; }
     if (ok) {
-      load_vec<4>(xv, a.x + (size_t)r * a.d + c0);
-      load_vec<4>(mv, a.m + (size_t)r * a.d + c0);
-      load_vec<4>(g, a.gh + (size_t)r * a.d + c0);
+      load_t<T, VEC>(xv, X + (size_t)r * a.d + c0);
+      load_t<T, VEC>(mv, M + (size_t)r * a.d + c0);
+      load_t<T, VEC>(g, GH + (size_t)r * a.d + c0);
     }
     float qx = 0.f, qm = 0.f, gd = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { qx = fmaf(xv[i], xv[i], qx); qm = fmaf(mv[i], mv[i], qm); gd = fmaf(g[i], mv[i], gd); }
+    for (int i = 0; i < VEC; ++i) { qx = fmaf(xv[i], xv[i], qx); qm = fmaf(mv[i], mv[i], qm); gd = fmaf(g[i], mv[i], gd); }
     const float nx = sqrtf(group_sum<LPR_LOG2>(qx));
     const float nm_raw = sqrtf(group_sum<LPR_LOG2>(qm));
     const float nm = fmaxf(nm_raw, kNormEps);
@@ -410,11 +422,11 @@ __global__ __launch_bounds__(kBlock) void msgnorm_add_bwd_kernel(const MnArgs a)
     const float km = (nm_raw > kNormEps) ? c / (nm * nm) * gd : 0.f;       // clamp branch: norm is constant
     const float kx = (nx > 0.f) ? gd * s / (nm * nx) : 0.f;               // torch: d||x||/dx = 0 at x = 0
     if (ok) {
-      float om[4], ox[4];
+      float om[VEC], ox[VEC];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { om[i] = fmaf(g[i], c, -km * mv[i]); ox[i] = fmaf(kx, xv[i], g[i]); }
-      store_vec<4>(a.gm + (size_t)r * a.d + c0, om);
-      store_vec<4>(a.gx + (size_t)r * a.d + c0, ox);
+      for (int i = 0; i < VEC; ++i) { om[i] = fmaf(g[i], c, -km * mv[i]); ox[i] = fmaf(kx, xv[i], g[i]); }
+      store_t<T, VEC>(GM + (size_t)r * a.d + c0, om);
+      store_t<T, VEC>(GX + (size_t)r * a.d + c0, ox);
     }
     if (cl == 0 && r < a.rows) gs += gd * nx / nm;
   }
@@ -430,25 +442,38 @@ __global__ __launch_bounds__(kBlock) void msgnorm_add_bwd_kernel(const MnArgs a)
   }
 }
 
+// one row per wave at most: fp32 d <= 256 (4 channels per lane), bf16 d <= 512 (8 channels per lane)
+static bool mn_ok(int64_t d, int dtype) {
+  if (dtype == MLGNN_DTYPE_F32) return d > 0 && d <= 256 && d % 4 == 0;
+  if (dtype == MLGNN_DTYPE_BF16) return d > 0 && d <= 512 && d % 8 == 0;
+  return false;
+}
+
 }  // namespace mlgnn
 
 extern "C" int64_t mlgnn_msgnorm_bwd_workspace_floats(int64_t rows, int64_t d) {
-  if (rows < 0 || !mlgnn::ln_ok(d)) return MLGNN_E_SHAPE;
-  return mlgnn::ln_grid(rows, mlgnn::lanes_per_row_log2(d, 4));
+  if (rows < 0 || d <= 0 || d > 512 || d % 4 != 0) return MLGNN_E_SHAPE;
+  return mlgnn::ln_grid(rows, mlgnn::lanes_per_row_log2(d, 4));          // the fp32 layout's grid: the larger of the two
 }
 
 extern "C" int mlgnn_msgnorm_add_fwd(const void* x, const void* m, const float* scale, void* h,
                                      int64_t rows, int64_t d, int dtype, void* stream) {
   using namespace mlgnn;
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
-  if (rows < 0 || rows > INT32_MAX || !ln_ok(d)) return MLGNN_E_SHAPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
+  if (rows < 0 || rows > INT32_MAX || !mn_ok(d, dtype)) return MLGNN_E_SHAPE;
   if (rows == 0) return 0;
   if (!x || !m || !scale || !h) return MLGNN_E_NULL;
   if (!a16(x) || !a16(m) || !a16(h)) return MLGNN_E_ALIGN;
   MnArgs a{};
-  a.x = (const float*)x; a.m = (const float*)m; a.scale = scale; a.h = (float*)h; a.rows = (int)rows; a.d = (int)d;
-  const int lpr = lanes_per_row_log2(d, 4);
-  MLGNN_LN_LAUNCH(msgnorm_add_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), dim3(kBlock), 0, (hipStream_t)stream, a)
+  a.x = x; a.m = m; a.scale = scale; a.h = h; a.rows = (int)rows; a.d = (int)d;
+  const int vec = dtype == MLGNN_DTYPE_BF16 ? 8 : 4;
+  const int lpr = lanes_per_row_log2(d, vec);
+  const dim3 grid(ln_grid(rows, lpr)), block(kBlock);
+  if (dtype == MLGNN_DTYPE_BF16) {
+    MLGNN_LNT_LAUNCH(msgnorm_add_fwd_kernel, bf16_t, 8, lpr, grid, block, 0, (hipStream_t)stream, a)
+  } else {
+    MLGNN_LNT_LAUNCH(msgnorm_add_fwd_kernel, float, 4, lpr, grid, block, 0, (hipStream_t)stream, a)
+  }
   return (int)hipGetLastError();
 }
 
@@ -456,19 +481,24 @@ extern "C" int mlgnn_msgnorm_add_bwd(const void* grad_h, const void* x, const vo
                                      void* grad_x, void* grad_m, float* grad_scale, float* workspace,
                                      int64_t workspace_floats, int64_t rows, int64_t d, int dtype, void* stream) {
   using namespace mlgnn;
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
-  if (rows < 0 || rows > INT32_MAX || !ln_ok(d)) return MLGNN_E_SHAPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
+  if (rows < 0 || rows > INT32_MAX || !mn_ok(d, dtype)) return MLGNN_E_SHAPE;
   if (!grad_scale || !workspace || !scale) return MLGNN_E_NULL;
-  const int lpr = lanes_per_row_log2(d, 4);
+  const int vec = dtype == MLGNN_DTYPE_BF16 ? 8 : 4;
+  const int lpr = lanes_per_row_log2(d, vec);
   const int nblk = ln_grid(rows, lpr);
   if (workspace_floats < nblk) return MLGNN_E_WORKSPACE;
   if (rows > 0 && (!grad_h || !x || !m || !grad_x || !grad_m)) return MLGNN_E_NULL;
   if (!a16(x) || !a16(m) || !a16(grad_h) || !a16(grad_x) || !a16(grad_m)) return MLGNN_E_ALIGN;
   MnArgs a{};
-  a.x = (const float*)x; a.m = (const float*)m; a.gh = (const float*)grad_h; a.scale = scale;
-  a.gx = (float*)grad_x; a.gm = (float*)grad_m; a.ws = workspace; a.rows = (int)rows; a.d = (int)d;
+  a.x = x; a.m = m; a.gh = grad_h; a.scale = scale;
+  a.gx = grad_x; a.gm = grad_m; a.ws = workspace; a.rows = (int)rows; a.d = (int)d;
   hipStream_t s = (hipStream_t)stream;
-  MLGNN_LN_LAUNCH(msgnorm_add_bwd_kernel, lpr, dim3(nblk), dim3(kBlock), 0, s, a)
+  if (dtype == MLGNN_DTYPE_BF16) {
+    MLGNN_LNT_LAUNCH(msgnorm_add_bwd_kernel, bf16_t, 8, lpr, dim3(nblk), dim3(kBlock), 0, s, a)
+  } else {
+    MLGNN_LNT_LAUNCH(msgnorm_add_bwd_kernel, float, 4, lpr, dim3(nblk), dim3(kBlock), 0, s, a)
+  }
   int err = (int)hipGetLastError();
   if (err) return err;
   launch_reduce_partials(workspace, grad_scale, nblk, 1, s);

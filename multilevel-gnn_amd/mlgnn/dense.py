@@ -236,6 +236,11 @@ def dense_sage(x, adj, w_rel, w_root, b_root, normalize=True):
     x = x.unsqueeze(0) if x.dim() == 2 else x
     adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
     B, n, c = x.shape
+    if (x.is_cuda and x.dtype == torch.bfloat16 and adj.shape[0] in (1, B) and adj.shape[-1] == n and adj.shape[-2] == n
+            and _lib.lib.mlgnn_dense_sage_supported(n, c, w_rel.shape[0], int(adj.requires_grad))):
+        # bf16 model, small pooled graph: the fused fp32-MFMA kernel behind casts (tensors of a few hundred KB)
+        return dense_sage(x.float(), adj.float(), w_rel.float(), w_root.float(),
+                          None if b_root is None else b_root.float(), normalize).to(torch.bfloat16)
     if (x.is_cuda and x.dtype == torch.float32 and adj.dtype == torch.float32 and adj.shape[0] in (1, B)
             and adj.shape[-1] == n and adj.shape[-2] == n
             and _lib.lib.mlgnn_dense_sage_supported(n, c, w_rel.shape[0], int(adj.requires_grad))):
@@ -398,6 +403,10 @@ def dense_diff_pool(z, adj, s, adj_symmetric=False):
     if (z.is_cuda and z.dtype == torch.float32 and adj.shape[0] in (1, B)
             and _lib.lib.mlgnn_diffpool_fwd_supported(N, K, C)):
         return _DiffPoolFused.apply(z, adj, s)
+    if (z.is_cuda and z.dtype == torch.bfloat16 and adj.shape[0] in (1, B)
+            and _lib.lib.mlgnn_diffpool_fwd_supported(N, K, C)):
+        # bf16 model, small pooled graph: the fused fp32-MFMA kernel behind casts
+        return tuple(t.to(torch.bfloat16) for t in _DiffPoolFused.apply(z.float(), adj.float(), s.float()))
     if adj.shape[0] in (1, B) and diff_pool_large_supported(z, adj, s):
         return _diff_pool_large(z, adj, s, adj_symmetric)
     return _diff_pool_library(z, adj, s)

@@ -8,6 +8,10 @@ from . import _lib
 from .ops import _DTYPE_IDS, DTYPE_F32, _stream, tag_row_max
 
 
+def _dtype_id(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
 def fused_supported(x):
     """fp32: d <= 256 with d % 4 == 0, or d <= 512 with d % 8 == 0; bf16 storage (fp32 arithmetic): d <= 512, d % 8 == 0."""
     if not (x.is_cuda and x.dim() == 2):
@@ -156,10 +160,12 @@ class _MsgNormAdd(torch.autograd.Function):
         x, m = x.contiguous(), m.contiguous()
         rows, d = x.shape
         h = torch.empty_like(x)
-        rc = _lib.lib.mlgnn_msgnorm_add_fwd(x.data_ptr(), m.data_ptr(), scale.data_ptr(), h.data_ptr(), rows, d,
-                                            DTYPE_F32, _stream())
+        scale32 = scale if scale.dtype == torch.float32 else scale.float()       # the learnable scalar stays fp32
+        rc = _lib.lib.mlgnn_msgnorm_add_fwd(x.data_ptr(), m.data_ptr(), scale32.data_ptr(), h.data_ptr(), rows, d,
+                                            _dtype_id(x), _stream())
         _lib.check(rc, "mlgnn_msgnorm_add_fwd")
-        ctx.save_for_backward(x, m, scale)
+        ctx.save_for_backward(x, m, scale32)
+        ctx.scale_dtype = scale.dtype
         return h
 
     @staticmethod
@@ -173,14 +179,16 @@ class _MsgNormAdd(torch.autograd.Function):
         ws = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
         rc = _lib.lib.mlgnn_msgnorm_add_bwd(gh.data_ptr(), x.data_ptr(), m.data_ptr(), scale.data_ptr(),
                                             gx.data_ptr(), gm.data_ptr(), gs.data_ptr(), ws.data_ptr(), n, rows, d,
-                                            DTYPE_F32, _stream())
+                                            _dtype_id(x), _stream())
         _lib.check(rc, "mlgnn_msgnorm_add_bwd")
-        return gx, gm, (gs if ctx.needs_input_grad[2] else None)
+        return gx, gm, (gs.to(ctx.scale_dtype) if ctx.needs_input_grad[2] else None)
 
 
 def msg_norm_add(x, m, scale):
     """``x + normalize(m, dim=1) * ||x|| * scale`` (MsgNorm + GENConv root add, torch_message.py:175-179,
     torch_vertex.py:86-89) in one HIP pass each way; ATen ops for widths the kernel does not cover."""
-    if fused_supported(x) and x.dtype == torch.float32 and m.shape == x.shape:
+    if (m.shape == x.shape and m.dtype == x.dtype and x.is_cuda and x.dim() == 2
+            and ((x.dtype == torch.float32 and 0 < x.shape[1] <= 256 and x.shape[1] % 4 == 0)
+                 or (x.dtype == torch.bfloat16 and 0 < x.shape[1] <= 512 and x.shape[1] % 8 == 0))):
         return _MsgNormAdd.apply(x, m, scale)
     return x + F.normalize(m, p=2.0, dim=1) * x.norm(p=2, dim=1, keepdim=True) * scale

@@ -107,6 +107,11 @@ def segment_project(x_nodes, gene_pca_match, raw_indice, weights, nodes_per_grap
     B = gene_pca_match.shape[0]
     tables = membership_tables(gene_pca_match, raw_indice, nodes_per_graph, n_segments, x_nodes.shape[0],
                                match_mask)
-    out_t = _SegmentProject.apply(x_nodes, weights, tables)          # [B*S, k, C]
+    if x_nodes.dtype == torch.bfloat16:
+        # bf16 model: the gather-reduce kernels take fp32 rows (fp32 accumulation either way); the result goes back
+        # to the model's storage type
+        out_t = _SegmentProject.apply(x_nodes.float(), weights.float(), tables).to(torch.bfloat16)
+    else:
+        out_t = _SegmentProject.apply(x_nodes, weights, tables)      # [B*S, k, C]
     k, C = out_t.shape[1], out_t.shape[2]
     return out_t.reshape(B, n_segments, k, C).permute(0, 3, 1, 2)    # [B, C, S, k]

@@ -249,3 +249,61 @@ def test_bf16_wgrad_random_matches_fp64_and_is_deterministic():
     err = float((gw.cpu().double() - ref).abs().max()) / float(ref.abs().max())
     assert err < 1e-5, err                                                     # exact products, fp32 accumulation
     assert_close(gb.cpu(), go.double().sum(0), 1e-5, "bias gradient")
+
+
+@pytest.mark.parametrize("rows,d", [(1000, 128), (4097, 256), (33, 512), (70000, 64)])
+def test_bf16_msg_norm_add(rows, d):
+    """MsgNorm + root add (torch_message.py:175-179, torch_vertex.py:86-89) with bf16 storage on the HIP kernel: fp32
+    arithmetic inside, one rounding per output; reference = fp32 on the bf16-rounded inputs."""
+    import torch.nn.functional as F
+    from mlgnn.norm import msg_norm_add
+    from torch.profiler import ProfilerActivity, profile
+    gen = torch.Generator().manual_seed(rows + d)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    x = rb(torch.randn(rows, d, generator=gen)).requires_grad_(True)
+    m = rb(torch.rand(rows, d, generator=gen) * 3).requires_grad_(True)
+    with torch.no_grad():
+        m[0] = 0.0
+    s = torch.tensor([0.7], requires_grad=True)
+    cot = rb(torch.randn(rows, d, generator=gen))
+    ref = x + F.normalize(m, p=2.0, dim=1) * x.norm(p=2, dim=1, keepdim=True) * s
+    gr = torch.autograd.grad((ref * cot).sum(), [x, m, s])
+    dev = "cuda:0"
+    xd, md = (t.detach().to(dev).to(torch.bfloat16).requires_grad_(True) for t in (x, m))
+    sd = s.detach().to(dev).requires_grad_(True)
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        out = msg_norm_add(xd, md, sd)
+        got = torch.autograd.grad((out.float() * cot.to(dev)).sum(), [xd, md, sd])
+    assert "aten::linalg_vector_norm" not in {e.key for e in prof.key_averages()}      # the HIP kernel ran, not ATen
+    assert out.dtype == torch.bfloat16
+    assert_close(out.float(), ref, 2.0 ** -8, "bf16 msgnorm fwd", elementwise=True)
+    for name, g, r in zip(("x", "m", "scale"), got, gr):
+        assert_close(g.float(), r, 2.0 ** -7, "bf16 msgnorm grad " + name)
+
+
+def test_bf16_pooled_levels_run_on_the_native_kernels():
+    """A bf16 model's small pooled levels (DenseSAGE, DiffPool <= 160 nodes, projection pooling) go through the
+    hand-written fp32 kernels behind casts instead of ATen formulas; numbers = fp32 oracle on the rounded inputs."""
+    from mlgnn.dense import dense_diff_pool, dense_sage
+    from oracle import primitives as OP
+    gen = torch.Generator().manual_seed(3)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    B, n, C, O, K = 6, 146, 32, 32, 37
+    x = rb(torch.randn(B, n, C, generator=gen))
+    adj = rb(torch.rand(n, n, generator=gen))
+    wr, wo = rb(torch.randn(O, C, generator=gen) * 0.2), rb(torch.randn(O, C, generator=gen) * 0.2)
+    b = rb(torch.randn(O, generator=gen) * 0.1)
+    dev = "cuda:0"
+
+    y = dense_sage(x.to(dev).bfloat16(), adj.to(dev).bfloat16(), wr.to(dev).bfloat16(), wo.to(dev).bfloat16(), b.to(dev).bfloat16())
+    ref = OP.dense_sage_conv(x, adj, wr, wo, b, normalize=True)
+    assert y.dtype == torch.bfloat16
+    assert_close(y.float(), ref, 2.0 ** -7, "bf16 DenseSAGE")
+    s = rb(torch.randn(B, n, K, generator=gen))
+    z = rb(torch.randn(B, n, C, generator=gen))
+    ox, oa, ol, oe = dense_diff_pool(z.to(dev).bfloat16(), adj.to(dev).bfloat16(), s.to(dev).bfloat16())
+    rx, ra, rl, re = OP.dense_diff_pool(z, adj, s)
+    assert ox.dtype == torch.bfloat16 and oa.dtype == torch.bfloat16
+    assert_close(ox.float(), rx, 2.0 ** -7, "bf16 small DiffPool x")
+    assert_close(oa.float(), ra, 2.0 ** -7, "bf16 small DiffPool adj")
+    assert abs(float(ol) - float(rl)) <= 2.0 ** -7 * float(rl) and abs(float(oe) - float(re)) <= 2.0 ** -7 * abs(float(re))

@@ -193,6 +193,7 @@ def main():
         with torch.cuda.stream(side_stream):
             g = CSRGraph(batch.edge_index, batch.x.shape[0])
             tables = g.edge_table(batch.edge_attr[:, 0].reshape(-1, 1), 1)      # the key RankOneEdge will look up
+            g.hub_tables("dst"), g.hub_tables("src")                            # long-row tables (csrc/hub.hip)
             ev = torch.cuda.Event()
             ev.record(side_stream)
         ahead[i] = (g, tables, ev)
@@ -206,7 +207,8 @@ def main():
                 build_topology(i)
             g, tables, ev = ahead.pop(i)
             main_stream.wait_event(ev)
-            for t in (g.rowptr, g.col, g.eid, g.rowptr_t, g.col_t, g.pos_t, g.eid_t) + tuple(tables):
+            hub_tabs = tuple(t for d in ("dst", "src") for t in (g.hub_tables(d) or ())[:3])
+            for t in (g.rowptr, g.col, g.eid, g.rowptr_t, g.col_t, g.pos_t, g.eid_t) + tuple(tables) + hub_tabs:
                 t.record_stream(main_stream)
             batch.csr = g
             if not last:

@@ -56,7 +56,13 @@ class CSRGraph:
             rc = _lib.lib.mlgnn_hub_rows(rowptr.data_ptr(), self.num_nodes, HUB_CAP, cap_rows, vrows.data_ptr(),
                                          hubs.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "mlgnn_hub_rows")
-            hit = self._hub[direction] = (vrows, hubs, counts, cap_rows)
+            # the counts also travel to pinned host memory, asynchronously: once that copy is known to have finished
+            # (event.query(), never a wait) a graph without long rows skips the two empty launches per aggregation
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(counts, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            hit = self._hub[direction] = [vrows, hubs, counts, cap_rows, host, done, None]
         return hit
 
     def hub_arg(self, direction, d):
@@ -65,8 +71,12 @@ class CSRGraph:
         tabs = self.hub_tables(direction)
         if tabs is None:
             return None, ()
+        if tabs[6] is None and tabs[5].query():
+            tabs[6] = int(tabs[4][0]) > 0               # known on the host now, without ever having waited for it
+        if tabs[6] is False:
+            return None, ()                               # no row longer than HUB_CAP in this direction
         from . import _lib
-        vrows, hubs, counts, cap_rows = tabs
+        vrows, hubs, counts, cap_rows = tabs[:4]
         nbytes = int(_lib.lib.mlgnn_hub_scratch_bytes(cap_rows, d))
         tmp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         st = _lib.HubStruct(HUB_CAP, cap_rows, vrows.data_ptr(), hubs.data_ptr(), counts.data_ptr(), tmp.data_ptr(), nbytes)

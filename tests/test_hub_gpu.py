@@ -134,6 +134,9 @@ def test_graph_without_long_rows_is_untouched():
     g = CSRGraph(ei, N)
     assert g.hub_tables("dst")[2].cpu().tolist() == [0, 0] and g.hub_tables("src")[2].cpu().tolist() == [0, 0]
     out = gen_aggregate(x, g, None, aggr="softmax")
+    torch.cuda.synchronize()
+    assert g.hub_arg("dst", d)[0] is None and g.hub_arg("src", d)[0] is None     # known hub-free by now: launches skipped
+    assert torch.equal(gen_aggregate(x, g, None, aggr="softmax"), out)
     graph_mod.HUB_CAP = 0
     try:
         ref = gen_aggregate(x, CSRGraph(ei, N), None, aggr="softmax")

@@ -355,10 +355,82 @@ def _dt(t):
     return 1 if t.dtype == torch.bfloat16 else 0
 
 
+def _split_bf16(x):
+    """fp32 ``x = hi + lo`` up to 2^-17 relative: two bf16 terms (``lo`` carries the next 8 significant bits)."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def _matmul_nt_3term(a, b, out=None, accumulate=False, splits=1):
+    """``a [M,K] @ b [N,K]^T`` for fp32 operands at fp32-level accuracy on the bf16 matrix cores: both operands are
+    split into two bf16 terms and the three leading partial products run as ONE multi-term launch of
+    ``mlgnn_gemm_bf16_nt`` (fp32 accumulation; the dropped ``lo x lo`` term is 2^-18 relative).  ``a`` / ``b`` may be
+    ``(hi, lo)`` pairs already.  ``accumulate``: add to ``out`` (the kernel's ``C + 1 * aux`` epilogue)."""
+    from .gemm import gemm_bf16_nt
+    ah, al = a if isinstance(a, tuple) else _split_bf16(a)
+    bh, bl = b if isinstance(b, tuple) else _split_bf16(b)
+    segs = [(ah, bh), (ah, bl), (al, bh)]
+    if splits > 1:
+        return gemm_bf16_nt(segs, splits=splits)["slab"].sum(0)
+    r = gemm_bf16_nt(segs, out_dtype=torch.float32, aux=out if accumulate else None, alpha=1.0 if accumulate else 0.0)["c"]
+    return r
+
+
+class _DiffPoolLargeFP32(torch.autograd.Function):
+    """fp32 inputs at sizes past the fused small-graph kernel (multiples of 128): the same product chain as
+    :class:`_DiffPoolLarge`, every product as three bf16 terms on the matrix cores (fp32-level accuracy, 1e-5 of the
+    absolute-value bound), the streaming pieces (softmax, splits, transposes) on ATen.  Orchestrated from Python: three
+    times the matrix work of the bf16 chain and a few dozen small launches -- still ahead of the library's fp32 GEMMs."""
+
+    @staticmethod
+    def forward(ctx, z, adj, s, adj_symmetric):
+        N, C = z.shape
+        K = s.shape[1]
+        S = torch.softmax(s, dim=-1)
+        ent = (-S * torch.log(S + DIFFPOOL_EPS)).sum(dim=-1).mean()
+        Sp, Stp, Ap = _split_bf16(S), _split_bf16(S.t().contiguous()), _split_bf16(adj)
+        T = _matmul_nt_3term(Ap, Stp)                                        # A S  [N,K]
+        Ttp = _split_bf16(T.t().contiguous())
+        tiles = (K // 128) * (K // 128)
+        sp = max(1, min(256 // tiles, 3 * N // 64))
+        a_out = _matmul_nt_3term(Stp, Ttp, splits=sp)                        # S^T (A S)  [K,K]
+        G = _matmul_nt_3term(Stp, Stp, splits=sp)                            # S^T S
+        x_out = _matmul_nt_3term(Stp, _split_bf16(z.t().contiguous()), splits=max(1, min(256 // ((K // 128) * (C // 128)), 3 * N // 64)))
+        sq = (adj * adj).sum() - 2.0 * (S * T).sum() + (G * G).sum()         # ||A - S S^T||_F^2 (csrc/diffpool_large.hip)
+        norm = torch.sqrt(sq.clamp(min=0.0))
+        ctx.save_for_backward(z, adj, S, T, G, norm)
+        ctx.sym = bool(adj_symmetric)
+        return x_out, a_out, norm / adj.numel(), ent
+
+    @staticmethod
+    def backward(ctx, gx, ga, g_link, g_ent):
+        z, adj, S, T, G, norm = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("the large DiffPool path treats the adjacency as a constant (no gradient)")
+        N, C = z.shape
+        K = S.shape[1]
+        c = g_link / (adj.numel() * norm)
+        eye = torch.eye(K, device=z.device, dtype=torch.float32)
+        Sp = _split_bf16(S)
+        T2 = T if ctx.sym else _matmul_nt_3term(_split_bf16(adj.t().contiguous()), _split_bf16(S.t().contiguous()))
+        ga = ga.float()
+        dS = _matmul_nt_3term(z, gx.float().contiguous())                                     # Z dX'^T
+        dS = _matmul_nt_3term(T, (ga - c * eye).contiguous(), out=dS, accumulate=True)        # T (dA' - cI)^T
+        dS = _matmul_nt_3term(T2, (ga.t() - c * eye).contiguous(), out=dS, accumulate=True)   # T2 (dA'^T - cI)^T
+        dS = _matmul_nt_3term(Sp, (2.0 * c * G).contiguous(), out=dS, accumulate=True)        # S (2cG)
+        dS = dS - (g_ent / N) * (torch.log(S + DIFFPOOL_EPS) + S / (S + DIFFPOOL_EPS))
+        gs = S * (dS - (dS * S).sum(dim=-1, keepdim=True))
+        tiles = (N // 128) * (C // 128)
+        gz = _matmul_nt_3term(Sp, gx.float().t().contiguous(), splits=max(1, min(256 // tiles, 3 * K // 64)))
+        return gz, None, gs, None
+
+
 def diff_pool_large_supported(z, adj, s):
     B, N, C = z.shape
-    return (z.is_cuda and z.dtype == torch.bfloat16 and s.dtype == torch.bfloat16 and adj.dtype == torch.bfloat16
-            and not adj.requires_grad and bool(_lib.lib.mlgnn_diffpool_large_supported(N, s.shape[2], C)))
+    same = z.dtype == s.dtype == adj.dtype and z.dtype in (torch.bfloat16, torch.float32)
+    return (z.is_cuda and same and not adj.requires_grad
+            and bool(_lib.lib.mlgnn_diffpool_large_supported(N, s.shape[2], C)))
 
 
 def _diff_pool_large(z, adj, s, adj_symmetric=False):
@@ -368,7 +440,8 @@ def _diff_pool_large(z, adj, s, adj_symmetric=False):
     xs, as_, l2, es = [], [], [], []
     for b in range(B):
         a_b = adj[b if adj.shape[0] == B and B > 1 else 0]
-        x, a, link, ent = _DiffPoolLarge.apply(z[b], a_b, s[b], adj_symmetric)
+        fn = _DiffPoolLarge if z.dtype == torch.bfloat16 else _DiffPoolLargeFP32
+        x, a, link, ent = fn.apply(z[b], a_b.contiguous(), s[b], adj_symmetric)
         xs.append(x)
         as_.append(a)
         l2.append((link.float() * a_b.numel()) ** 2)
@@ -392,9 +465,9 @@ def _diff_pool_library(z, adj, s):
 def dense_diff_pool(z, adj, s, adj_symmetric=False):
     """``S = softmax(s)``; returns ``(S^T Z, S^T A S, ||A - S S^T||_F / numel(A), mean entropy)``.
     Pooled graphs of up to 160 nodes / 48 clusters / 64 channels (the reference's 146 -> 37 -> 10)
-    run as one fused fp32-MFMA launch; bf16 graphs whose sizes are multiples of 128 (BASELINE configs[4]:
-    4096 nodes, 1024 clusters) as the matrix-core product chain of csrc/diffpool_large.hip; anything else as
-    batched library GEMMs.  ``adj_symmetric`` promises ``adj == adj^T`` (saves a third of the large backward)."""
+    run as one fused fp32-MFMA launch; graphs whose sizes are multiples of 128 (BASELINE configs[4]:
+    4096 nodes, 1024 clusters) as the matrix-core product chain of csrc/diffpool_large.hip (bf16) or its three-term
+    fp32-accurate form; anything else as batched library GEMMs.  ``adj_symmetric`` promises ``adj == adj^T`` (saves a third of the large backward)."""
     z = z.unsqueeze(0) if z.dim() == 2 else z
     adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
     s = s.unsqueeze(0) if s.dim() == 2 else s

@@ -173,3 +173,36 @@ def test_configs4_size_properties():
     assert torch.isfinite(zc.grad).all() and torch.isfinite(sc.grad).all()
     # d/dz of sum(S^T z) is the row sum of S = 1 for every entry
     assert ((zc.grad.float() - 1.0).abs() <= 2.0 ** -6).all()
+
+
+# ---- fp32 inputs: every product as three bf16 terms on the matrix cores (fp32-level accuracy) ------------------------
+
+@pytest.mark.parametrize("N,K,C", SIZES + [(4096, 1024, 256)])
+def test_fp32_path_matches_fp64_oracle_to_1e4(N, K, C):
+    """north_star's fp32 bar on the large path: outputs within 1e-4 of the fp64 oracle, elementwise against the
+    absolute-value bound of each product (the three-term split leaves 2^-17 per operand), gradients likewise."""
+    from mlgnn.dense import dense_diff_pool
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn(N, C, generator=g)
+    a = torch.rand(N, N, generator=g) + torch.eye(N)
+    s = torch.randn(N, K, generator=g) * 2.0
+    dev = "cuda:0"
+    # the oracle itself runs on the GPU here, in fp64 (it is plain torch): 80 GFLOP of fp64 at the full size
+    zd, ad, sd = z.double().to(dev).requires_grad_(True), a.double().to(dev), s.double().to(dev).requires_grad_(True)
+    rx, ra, rl, re = OP.dense_diff_pool(zd, ad, sd)
+    wx, wa = torch.randn(K, C, generator=g).double().to(dev), (torch.randn(K, K, generator=g) / K).double().to(dev)
+    ((rx[0] * wx).sum() + (ra[0] * wa).sum() + rl * 3e4 + re * 2.0).backward()
+    zc, sc = z.to(dev).requires_grad_(True), s.to(dev).requires_grad_(True)
+    x, ao, link, ent = dense_diff_pool(zc, a.to(dev), sc)
+    assert x.dtype == torch.float32 and x.shape == (1, K, C)
+    soft = torch.softmax(sd.detach(), -1)
+    bound_x = soft.t() @ zd.detach().abs()
+    bound_a = soft.t() @ ad @ soft
+    assert ((x[0].double() - rx[0].detach()).abs() <= 1e-4 * bound_x).all()
+    assert ((ao[0].double() - ra[0].detach()).abs() <= 1e-4 * bound_a).all()
+    assert abs(float(link) - float(rl)) <= 1e-4 * float(rl)
+    assert abs(float(ent) - float(re)) <= 1e-4 * abs(float(re))
+    ((x[0] * wx.float()).sum() + (ao[0] * wa.float()).sum() + link * 3e4 + ent * 2.0).backward()
+    for got, ref, name in ((zc.grad, zd.grad, "grad z"), (sc.grad, sd.grad, "grad logits")):
+        err = float((got.double() - ref).abs().max())
+        assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (name, err)

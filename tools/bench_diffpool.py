@@ -40,14 +40,17 @@ def main():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--json", default=None)
     ap.add_argument("--skip-library", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
+                    help="fp32: the three-term fp32-accurate form of the chain against the library's fp32 GEMMs")
     a = ap.parse_args()
     from mlgnn import dense
     N, K, C = a.nodes, a.clusters, a.channels
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(7)
-    z = torch.randn(1, N, C, generator=g).to(dev).bfloat16().requires_grad_(True)
-    s = torch.randn(1, N, K, generator=g).to(dev).bfloat16().requires_grad_(True)
-    adj = (torch.rand(N, N, generator=g) + torch.eye(N)).to(dev).bfloat16().unsqueeze(0)
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    z = torch.randn(1, N, C, generator=g).to(dev).to(dt).requires_grad_(True)
+    s = torch.randn(1, N, K, generator=g).to(dev).to(dt).requires_grad_(True)
+    adj = (torch.rand(N, N, generator=g) + torch.eye(N)).to(dev).to(dt).unsqueeze(0)
 
     def fwd(fn):
         with torch.no_grad():
@@ -62,7 +65,10 @@ def main():
     exe_fwd = 2.0 * K * N * C + 2.0 * K * N * N + 2.0 * K * (2 * K) * N
     exe_bwd_sym = 2.0 * N * K * (C + 3 * K) + 2.0 * N * C * K
     exe_bwd = exe_bwd_sym + 2.0 * K * N * N
-    res = {"config": "dense_diff_pool N=%d K=%d C=%d bf16 (BASELINE configs[4] DiffPool)" % (N, K, C),
+    if a.dtype == "fp32":                                   # three bf16 terms per product
+        exe_fwd, exe_bwd, exe_bwd_sym = 3 * exe_fwd, 3 * exe_bwd, 3 * exe_bwd_sym
+    res = {"config": "dense_diff_pool N=%d K=%d C=%d %s (BASELINE configs[4] DiffPool%s)" % (
+               N, K, C, a.dtype, "" if a.dtype == "bf16" else "; fp32 inputs, three-term bf16 products"),
            "dense_peak_TFLOPs_bf16": 2500.0, "reference_fwd_GFLOP": ref_flop / 1e9, "executed_fwd_GFLOP": exe_fwd / 1e9,
            "executed_bwd_GFLOP": exe_bwd / 1e9}
     t_f = timed(lambda: fwd(dense.dense_diff_pool), a.iters)

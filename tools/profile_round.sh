@@ -6,7 +6,7 @@
 #    once the kernel sources change), <tag>_bench.json (the bench line of the un-profiled run)
 # 2. configs[4] stress run (bf16): stats -> profiles/<tag>_stress_bf16_kernel_stats.md, <tag>_stress_configs4_bf16.json
 # 3. configs[4] DiffPool (4096 nodes / 1024 clusters): bench + stats + MFMA counters
-#    -> profiles/<tag>_diffpool_configs4.json, <tag>_diffpool_kernel_stats.md, <tag>_diffpool_mfma_pmc.json
+#    -> profiles/<tag>_diffpool_configs4.json (+ _fp32.json), <tag>_diffpool_kernel_stats.md, <tag>_diffpool_mfma_pmc.json
 # 4. hub-row benchmark -> profiles/<tag>_skew.json
 # The program always follows `rocprofv3 ... --` directly (no wrapper process).  Outputs: gpurun_out/prof_*_<tag>/.
 set -e
@@ -38,6 +38,7 @@ m = txt[txt.index("{"):]
 open("profiles/${TAG}_stress_configs4_bf16.json", "w").write(m)
 PY
 python3 tools/bench_diffpool.py --json profiles/${TAG}_diffpool_configs4.json > gpurun_out/dp_$TAG.log 2>&1
+python3 tools/bench_diffpool.py --dtype fp32 --iters 10 --json profiles/${TAG}_diffpool_configs4_fp32.json > gpurun_out/dp32_$TAG.log 2>&1
 python3 tools/bench_skew.py > gpurun_out/skew_$TAG.log 2>&1
 grep '^{' gpurun_out/skew_$TAG.log | tail -1 > profiles/${TAG}_skew.json
 python3 tools/summarize_prof.py --stats "gpurun_out/prof_stats_$TAG/**/*kernel_stats.csv" --tag $TAG --commit "$MLGNN_COMMIT" \

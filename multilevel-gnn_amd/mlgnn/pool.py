@@ -48,22 +48,17 @@ def global_pool(x, batch, kind, num_graphs=None):
     device->host sync of ``batch.max() + 1`` the reference pays."""
     B = int(num_graphs) if num_graphs is not None else int(batch.max().item()) + 1
     batch = batch.to(torch.long)
-    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 2 and x.shape[1] % 4 == 0:
+    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 2:
         ptr = torch.zeros(B + 1, dtype=torch.int64, device=x.device)
         torch.cumsum(torch.bincount(batch, minlength=B), 0, out=ptr[1:])
         # bf16 storage: the readout sums thousands of rows per graph, which a bf16 accumulator (ATen's index_add_
-        # on bf16) cannot hold -- reduce in fp32 (one up-cast pass per step), round the [B, d] result once
-        out = _SegmentPool.apply(x.float(), ptr.to(torch.int32), batch, _KINDS[kind])
-        return out.to(x.dtype)
-    # widths the kernel does not cover (d % 4 != 0): ATen on the same device
-    if kind in ("sum", "add", "mean"):
-        out = x.new_zeros((B, x.shape[1])).index_add_(0, batch, x)
-        if kind == "mean":
-            cnt = x.new_zeros(B).index_add_(0, batch, x.new_ones(x.shape[0]))
-            out = out / cnt.clamp(min=1)[:, None]
-        return out
-    if kind == "max":
-        idx = batch[:, None].expand_as(x)
-        out = x.new_full((B, x.shape[1]), float("-inf")).scatter_reduce(0, idx, x, reduce="amax", include_self=True)
-        return torch.where(torch.isinf(out), torch.zeros_like(out), out)
-    raise ValueError(kind)
+        # on bf16) cannot hold -- reduce in fp32 (one up-cast pass per step), round the [B, d] result once.
+        # A width that is not a multiple of 4 (the kernel's 16-byte rows) is zero padded for the call: still the
+        # deterministic two-stage kernel, never an atomic scatter.
+        d = x.shape[1]
+        xf = x.float()
+        if d % 4:
+            xf = torch.nn.functional.pad(xf, (0, 4 - d % 4))
+        out = _SegmentPool.apply(xf, ptr.to(torch.int32), batch, _KINDS[kind])
+        return out[:, :d].to(x.dtype)
+    raise TypeError("global_pool wants a 2-D fp32 / bf16 CUDA tensor (the accelerated path has no CPU fallback)")

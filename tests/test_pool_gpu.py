@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kind", ["sum", "mean", "max"])
-@pytest.mark.parametrize("d", [4, 32, 100, 128, 320])
+@pytest.mark.parametrize("d", [3, 4, 32, 100, 101, 128, 320])
 def test_global_pool(kind, d):
     from mlgnn.pool import global_pool
     gen = torch.Generator().manual_seed(d)

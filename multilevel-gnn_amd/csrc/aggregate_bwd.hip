@@ -155,8 +155,11 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
               if (MODE == M_GEN_FULL) load_t<T, VEC>(ef[u], EF + (size_t)e0[u] * a.d + c0);
             }
           }
+          // lane-group chunks of a partial batch past the row's last edge contribute nothing: skipped as a whole
+          const int live = FULL ? kUnroll : (cnt - k + groups - 1) >> (6 - a.lpr_log2);
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) {
+            if (!FULL && u >= live) continue;
             float dz[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {

@@ -103,23 +103,85 @@ __device__ __forceinline__ float pre_act(float xj, const float* a, const float* 
   else return xj;
 }
 
-// Non-finite inputs.  relu / max / the power clamp are v_max / v_min here, which return the OTHER operand when one is
-// NaN: a NaN (or Inf) in x_j or in the edge term would silently vanish from the aggregate, where the reference carries
-// it to the loss (relu(NaN) = NaN, torch_vertex.py:94-101).  Every GEN message is therefore re-poisoned after its
-// relu:  m = fma(z, 0, m)  leaves m unchanged for finite z (z * 0 = +-0) and makes it NaN for NaN / +-Inf, from
-// where the sums / exponentials carry it to the row's result by themselves.  One VALU op per gathered element and no
-// extra register (a per-channel accumulator cost the softmax forward an occupancy step: 78 -> 82 VGPRs).  Inline
-// asm: this translation unit is built with -fno-honor-nans, under which the compiler may fold z * 0.
-__device__ __forceinline__ void keep_nonfinite(float& m, float z) {
-  asm("v_fma_f32 %0, %1, 0, %0" : "+v"(m) : "v"(z));
+// Non-finite inputs.  relu / max / the power clamp as v_max / v_min return the OTHER operand when one is NaN: a NaN in
+// x_j or in the edge term would silently vanish from the aggregate, where the reference carries it to the loss
+// (relu(NaN) = NaN, torch_vertex.py:94-101).  gfx950 has the IEEE-754-2019 forms (v_maximum3_f32 / v_minimum3_f32:
+// NaN if any operand is NaN), so the GEN relu and the power clamp keep a NaN at no extra cost; +-Inf follow torch too
+// (relu(+Inf) = +Inf, relu(-Inf) = 0) and the sums / exponentials carry them to the row's result by themselves.
+// Inline asm: the aggregation translation units are built with -fno-honor-nans.
+__device__ __forceinline__ float relu_nan(float z) {
+  float m;
+  asm("v_maximum3_f32 %0, %1, 0, 0" : "=v"(m) : "v"(z));
+  return m;
 }
-
+__device__ __forceinline__ float clamp_nan(float x, float lo, float hi) {
+  float t, r;
+  asm("v_maximum3_f32 %0, %1, %2, %2" : "=v"(t) : "v"(x), "v"(lo));
+  asm("v_minimum3_f32 %0, %1, %2, %2" : "=v"(r) : "v"(t), "v"(hi));
+  return r;
+}
 template <int MODE, bool ADD_EPS>
 __device__ __forceinline__ float message(float xj, const float* a, const float* u, float v, float ef, float eps) {
   if constexpr (MODE == M_IDENTITY) return xj;
   else if constexpr (MODE == M_WEIGHTED) return xj * a[0];
   else if constexpr (ADD_EPS) return fmaxf(pre_act<MODE>(xj, a, u, v, ef), 0.0f) + eps;
   else return fmaxf(pre_act<MODE>(xj, a, u, v, ef), 0.0f);
+}
+
+// The messages of one gathered row chunk (VEC channels of one neighbour), two channels per instruction where the width
+// allows: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 run two fp32 lanes per VALU slot and these kernels are bound by
+// VALU issue (SQ_ACTIVE_INST_VALU 97 % of the cycles at config 1).  z (GEN modes): the pre-activation, for the backward.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+template <int MODE, int VEC, int ESA, bool KEEP_NAN, bool ADD_EPS>
+__device__ __forceinline__ void row_messages(float (&m)[VEC], float (&z)[VEC], const float (&xv)[VEC], const float (&wa)[ESA],
+                                             const float (&eu)[VEC][ESA], const float (&ev)[VEC], const float (&ef)[VEC],
+                                             float eps) {
+  if constexpr (VEC % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 2) {
+      f32x2 x2 = {xv[i], xv[i + 1]};
+      if constexpr (MODE == M_IDENTITY) {
+        m[i] = x2.x; m[i + 1] = x2.y;
+        z[i] = x2.x; z[i + 1] = x2.y;
+      } else if constexpr (MODE == M_WEIGHTED) {
+        const f32x2 w2 = {wa[0], wa[0]};
+        x2 = x2 * w2;
+        m[i] = x2.x; m[i + 1] = x2.y;
+        z[i] = x2.x; z[i + 1] = x2.y;
+      } else {
+        if constexpr (rank_of<MODE>() > 0) {
+          f32x2 e2 = {ev[i], ev[i + 1]};
+#pragma unroll
+          for (int k = 0; k < rank_of<MODE>(); ++k) {
+            const f32x2 a2 = {wa[k], wa[k]}, u2 = {eu[i][k], eu[i + 1][k]};
+            e2 = __builtin_elementwise_fma(a2, u2, e2);
+          }
+          x2 = x2 + e2;
+        } else if constexpr (MODE == M_GEN_FULL) {
+          const f32x2 e2 = {ef[i], ef[i + 1]};
+          x2 = x2 + e2;
+        }
+        z[i] = x2.x; z[i + 1] = x2.y;
+        f32x2 r2;
+        r2.x = KEEP_NAN ? relu_nan(x2.x) : fmaxf(x2.x, 0.0f);
+        r2.y = KEEP_NAN ? relu_nan(x2.y) : fmaxf(x2.y, 0.0f);
+        if constexpr (ADD_EPS) { const f32x2 eps2 = {eps, eps}; r2 = r2 + eps2; }
+        m[i] = r2.x; m[i + 1] = r2.y;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if constexpr (!is_gen<MODE>()) {
+        m[i] = message<MODE, false>(xv[i], wa, eu[i], ev[i], ef[i], eps);
+        z[i] = m[i];
+      } else {
+        z[i] = pre_act<MODE>(xv[i], wa, eu[i], ev[i], ef[i]);
+        const float r = KEEP_NAN ? relu_nan(z[i]) : fmaxf(z[i], 0.0f);
+        m[i] = ADD_EPS ? r + eps : r;
+      }
+    }
+  }
 }
 
 // csrc/hub.hip

@@ -93,6 +93,14 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
         mx[i] = FAST ? 0.f : kNegBig; w1[i] = 0.f; w2[i] = 0.f; bpos[i] = -1;
       }
 
+      // FAST sums as register pairs from start to end (pairs rebuilt from scalars per batch cost v_movs at every
+      // loop boundary): pa = S, p1 = sum w m, p2 = sum w m^2
+      constexpr bool kPairs = AGGR == A_SOFTMAX && FAST && VEC % 2 == 0;
+      constexpr int NP = VEC % 2 == 0 ? VEC / 2 : 1;
+      f32x2 pa[NP], p1[NP], p2[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) { pa[i] = {0.f, 0.f}; p1[i] = {0.f, 0.f}; p2[i] = {0.f, 0.f}; }
+
       for (int base = beg; base < end; base += kWave) {
         const int cnt = min(kWave, end - base);
         uint32_t my_off = 0;
@@ -131,46 +139,63 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
                 if (MODE == M_GEN_FULL) load_t<T, VEC>(ef[u], EF + (size_t)e0 * a.d + c0);
               }
             }
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) {
-                if constexpr (kTrack) {
-                  const float z = pre_act<MODE>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i]);
-                  m[u][i] = kLateEps ? fmaxf(z, 0.0f) : fmaxf(z, 0.0f) + a.eps;
-                  keep_nonfinite(m[u][i], z);
-                } else {
-                  m[u][i] = message<MODE, !kLateEps>(xv[u][i], wa[u], eu[i], ev[i], ef[u][i], a.eps);
-                }
-              }
-          }
-
-          if constexpr (AGGR == A_SUM) {
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) acc[i] += (FULL || valid[u]) ? m[u][i] : 0.f;
-          } else if constexpr (AGGR == A_MAX) {
+            // lane-group chunks of a partial batch that lie past the row's last edge are skipped as a whole
+            // (wave-uniform branch): a row of 16 edges ends in a partial batch more often than not
+            const int live = FULL ? kUnroll : (cnt - k + groups - 1) >> (6 - a.lpr_log2);
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
-              const int pos = base + k + u * groups + sub;
+              if (!FULL && u >= live) {
 #pragma unroll
-              for (int i = 0; i < VEC; ++i)
-                if ((FULL || valid[u]) && m[u][i] > acc[i]) { acc[i] = m[u][i]; bpos[i] = pos; }
-            }
-          } else if constexpr (AGGR == A_SOFTMAX) {
-            if constexpr (FAST) {
+                for (int i = 0; i < VEC; ++i) m[u][i] = 0.f;
+                continue;
+              }
+              float zu[VEC];
+              row_messages<MODE, VEC, ESA, kTrack, !kLateEps>(m[u], zu, xv[u], wa[u], eu, ev, ef[u], a.eps);
+              const bool ok = FULL || valid[u];
+              if constexpr (AGGR == A_SUM) {
 #pragma unroll
-              for (int u = 0; u < kUnroll; ++u)
+                for (int i = 0; i < VEC; ++i) acc[i] += ok ? m[u][i] : 0.f;
+              } else if constexpr (AGGR == A_MAX) {
+                const int pos = base + k + u * groups + sub;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                  if (ok && m[u][i] > acc[i]) { acc[i] = m[u][i]; bpos[i] = pos; }
+              } else if constexpr (AGGR == A_SOFTMAX && FAST) {
+                if constexpr (kPairs) {
+#pragma unroll
+                  for (int i = 0; i < VEC; i += 2) {
+                    const f32x2 m2 = {m[u][i], m[u][i + 1]}, t2 = {sc.t_log2e, sc.t_log2e};
+                    const f32x2 tm = m2 * t2;
+                    f32x2 pe = {fast_exp2(tm.x), fast_exp2(tm.y)};
+                    if (!FULL) { pe.x = ok ? pe.x : 0.f; pe.y = ok ? pe.y : 0.f; }
+                    pa[i / 2] = pa[i / 2] + pe;
+                    p1[i / 2] = __builtin_elementwise_fma(pe, m2, p1[i / 2]);
+                    if (SECOND) p2[i / 2] = __builtin_elementwise_fma(pe * m2, m2, p2[i / 2]);
+                  }
+                } else {
+#pragma unroll
+                  for (int i = 0; i < VEC; ++i) {
+                    float pe = fast_exp2(sc.t_log2e * m[u][i]);
+                    if (!FULL) pe = ok ? pe : 0.f;
+                    acc[i] += pe;
+                    w1[i] = fmaf(pe, m[u][i], w1[i]);
+                    if (SECOND) w2[i] = fmaf(pe * m[u][i], m[u][i], w2[i]);
+                  }
+                }
+              } else if constexpr (AGGR == A_POWER) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
-                  float pe = fast_exp2(sc.t_log2e * m[u][i]);
-                  if (!FULL) pe = valid[u] ? pe : 0.f;
-                  acc[i] += pe;
-                  w1[i] = fmaf(pe, m[u][i], w1[i]);
-                  if (SECOND) w2[i] = fmaf(pe * m[u][i], m[u][i], w2[i]);
+                  const float mc = clamp_nan(m[u][i], kPowLo, kPowHi);     // torch.clamp carries a NaN message
+                  const float l2 = fast_log2(mc);
+                  const float pw = fast_exp2(sc.p * l2);
+                  acc[i] += ok ? pw : 0.f;
+                  if (SECOND) w2[i] += ok ? pw * l2 * kLn2 : 0.f;
                 }
-            } else {
+              }
+            }
+          }
+
+          if constexpr (AGGR == A_SOFTMAX && !FAST) {
             // online softmax, one rescale per batch of kUnroll neighbours; units: log2.  t*m is monotone in m:
             // the batch extremum of m (max for t >= 0, min for t < 0) gives the extremum of t*m.
 #pragma unroll
@@ -195,19 +220,6 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
               }
               acc[i] = s; w1[i] = s1; w2[i] = s2; mx[i] = zmax;
             }
-            }
-          } else {  // A_POWER
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) {
-                float mc = fminf(fmaxf(m[u][i], kPowLo), kPowHi);
-                keep_nonfinite(mc, m[u][i]);            // torch.clamp carries a NaN message; v_min / v_max drop it
-                const float l2 = fast_log2(mc);
-                const float pw = fast_exp2(sc.p * l2);
-                acc[i] += (FULL || valid[u]) ? pw : 0.f;
-                if (SECOND) w2[i] += (FULL || valid[u]) ? pw * l2 * kLn2 : 0.f;
-              }
           }
         };
 
@@ -215,6 +227,14 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
         int k = 0;
         for (; k + step <= cnt; k += step) batch(BC<true>{}, k);
         if (k < cnt) batch(BC<false>{}, k);
+      }
+      if constexpr (kPairs) {
+#pragma unroll
+        for (int i = 0; i < VEC; i += 2) {
+          acc[i] = pa[i / 2].x; acc[i + 1] = pa[i / 2].y;
+          w1[i] = p1[i / 2].x; w1[i + 1] = p1[i / 2].y;
+          w2[i] = p2[i / 2].x; w2[i + 1] = p2[i / 2].y;
+        }
       }
 
       // ---- combine the lane groups (xor-shuffle over the group bits) ----
@@ -286,8 +306,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
             } else { o[i] = 0.f; }
           } else {  // POWER
             const float mu = acc[i] * inv;
-            float muc = fminf(fmaxf(mu, kPowLo), kPowHi);
-            keep_nonfinite(muc, mu);                             // the outer clamp carries NaN too (torch_message.py:72)
+            const float muc = clamp_nan(mu, kPowLo, kPowHi);      // the outer clamp carries NaN too (torch_message.py:72)
             o[i] = fast_exp2(fast_log2(muc) * __builtin_amdgcn_rcpf(sc.p));
             ax[i] = mu;
             ax2[i] = w2[i] * inv;

@@ -2,7 +2,7 @@
 // clusters, 256 channels: S^T Z, A S, S^T (A S), S^T S -- reference: torch_geometric dense_diff_pool as called from
 // DiffPoolLayer.forward, models/diff_pooling.py:59-65).  This is the one genuinely MFMA-bound piece of the path.
 //
-//     C[M,N] = sum_s A_s[M,K_s] * B_s[N,K_s]^T        bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16)
+//     C[M,N] = sum_s A_s[M,K_s] * B_s[N,K_s]^T        bf16 operands, fp32 accumulation (v_mfma_f32_16x16x32_bf16)
 //
 // Both operands have the contraction index contiguous ("NT"): every product of the DiffPool chain is brought into
 // this form by the producers of its operands (the softmax writes S and S^T, the A S product writes T and T^T).
@@ -17,8 +17,11 @@
 //     the 2 MB a workgroup of the 4096 x 1024 x 4096 product streams), which at this tile size is about as long as
 //     the MFMAs themselves (30 us): when the same waves issued DMA and MFMA, a full memory queue held up the MFMAs
 //     behind it (48 us); with the issue on its own waves the two overlap (39 us).
-//   * MFMA waves (4) own a 64 x 64 quadrant each: 16 x v_mfma_f32_32x32x16_bf16 per K-step, fragments in four register
-//     sets (one per 16-deep k-step) that are refilled two MFMA groups before their use, across the K-step boundary.
+//   * MFMA waves (4) own a 64 x 64 quadrant each: 4 x 4 tiles of v_mfma_f32_16x16x32_bf16, 32 MFMAs per K-step, fragments
+//     in two register sets (one per 32-deep k-step: 4 A + 4 B tiles) that are refilled one MFMA group before their
+//     use, across the K-step boundary.  The 16x16x32 shape measured 7-9 % faster than 32x32x16 in this kernel (same
+//     process, alternating launches: 4096 x 1024 x 4096 35 vs 39 us, 4096^3 130 vs 140 us) and needs 164 instead of
+//     215 VGPRs.
 //   * ONE barrier per K-step joins loaders ("K-step t + 1 has landed": counted vmcnt, the later K-steps stay in
 //     flight across the barrier) and MFMA waves ("K-step t - 1 is in registers, its stage may be refilled").
 //   * LDS image of a stage: [128 rows][64 k] bf16 per operand, 128-byte rows, 16-byte chunks XOR-swizzled by
@@ -29,8 +32,8 @@
 //     cannot be scheduled above them, and sched_barriers keep the read / MFMA interleave as written.
 //   * workgroup -> tile: XCD-aware (workgroups b and b+8 share an XCD's L2): every XCD owns a contiguous range of
 //     tiles, ordered in groups of 4 tile rows so that the range is a compact block of the output.
-// Measured (MI355X, random data): 4096 x 1024 x 4096 in 39 us = 880 TFLOP/s (35 % of the 2.5 PFLOP/s dense bf16 peak;
-// SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) = 0.35); the MFMA stream alone (no LDS traffic) runs
+// Measured (MI355X, random data): 4096 x 1024 x 4096 in 35 us = 980 TFLOP/s (39 % of the 2.5 PFLOP/s dense bf16 peak);
+// the L2 -> LDS ingest of one CU bounds this tile size at 28 us.  With the 32x32x16 shape the MFMA stream alone ran
 // at 1.58 PFLOP/s in this kernel, with its fragment reads at 1.13.  Also measured and not kept: loader waves that
 // stage through registers (global_load_dwordx4 two K-steps ahead, ds_write_b128 one K-step later -- plain loads take in
 // more per CU than LDS-DMA): 46 us, the LDS write traffic next to the fragment reads costs more than the loads gain;
@@ -42,7 +45,7 @@
 namespace mlgnn {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -59,17 +62,12 @@ struct GemmArgs {
   int tiles_m, tiles_n, ktiles;
 };
 
-__device__ __forceinline__ i32x4 lds_read16(uint32_t addr) {
+template <int OFF>
+__device__ __forceinline__ i32x4 lds_read16_at(uint32_t addr) {
   i32x4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
-__device__ __forceinline__ i32x4 lds_read16_hi(uint32_t addr) {          // + 32 rows (32 * 128 bytes)
-  i32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(v) : "v"(addr));
-  return v;
-}
-
 template <int N>
 __device__ __forceinline__ void wait_dma_tiles() {              // all but the N youngest tiles (8 DMAs each) have landed
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -172,118 +170,92 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
   }
 
   // ================= MFMA waves: one per SIMD, a 64 x 64 quadrant each ==========================================
-  // Fragments of K-step t + 1 are read (into the other register set) while the MFMAs of K-step t run.
+  // v_mfma_f32_16x16x32_bf16: 4 x 4 tiles of 16 x 16 per quadrant, two 32-deep k-steps per stage.  Lane l holds
+  // A[row l & 15][k = 8 (l >> 4) ..+8] of a tile: 16-byte chunk 4 ks + (l >> 4) of the row, swizzled as the DMA wrote
+  // it; tiles 1..3 of an operand are 16 rows = 2048 bytes further on (the immediate offset of the read).
   const int wm = wave >> 1, wn = wave & 1;
-  const int r31 = lane & 31, h = lane >> 5;
+  const int l15 = lane & 15, q4 = lane >> 4;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int sw = (r31 >> 1) & 7;
-  const uint32_t a_row = lds0 + (uint32_t)(64 * wm + r31) * 128;
-  const uint32_t b_row = lds0 + 16384 + (uint32_t)(64 * wn + r31) * 128;
-  uint32_t a_at[4], b_at[4];                                     // k-step s of a stage: 16-byte chunk 2 s + h, swizzled
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    const uint32_t c = (uint32_t)(((2 * s4 + h) ^ sw) << 4);
-    a_at[s4] = a_row + c;
-    b_at[s4] = b_row + c;
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  {
+    const int sw16 = (l15 >> 1) & 7;
+    const uint32_t a16 = lds0 + (uint32_t)(64 * wm + l15) * 128, b16 = lds0 + 16384 + (uint32_t)(64 * wn + l15) * 128;
+    const uint32_t ck0 = (uint32_t)((q4 ^ sw16) << 4), ck1 = (uint32_t)(((4 + q4) ^ sw16) << 4);
+    // Fragment registers: x* hold k-step 0 of a stage, y* k-step 1 (4 A tiles and 4 B tiles each).  A set is refilled
+    // one MFMA group (16 MFMAs) before its use, across the K-step boundary: at most 16 LDS reads are outstanding.
+    i32x4 xa[4], xb[4], ya[4], yb[4];                            // k-step 0 / k-step 1 of a stage: 4 A and 4 B tiles
+#define MLGNN_READ16(SA, SB, CK, ST)                      \
+  do {                                                    \
+    SA[0] = lds_read16_at<0>(a16 + (CK) + (ST));          \
+    SA[1] = lds_read16_at<2048>(a16 + (CK) + (ST));       \
+    SA[2] = lds_read16_at<4096>(a16 + (CK) + (ST));       \
+    SA[3] = lds_read16_at<6144>(a16 + (CK) + (ST));       \
+    SB[0] = lds_read16_at<0>(b16 + (CK) + (ST));          \
+    SB[1] = lds_read16_at<2048>(b16 + (CK) + (ST));       \
+    SB[2] = lds_read16_at<4096>(b16 + (CK) + (ST));       \
+    SB[3] = lds_read16_at<6144>(b16 + (CK) + (ST));       \
+  } while (0)
+#define MLGNN_LANDED16(SA, SB, CNT)                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                    \
+               : "+v"(SA[0]), "+v"(SA[1]), "+v"(SA[2]), "+v"(SA[3]), "+v"(SB[0]), "+v"(SB[1]), "+v"(SB[2]), "+v"(SB[3])::"memory")
+#define MLGNN_MFMA16(SA, SB)                                                                                          \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                  \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, SA[mt]),                    \
+                                                              __builtin_bit_cast(bf16x8, SB[nt]), acc[mt][nt], 0, 0, 0)
+    __builtin_amdgcn_s_barrier();                                 // K-step 0 has landed
+    uint32_t st = 0;
+    MLGNN_READ16(xa, xb, ck0, st);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t + 1 < T; ++t) {
+      const uint32_t st_next = st + kGStageBytes == STAGES * kGStageBytes ? 0 : st + kGStageBytes;
+      MLGNN_READ16(ya, yb, ck1, st);
+      MLGNN_LANDED16(xa, xb, 8);
+      MLGNN_MFMA16(xa, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                               // K-step t + 1 has landed
+      MLGNN_READ16(xa, xb, ck0, st_next);
+      MLGNN_LANDED16(ya, yb, 8);
+      MLGNN_MFMA16(ya, yb);
+      __builtin_amdgcn_sched_barrier(0);
+      st = st_next;
+    }
+    MLGNN_READ16(ya, yb, ck1, st);
+    MLGNN_LANDED16(xa, xb, 8);
+    MLGNN_MFMA16(xa, xb);
+    MLGNN_LANDED16(ya, yb, 0);
+    MLGNN_MFMA16(ya, yb);
+#undef MLGNN_READ16
+#undef MLGNN_LANDED16
+#undef MLGNN_MFMA16
   }
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // Fragment registers: set s holds k-step s of the current K-step's stage (4 x 16 bytes: A rows +0 / +32, B rows
-  // +0 / +32).  A set is refilled, with the same k-step of the NEXT stage or of this one, two MFMA groups before it
-  // is used: the reads of g + 3 are issued behind the MFMAs of g, so that at most 12 LDS reads are outstanding.
-  i32x4 fa0[4], fa1[4], fb0[4], fb1[4];
-#define MLGNN_READ(SET, ST)                          \
-  do {                                               \
-    fa0[SET] = lds_read16(a_at[SET] + (ST));         \
-    fa1[SET] = lds_read16_hi(a_at[SET] + (ST));      \
-    fb0[SET] = lds_read16(b_at[SET] + (ST));         \
-    fb1[SET] = lds_read16_hi(b_at[SET] + (ST));      \
-  } while (0)
-#define MLGNN_LANDED(SET, CNT) \
-  asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa0[SET]), "+v"(fa1[SET]), "+v"(fb0[SET]), "+v"(fb1[SET])::"memory")
-#define MLGNN_MFMA(SET)                                                                                                   \
-  do {                                                                                                                    \
-    {                                                                                                                     \
-      const bf16x8 xa0 = __builtin_bit_cast(bf16x8, fa0[SET]), xa1 = __builtin_bit_cast(bf16x8, fa1[SET]);                \
-      const bf16x8 xb0 = __builtin_bit_cast(bf16x8, fb0[SET]), xb1 = __builtin_bit_cast(bf16x8, fb1[SET]);                \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb0, acc[0][0], 0, 0, 0);                                  \
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb1, acc[0][1], 0, 0, 0);                                  \
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb0, acc[1][0], 0, 0, 0);                                  \
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb1, acc[1][1], 0, 0, 0);                                  \
-    }                                                                                                                     \
-  } while (0)
-
-  // sched_barrier: the compiler may not move anything across (it would otherwise collect the MFMAs behind the reads)
-#define MLGNN_PIN() __builtin_amdgcn_sched_barrier(0)
-  __builtin_amdgcn_s_barrier();                                   // K-step 0 has landed
-  uint32_t st = 0;                                               // byte offset of the stage being multiplied
-  MLGNN_READ(0, st);
-  MLGNN_READ(1, st);
-  MLGNN_READ(2, st);
-  MLGNN_PIN();
-  for (int t = 0; t + 1 < T; ++t) {
-    const uint32_t st_next = st + kGStageBytes == STAGES * kGStageBytes ? 0 : st + kGStageBytes;
-    MLGNN_LANDED(0, 8);
-    MLGNN_MFMA(0);
-    MLGNN_PIN();
-    MLGNN_READ(3, st);
-    MLGNN_LANDED(1, 8);
-    MLGNN_MFMA(1);
-    MLGNN_PIN();
-    __builtin_amdgcn_s_barrier();                                 // K-step t + 1 has landed
-    MLGNN_READ(0, st_next);
-    MLGNN_LANDED(2, 8);
-    MLGNN_MFMA(2);
-    MLGNN_PIN();
-    MLGNN_READ(1, st_next);
-    MLGNN_LANDED(3, 8);
-    MLGNN_MFMA(3);
-    MLGNN_PIN();
-    MLGNN_READ(2, st_next);
-    MLGNN_PIN();
-    st = st_next;
-  }
-  MLGNN_LANDED(0, 8);
-  MLGNN_MFMA(0);
-  MLGNN_PIN();
-  MLGNN_READ(3, st);
-  MLGNN_LANDED(1, 8);
-  MLGNN_MFMA(1);
-  MLGNN_LANDED(2, 4);
-  MLGNN_MFMA(2);
-  MLGNN_LANDED(3, 0);
-  MLGNN_MFMA(3);
-#undef MLGNN_PIN
-#undef MLGNN_READ
-#undef MLGNN_LANDED
-#undef MLGNN_MFMA
-
-  // this wave owns rows  m0 + 64 wm + 32 mi + (r & 3) + 8 (r >> 2) + 4 h,  columns  n0 + 64 wn + 32 ni + r31
-  const int row_base = m0 + 64 * wm + 4 * h;
-  const int col_base = n0 + 64 * wn + r31;
-#define MLGNN_FOR_ACC(BODY)                                                              \
-  _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                   \
-    const int row = row_base + 32 * mi + (r & 3) + 8 * (r >> 2), col = col_base + 32 * ni;             \
-    BODY                                                                                 \
+  // accumulator register r of tile (mi, ni): row m0 + 64 wm + 16 mi + 4 (l >> 4) + r, column n0 + 64 wn + 16 ni + (l & 15)
+  const int row_base = m0 + 64 * wm + 4 * q4;
+  const int col_base = n0 + 64 * wn + l15;
+#define MLGNN_FOR_ACC(BODY)                                                                           \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)   \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
+    const int row = row_base + 16 * mi + r, col = col_base + 16 * ni;                                 \
+    float v = acc[mi][ni][r];                                                                         \
+    BODY                                                                                              \
+    acc[mi][ni][r] = v;                                                                               \
   }
 
   if (p.d.slab) {
     float* slab = p.d.slab + (size_t)split * p.d.M * p.d.N;
-    MLGNN_FOR_ACC(slab[(size_t)row * p.d.N + col] = acc[mi][ni][r];)
+    MLGNN_FOR_ACC(slab[(size_t)row * p.d.N + col] = v;)
     return;
   }
   if (p.d.dot || p.d.ct) __syncthreads();                         // every wave has read its last fragments: LDS is free
   if (p.d.dot) {
     float part = 0.f;
-    MLGNN_FOR_ACC(part += acc[mi][ni][r] * bf16_to_f32(p.d.dot[(size_t)row * p.d.lddot + col]);)
+    MLGNN_FOR_ACC(part += v * bf16_to_f32(p.d.dot[(size_t)row * p.d.lddot + col]);)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
     float* wsum = reinterpret_cast<float*>(smem + 40960);        // behind the transposed staging image
@@ -294,30 +266,28 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
   if (p.d.aux) {
     MLGNN_FOR_ACC(
         const size_t at = (size_t)row * p.d.ldaux + col;
-        acc[mi][ni][r] += p.d.alpha * (p.d.aux_f32 ? reinterpret_cast<const float*>(p.d.aux)[at]
+        v += p.d.alpha * (p.d.aux_f32 ? reinterpret_cast<const float*>(p.d.aux)[at]
                                                    : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.d.aux)[at]));)
   }
   if (p.d.c) {
     if (p.d.c_f32) {
-      MLGNN_FOR_ACC(reinterpret_cast<float*>(p.d.c)[(size_t)row * p.d.ldc + col] = acc[mi][ni][r];)
+      MLGNN_FOR_ACC(reinterpret_cast<float*>(p.d.c)[(size_t)row * p.d.ldc + col] = v;)
     } else {
-      MLGNN_FOR_ACC(reinterpret_cast<uint16_t*>(p.d.c)[(size_t)row * p.d.ldc + col] = f32_to_bf16(acc[mi][ni][r]);)
+      MLGNN_FOR_ACC(reinterpret_cast<uint16_t*>(p.d.c)[(size_t)row * p.d.ldc + col] = f32_to_bf16(v);)
     }
   }
   if (p.d.ct) {
     // transposed copy through LDS: image[n][m] bf16 (pitch 272 B), a lane's 4 consecutive rows = one 8-byte write
     unsigned char* img = smem;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2 w;
-          w.x = (uint32_t)f32_to_bf16(acc[mi][ni][4 * g]) | ((uint32_t)f32_to_bf16(acc[mi][ni][4 * g + 1]) << 16);
-          w.y = (uint32_t)f32_to_bf16(acc[mi][ni][4 * g + 2]) | ((uint32_t)f32_to_bf16(acc[mi][ni][4 * g + 3]) << 16);
-          *reinterpret_cast<uint2*>(img + (64 * wn + 32 * ni + r31) * kGCtPitch + (64 * wm + 32 * mi + 8 * g + 4 * h) * 2) = w;
-        }
+      for (int ni = 0; ni < 4; ++ni) {
+        uint2 w;
+        w.x = (uint32_t)f32_to_bf16(acc[mi][ni][0]) | ((uint32_t)f32_to_bf16(acc[mi][ni][1]) << 16);
+        w.y = (uint32_t)f32_to_bf16(acc[mi][ni][2]) | ((uint32_t)f32_to_bf16(acc[mi][ni][3]) << 16);
+        *reinterpret_cast<uint2*>(img + (64 * wn + 16 * ni + l15) * kGCtPitch + (64 * wm + 16 * mi + 4 * q4) * 2) = w;
+      }
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
@@ -404,7 +374,7 @@ int gemm_nt_launch(const GemmDesc& d, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<kStages>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_nt_kernel<kStages>, dim3(gemm_nt_workgroups(d)), dim3(kGThreads), lds, s, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<kStages>), dim3(gemm_nt_workgroups(d)), dim3(kGThreads), lds, s, p);
   return (int)hipGetLastError();
 }
 

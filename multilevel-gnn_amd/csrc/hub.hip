@@ -108,8 +108,7 @@ __global__ __launch_bounds__(kBlock) void hub_combine_fwd_kernel(const HubFwdArg
         mu /= deg;
         a2 /= deg;
         lse = mu;
-        float muc = fminf(fmaxf(mu, kPowLo), kPowHi);
-        keep_nonfinite(muc, mu);
+        const float muc = clamp_nan(mu, kPowLo, kPowHi);
         res = fast_exp2(fast_log2(muc) / p);
       }
       if (a.add_root) {

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """MFMA counters of the large GEMM (csrc/gemm_nt.hip) from a rocprofv3 --pmc pass:
   python tools/summarize_mfma.py <counter_collection.csv glob> <kernel_stats.csv glob> <out.json> [commit]
-Per distinct product (grouped by its MFMA instruction count): SQ_VALU_MFMA_BUSY_CYCLES (= 32 cycles per
-v_mfma_f32_32x32x16_bf16, summed over the 1024 SIMDs), SQ_INSTS_VALU_MFMA_MOPS_BF16, GRBM_GUI_ACTIVE (sum over the 8
+Per distinct product (grouped by its MFMA instruction count): SQ_VALU_MFMA_BUSY_CYCLES (= 16 cycles per
+v_mfma_f32_16x16x32_bf16, i.e. 1024 FLOP per busy cycle, summed over the 1024 SIMDs), SQ_INSTS_VALU_MFMA_MOPS_BF16, GRBM_GUI_ACTIVE (sum over the 8
 XCDs) and the utilisation  busy / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)."""
 import collections
 import csv
@@ -33,7 +33,7 @@ def main():
     for busy, vs in sorted(groups.items()):
         n = len(vs)
         grbm = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in vs) / n
-        rows.append({"mfma_instructions": busy / 32.0, "GFLOP": busy / 32.0 * 32 * 32 * 16 * 2 / 1e9, "dispatches": n,
+        rows.append({"mfma_instructions": busy / 16.0, "GFLOP": busy / 16.0 * 16 * 16 * 32 * 2 / 1e9, "dispatches": n,
                      "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_INSTS_VALU_MFMA_MOPS_BF16": vs[0].get("SQ_INSTS_VALU_MFMA_MOPS_BF16"),
                      "SQ_BUSY_CYCLES": sum(v.get("SQ_BUSY_CYCLES", 0.0) for v in vs) / n, "GRBM_GUI_ACTIVE": grbm,
                      "mfma_utilisation": busy / 1024.0 / (grbm / 8.0) if grbm else None})

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 11
+#define MLGNN_ABI_VERSION 12
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -372,6 +372,24 @@ int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J, int dtype);
 int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transposed, const float* bias, const void* residual,
                       const float* row_max, int ln_mode, const float* gamma, const float* beta, float ln_eps,
                       float* rstd_out, float* row_max_out, void* c, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
+
+/*
+ * The MLP's second Linear run backwards with the ReLU + LayerNorm backward in the epilogue (fp32):
+ *     dA = grad_out [N,R] * W [R,J] (w_transposed != 0: W is the Linear's own weight [R,J]; 0: its transpose [J,R]),
+ *     gy = dA [gamma xhat + beta > 0],  g = gamma gy,
+ *     grad_h [N,J] = rstd (g - mean_row(g) - xhat mean_row(g xhat)),
+ *     grad_gamma_beta [2,J] = (sum_rows gy xhat, sum_rows gy),  row_max_out [N] = max_c |grad_h|
+ * Replaces: the autograd of Linear <- ReLU <- LayerNorm inside MLP (models/gcn_lib/sparse/torch_nn.py:54-75) for a
+ * hidden activation stored normalised (xhat, rstd: mlgnn_tallgemm_nt ln_mode 1) -- the product dA never reaches memory.
+ * R, J in {64, 128, 256} with R * J * 4 <= 128 KiB, N * J * 4 < 4 GiB; row_max [N] or NULL: max |grad_out[i]|.
+ * workspace: mlgnn_tallgemm_lnbwd_workspace_bytes(R, J) bytes.  Deterministic (fixed-order partial sums).
+ */
+int mlgnn_tallgemm_lnbwd_supported(int64_t N, int64_t R, int64_t J);
+int64_t mlgnn_tallgemm_lnbwd_workspace_bytes(int64_t R, int64_t J);
+int mlgnn_tallgemm_lnbwd(const float* grad_out, const float* w, int w_transposed, const float* row_max,
+                         const float* xhat, const float* rstd, const float* gamma, const float* beta,
+                         float* grad_h, float* row_max_out, float* grad_gamma_beta, void* workspace,
+                         int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream);
 
 /*
  * Gradient of an embedding lookup e = table[idx] for a dense cotangent:

@@ -88,11 +88,15 @@ __global__ __launch_bounds__(kBlock) void tallgemm_split_weight_kernel(const flo
 struct TgArgs {
   const float* a; const f16x8* image; const float* bias; const float* res; const float* rowmax; float* c;
   const float* gamma; const float* beta; float* rstd_out; float* rowmax_out; float ln_eps;
+  const float* xhat; const float* rstd_in; float* ws;        // LN = 3
   int N; int R; int J;
 };
 
 constexpr int kTgBlock = 512;              // 8 waves: two per SIMD share the LDS image and hide each other's loads
 constexpr int kTgWaves = kTgBlock / kWave;
+// LN = 3 at 8 column tiles: 128 accumulator registers + the epilogue's operands do not fit the 256 registers a wave has
+// at two waves per SIMD (the compiler spilled 75 of them: 0.67 ms); one wave per SIMD has 512 and runs without spills
+template <int JT, int LN> constexpr int tg_block() { return (LN == 3 && JT == 8) ? 256 : kTgBlock; }
 
 // LN = 0: plain.  LN = 1: the result rows are layer-normalised in the epilogue -- c receives
 // xhat = (v - mean) * rstd (no affine), rstd_out the per-row 1/sigma and rowmax_out max |relu(gamma xhat + beta)|,
@@ -101,8 +105,14 @@ constexpr int kTgWaves = kTgBlock / kWave;
 // a normalised activation: relu(gamma[k] a + beta[k]) is applied while it is loaded.  Together they remove the
 // LayerNorm+ReLU pass between the two Linears of the MLP (torch_nn.py:54-75): the hidden activation is written
 // once (normalised) and read by its consumers directly.
+// LN = 3: the product is the gradient arriving at such a hidden activation, dA = dY W (the MLP's second Linear run
+// backwards); the epilogue takes it through the ReLU and the LayerNorm it came out of --
+//     gy = dA [gamma xhat + beta > 0],  g = gamma gy,  c = rstd (g - mean(g) - xhat mean(g xhat)),
+// d gamma / d beta partials per workgroup to ws, max |c| per row to rowmax_out -- so dA [N,J] is never written and
+// read back (1.3 GB per layer at config 1) and the separate LayerNorm backward pass does not exist.
 template <int JT, int KS, int LN>       // 32-column tiles = J / 32, 16-deep k-steps = R / 16
-__global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
+__global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const TgArgs p) {
+  constexpr int kTgBlock = tg_block<JT, LN>(), kTgWaves = kTgBlock / kWave;      // (shadow the defaults above)
   extern __shared__ f16x8 wlds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -117,13 +127,20 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
 
   float bias[JT];
 #pragma unroll
-  for (int t = 0; t < JT; ++t) bias[t] = p.bias ? p.bias[32 * t + r31] : 0.f;
+  for (int t = 0; t < JT; ++t) bias[t] = (LN != 3 && p.bias) ? p.bias[32 * t + r31] : 0.f;
   // LN = 1: affine parameters of this lane's output columns; LN = 2: those of the k index, staged in LDS
   float og[LN == 1 ? JT : 1], ob[LN == 1 ? JT : 1];
+  float dg[LN == 3 ? JT : 1], db[LN == 3 ? JT : 1];          // LN = 3: this lane's share of d gamma / d beta
+#pragma unroll
+  for (int t = 0; t < (LN == 3 ? JT : 1); ++t) { dg[t] = 0.f; db[t] = 0.f; }
   float* kg = reinterpret_cast<float*>(wlds + n_frag);         // [R] gamma then [R] beta, behind the image
   if constexpr (LN == 1) {
 #pragma unroll
     for (int t = 0; t < JT; ++t) { og[t] = p.gamma[32 * t + r31]; ob[t] = p.beta[32 * t + r31]; }
+  }
+  if constexpr (LN == 3) {             // gamma / beta of the OUTPUT columns, read from LDS in the epilogue (registers are short)
+    for (int i = threadIdx.x; i < 32 * JT; i += kTgBlock) { kg[i] = p.gamma[i]; kg[32 * JT + i] = p.beta[i]; }
+    __syncthreads();
   }
   if constexpr (LN == 2) {
     for (int i = threadIdx.x; i < R; i += kTgBlock) { kg[i] = p.gamma[i]; kg[R + i] = p.beta[i]; }
@@ -183,6 +200,9 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
       }
     }
 
+    float my_rstd = 0.f;
+    if constexpr (LN == 3) my_rstd = p.rstd_in[arow];
+
     f32x16 acc[JT];
 #pragma unroll
     for (int t = 0; t < JT; ++t)
@@ -218,6 +238,26 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
       }
     }
 
+    // LN = 3: the stored normalised activation at this lane's result positions, kXhRows result rows ahead of their use
+    // (32-bit byte offsets from the uniform base: [N, J] fp32 < 4 GiB, checked on the host); the accumulators of the rows
+    // already written free the registers for it as the epilogue advances
+    constexpr int kXhRows = JT >= 8 ? 8 : 4;
+    float xh[LN == 3 ? kXhRows : 1][JT];
+    auto load_xhat = [&](float (&dst)[JT], int r) {
+      const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * h, p.N - 1);
+      const uint32_t off = ((uint32_t)row * (uint32_t)(32 * JT) + (uint32_t)r31) * 4u;
+#pragma unroll
+      for (int t = 0; t < JT; ++t)
+        dst[t] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.xhat) + off + 128u * t);
+    };
+    if constexpr (LN == 3) {
+      // (compiler barrier: the gamma / beta reads of the epilogue are invariant across tiles and would otherwise be
+      // hoisted out of the tile loop into registers that the k-loop needs)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < kXhRows; ++r) load_xhat(xh[r], r);
+    }
+
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);
     // the row scale lives in the lane that loaded that row
 #pragma unroll
@@ -250,6 +290,39 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
           for (int t = 0; t < JT; ++t) p.c[(size_t)row * p.J + 32 * t + r31] = v[t];
           if (r31 == 0) { p.rstd_out[row] = rs; p.rowmax_out[row] = ym; }
         }
+      } else if constexpr (LN == 3) {
+        const float rs = __shfl(my_rstd, rr);
+        const bool live = row < p.N;                               // rows past N shadow the last row: no contribution
+        float x[JT], gg[JT], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+          x[t] = xh[r % kXhRows][t];
+          const float gam = kg[32 * t + r31];
+          const float y = fmaf(x[t], gam, kg[32 * JT + 32 * t + r31]);
+          const float gy = (live && y > 0.f) ? acc[t][r] * us : 0.f;
+          dg[t] = fmaf(gy, x[t], dg[t]);
+          db[t] += gy;
+          gg[t] = gy * gam;
+          s1 += gg[t];
+          s2 = fmaf(gg[t], x[t], s2);
+        }
+        if (r + kXhRows < 16) load_xhat(xh[r % kXhRows], r + kXhRows);     // this group of registers is free again
+        s1 = half_sum(s1) * (1.0f / (32 * JT));
+        s2 = half_sum(s2) * (1.0f / (32 * JT));
+        float om = 0.f;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+          gg[t] = rs * (gg[t] - s1 - x[t] * s2);
+          om = fmaxf(om, fabsf(gg[t]));
+        }
+        om = half_max(om);
+        if (live) {
+          const uint32_t off = ((uint32_t)row * (uint32_t)(32 * JT) + (uint32_t)r31) * 4u;
+#pragma unroll
+          for (int t = 0; t < JT; ++t) *reinterpret_cast<float*>(reinterpret_cast<char*>(p.c) + off + 128u * t) = gg[t];
+          if (r31 == 0) p.rowmax_out[row] = om;
+        }
+        asm volatile("" ::: "memory");                             // keep the rows apart: gamma / beta are re-read per row
       } else if (row < p.N) {
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
@@ -258,6 +331,29 @@ __global__ __launch_bounds__(kTgBlock) void tallgemm_kernel(const TgArgs p) {
           p.c[(size_t)row * p.J + 32 * t + r31] = v;
         }
       }
+    }
+  }
+
+  if constexpr (LN == 3) {
+    // d gamma / d beta: the two half-waves hold the same columns -> waves (through the LDS the weight image no longer
+    // needs) -> one [2, J] partial per workgroup, summed in a fixed order by reduce_partials
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(wlds);                 // [wave][2][J]
+#pragma unroll
+    for (int t = 0; t < JT; ++t) {
+      dg[t] += __shfl_xor(dg[t], 32);
+      db[t] += __shfl_xor(db[t], 32);
+      if (h == 0) {
+        red[(wave * 2 + 0) * 32 * JT + 32 * t + r31] = dg[t];
+        red[(wave * 2 + 1) * 32 * JT + 32 * t + r31] = db[t];
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * 32 * JT; idx += kTgBlock) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < kTgWaves; ++w) sum += red[w * 2 * 32 * JT + idx];
+      p.ws[(size_t)blockIdx.x * 2 * 32 * JT + idx] = sum;
     }
   }
 }
@@ -328,6 +424,7 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transpose
   p.a = (const float*)a; p.image = (const f16x8*)workspace; p.bias = bias; p.res = (const float*)residual;
   p.rowmax = row_max; p.c = (float*)c;
   p.gamma = gamma; p.beta = beta; p.rstd_out = rstd_out; p.rowmax_out = row_max_out; p.ln_eps = ln_eps;
+  p.xhat = nullptr; p.rstd_in = nullptr; p.ws = nullptr;
   p.N = (int)N; p.R = (int)R; p.J = (int)J;
   const size_t lds = (size_t)R * J * 4 + (ln_mode == 2 ? (size_t)R * 8 : 0);
   const int64_t tiles = (N + 31) / 32;
@@ -358,5 +455,71 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transpose
 #undef MLGNN_TG_CASE
 #undef MLGNN_TG_LAUNCH
   if (!launched) return MLGNN_E_SHAPE;
+  return (int)hipGetLastError();
+}
+
+// ---- dA = go W through ReLU + LayerNorm backward in the epilogue (LN = 3 above) --------------------------------------
+namespace mlgnn {
+constexpr int kTgLnBwdBlocks = 256;        // persistent workgroups = rows of the d gamma / d beta partial table
+}
+
+extern "C" int mlgnn_tallgemm_lnbwd_supported(int64_t N, int64_t R, int64_t J) {
+  const bool ok = (J == 64 || J == 128 || J == 256) && (R == 64 || R == 128 || R == 256) && R * J * 4 <= kTgMaxLds;
+  return (N > 0 && N <= INT32_MAX && ok) ? 1 : 0;
+}
+
+extern "C" int64_t mlgnn_tallgemm_lnbwd_workspace_bytes(int64_t R, int64_t J) {
+  if (R <= 0 || J <= 0) return MLGNN_E_SHAPE;
+  return R * J * 4 + kTgHeader * 16 + (int64_t)kTgLnBwdBlocks * 2 * J * 4;
+}
+
+extern "C" int mlgnn_tallgemm_lnbwd(const float* go, const float* w, int w_transposed, const float* row_max,
+                                    const float* xhat, const float* rstd, const float* gamma, const float* beta,
+                                    float* grad_h, float* row_max_out, float* grad_gamma_beta, void* workspace,
+                                    int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream) {
+  if (N < 0 || N > INT32_MAX) return MLGNN_E_SHAPE;
+  if (R <= 0 || J <= 0 || !mlgnn_tallgemm_lnbwd_supported(N > 0 ? N : 1, R, J)) return MLGNN_E_SHAPE;
+  if (N * J * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;               // 32-bit byte offsets into xhat / grad_h
+  if (!grad_gamma_beta) return MLGNN_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) return (int)hipMemsetAsync(grad_gamma_beta, 0, 2 * J * sizeof(float), s);
+  if (!go || !w || !xhat || !rstd || !gamma || !beta || !grad_h || !row_max_out || !workspace) return MLGNN_E_NULL;
+  if (workspace_bytes < mlgnn_tallgemm_lnbwd_workspace_bytes(R, J)) return MLGNN_E_WORKSPACE;
+  if (((reinterpret_cast<uintptr_t>(go) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
+    return MLGNN_E_ALIGN;
+  const int n_frag_lanes = (int)(R / 16) * (int)(J / 32) * 64;
+  hipLaunchKernelGGL(tallgemm_split_weight_kernel, dim3((n_frag_lanes + 255) / 256), dim3(256), 0, s, w,
+                     (f16x8*)workspace, (int)J, (int)R, w_transposed);
+  int err = (int)hipGetLastError();
+  if (err) return err;
+  TgArgs p;
+  p.a = go; p.image = (const f16x8*)workspace; p.bias = nullptr; p.res = nullptr; p.rowmax = row_max; p.c = grad_h;
+  p.gamma = gamma; p.beta = beta; p.rstd_out = nullptr; p.rowmax_out = row_max_out; p.ln_eps = 0.f;
+  p.xhat = xhat; p.rstd_in = rstd;
+  p.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + R * J * 4 + kTgHeader * 16);
+  p.N = (int)N; p.R = (int)R; p.J = (int)J;
+  size_t lds = (size_t)R * J * 4 + (size_t)J * 8;                        // weight image, then gamma / beta of the J columns
+  if (lds < (size_t)kTgWaves * 2 * J * 4) lds = (size_t)kTgWaves * 2 * J * 4;   // ... re-used for the partials at the end
+  const int64_t tiles = (N + 31) / 32;
+  const int block = J == 256 ? tg_block<8, 3>() : kTgBlock, waves = block / kWave;
+  int grid = (int)((tiles + waves - 1) / waves);
+  if (grid > kTgLnBwdBlocks) grid = kTgLnBwdBlocks;
+  const dim3 g(grid), b(block);
+  bool launched = false;
+#define MLGNN_TG_LNBWD(JT_, KS_)                                                                      \
+  if (!launched && J == 32 * JT_ && R == 16 * KS_) {                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, 3>),           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds + 2048);          \
+    hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, 3>), g, b, lds, s, p);                               \
+    launched = true;                                                                                  \
+  }
+  MLGNN_TG_LNBWD(2, 4) MLGNN_TG_LNBWD(2, 8) MLGNN_TG_LNBWD(2, 16)
+  MLGNN_TG_LNBWD(4, 4) MLGNN_TG_LNBWD(4, 8) MLGNN_TG_LNBWD(4, 16)
+  MLGNN_TG_LNBWD(8, 4) MLGNN_TG_LNBWD(8, 8)
+#undef MLGNN_TG_LNBWD
+  if (!launched) return MLGNN_E_SHAPE;
+  err = (int)hipGetLastError();
+  if (err) return err;
+  launch_reduce_partials(p.ws, grad_gamma_beta, grid, 2 * (int)J, s);
   return (int)hipGetLastError();
 }

@@ -50,6 +50,31 @@ def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None, bt_tr
     return (out, rstd, rmax) if mode == 1 else out
 
 
+def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
+    """``dA = go [N,R] @ w [R,J]`` (``w``: the Linear's own weight) taken through ReLU + LayerNorm backward in the GEMM's
+    epilogue (``csrc/tallgemm.hip`` LN = 3): ``-> (grad_h [N,J], grad_gamma, grad_beta, max |grad_h| per row)`` for a
+    hidden activation stored normalised (``xhat``, ``rstd``).  The caller checks :func:`tall_matmul_ln_backward_supported`."""
+    N, R = go.shape
+    J = w.shape[1]
+    go, w, xhat = go.contiguous(), w.contiguous(), xhat.contiguous()
+    gh = torch.empty((N, J), dtype=torch.float32, device=go.device)
+    ggb = torch.empty((2, J), dtype=torch.float32, device=go.device)
+    rmax = torch.empty(N, dtype=torch.float32, device=go.device)
+    nbytes = int(_lib.lib.mlgnn_tallgemm_lnbwd_workspace_bytes(R, J))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
+    ROW_MAX_STATS["given" if row_max is not None else "computed"] += 1
+    rc = _lib.lib.mlgnn_tallgemm_lnbwd(go.data_ptr(), w.data_ptr(), 1, _lib.ptr(row_max), xhat.data_ptr(), rstd.data_ptr(),
+                                       gamma.contiguous().data_ptr(), beta.contiguous().data_ptr(), gh.data_ptr(),
+                                       rmax.data_ptr(), ggb.data_ptr(), ws.data_ptr(), nbytes, N, R, J,
+                                       torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mlgnn_tallgemm_lnbwd")
+    return gh, ggb[0], ggb[1], rmax
+
+
+def tall_matmul_ln_backward_supported(N, R, J):
+    return bool(_lib.lib.mlgnn_tallgemm_lnbwd_supported(N, R, J)) and N * J * 4 < (1 << 32)
+
+
 def tall_matmul_supported(N, R, J, dtype=torch.float32):
     return dtype in _DTYPE_IDS and bool(_lib.lib.mlgnn_tallgemm_supported(N, R, J, _DTYPE_IDS[dtype]))
 
@@ -141,8 +166,12 @@ class _FusedMLP2(torch.autograd.Function):
         has_b1, has_b2 = ctx.flags
         go = go.contiguous()
         gw2, gb2 = _wgrad(go, xhat, gamma.contiguous(), beta.contiguous())          # go^T relu(gamma xhat + beta)
-        gy = tall_matmul_nt(go, w2, row_max=_rm(go), bt_transposed=True)
-        gh, ggamma, gbeta, gh_max = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
+        if tall_matmul_ln_backward_supported(go.shape[0], go.shape[1], w2.shape[1]):
+            # dA = go W2 never reaches memory: ReLU + LayerNorm backward run in the product's epilogue
+            gh, ggamma, gbeta, gh_max = tall_matmul_ln_backward(go, w2, xhat, rstd, gamma, beta, _rm(go))
+        else:
+            gy = tall_matmul_nt(go, w2, row_max=_rm(go), bt_transposed=True)
+            gh, ggamma, gbeta, gh_max = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
         gw1, gb1 = _wgrad(gh, x)
         gx = tall_matmul_nt(gh, w1, row_max=gh_max, bt_transposed=True) if ctx.needs_input_grad[0] else None
         return (gx, gw1, gb1 if has_b1 else None, ggamma, gbeta, gw2, gb2 if has_b2 else None,

@@ -72,3 +72,64 @@ def test_unsupported_shapes_are_reported():
     assert not tall_matmul_supported(1000, 100, 64)          # R not 16 * 2^k
     assert not tall_matmul_supported(1000, 512, 64)          # R beyond the supported widths
     assert not tall_matmul_supported(1000, 256, 256)         # weight image > 128 KiB
+
+
+@pytest.mark.parametrize("N,R,J", [(33, 64, 64), (4097, 128, 256), (20000, 256, 128), (70001, 128, 256), (9000, 64, 128),
+                                   (8191, 128, 64)])
+def test_layernorm_backward_epilogue_vs_fp64(N, R, J):
+    """``dA = go W`` taken through ReLU + LayerNorm backward inside the product (LN = 3 epilogue) against the same
+    chain in fp64 autograd: grad_h elementwise to 1e-5 of the row's scale, d gamma / d beta (sums over N rows) to 1e-5,
+    the per-row maxima exact for the grad_h the kernel wrote."""
+    from mlgnn.dense import tall_matmul_ln_backward, tall_matmul_ln_backward_supported
+    assert tall_matmul_ln_backward_supported(N, R, J)
+    gen = torch.Generator().manual_seed(N + J)
+    y1 = torch.randn(N, J, generator=gen, dtype=torch.float64) * 2 + 0.3
+    gamma = (torch.rand(J, generator=gen, dtype=torch.float64) + 0.5) * torch.where(torch.rand(J, generator=gen) < 0.2, -1.0, 1.0)
+    beta = torch.randn(J, generator=gen, dtype=torch.float64) * 0.3
+    w = torch.randn(R, J, generator=gen, dtype=torch.float64) / R ** 0.5      # the second Linear's weight [out=R, in=J]
+    go = torch.randn(N, R, generator=gen, dtype=torch.float64)
+    go[::5] *= 1e-3
+    eps = 1e-5
+    mu, var = y1.mean(1, keepdim=True), y1.var(1, unbiased=False, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    xhat = ((y1 - mu) * rstd).float()                           # what the forward stored (fp32)
+    rstd32 = rstd.squeeze(1).float()
+    # fp64 reference on exactly those stored values
+    xh = xhat.double().requires_grad_(True)
+    g64, b64 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a = torch.relu(xh * g64 + b64)
+    (a @ w.t() * go).sum().backward()
+    gxh = xh.grad                                               # gradient at xhat; LayerNorm backward from there:
+    r = rstd32.double()[:, None]
+    ref_h = r * (gxh - gxh.mean(1, keepdim=True) - xh.detach() * (gxh * xh.detach()).mean(1, keepdim=True))
+    gh, gg, gb, rmax = tall_matmul_ln_backward(go.float().cuda(), w.float().cuda(), xhat.cuda(), rstd32.cuda(),
+                                               gamma.float().cuda(), beta.float().cuda())
+    gh, gg, gb, rmax = gh.cpu(), gg.cpu(), gb.cpu(), rmax.cpu()
+    # entries whose pre-activation sits within rounding of the ReLU kink may fall on either side
+    kink = ((xhat.double() * gamma + beta).abs() < 1e-6)
+    assert int(kink.sum()) < 50
+    clean = ~kink.any(1)
+    scale = ref_h.abs().amax(1, keepdim=True).clamp(min=1e-30)
+    err = ((gh.double() - ref_h).abs() / scale)[clean].max().item()
+    assert err < 1e-5, err
+    assert_close(gg[~kink.any(0)], g64.grad[~kink.any(0)].float(), 1e-5, "grad gamma")
+    assert_close(gb[~kink.any(0)], b64.grad[~kink.any(0)].float(), 1e-5, "grad beta")
+    assert torch.equal(rmax, gh.abs().amax(1))
+
+
+def test_layernorm_backward_epilogue_equals_two_pass():
+    """The fused epilogue against the two launches it replaces (tall GEMM, then LayerNorm backward) on the same inputs."""
+    from mlgnn.dense import tall_matmul_ln_backward, tall_matmul_nt
+    from mlgnn.norm import ln_backward_normalised
+    gen = torch.Generator().manual_seed(5)
+    N, R, J = 30000, 128, 256
+    xhat = torch.nn.functional.layer_norm(torch.randn(N, J, generator=gen), (J,)).cuda()
+    rstd = (torch.rand(N, generator=gen) + 0.5).cuda()
+    gamma, beta = (torch.rand(J, generator=gen) + 0.5).cuda(), (torch.randn(J, generator=gen) * 0.2).cuda()
+    w = (torch.randn(R, J, generator=gen) / R ** 0.5).cuda()
+    go = torch.randn(N, R, generator=gen).cuda()
+    gy = tall_matmul_nt(go, w, bt_transposed=True)
+    ref = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
+    out = tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta)
+    for a, b, what in zip(out, ref, ("grad_h", "grad_gamma", "grad_beta", "row_max")):
+        assert_close(a, b, 1e-6, what)

@@ -28,8 +28,10 @@
 
 namespace mlgnn {
 
+// columns [0, n_a) -> ca, [n_a, n_b) -> cb (bf16, + sum of squares), [n_b, N) -> cc; cc == nullptr: two ranges
 int slab_reduce_launch(const float* slab, int splits, int M, int N, int n_a, void* ca, int64_t lda, int ca_f32,
-                       uint16_t* cb, int64_t ldb, float* sq_partial, int blocks, hipStream_t s);
+                       uint16_t* cb, int64_t ldb, float* sq_partial, int blocks, hipStream_t s, int n_b = 0,
+                       void* cc = nullptr, int64_t ldc = 0, int cc_f32 = 0);
 
 constexpr float kDplEps = 1e-15f;
 constexpr int kDplPartials = 1024;       // workgroups of the streaming reductions (= partial sums each)
@@ -295,7 +297,7 @@ inline int dpl_splits(int tiles, int ktiles) {
 struct DplLayout {       // byte offsets into the forward workspace (kept for the backward) and scratch
   size_t stack, T, G, scratch, total;      // stack [2K + C, N]: T^T, S~^T, Z^T;  T [N,K];  G [K,K]
   size_t slab, part_a2, part_dot, part_g2, part_ent;
-  int splits_ag, splits_x;
+  int splits_ag;
 };
 
 DplLayout dpl_layout(int64_t N, int64_t K, int64_t C) {
@@ -305,11 +307,13 @@ DplLayout dpl_layout(int64_t N, int64_t K, int64_t C) {
   L.T = o; o += dpl_align((size_t)N * K * 2);
   L.G = o; o += dpl_align((size_t)K * K * 2);
   L.scratch = o;
-  const int tiles_ag = (int)((K / kGemmTile) * (2 * K / kGemmTile)), tiles_x = (int)((K / kGemmTile) * (C / kGemmTile));
-  L.splits_ag = dpl_splits(tiles_ag, (int)(N / kGemmBK));
-  L.splits_x = dpl_splits(tiles_x, (int)(N / kGemmBK));
-  const size_t slab_ag = (size_t)L.splits_ag * K * 2 * K * 4, slab_x = (size_t)L.splits_x * K * C * 4;
-  L.slab = o; o += dpl_align(slab_ag > slab_x ? slab_ag : slab_x);
+  // [A' | G | X'] = S~^T [T | S~ | Z] is ONE product over the whole stack, split along K into about 1.5 workgroups
+  // per CU (measured at 4096 / 1024 / 256, 144 tiles: 2 / 3 / 4 / 6 splits 0.110 / 0.104 / 0.109 / 0.113 ms forward)
+  const int tiles_agx = (int)((K / kGemmTile) * ((2 * K + C) / kGemmTile));
+  int sp = (384 + tiles_agx / 2) / tiles_agx;
+  if (sp > (int)(N / kGemmBK)) sp = (int)(N / kGemmBK);
+  L.splits_ag = sp < 1 ? 1 : sp;
+  L.slab = o; o += dpl_align((size_t)L.splits_ag * K * (2 * K + C) * 4);
   L.part_a2 = o; o += dpl_align(kDplPartials * 4);
   L.part_dot = o; o += dpl_align((size_t)(N / kGemmTile) * (K / kGemmTile) * 4);
   L.part_g2 = o; o += dpl_align(kDplPartials * 4);
@@ -400,25 +404,15 @@ extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const vo
     d.dot = S; d.lddot = K; d.dot_partial = p_dot;
     DPL_CHECK(gemm_nt_launch(d, st));
   }
-  // 4. [A' | G] = S~^T [T | S~]
+  // 4. [A' | G | X'] = S~^T [T | S~ | Z]: one product over the whole stack (T^T, S~^T, Z^T are its rows), one reduce
   {
     GemmDesc d{};
     d.nseg = 1;
-    d.seg[0] = GemmSeg{St, Tt, N, N, n};               // B operand: rows 0 .. 2K of the stack (T^T then S~^T)
-    d.M = k; d.N = 2 * k; d.splits = L.splits_ag; d.slab = slab;
+    d.seg[0] = GemmSeg{St, Tt, N, N, n};
+    d.M = k; d.N = 2 * k + c; d.splits = L.splits_ag; d.slab = slab;
     DPL_CHECK(gemm_nt_launch(d, st));
-    DPL_CHECK(slab_reduce_launch(slab, L.splits_ag, k, 2 * k, k, adj_out, K, out_dtype == MLGNN_DTYPE_F32, G, K, p_g2,
-                                 kDplPartials, st));
-  }
-  // 5. X' = S~^T Z
-  {
-    GemmDesc d{};
-    d.nseg = 1;
-    d.seg[0] = GemmSeg{St, Zt, N, N, n};
-    d.M = k; d.N = c; d.splits = L.splits_x; d.slab = slab;
-    DPL_CHECK(gemm_nt_launch(d, st));
-    DPL_CHECK(slab_reduce_launch(slab, L.splits_x, k, c, c, x_out, C, out_dtype == MLGNN_DTYPE_F32, nullptr, 0, nullptr,
-                                 kDplPartials, st));
+    DPL_CHECK(slab_reduce_launch(slab, L.splits_ag, k, 2 * k + c, k, adj_out, K, out_dtype == MLGNN_DTYPE_F32, G, K, p_g2,
+                                 kDplPartials, st, 2 * k, x_out, C, out_dtype == MLGNN_DTYPE_F32));
   }
   // 6. link / entropy
   DplFinalArgs f{p_a2, kDplPartials, p_dot, (int)((N / kGemmTile) * (K / kGemmTile)), p_g2, kDplPartials, p_ent, sm_blocks,

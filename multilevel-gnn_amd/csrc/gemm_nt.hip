@@ -303,9 +303,10 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
 // dimension lda), columns [n_a, N) to `cb` (bf16, leading dimension ldb) with their squares summed per workgroup
 // into sq_partial (||.||_F^2 of that column range).
 struct SlabReduceArgs {
-  const float* slab; int splits; int M, N, n_a;
+  const float* slab; int splits; int M, N, n_a, n_b;
   void* ca; int64_t lda; int ca_f32;
   uint16_t* cb; int64_t ldb; float* sq_partial;
+  void* cc; int64_t ldc; int cc_f32;
 };
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs p) {
@@ -320,14 +321,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs p
       const float4 v = reinterpret_cast<const float4*>(p.slab + (size_t)z * p.M * p.N)[i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    if (col < p.n_a) {
-      if (p.ca_f32) {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.ca) + (size_t)row * p.lda + col) = s;
+    if (col < p.n_a || col >= p.n_b) {
+      const bool first = col < p.n_a;
+      void* dst = first ? p.ca : p.cc;
+      const size_t at = first ? (size_t)row * p.lda + col : (size_t)row * p.ldc + (col - p.n_b);
+      if (first ? p.ca_f32 : p.cc_f32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + at) = s;
       } else {
         uint2 w;
         w.x = (uint32_t)f32_to_bf16(s.x) | ((uint32_t)f32_to_bf16(s.y) << 16);
         w.y = (uint32_t)f32_to_bf16(s.z) | ((uint32_t)f32_to_bf16(s.w) << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.ca) + (size_t)row * p.lda + col) = w;
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + at) = w;
       }
     } else {
       sq += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
@@ -379,9 +383,11 @@ int gemm_nt_launch(const GemmDesc& d, hipStream_t s) {
 }
 
 int slab_reduce_launch(const float* slab, int splits, int M, int N, int n_a, void* ca, int64_t lda, int ca_f32,
-                       uint16_t* cb, int64_t ldb, float* sq_partial, int blocks, hipStream_t s) {
-  if (N % 4 || n_a % 4 || lda % 4 || (cb && ldb % 4)) return MLGNN_E_SHAPE;
-  SlabReduceArgs p{slab, splits, M, N, n_a, ca, lda, ca_f32, cb, ldb, sq_partial};
+                       uint16_t* cb, int64_t ldb, float* sq_partial, int blocks, hipStream_t s, int n_b, void* cc,
+                       int64_t ldc, int cc_f32) {
+  if (!cc) n_b = N;                                    // two ranges: [0, n_a) -> ca, [n_a, N) -> cb
+  if (N % 4 || n_a % 4 || n_b % 4 || lda % 4 || (cb && ldb % 4) || (cc && ldc % 4) || n_b < n_a || n_b > N) return MLGNN_E_SHAPE;
+  SlabReduceArgs p{slab, splits, M, N, n_a, n_b, ca, lda, ca_f32, cb, ldb, sq_partial, cc, ldc, cc_f32};
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
   return (int)hipGetLastError();
 }

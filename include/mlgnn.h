@@ -402,7 +402,7 @@ int mlgnn_embedding_bwd(const float* grad_e, const int32_t* perm, const int32_t*
                         int64_t T, int64_t d, int dtype, void* stream);
 
 /*
- * Large bf16 GEMM with fp32 accumulation on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), both operands with the
+ * Large bf16 GEMM with fp32 accumulation on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16), both operands with the
  * contraction index contiguous:
  *     C[M,N] = sum_{s < nseg} A_s[M,K_s] * B_s[N,K_s]^T  (+ alpha * aux[M,N])
  * Replaces: the dense products of torch_geometric's dense_diff_pool (s^T x, s^T adj s, s s^T) as called from

@@ -14,6 +14,13 @@
 // dropped terms (ml, lm, ll) are <= 2^-24 relative, i.e. the result carries fp32-level error
 // (~2e-7 relative per product, tests/test_wgrad_gpu.py) at 6/16 of the fp32-MFMA cost per FLOP -- fast
 // enough that the kernel is bound by reading A and B once from HBM.  db is summed in plain fp32.
+//
+// F16 (the caller knows max |A| and max |B|, e.g. from the row maxima their producers emit): the scaled two-way fp16
+// split of tallgemm.hip instead -- each operand times an exact power of two that puts its largest magnitude into
+// [2^13, 2^14), x = x_hi + x_lo in fp16, three MFMAs (hi hi + lo hi + hi lo) on v_mfma_f32_32x32x16_f16, exact
+// un-scaling of the partial.  Elements within 2^-17 of the maximum keep 22 significant bits (3 * 2^-22 = 7e-7 per
+// product at worst, rms far below), smaller ones lose them gradually down to 2^-38 of the maximum; half the MFMAs and
+// two LDS planes instead of three: 0.29 -> 0.21 ms at 640 000 x 128 x 256.
 #include <type_traits>
 
 #include "common.h"
@@ -23,11 +30,13 @@ namespace mlgnn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int kTile = 32;
 
 struct WgradArgs {
   const float* a; const float* b; float* ws;
   const float* b_gamma; const float* b_beta;      // non-NULL: the B operand is relu(b_gamma[col] * b + b_beta[col])
+  const float* a_max; const float* b_max;         // F16: device scalars, max |A| and max |B| (B after the affine + ReLU)
   int N; int M; int K; int out_cols;      // out_cols = M*K + M
   int row0;                               // first row of this launch
   int rows;                               // rows of this launch (a multiple of the stage when !MASKED)
@@ -61,6 +70,25 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m
   h = __builtin_bit_cast(bf16x8, hw); m = __builtin_bit_cast(bf16x8, mw); l = __builtin_bit_cast(bf16x8, lw);
 }
 
+// power of two s with  max * s in [2^13, 2^14)  and its inverse; max = 0 or denormal -> 1  (as in tallgemm.hip)
+__device__ __forceinline__ void wg_pow2_scale(float max_abs, float& s, float& inv) {
+  int e = (int)((__builtin_bit_cast(uint32_t, max_abs) >> 23) & 0xff);       // biased exponent
+  e = min(max(e, 20), 234);
+  s = __builtin_bit_cast(float, (uint32_t)(254 + 13 - e) << 23);
+  inv = __builtin_bit_cast(float, (uint32_t)(e - 13) << 23);
+}
+
+// scaled two-way split of 8 floats: hi = fp16(x s), lo = fp16(x s - hi)
+__device__ __forceinline__ void split2(const float (&v)[8], float s, f16x8& h, f16x8& l) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * s;
+    const _Float16 hh = (_Float16)x;
+    h[j] = hh;
+    l[j] = (_Float16)(x - (float)hh);
+  }
+}
+
 // NW waves per workgroup laid out WM x WK over the output, TM x TK tiles of 32x32 per wave.  The row slab of
 // the workgroup is walked in stages of 32 (16) rows.  Work item of the loader = (operand column, group of
 // 8 consecutive rows): 8 dword loads (each coalesced across the lanes: consecutive lanes hold consecutive
@@ -75,7 +103,7 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m
 // `global_load_dword v, v_offset, s[row base]` with the per-thread byte offset fixed for the whole kernel and
 // one scalar row base per load, and nothing is masked.  MASKED = true: row clamps and zero fill (tile padding,
 // the last N % 32 rows).
-template <int NW, int WM, int WK, int TM, int TK, bool DB, bool MASKED>
+template <int NW, int WM, int WK, int TM, int TK, bool DB, bool MASKED, bool F16>
 __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArgs p) {
   static_assert(WM * WK == NW, "wave layout must cover the workgroup");
   constexpr int kThreads = NW * kWave;
@@ -85,7 +113,8 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
   constexpr int UA = MP * kGroups, UB = KP * kGroups;                       // (column, row group) items per stage
   constexpr int PA = (UA + kThreads - 1) / kThreads, PB = (UB + kThreads - 1) / kThreads;
   constexpr int kPlane = kGroups * W;                                       // 16-byte entries per plane
-  constexpr int kBuf = 3 * kPlane;
+  constexpr int kPlanes = F16 ? 2 : 3;
+  constexpr int kBuf = kPlanes * kPlane;
   __shared__ bf16x8 tile[(DB ? 2 : 1) * kBuf];
   static_assert(sizeof(bf16x8) == 16, "operand entry is one ds_read_b128");
 
@@ -132,8 +161,15 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
     ub[q].off = (uint32_t)(ub[q].grp * 8 * p.K + min(ub[q].col, p.K - 1)) * 4u;
   }
 
+  float sa = 1.f, sb = 1.f, unscale = 1.f;        // F16: operand scales (exact powers of two) and their inverse product
+  if constexpr (F16) {
+    float ia, ib;
+    wg_pow2_scale(*p.a_max, sa, ia);
+    wg_pow2_scale(*p.b_max, sb, ib);
+    unscale = ia * ib;
+  }
   constexpr int kSets = DB ? 2 : 1;               // DB: two stages of loads in flight (register sets by stage parity)
-  float sa[kSets][PA][8], sb[kSets][PB][8];
+  float sa_[kSets][PA][8], sb_[kSets][PB][8];      // staged loads
   float bg[PB], bb[PB];                             // affine + ReLU applied to the B operand (layer-normalised input)
 #pragma unroll
   for (int q = 0; q < PB; ++q) {
@@ -157,26 +193,26 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
         const char* aj = arow + (size_t)j * p.M * 4;
         const char* bj = brow + (size_t)j * p.K * 4;
 #pragma unroll
-        for (int q = 0; q < PA; ++q) sa[S][q][j] = *reinterpret_cast<const float*>(aj + ua[q].off);
+        for (int q = 0; q < PA; ++q) sa_[S][q][j] = *reinterpret_cast<const float*>(aj + ua[q].off);
 #pragma unroll
-        for (int q = 0; q < PB; ++q) sb[S][q][j] = *reinterpret_cast<const float*>(bj + ub[q].off);
+        for (int q = 0; q < PB; ++q) sb_[S][q][j] = *reinterpret_cast<const float*>(bj + ub[q].off);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
 #pragma unroll
         for (int q = 0; q < PA; ++q)
-          sa[S][q][j] = p.a[(size_t)min(r0 + ua[q].grp * 8 + j, p.N - 1) * p.M + min(ua[q].col, p.M - 1)];
+          sa_[S][q][j] = p.a[(size_t)min(r0 + ua[q].grp * 8 + j, p.N - 1) * p.M + min(ua[q].col, p.M - 1)];
 #pragma unroll
         for (int q = 0; q < PB; ++q)
-          sb[S][q][j] = p.b[(size_t)min(r0 + ub[q].grp * 8 + j, p.N - 1) * p.K + min(ub[q].col, p.K - 1)];
+          sb_[S][q][j] = p.b[(size_t)min(r0 + ub[q].grp * 8 + j, p.N - 1) * p.K + min(ub[q].col, p.K - 1)];
       }
     }
   };
   // valid == false (a stage past the end of the slab, DB pipeline only): the stage is committed as zeros, so
   // multiplying it is a no-op and the loop body stays free of branches (see below)
   auto commit_one = [&](bf16x8* t, const Unit& un, float (&st)[8], int r0, bool valid, float* sum, float g, float b,
-                        bool act) {
+                        bool act, float scale) {
     if (act) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) st[j] = relu_keep_nan(fmaf(st[j], g, b));
@@ -195,27 +231,33 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
       for (int j = 0; j < 8; ++j) s += st[j];
       *sum += s;
     }
-    bf16x8 h, m, l;
-    split3(st, h, m, l);
-    t[un.lds] = h; t[kPlane + un.lds] = m; t[2 * kPlane + un.lds] = l;
+    if constexpr (F16) {
+      f16x8 h, l;
+      split2(st, scale, h, l);
+      t[un.lds] = __builtin_bit_cast(bf16x8, h); t[kPlane + un.lds] = __builtin_bit_cast(bf16x8, l);
+    } else {
+      bf16x8 h, m, l;
+      split3(st, h, m, l);
+      t[un.lds] = h; t[kPlane + un.lds] = m; t[2 * kPlane + un.lds] = l;
+    }
   };
   auto commit = [&](auto set_c, int buf, int r0, bool valid) {
     constexpr int S = decltype(set_c)::value;
     bf16x8* t = tile + buf * kBuf;
 #pragma unroll
     for (int q = 0; q < PA; ++q)
-      if (UA % kThreads == 0 || threadIdx.x + q * kThreads < UA) commit_one(t, ua[q], sa[S][q], r0, valid, &bsum[q], 1.f, 0.f, false);
+      if (UA % kThreads == 0 || threadIdx.x + q * kThreads < UA) commit_one(t, ua[q], sa_[S][q], r0, valid, &bsum[q], 1.f, 0.f, false, sa);
 #pragma unroll
     for (int q = 0; q < PB; ++q)
-      if (UB % kThreads == 0 || threadIdx.x + q * kThreads < UB) commit_one(t, ub[q], sb[S][q], r0, valid, nullptr, bg[q], bb[q], p.b_gamma != nullptr);
+      if (UB % kThreads == 0 || threadIdx.x + q * kThreads < UB) commit_one(t, ub[q], sb_[S][q], r0, valid, nullptr, bg[q], bb[q], p.b_gamma != nullptr, sb);
   };
   auto multiply = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < kStageRows / 16; ++kk) {
       const bf16x8* g = tile + buf * kBuf + (2 * kk + half) * W;
-      bf16x8 a[TM][3], b[TK][3];
+      bf16x8 a[TM][kPlanes], b[TK][kPlanes];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < kPlanes; ++pl) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i][pl] = g[pl * kPlane + m_base + i * kTile + l31];
 #pragma unroll
@@ -226,6 +268,15 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
 #pragma unroll
         for (int j = 0; j < TK; ++j) {
           f32x16 c = acc[i][j];                       // small terms first
+          if constexpr (F16) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, a[i][0]), al = __builtin_bit_cast(f16x8, a[i][1]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, b[j][0]), bl = __builtin_bit_cast(f16x8, b[j][1]);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+            acc[i][j] = c;
+            continue;
+          }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
@@ -286,7 +337,7 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m_base + i * kTile + (r & 3) + 8 * (r >> 2) + 4 * half;    // C/D layout of 32x32 MFMA
-        if (m < p.M && k < p.K) out[(size_t)m * p.K + k] = acc[i][j][r];
+        if (m < p.M && k < p.K) out[(size_t)m * p.K + k] = F16 ? acc[i][j][r] * unscale : acc[i][j][r];
       }
     }
   // db: fold the row groups of each A column through LDS (fixed order)
@@ -338,13 +389,13 @@ static int wgrad_blocks(int64_t N, const WgradPlan& pl) {
   return (int)b;
 }
 
-template <bool MASKED>
+template <bool MASKED, bool F16>
 static bool launch_wgrad(const WgradPlan& pl, const WgradArgs& a, int nblk, hipStream_t s) {
   const dim3 grid(nblk);
   bool launched = false;
 #define MLGNN_WG_CASE(NW_, WM_, WK_, TM_, TK_)                                                       \
   if (pl.nw == NW_ && pl.wm == WM_ && pl.wk == WK_ && pl.tm == TM_ && pl.tk == TK_) {                \
-    hipLaunchKernelGGL((linear_wgrad_kernel<NW_, WM_, WK_, TM_, TK_, NW_ == 8, MASKED>), grid,       \
+    hipLaunchKernelGGL((linear_wgrad_kernel<NW_, WM_, WK_, TM_, TK_, NW_ == 8, MASKED, F16>), grid,  \
                        dim3(NW_ * kWave), 0, s, a);                                                  \
     launched = true;                                                                                 \
   }
@@ -379,7 +430,7 @@ extern "C" int64_t mlgnn_linear_wgrad_workspace_floats(int64_t N, int64_t M, int
 }
 
 extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const float* x_gamma, const float* x_beta,
-                                  float* grad_w_b, float* workspace,
+                                  const float* grad_out_max, const float* x_max, float* grad_w_b, float* workspace,
                                   int64_t workspace_floats, int64_t N, int64_t M, int64_t K, int dtype,
                                   void* stream) {
   if (dtype == MLGNN_DTYPE_BF16) {                          // grad_out, x bf16; grad_w_b fp32
@@ -408,6 +459,8 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const flo
   WgradArgs a;
   a.a = (const float*)grad_out; a.b = (const float*)x; a.ws = workspace;
   a.b_gamma = x_gamma; a.b_beta = x_gamma ? x_beta : nullptr;
+  const bool f16 = grad_out_max != nullptr && x_max != nullptr;       // both maxima known: scaled fp16 split
+  a.a_max = grad_out_max; a.b_max = x_max;
   if (x_gamma && !x_beta) return MLGNN_E_NULL;
   a.N = (int)N; a.M = (int)M; a.K = (int)K; a.out_cols = cols;
   // unpadded operands: whole stages go through the unmasked kernel, the last N % 32 rows through the masked one
@@ -416,13 +469,13 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const flo
   int slots = 0;
   if (main_rows > 0) {
     a.row0 = 0; a.rows = main_rows; a.slot0 = 0;
-    if (!launch_wgrad<false>(pl, a, nblk, s)) return MLGNN_E_SHAPE;
+    if (!(f16 ? launch_wgrad<false, true>(pl, a, nblk, s) : launch_wgrad<false, false>(pl, a, nblk, s))) return MLGNN_E_SHAPE;
     slots = nblk;
   }
   if (main_rows < N || N == 0) {
     a.row0 = main_rows; a.rows = (int)N - main_rows; a.slot0 = slots;
     const int nb = padded ? nblk : 1;
-    if (!launch_wgrad<true>(pl, a, nb, s)) return MLGNN_E_SHAPE;
+    if (!(f16 ? launch_wgrad<true, true>(pl, a, nb, s) : launch_wgrad<true, false>(pl, a, nb, s))) return MLGNN_E_SHAPE;
     slots += nb;
   }
   int err = (int)hipGetLastError();

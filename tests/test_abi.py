@@ -25,7 +25,7 @@ def test_header_and_binding_agree():
 def test_version_and_error_codes():
     from mlgnn import _lib
     lib = _lib.lib
-    assert lib.mlgnn_version() == 12
+    assert lib.mlgnn_version() == 13
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 1, 0, 0) == (8 + 256) * 2 * 128      # 8 workgroups minimum + the long-row launch
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 8, 0, 0) == (8 + 256) * 9 * 128
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 9, 0, 0) == -2
@@ -94,7 +94,7 @@ def test_argument_errors_of_the_dense_and_embedding_entry_points():
     assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 100, 256, BF16) == -2       # M % 64 != 0
     assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 256, 256, F32) == -2        # fp32: 64 tiles > 32
     assert lib.mlgnn_linear_wgrad_workspace_floats(10000, 128, 128, 9) == -4
-    wg = lambda dtype, M, K, ws=1 << 30: lib.mlgnn_linear_wgrad(None, None, None, None, None, None, ws, 1000, M, K, dtype, None)
+    wg = lambda dtype, M, K, ws=1 << 30: lib.mlgnn_linear_wgrad(None, None, None, None, None, None, None, None, ws, 1000, M, K, dtype, None)
     assert wg(BF16, 512, 256) == -1 and wg(BF16, 512, 200) == -2 and wg(3, 128, 128) == -4
     # LayerNorm: widths per storage type
     assert lib.mlgnn_layernorm_bwd_workspace_floats(1000, 512, F32) > 0 and lib.mlgnn_layernorm_bwd_workspace_floats(1000, 512, BF16) > 0

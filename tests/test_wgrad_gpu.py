@@ -53,7 +53,7 @@ def test_wgrad_keeps_fp32_accuracy_at_any_magnitude(scale):
     n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K, 0))
     ws = torch.empty(n, device=dev)
     out = torch.empty(M * K + M, device=dev)
-    rc = _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), None, None, out.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
+    rc = _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), None, None, None, None, out.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
                                      torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     got = out[:M * K].view(M, K).cpu().double()
@@ -65,9 +65,57 @@ def test_wgrad_keeps_fp32_accuracy_at_any_magnitude(scale):
     assert_close(out[M * K:].cpu().double() / scale, ref_b / scale, 1e-5, "bias grad")
     # bitwise reproducible (fixed summation order)
     out2 = torch.empty_like(out)
-    _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), None, None, out2.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
+    _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), None, None, None, None, out2.data_ptr(), ws.data_ptr(), n, N, M, K, 0,
                                 torch.cuda.current_stream().cuda_stream)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-12, 1e9])
+@pytest.mark.parametrize("slack", [1.0, 37.0])
+def test_wgrad_scaled_fp16_split_accuracy(scale, slack):
+    """With max |grad_out| and max |x| supplied the kernel takes the scaled two-way fp16 split (3 MFMAs per product):
+    still fp32-GEMM-level error at any magnitude, also when the supplied bounds are loose (`slack` x the true maxima),
+    for rows a thousand times smaller than the largest, and bitwise reproducible."""
+    from mlgnn import _lib
+    N, M, K = 30000, 128, 256
+    gen = torch.Generator().manual_seed(4)
+    g = torch.randn(N, M, generator=gen) * scale
+    g[::7] *= 1e-3
+    x = torch.randn(N, K, generator=gen)
+    x[::11] *= 1e-2
+    ref = g.double().t() @ x.double()
+    mag = (g.double().abs().t() @ x.double().abs())
+    dev = "cuda:0"
+    gd, xd = g.to(dev), x.to(dev)
+    gmax, xmax = (gd.abs().amax() * slack).reshape(1), (xd.abs().amax() * slack).reshape(1)
+    n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K, 0))
+    ws = torch.empty(n, device=dev)
+    out = torch.empty(M * K + M, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), None, None, gmax.data_ptr(), xmax.data_ptr(), out.data_ptr(),
+                                     ws.data_ptr(), n, N, M, K, 0, st)
+    assert rc == 0
+    got = out[:M * K].view(M, K).cpu().double()
+    err = ((got - ref).abs() / mag).max().item()
+    lib = (gd.t() @ xd).cpu().double()
+    lib_err = ((lib - ref).abs() / mag).max().item()
+    assert err < 1e-6, err
+    assert err < 4 * lib_err + 1e-7, (err, lib_err)
+    assert_close(out[M * K:].cpu().double() / scale, g.double().sum(0) / scale, 1e-5, "bias grad")
+    out2 = torch.empty_like(out)
+    _lib.lib.mlgnn_linear_wgrad(gd.data_ptr(), xd.data_ptr(), None, None, gmax.data_ptr(), xmax.data_ptr(), out2.data_ptr(),
+                                ws.data_ptr(), n, N, M, K, 0, st)
+    assert torch.equal(out, out2)
+    # the small rows alone: their share of the result keeps its accuracy next to the large rows
+    small = torch.zeros(N, dtype=torch.bool)
+    small[::7] = True
+    ref_s = g[small].double().t() @ x[small].double()
+    g2 = torch.where(small[:, None], g, torch.zeros_like(g)).to(dev)
+    _lib.lib.mlgnn_linear_wgrad(g2.data_ptr(), xd.data_ptr(), None, None, gmax.data_ptr(), xmax.data_ptr(), out2.data_ptr(),
+                                ws.data_ptr(), n, N, M, K, 0, st)
+    mag_s = (g[small].double().abs().t() @ x[small].double().abs())
+    err_s = ((out2[:M * K].view(M, K).cpu().double() - ref_s).abs() / mag_s).max().item()
+    assert err_s < (2e-5 if slack > 1 else 2e-6), err_s    # 2^-10 of the maximum (x a loose bound): bits run out gradually
 
 
 def test_unsupported_shapes_use_library_gemm():

@@ -42,7 +42,7 @@ for (K, O) in [(128, 256), (256, 128), (3, 128)]:
     ws = torch.empty(n, device=dev)
     outb = torch.empty(O * K + O, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    r["mlgnn_linear_wgrad"] = timed(lambda: _lib.lib.mlgnn_linear_wgrad(go.data_ptr(), x.data_ptr(), None, None, outb.data_ptr(),
+    r["mlgnn_linear_wgrad"] = timed(lambda: _lib.lib.mlgnn_linear_wgrad(go.data_ptr(), x.data_ptr(), None, None, None, None, outb.data_ptr(),
                                                                          ws.data_ptr(), n, N, O, K, 0, st))
     from mlgnn.dense import tall_matmul_nt, tall_matmul_supported
     if tall_matmul_supported(N, K, O):

@@ -126,3 +126,29 @@ def test_unsupported_shapes_use_library_gemm():
     w = torch.randn(256, 256, device="cuda:0", requires_grad=True)
     linear(x, w).sum().backward()
     assert_close(w.grad, x.detach().sum(0)[None, :].expand(256, 256), 1e-4)
+
+
+@pytest.mark.parametrize("N,M,K", [(9001, 37, 128), (10000, 64, 64), (8195, 128, 10), (12345, 256, 128), (8192, 32, 32),
+                                   (20011, 200, 40)])
+@pytest.mark.parametrize("act", [False, True])
+def test_wgrad_scaled_split_every_layout(N, M, K, act):
+    """The scaled fp16 split through every kernel layout the planner picks (4- and 8-wave workgroups, padded tiles, the
+    masked remainder launch, the affine + ReLU operand prologue) against fp64."""
+    from mlgnn.dense import _wgrad
+    gen = torch.Generator().manual_seed(N + M)
+    go = torch.randn(N, M, generator=gen)
+    x = torch.randn(N, K, generator=gen)
+    gamma, beta = torch.rand(K, generator=gen) + 0.5, torch.randn(K, generator=gen) * 0.3
+    xa = torch.relu(x.double() * gamma.double() + beta.double()) if act else x.double()
+    ref_w, ref_b = go.double().t() @ xa, go.double().sum(0)
+    mag = go.double().abs().t() @ xa.abs() + 1e-30
+    god, xd = go.cuda(), x.cuda()
+    kw = dict(x_gamma=gamma.cuda(), x_beta=beta.cuda()) if act else {}
+    gmax = god.abs().amax().reshape(1)
+    xmax = xa.abs().amax().float().cuda().reshape(1)
+    w, b = _wgrad(god, xd, go_max=gmax, x_max=xmax, **kw)
+    w0, b0 = _wgrad(god, xd, **kw)                                  # the exact three-way split, for scale
+    err = ((w.cpu().double() - ref_w).abs() / mag).max().item()
+    err0 = ((w0.cpu().double() - ref_w).abs() / mag).max().item()
+    assert err < 1e-6 and err < 8 * err0 + 2e-7, (err, err0)
+    assert_close(b.cpu().double(), ref_b, 1e-5, "bias grad")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 13
+#define MLGNN_ABI_VERSION 14
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -233,16 +233,17 @@ int mlgnn_layernorm_act_bwd(const void* grad_out, const void* x, const float* ga
  * (the caller then uses a library GEMM).  workspace: mlgnn_linear_wgrad_workspace_floats floats.
  * x_gamma, x_beta [K] or NULL: x is a layer-normalised activation (mlgnn_tallgemm_nt ln_mode 1) and the Linear's
  * real input was relu(x_gamma x + x_beta): applied to the operand as it is loaded.
- * grad_out_max, x_max: device scalars or NULL (fp32 only).  Both given -- max |grad_out| and max |x| (of the activated
- * x when x_gamma is set; any upper bound within a few binades will do), e.g. the maxima of the row_max side outputs of
- * the kernels that produced the operands: the operands are scaled by exact powers of two and split in two fp16 terms
- * (three MFMAs per product instead of six; 7e-7 per product at worst for elements within 2^-17 of the maximum).
+ * grad_out_row_max, x_row_max [N] or NULL (fp32 only): max |row| of grad_out and of x (of the activated x when x_gamma
+ * is set; upper bounds within a few binades will do) -- the row_max side outputs of the kernels that produced the
+ * operands.  Both given: the operands are scaled by exact powers of two derived from their global maxima and split in
+ * two fp16 terms (three MFMAs per product instead of six; 7e-7 per product at worst for elements within 2^-17 of the
+ * maximum).
  * MLGNN_DTYPE_BF16 (BASELINE configs[4]): grad_out, x are bf16, grad_w_b stays fp32 (bf16 products accumulated in
  * fp32, per-slab partials summed in fixed order); M % 64 == 0, K % 128 == 0, x_gamma / x_beta must be NULL.
  */
 int64_t mlgnn_linear_wgrad_workspace_floats(int64_t N, int64_t M, int64_t K, int dtype);
 int mlgnn_linear_wgrad(const void* grad_out, const void* x, const float* x_gamma, const float* x_beta,
-                       const float* grad_out_max, const float* x_max, float* grad_w_b, float* workspace,
+                       const float* grad_out_row_max, const float* x_row_max, float* grad_w_b, float* workspace,
                        int64_t workspace_floats, int64_t N, int64_t M, int64_t K, int dtype,
                        void* stream);
 

@@ -36,7 +36,8 @@ constexpr int kTile = 32;
 struct WgradArgs {
   const float* a; const float* b; float* ws;
   const float* b_gamma; const float* b_beta;      // non-NULL: the B operand is relu(b_gamma[col] * b + b_beta[col])
-  const float* a_max; const float* b_max;         // F16: device scalars, max |A| and max |B| (B after the affine + ReLU)
+  const float* a_max; const float* b_max;         // F16: kMaxParts partial maxima each of max |A| and max |B| (B after
+                                                  // the affine + ReLU), written by rowmax_partials_kernel
   int N; int M; int K; int out_cols;      // out_cols = M*K + M
   int row0;                               // first row of this launch
   int rows;                               // rows of this launch (a multiple of the stage when !MASKED)
@@ -76,6 +77,36 @@ __device__ __forceinline__ void wg_pow2_scale(float max_abs, float& s, float& in
   e = min(max(e, 20), 234);
   s = __builtin_bit_cast(float, (uint32_t)(254 + 13 - e) << 23);
   inv = __builtin_bit_cast(float, (uint32_t)(e - 13) << 23);
+}
+
+// F16: the operands' global maxima come from the row maxima their producers wrote ([N] each): kMaxParts slices are
+// reduced by a small launch in front, every wave of the main kernel folds the partials itself (no atomics, no host
+// round trip, one launch instead of two library reductions)
+constexpr int kMaxParts = 256;
+__global__ __launch_bounds__(256) void rowmax_partials_kernel(const float* __restrict__ a_rm, const float* __restrict__ b_rm,
+                                                              int n, float* __restrict__ part) {
+  __shared__ float red[2][4];
+  const int per = (n + kMaxParts - 1) / kMaxParts;
+  const int lo = blockIdx.x * per, hi = min(n, lo + per);
+  float ma = 0.f, mb = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) { ma = fmaxf(ma, a_rm[i]); mb = fmaxf(mb, b_rm[i]); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, off)); mb = fmaxf(mb, __shfl_xor(mb, off)); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ma; red[1][threadIdx.x >> 6] = mb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    part[kMaxParts + blockIdx.x] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  }
+}
+__device__ __forceinline__ float fold_max_parts(const float* part) {          // the same value in every lane
+  const int lane = threadIdx.x & (kWave - 1);
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxParts / kWave; ++i) m = fmaxf(m, part[lane + i * kWave]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  return m;
 }
 
 // scaled two-way split of 8 floats: hi = fp16(x s), lo = fp16(x s - hi)
@@ -164,8 +195,8 @@ __global__ __launch_bounds__(NW * kWave) void linear_wgrad_kernel(const WgradArg
   float sa = 1.f, sb = 1.f, unscale = 1.f;        // F16: operand scales (exact powers of two) and their inverse product
   if constexpr (F16) {
     float ia, ib;
-    wg_pow2_scale(*p.a_max, sa, ia);
-    wg_pow2_scale(*p.b_max, sb, ib);
+    wg_pow2_scale(fold_max_parts(p.a_max), sa, ia);
+    wg_pow2_scale(fold_max_parts(p.b_max), sb, ib);
     unscale = ia * ib;
   }
   constexpr int kSets = DB ? 2 : 1;               // DB: two stages of loads in flight (register sets by stage parity)
@@ -426,11 +457,11 @@ extern "C" int64_t mlgnn_linear_wgrad_workspace_floats(int64_t N, int64_t M, int
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   WgradPlan pl;
   if (!plan_wgrad((int)((M + kTile - 1) / kTile), (int)((K + kTile - 1) / kTile), &pl)) return MLGNN_E_SHAPE;
-  return (int64_t)(wgrad_blocks(N, pl) + 1) * (M * K + M);
+  return (int64_t)(wgrad_blocks(N, pl) + 1) * (M * K + M) + 2 * kMaxParts;      // partials per slab, then the operands' maxima
 }
 
 extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const float* x_gamma, const float* x_beta,
-                                  const float* grad_out_max, const float* x_max, float* grad_w_b, float* workspace,
+                                  const float* grad_out_row_max, const float* x_row_max, float* grad_w_b, float* workspace,
                                   int64_t workspace_floats, int64_t N, int64_t M, int64_t K, int dtype,
                                   void* stream) {
   if (dtype == MLGNN_DTYPE_BF16) {                          // grad_out, x bf16; grad_w_b fp32
@@ -454,13 +485,18 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const flo
   if (N > 0 && (!grad_out || !x)) return MLGNN_E_NULL;
   const int nblk = wgrad_blocks(N, pl);
   const int cols = (int)(M * K + M);
-  if (workspace_floats < (int64_t)(nblk + 1) * cols) return MLGNN_E_WORKSPACE;
+  if (workspace_floats < (int64_t)(nblk + 1) * cols + 2 * kMaxParts) return MLGNN_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   WgradArgs a;
   a.a = (const float*)grad_out; a.b = (const float*)x; a.ws = workspace;
   a.b_gamma = x_gamma; a.b_beta = x_gamma ? x_beta : nullptr;
-  const bool f16 = grad_out_max != nullptr && x_max != nullptr;       // both maxima known: scaled fp16 split
-  a.a_max = grad_out_max; a.b_max = x_max;
+  const bool f16 = grad_out_row_max != nullptr && x_row_max != nullptr && N > 0;     // row maxima of both: scaled fp16 split
+  a.a_max = a.b_max = nullptr;
+  if (f16) {
+    float* part = workspace + (int64_t)(nblk + 1) * cols;
+    hipLaunchKernelGGL(rowmax_partials_kernel, dim3(kMaxParts), dim3(256), 0, s, grad_out_row_max, x_row_max, (int)N, part);
+    a.a_max = part; a.b_max = part + kMaxParts;
+  }
   if (x_gamma && !x_beta) return MLGNN_E_NULL;
   a.N = (int)N; a.M = (int)M; a.K = (int)K; a.out_cols = cols;
   // unpadded operands: whole stages go through the unmasked kernel, the last N % 32 rows through the masked one

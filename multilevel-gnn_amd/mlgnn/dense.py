@@ -86,26 +86,23 @@ _WGRAD_EXACT = os.environ.get("MLGNN_WGRAD_EXACT", "0") == "1"        # always t
 
 def _wgrad(go, x, x_gamma=None, x_beta=None, go_max=None, x_max=None):
     """``(go^T x' [M,K], colsum go [M])`` with ``x' = x`` or ``relu(x_gamma x + x_beta)`` (``csrc/wgrad.hip``).
-    ``go_max`` / ``x_max``: one-element device tensors with (upper bounds of) ``max |go|`` and ``max |x'|``; when both are
-    given (fp32) the kernel uses the scaled two-way fp16 split -- half the MFMAs of the exact three-way bf16 split."""
+    ``go_max`` / ``x_max``: ``max |row|`` of ``go`` and of ``x'`` ([N] fp32, the side outputs of the kernels that produced
+    them); when both are given (fp32) the kernel uses the scaled two-way fp16 split -- half the MFMAs of the exact
+    three-way bf16 split."""
     N, K = x.shape
     M = go.shape[1]
     dt = _DTYPE_IDS[x.dtype]
     n = int(_lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K, dt))
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     out = torch.empty(M * K + M, dtype=torch.float32, device=x.device)          # fp32 for either storage type
-    if x.dtype != torch.float32 or go_max is None or x_max is None or _WGRAD_EXACT:
+    if (x.dtype != torch.float32 or go_max is None or x_max is None or _WGRAD_EXACT
+            or go_max.shape[0] != N or x_max.shape[0] != N):
         go_max = x_max = None
     rc = _lib.lib.mlgnn_linear_wgrad(go.data_ptr(), x.data_ptr(), _lib.ptr(x_gamma), _lib.ptr(x_beta), _lib.ptr(go_max),
                                      _lib.ptr(x_max), out.data_ptr(), ws.data_ptr(), n, N, M, K, dt,
                                      torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_linear_wgrad")
     return out[:M * K].view(M, K), out[M * K:]
-
-
-def _global_max(row_max):
-    """max over a ``max |row|`` side output ([N] -> one-element device tensor), or None when there is none."""
-    return None if row_max is None else row_max.amax().reshape(1)
 
 
 class _TallLinear(torch.autograd.Function):
@@ -118,7 +115,7 @@ class _TallLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        ctx.x_max = _global_max(row_max_of(x)) if x.dtype == torch.float32 else None
+        ctx.x_max = row_max_of(x) if x.dtype == torch.float32 else None
         if tall_matmul_supported(x.shape[0], x.shape[1], weight.shape[0], x.dtype):
             # fp32: the kernel holds the residual tile in registers (<= 128 columns); bf16: any width
             fuse = residual is not None and (weight.shape[0] <= 128 or x.dtype == torch.bfloat16)
@@ -145,8 +142,7 @@ class _TallLinear(torch.autograd.Function):
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if x.dtype == torch.float32 or _lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K, _DTYPE_IDS[x.dtype]) > 0:
-                gw, gb = _wgrad(go, x, go_max=_global_max(row_max_of(go)) if ctx.x_max is not None else None,
-                                x_max=ctx.x_max)
+                gw, gb = _wgrad(go, x, go_max=row_max_of(go), x_max=ctx.x_max)
                 gw, gb = gw.to(x.dtype), (gb.to(x.dtype) if ctx.has_bias else None)
             else:                                    # bf16 widths the transposed-read kernel does not tile
                 gw = go.t().mm(x)
@@ -173,8 +169,8 @@ class _FusedMLP2(torch.autograd.Function):
             out = out + residual
         ctx.save_for_backward(x, xhat, rstd, w1, w2, gamma, beta)
         ctx.flags = (b1 is not None, b2 is not None)
-        # global maxima of the weight-gradient operands (x; the activated hidden layer), from the row maxima at hand
-        ctx.maxima = (_global_max(_rm(x)), _global_max(rmax))
+        # row maxima of the weight-gradient operands (x; the activated hidden layer): their scales in the backward
+        ctx.maxima = (_rm(x), rmax)
         return out
 
     @staticmethod
@@ -185,15 +181,14 @@ class _FusedMLP2(torch.autograd.Function):
         has_b1, has_b2 = ctx.flags
         go = go.contiguous()
         x_max, act_max = ctx.maxima
-        go_max = _global_max(_rm(go))
-        gw2, gb2 = _wgrad(go, xhat, gamma.contiguous(), beta.contiguous(), go_max=go_max, x_max=act_max)   # go^T relu(gamma xhat + beta)
+        gw2, gb2 = _wgrad(go, xhat, gamma.contiguous(), beta.contiguous(), go_max=_rm(go), x_max=act_max)   # go^T relu(gamma xhat + beta)
         if tall_matmul_ln_backward_supported(go.shape[0], go.shape[1], w2.shape[1]):
             # dA = go W2 never reaches memory: ReLU + LayerNorm backward run in the product's epilogue
             gh, ggamma, gbeta, gh_max = tall_matmul_ln_backward(go, w2, xhat, rstd, gamma, beta, _rm(go))
         else:
             gy = tall_matmul_nt(go, w2, row_max=_rm(go), bt_transposed=True)
             gh, ggamma, gbeta, gh_max = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
-        gw1, gb1 = _wgrad(gh, x, go_max=_global_max(gh_max), x_max=x_max)
+        gw1, gb1 = _wgrad(gh, x, go_max=gh_max, x_max=x_max)
         gx = tall_matmul_nt(gh, w1, row_max=gh_max, bt_transposed=True) if ctx.needs_input_grad[0] else None
         return (gx, gw1, gb1 if has_b1 else None, ggamma, gbeta, gw2, gb2 if has_b2 else None,
                 go if ctx.needs_input_grad[7] else None, None)

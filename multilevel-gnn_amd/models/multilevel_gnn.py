@@ -15,6 +15,20 @@ import torch.nn as nn
 from mlgnn.project import segment_project
 from .gcn_lib.sparse.torch_vertex import GraphConv
 
+
+class HeadConv2d(nn.Conv2d):
+    """``nn.Conv2d`` of the pathway head (multilevel_gnn.py:98-104) with the same parameters and ``state_dict`` keys.  A
+    1x1 kernel (the reference's configs: ``conv_kernel_list: [1, 1]``) is a product over the channel dimension and runs
+    as one GEMM on the channel-last view instead of through the convolution library, whose first call per shape
+    searches / compiles solvers at run time."""
+
+    def forward(self, x):
+        if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.dilation == (1, 1)
+                and self.groups == 1 and self.padding_mode == "zeros" and x.dim() == 4):
+            y = torch.nn.functional.linear(x.permute(0, 2, 3, 1), self.weight[:, :, 0, 0], self.bias)
+            return y.permute(0, 3, 1, 2)
+        return super().forward(x)
+
 N_PATHWAYS = 146          # hard-coded in the reference's forward (:239) and head sizing (:121)
 N_OMICS = 3
 
@@ -100,7 +114,7 @@ class MultilevelGNN(nn.Module):
         """Level 2 (:98-128): conv stack, max-pool, dropout, MLP head -- attributes of the model itself."""
         convs, cin = [], args.final_channels
         for cout, kern in zip(args.conv_channel_list, args.conv_kernel_list):
-            convs += [nn.Conv2d(cin, cout, kern, padding=kern // 2), nn.ReLU()]
+            convs += [HeadConv2d(cin, cout, kern, padding=kern // 2), nn.ReLU()]
             cin = cout
         self.conv_model = nn.ModuleList(convs)
 

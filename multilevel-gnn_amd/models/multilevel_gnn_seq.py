@@ -10,7 +10,7 @@ omics selection is the ``only_mrna_pred`` switch (first two columns of the conv 
 import torch
 import torch.nn as nn
 
-from .multilevel_gnn import N_OMICS, N_PATHWAYS, MultilevelGNN
+from .multilevel_gnn import N_OMICS, N_PATHWAYS, HeadConv2d, MultilevelGNN
 
 
 class PathwayHeadSeq(nn.Module):
@@ -29,7 +29,7 @@ class PathwayHeadSeq(nn.Module):
 
         convs, cin = [], args.final_channels
         for cout, kern in zip(args.conv_channel_list, args.conv_kernel_list):
-            convs += [nn.Conv2d(cin, cout, kern, padding=kern // 2), nn.ReLU()]
+            convs += [HeadConv2d(cin, cout, kern, padding=kern // 2), nn.ReLU()]
             cin = cout
         self.conv_model = nn.ModuleList(convs)
         self.pooling = nn.MaxPool2d((self.pathway_pool_dim, self.pca_pool_dim))

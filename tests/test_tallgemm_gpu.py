@@ -133,3 +133,26 @@ def test_layernorm_backward_epilogue_equals_two_pass():
     out = tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta)
     for a, b, what in zip(out, ref, ("grad_h", "grad_gamma", "grad_beta", "row_max")):
         assert_close(a, b, 1e-6, what)
+
+
+def test_layernorm_backward_epilogue_full_size_properties():
+    """BASELINE configs[1] size (640 000 rows, 128 -> 256): the fused epilogue equals the two launches it replaces, and
+    it is linear in the cotangent (the ReLU mask and the statistics depend on the stored activation only)."""
+    from mlgnn.dense import tall_matmul_ln_backward, tall_matmul_nt
+    from mlgnn.norm import ln_backward_normalised
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    N, R, J = 640000, 128, 256
+    xhat = torch.nn.functional.layer_norm(torch.randn(N, J, device="cuda", generator=gen), (J,))
+    rstd = torch.rand(N, device="cuda", generator=gen) + 0.5
+    gamma, beta = torch.rand(J, device="cuda", generator=gen) + 0.5, torch.randn(J, device="cuda", generator=gen) * 0.2
+    w = torch.randn(R, J, device="cuda", generator=gen) / R ** 0.5
+    g1, g2 = torch.randn(N, R, device="cuda", generator=gen), torch.randn(N, R, device="cuda", generator=gen)
+    out1 = tall_matmul_ln_backward(g1, w, xhat, rstd, gamma, beta)
+    ref1 = ln_backward_normalised(tall_matmul_nt(g1, w, bt_transposed=True), xhat, gamma, beta, rstd, relu=True)
+    for a, b, what in zip(out1, ref1, ("grad_h", "grad_gamma", "grad_beta", "row_max")):
+        assert_close(a, b, 2e-6, what)
+    out2 = tall_matmul_ln_backward(g2, w, xhat, rstd, gamma, beta)
+    mix = tall_matmul_ln_backward(0.5 * g1 - 2.0 * g2, w, xhat, rstd, gamma, beta)
+    assert_close(mix[0], 0.5 * out1[0] - 2.0 * out2[0], 2e-6, "linearity of grad_h")
+    assert_close(mix[1], 0.5 * out1[1] - 2.0 * out2[1], 1e-5, "linearity of grad_gamma")
+    assert_close(mix[2], 0.5 * out1[2] - 2.0 * out2[2], 1e-5, "linearity of grad_beta")

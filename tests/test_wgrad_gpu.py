@@ -152,3 +152,22 @@ def test_wgrad_scaled_split_every_layout(N, M, K, act):
     err0 = ((w0.cpu().double() - ref_w).abs() / mag).max().item()
     assert err < 1e-6 and err < 8 * err0 + 2e-7, (err, err0)
     assert_close(b.cpu().double(), ref_b, 1e-5, "bias grad")
+
+
+def test_wgrad_scaled_split_full_size_against_exact_split():
+    """BASELINE configs[1] size (640 000 rows, 128 x 256, the ReLU-affine operand prologue): the scaled fp16 split against
+    the exact three-way bf16 split of the same kernel, relative to the magnitudes each output sums; bias gradients equal."""
+    from mlgnn.dense import _wgrad
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    N, M, K = 640000, 128, 256
+    go = torch.randn(N, M, device="cuda", generator=gen)
+    go[::9] *= 1e-3
+    xhat = torch.nn.functional.layer_norm(torch.randn(N, K, device="cuda", generator=gen), (K,))
+    gamma, beta = torch.rand(K, device="cuda", generator=gen) + 0.5, torch.randn(K, device="cuda", generator=gen) * 0.2
+    act = torch.relu(xhat * gamma + beta)
+    w, b = _wgrad(go, xhat, gamma, beta, go_max=go.abs().amax(1), x_max=act.amax(1))
+    w0, b0 = _wgrad(go, xhat, gamma, beta)
+    mag = go.abs().t() @ act
+    err = ((w - w0).abs() / mag).max().item()
+    assert err < 1e-6, err
+    assert torch.equal(b, b0)

@@ -178,3 +178,24 @@ def test_live_ranges_and_step_lr():
         tsched.step()
         sched.step()
         assert abs(sched.get_last_lr()[0] - tsched.get_last_lr()[0]) < 1e-12
+
+
+def test_head_conv_1x1_equals_conv2d():
+    """The pathway head's 1x1 convolution as a GEMM over the channel-last view: same parameters / state_dict keys as
+    nn.Conv2d, same outputs and gradients; other kernel sizes go through nn.Conv2d itself."""
+    import torch
+    from models.multilevel_gnn import HeadConv2d
+    torch.manual_seed(0)
+    c, r = HeadConv2d(16, 8, 1, padding=0), torch.nn.Conv2d(16, 8, 1)
+    assert list(c.state_dict()) == list(r.state_dict())
+    r.load_state_dict(c.state_dict())
+    x = torch.randn(3, 16, 5, 7, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    y, y2 = c(x), r(x2)
+    assert y.shape == y2.shape and torch.allclose(y, y2, atol=1e-6)
+    (y * torch.arange(7.0)).sum().backward()
+    (y2 * torch.arange(7.0)).sum().backward()
+    assert torch.allclose(x.grad, x2.grad, atol=1e-6) and torch.allclose(c.weight.grad, r.weight.grad, atol=1e-4)
+    assert torch.allclose(c.bias.grad, r.bias.grad, atol=1e-4)
+    c3 = HeadConv2d(4, 4, 3, padding=1)
+    assert torch.equal(c3(x[:, :4]), torch.nn.functional.conv2d(x[:, :4], c3.weight, c3.bias, padding=1))

@@ -93,7 +93,7 @@ def main():
                                 "frac_of_8TBps": round(gbs / 8000.0, 3)}
 
     # DiffPool at the stress size (pooled graph of 4096 nodes, 1024 clusters): bf16 -> the matrix-core product chain of
-    # csrc/diffpool_large.hip (tools/bench_diffpool.py has the full report); fp32 -> library GEMMs
+    # csrc/diffpool_large.hip (tools/bench_diffpool.py has the full report); fp32 -> the same chain with three-term products
     P, K, C = 4096, 1024, a.hidden
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     peak = 2500.0 if a.dtype == "bf16" else 157.3                 # TFLOP/s dense: bf16 MFMA / fp32 matrix (MI355X_MICROARCH.md)
@@ -117,6 +117,8 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
 
+    from mlgnn.dense import diff_pool_large_supported
+    large_fp32 = a.dtype != "bf16" and bool(diff_pool_large_supported(z, adj.unsqueeze(0), s))
     with torch.no_grad():
         dtf = timed(pool_fwd)
     dtp = timed(pool)
@@ -126,7 +128,8 @@ def main():
                                  "approx_TFLOPs_fwd_bwd": 3 * flop_fwd / dtp / 1e12,
                                  "dense_peak_TFLOPs": peak,
                                  "path": "csrc/diffpool_large.hip + gemm_nt.hip (bf16 MFMA)" if a.dtype == "bf16"
-                                 else "library GEMMs (fp32)",
+                                 else ("gemm_nt.hip, every product as three bf16 terms (mlgnn.dense._DiffPoolLargeFP32)"
+                                       if large_fp32 else "library GEMMs (fp32)"),
                                  "note": "FLOP counted in the reference's formulation (incl. S S^T); see tools/bench_diffpool.py"}
     print(json.dumps(res, indent=1))
 

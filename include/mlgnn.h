@@ -478,14 +478,17 @@ int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logit
  * step_size = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t) for step count t (host doubles, like torch);
  * max_norm <= 0: no clipping (grads untouched); otherwise the clipped gradients are written back like
  * clip_grad_norm_ does and workspace[256] receives ||g||_2.
- * live_ranges (device, int64 [n_ranges][3] = first element, length, elements in the ranges before): the elements
- * whose parameter received a gradient this step, n_live in all, n_ranges <= 64; everything else is left untouched
- * (torch skips parameters whose .grad is None).  The norm is taken over all n gradients: the caller keeps the
- * gradients of unreached parameters at zero.  workspace: mlgnn_adam_workspace_floats() floats.
+ * max_norm's coefficient follows clip_grad_norm_ for a non-finite norm too (a NaN norm poisons every gradient).
+ * param_offsets (device, int64 [n_params + 1], first element of every parameter, last entry = n) and live (device,
+ * float [n_params], > 0 = this parameter received a gradient this step): elements of a parameter that is not live are
+ * left untouched (torch skips parameters whose .grad is None).  The flags are device data so that a data-parallel
+ * caller can append them to the gradient all-reduce (every rank then steps the union); live = NULL: every element is
+ * live (param_offsets is not read).  Any number of parameters.  The norm is taken over all n gradients: the caller
+ * keeps the gradients of unreached parameters at zero.  workspace: mlgnn_adam_workspace_floats() floats.
  */
 int64_t mlgnn_adam_workspace_floats(void);
 int mlgnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                    const int64_t* live_ranges, int n_ranges, int64_t n_live, float max_norm, float beta1,
+                    const int64_t* param_offsets, const float* live, int64_t n_params, float max_norm, float beta1,
                     float beta2, float eps, float weight_decay, float step_size, float bias2_sqrt,
                     float* workspace, void* stream);
 

@@ -7,18 +7,21 @@
 // (mlgnn.optim.FlatAdam lays the module's parameters out that way), so the step is
 //   1. adam_sumsq_kernel: per-workgroup partial sums of g^2 (fixed order -> bitwise reproducible norm),
 //   2. adam_step_kernel:  every workgroup re-derives  clip = min(1, max_norm / (||g|| + 1e-6))  from the partials (no
-//      host round trip, no separate scaling pass) and applies torch's single-tensor Adam formula element by element:
+//      host round trip, no separate scaling pass; a NaN norm gives a NaN factor, as clip_grad_norm_ does) and applies
+//      torch's single-tensor Adam formula element by element:
 //        g' = clip g (+ wd p);  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;
 //        p -= step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps),   step_size = lr / (1 - b1^t)
 // Parameters the backward did not reach are skipped exactly as torch skips `grad is None` (no decay, moments
-// untouched): the host passes the element ranges that are live this step.
+// untouched).  Which parameters are live is DEVICE data -- one float per parameter, > 0 = live -- so that under data
+// parallelism the flags can ride at the tail of the gradient all-reduce and every rank steps the union of what any
+// rank reached (mlgnn/dist.py); an element finds its parameter by bisection over the parameter offsets.
 #include "common.h"
 #include "mlgnn.h"
 
 namespace mlgnn {
 
 constexpr int kAdamPartials = 256;
-constexpr int kAdamMaxRanges = 64;
+constexpr int kAdamLdsParams = 2048;          // parameter offsets kept in LDS up to this many parameters
 
 __global__ __launch_bounds__(256) void adam_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
   __shared__ float wsum[4];
@@ -33,8 +36,10 @@ __global__ __launch_bounds__(256) void adam_sumsq_kernel(const float* __restrict
 
 struct AdamArgs {
   float* p; float* g; float* m; float* v;
-  const int64_t* ranges;        // [n_ranges][3]: first element, number of elements, elements before this range
-  int n_ranges; int64_t n_live;
+  int64_t n;
+  const int64_t* offsets;       // [n_params + 1]: first element of every parameter, offsets[n_params] = n
+  const float* live;            // [n_params]: > 0 = the parameter received a gradient; nullptr = all live
+  int n_params;
   const float* partial; float max_norm;
   float b1, b2, eps, wd, step_size, bias2_sqrt;
   float* norm_out;              // optional: total gradient norm (what clip_grad_norm_ returns)
@@ -42,8 +47,10 @@ struct AdamArgs {
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
   __shared__ float wsum[4];
-  __shared__ int64_t rg[kAdamMaxRanges][3];
-  for (int i = threadIdx.x; i < a.n_ranges * 3; i += 256) rg[i / 3][i % 3] = a.ranges[i];
+  __shared__ int64_t off_lds[kAdamLdsParams + 1];
+  const bool in_lds = a.n_params <= kAdamLdsParams;
+  if (in_lds)
+    for (int i = threadIdx.x; i <= a.n_params; i += 256) off_lds[i] = a.offsets[i];
   float clip = 1.f;
   if (a.max_norm > 0.f) {
     float acc = threadIdx.x < kAdamPartials ? a.partial[threadIdx.x] : 0.f;
@@ -52,14 +59,22 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
     const float norm = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
-    clip = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
+    // clip_grad_norm_: coef = max_norm / (norm + 1e-6) clamped to <= 1; a NaN norm makes the coefficient NaN and
+    // poisons every gradient (fminf alone would return 1 and hide it)
+    clip = (norm == norm) ? fminf(a.max_norm / (norm + 1e-6f), 1.0f) : norm;
     if (a.norm_out && blockIdx.x == 0 && threadIdx.x == 0) a.norm_out[0] = norm;
   }
   __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_live; i += (int64_t)gridDim.x * 256) {
-    int r = 0;
-    while (r + 1 < a.n_ranges && i >= rg[r + 1][2]) ++r;
-    const int64_t e = rg[r][0] + (i - rg[r][2]);
+  const int64_t* off = in_lds ? off_lds : a.offsets;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.n; e += (int64_t)gridDim.x * 256) {
+    if (a.live) {
+      int lo = 0, hi = a.n_params;                       // largest lo with off[lo] <= e  (empty parameters repeat an
+      while (hi - lo > 1) {                              //  offset: the bisection lands on the last of them, the one
+        const int mid = (lo + hi) >> 1;                  //  that owns the element)
+        if (off[mid] <= e) lo = mid; else hi = mid;
+      }
+      if (!(a.live[lo] > 0.f)) continue;
+    }
     const float p = a.p[e];
     float g = a.g[e] * clip;
     if (a.max_norm > 0.f) a.g[e] = g;                    // clip_grad_norm_ scales the gradients in place
@@ -80,19 +95,20 @@ using namespace mlgnn;
 extern "C" int64_t mlgnn_adam_workspace_floats(void) { return kAdamPartials + 1; }
 
 extern "C" int mlgnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                               const int64_t* live_ranges, int n_ranges, int64_t n_live, float max_norm, float beta1,
-                               float beta2, float eps, float weight_decay, float step_size, float bias2_sqrt,
-                               float* workspace, void* stream) {
-  if (n < 0 || n_live < 0 || n_live > n || n_ranges < 0 || n_ranges > kAdamMaxRanges) return MLGNN_E_SHAPE;
-  if (n == 0 || n_live == 0) return 0;
-  if (!params || !grads || !exp_avg || !exp_avg_sq || !live_ranges || !workspace) return MLGNN_E_NULL;
+                               const int64_t* param_offsets, const float* live, int64_t n_params, float max_norm,
+                               float beta1, float beta2, float eps, float weight_decay, float step_size,
+                               float bias2_sqrt, float* workspace, void* stream) {
+  if (n < 0 || n_params < 0 || n_params >= (1ll << 31)) return MLGNN_E_SHAPE;
+  if (n == 0) return 0;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !workspace) return MLGNN_E_NULL;
+  if (live && (!param_offsets || n_params == 0)) return MLGNN_E_NULL;
   if (!(bias2_sqrt > 0.f)) return MLGNN_E_MODE;
   hipStream_t s = (hipStream_t)stream;
   if (max_norm > 0.f)
     hipLaunchKernelGGL(adam_sumsq_kernel, dim3(kAdamPartials), dim3(256), 0, s, grads, n, workspace);
-  AdamArgs a{params, grads, exp_avg, exp_avg_sq, live_ranges, n_ranges, n_live, workspace, max_norm,
+  AdamArgs a{params, grads, exp_avg, exp_avg_sq, n, param_offsets, live, (int)n_params, workspace, max_norm,
              beta1, beta2, eps, weight_decay, step_size, bias2_sqrt, workspace + kAdamPartials};
-  int64_t blocks = (n_live + 255) / 256;
+  int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
   return (int)hipGetLastError();

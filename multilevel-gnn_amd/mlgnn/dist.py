@@ -18,11 +18,18 @@ class FlatGradBucket:
             raise ValueError("no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        # gradients, then one "reached" flag per parameter: the flags travel with the gradients in the ONE all-reduce,
+        # so every rank learns the union of what any rank's backward reached (a parameter reached on rank 0 only is
+        # stepped, with the averaged gradient, on every rank -- or the replicas would drift apart silently)
+        self.flat_all = torch.zeros(total + len(self.params), dtype=dt, device=dev)
+        self.flat = self.flat_all[:total]
+        self.live = self.flat_all[total:]
+        self.live.fill_(1)
         self.group = process_group
         off = 0
         self.views = []
-        self.reached = [True] * len(self.params)       # which parameters the last collected backward reached
+        self.reached = [True] * len(self.params)       # which parameters the last collected LOCAL backward reached
+        self._live_local = (tuple(self.reached), self.live.clone())
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
@@ -55,6 +62,11 @@ class FlatGradBucket:
                     d.copy_(s)
         for p, v in zip(self.params, self.views):
             p.grad = v
+        key = tuple(self.reached)
+        if key != self._live_local[0]:
+            self._live_local = (key, torch.tensor([1.0 if r else 0.0 for r in key], dtype=self.live.dtype,
+                                                  device=self.live.device))
+        self.live.copy_(self._live_local[1])       # (re-written every step: the all-reduce below leaves sums in it)
         # (torch.optim optimizers then see a zero gradient for an unreached parameter where the reference's
         # zero_grad(set_to_none) would make them skip it: with weight decay that parameter decays.
         # mlgnn.optim.FlatAdam reads `reached` and skips it like torch does.)
@@ -71,8 +83,12 @@ class FlatGradBucket:
         world = dist.get_world_size(self.group)
         if world == 1:
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(world)
+        dist.all_reduce(self.flat_all, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat_all.div_(world)                  # flags: (ranks that reached the parameter) / world, > 0 = live
+
+    def reached_anywhere(self):
+        """Per-parameter bools after :meth:`all_reduce_mean`: reached by some rank's backward (reads the device)."""
+        return [v > 0 for v in self.live.tolist()]
 
     def check_views(self):
         """True while every ``p.grad`` still aliases the bucket."""

@@ -150,10 +150,10 @@ class CSRGraph:
 
     def edge_scalar(self, a):
         """Per-edge scalar [E] (COO order) -> (by-destination order, by-source order).  The last result is kept:
-        the entry holds the source tensor itself (identity + version checked), so its storage cannot be freed and
-        handed to a different tensor with the same address under the cache."""
+        the entry holds the source tensor itself, so its storage cannot be freed and handed to a different tensor
+        with the same address under the cache; a lookup matches any view of the same elements (see :func:`_same_view`)."""
         ent = self._scalar_cache
-        if ent is not None and ent[0] is a and ent[1] == a._version:
+        if ent is not None and _same_view(ent[0], a) and ent[1] == a._version:
             return ent[2]
         flat = a.reshape(-1).to(torch.float32)
         by_dst = flat[self.eid.long()].contiguous()
@@ -170,7 +170,7 @@ class CSRGraph:
         if a.shape[0] != self.num_edges or a.shape[1] > width:
             raise ValueError("edge attributes must be [E=%d, <=%d], got %s" % (self.num_edges, width, tuple(a.shape)))
         ent = self._table_cache
-        hit = ent[3] if (ent is not None and ent[0] is src and ent[1] == src._version and ent[2] == width) else None
+        hit = ent[3] if (ent is not None and _same_view(ent[0], src) and ent[1] == src._version and ent[2] == width) else None
         if hit is None:
             if a.is_cuda and self.eid.is_cuda:
                 from . import _lib
@@ -193,6 +193,18 @@ class CSRGraph:
                 hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
             self._table_cache = (src, src._version, width, hit)      # holds `src`: see edge_scalar
         return hit
+
+
+def _same_view(held, t):
+    """``t`` names exactly the elements of the tensor a cache entry holds: the same object, or another view of the
+    same storage with the same offset / shape / strides / dtype (``a[:, 0]`` taken twice gives two objects).  The
+    entry keeps ``held`` alive, so an equal address cannot be a recycled allocation; versions are compared by the
+    caller (views of one storage share the counter)."""
+    if held is t:
+        return True
+    return (held.dtype == t.dtype and held.device == t.device and held.shape == t.shape
+            and held.stride() == t.stride() and held.storage_offset() == t.storage_offset()
+            and held.untyped_storage().data_ptr() == t.untyped_storage().data_ptr())
 
 
 def as_graph(edge_index, num_nodes):

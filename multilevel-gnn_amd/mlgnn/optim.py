@@ -13,24 +13,6 @@ import torch
 from . import _lib
 from .dist import FlatGradBucket
 
-MAX_RANGES = 64
-
-
-def live_ranges(sizes, reached):
-    """Element ranges ``[(first, length, elements before)]`` of the parameters that received a gradient, adjacent
-    parameters merged.  ``sizes``: numel per parameter in bucket order; ``reached``: bool per parameter."""
-    out, off, before = [], 0, 0
-    for n, ok in zip(sizes, reached):
-        if ok and n:
-            if out and out[-1][0] + out[-1][1] == off:
-                out[-1][1] += n
-            else:
-                out.append([off, n, before])
-            before += n
-        off += n
-    return [tuple(r) for r in out]
-
-
 class FlatAdam:
     """``torch.optim.Adam`` (L2 ``weight_decay``, no amsgrad) + optional ``clip_grad_norm_(max_norm)`` over a module
     whose parameters are re-laid into one flat fp32 buffer (``p.data`` become views of it; ``state_dict`` is
@@ -38,7 +20,11 @@ class FlatAdam:
 
         bucket.release(); loss.backward(); bucket.collect(); bucket.all_reduce_mean(); opt.step()
 
-    with ``bucket = opt.bucket``.  Parameters the backward did not reach are skipped like ``grad is None`` in torch.
+    with ``bucket = opt.bucket``.  Parameters the backward did not reach are skipped like ``grad is None`` in torch;
+    the kernel reads "reached" from the device flags behind the gradients in the bucket, which the all-reduce has turned
+    into "reached on any rank" -- all ranks step the same parameters (a parameter only some ranks reach gets the
+    averaged gradient everywhere, like DDP with ``find_unused_parameters``).  Any number of parameters, any
+    interleaving of reached and unreached ones.
     One global step count: a parameter that is reached only in some steps uses it too (torch counts per parameter);
     the shipped models reach a parameter either always or never."""
 
@@ -64,7 +50,10 @@ class FlatAdam:
         self.step_count = 0
         self._ws = torch.zeros(int(_lib.lib.mlgnn_adam_workspace_floats()), dtype=torch.float32, device=dev) \
             if dev.type == "cuda" else None
-        self._ranges_key, self._ranges_dev, self._n_live, self._n_ranges = None, None, 0, 0
+        offs = [0]
+        for n in self.sizes:
+            offs.append(offs[-1] + n)
+        self._offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
 
     @property
     def grad_norm(self):
@@ -74,18 +63,6 @@ class FlatAdam:
     def zero_grad(self, set_to_none=True):
         self.bucket.release()
 
-    def _ranges(self):
-        key = tuple(self.bucket.reached)
-        if key != self._ranges_key:
-            rg = live_ranges(self.sizes, key)
-            if len(rg) > MAX_RANGES:
-                raise RuntimeError("more than %d separate live parameter ranges" % MAX_RANGES)
-            self._ranges_dev = torch.tensor(rg if rg else [(0, 0, 0)], dtype=torch.int64, device=self.flat_p.device)
-            self._n_live = sum(r[1] for r in rg)
-            self._n_ranges = len(rg)
-            self._ranges_key = key
-        return self._ranges_dev
-
     def step(self):
         g = self.param_groups[0]
         b1, b2 = g["betas"]
@@ -93,11 +70,11 @@ class FlatAdam:
         t = self.step_count
         step_size = g["lr"] / (1.0 - b1 ** t)
         bias2_sqrt = math.sqrt(1.0 - b2 ** t)
-        rg = self._ranges()
         rc = _lib.lib.mlgnn_adam_step(self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
-                                      self.exp_avg_sq.data_ptr(), self.flat_p.numel(), rg.data_ptr(), self._n_ranges,
-                                      self._n_live, self.clip, b1, b2, g["eps"], g["weight_decay"], step_size, bias2_sqrt,
-                                      self._ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                      self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self._offsets.data_ptr(),
+                                      self.bucket.live.data_ptr(), len(self.sizes), self.clip, b1, b2, g["eps"],
+                                      g["weight_decay"], step_size, bias2_sqrt, self._ws.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_adam_step")
         # the kernel wrote parameters, moments and (when clipping) gradients behind torch's back: bump the version
         # counters (shared by every view of the flat buffers) so that version-keyed caches and autograd's

@@ -61,11 +61,80 @@ def _worker(rank, world, port, q):
         pass
 
 
-def _run_world(world):
+class _Branchy(torch.nn.Module):
+    """``extra`` is used by rank 0 only (a data-dependent branch / an empty shard), ``dead`` by nobody."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.base = torch.nn.Linear(6, 2)
+        self.extra = torch.nn.Linear(6, 2)
+        self.dead = torch.nn.Linear(2, 2)
+
+    def forward(self, x, use_extra):
+        return self.base(x) + (self.extra(x) if use_extra else 0.0)
+
+
+def _worker_reach(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "multilevel-gnn_amd"))
+    from mlgnn.dist import FlatGradBucket
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _Branchy()
+    bucket = FlatGradBucket(model)
+    x, y = _data()
+    shard = slice(rank * 4, rank * 4 + 4)
+    out = []
+    for it in range(2):                                 # twice: the flags are rewritten every step, sums do not pile up
+        bucket.release()
+        torch.nn.functional.mse_loss(model(x[shard], use_extra=(rank == 0)), y[shard]).backward()
+        bucket.collect()
+        local = list(bucket.reached)
+        bucket.all_reduce_mean()
+        out.append((local, bucket.reached_anywhere(), bucket.live.clone(), bucket.flat.clone()))
+    q.put((rank, out))
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def test_reached_flags_are_agreed_across_ranks():
+    """A parameter only rank 0's backward reaches: after the ONE all-reduce both ranks hold the same flags (the union)
+    and the same averaged gradient (rank 1 contributed zeros), so FlatAdam steps the same parameters everywhere; a
+    parameter no rank reaches stays skipped."""
+    world = 2
+    try:
+        got, codes = _run_world(world, _worker_reach)
+    except Exception:
+        got, codes = _run_world(world, _worker_reach)
+    assert codes == [0] * world, codes
+    by_rank = dict(got)
+    names = [n for n, _ in _Branchy().named_parameters()]
+    want_local = {0: [not n.startswith("dead") for n in names],
+                  1: [n.startswith("base") for n in names]}
+    model = _Branchy()
+    x, y = _data()
+    torch.nn.functional.mse_loss(model(x[:4], True), y[:4]).backward()
+    g_extra0 = torch.cat([model.extra.weight.grad.reshape(-1), model.extra.bias.grad.reshape(-1)])
+    for it in range(2):
+        l0, any0, live0, flat0 = by_rank[0][it]
+        l1, any1, live1, flat1 = by_rank[1][it]
+        assert l0 == want_local[0] and l1 == want_local[1]
+        assert any0 == any1 == want_local[0]                       # the union, on both ranks
+        assert torch.equal(live0, live1) and torch.equal(flat0, flat1)
+        assert live0.tolist() == [1.0, 1.0, 0.5, 0.5, 0.0, 0.0]
+        assert torch.allclose(flat0[14:28], g_extra0 / 2, atol=1e-7)
+
+
+def _run_world(world, target=None):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target or _worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     try:

@@ -33,6 +33,26 @@ def test_csr_graph_layout():
     assert sorted(zip(rows_t.tolist(), g.col_t.tolist())) == pairs
 
 
+def test_edge_caches_hit_for_equal_views_and_miss_after_an_edit():
+    """Two views of the same elements (``a[:, 0]`` taken twice: the bench pre-builds the table from one, the model looks
+    it up with another) share one cache entry; an in-place edit or a different slice does not."""
+    from mlgnn import CSRGraph
+    g = CSRGraph(torch.tensor([[2, 0, 2, 1, 0], [1, 1, 0, 1, 2]]), 4)
+    attr = torch.arange(10.).reshape(5, 2)
+    t1 = g.edge_table(attr[:, 0].reshape(-1, 1), 1)
+    t2 = g.edge_table(attr[:, 0].reshape(-1, 1), 1)
+    assert t1[0] is t2[0] and t1[1] is t2[1]
+    other = g.edge_table(attr[:, 1].reshape(-1, 1), 1)           # same storage, other offset
+    assert other[0] is not t1[0] and other[0][:, 0].tolist() == [5., 1., 3., 7., 9.]
+    s1 = g.edge_scalar(attr[:, 0])
+    assert g.edge_scalar(attr[:, 0])[0] is s1[0]
+    attr[0, 0] = 100.                                            # version bump: both caches must rebuild
+    assert g.edge_scalar(attr[:, 0])[0] is not s1[0]
+    t3 = g.edge_table(attr[:, 0].reshape(-1, 1), 1)
+    assert t3[0][:, 0].tolist() == [4., 100., 2., 6., 8.]
+    assert g.edge_table(attr[:, 0].clone().reshape(-1, 1), 1)[0] is not t3[0]      # equal values, other storage
+
+
 def test_sage_graph_matches_self_loop_rewrite():
     from mlgnn.graph import sage_graph
     ei = torch.tensor([[0, 1, 2, 2, 1], [1, 1, 0, 2, 0]])
@@ -160,11 +180,8 @@ def test_edge_cache_is_keyed_on_the_tensor_not_its_address():
     assert torch.equal(g.edge_table(t, 2)[0], by_dst + 1.0)
 
 
-def test_live_ranges_and_step_lr():
-    from mlgnn.optim import StepLR, live_ranges
-    assert live_ranges([4, 6, 2, 5], [True, True, False, True]) == [(0, 10, 0), (12, 5, 10)]
-    assert live_ranges([4, 6], [False, False]) == []
-    assert live_ranges([3, 0, 2], [True, True, True]) == [(0, 5, 0)]
+def test_step_lr():
+    from mlgnn.optim import StepLR
 
     class _Opt:
         param_groups = [dict(lr=0.1, initial_lr=0.1)]

@@ -70,3 +70,62 @@ def test_clip_writes_back_scaled_gradients():
     assert abs(float(opt.grad_norm) - norm) <= 1e-5 * norm
     want = raw * min(1.0, 0.01 / (norm + 1e-6))
     assert float((opt.bucket.flat - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+class _Interleaved(nn.Module):
+    """100 small layers, every other one never called: 100 separate live parameter ranges (a table of 64 ranges was the
+    limit of the first version of the kernel)."""
+
+    def __init__(self):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.Linear(8, 8) for _ in range(200)])
+
+    def forward(self, x):
+        for l in self.layers[::2]:
+            x = torch.tanh(l(x)) + x
+        return x
+
+
+def test_many_interleaved_unreached_parameters():
+    from mlgnn.optim import FlatAdam
+    torch.manual_seed(4)
+    ref = _Interleaved().to(DEV)
+    mine = copy.deepcopy(ref)
+    topt = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-2)
+    fopt = FlatAdam(mine, lr=1e-2, weight_decay=1e-2, clip_grad_norm=1.0)
+    x = torch.randn(16, 8, device=DEV)
+    for _ in range(5):
+        topt.zero_grad(set_to_none=True)
+        ref(x).pow(2).sum().backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        topt.step()
+        fopt.zero_grad()
+        mine(x).pow(2).sum().backward()
+        fopt.bucket.collect()
+        fopt.step()
+    assert fopt.bucket.reached == [i % 4 < 2 for i in range(400)]
+    for (n, p), q in zip(ref.named_parameters(), mine.parameters()):
+        assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(p.abs().max())), n
+
+
+def test_nan_gradient_poisons_the_step_like_clip_grad_norm():
+    """``clip_grad_norm_`` with a NaN total norm multiplies every gradient by NaN: the failure is visible in every
+    reached parameter after the step (``fminf(NaN, 1) = 1`` would have hidden it)."""
+    from mlgnn.optim import FlatAdam
+    torch.manual_seed(5)
+    ref = _Net().to(DEV)
+    mine = copy.deepcopy(ref)
+    topt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    fopt = FlatAdam(mine, lr=1e-3, clip_grad_norm=20.0)
+    x = torch.randn(8, 24, device=DEV)
+    x[3, 5] = float("nan")
+    ref(x).sum().backward()
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 20.0)
+    topt.step()
+    fopt.zero_grad()
+    mine(x).sum().backward()
+    fopt.bucket.collect()
+    fopt.step()
+    for (n, p), q in zip(ref.named_parameters(), mine.parameters()):
+        assert torch.equal(torch.isnan(p), torch.isnan(q)), n
+    assert bool(torch.isnan(mine.a.weight).all()) and not bool(torch.isnan(mine.dead.weight).any())

@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="build each batch's CSR in line instead of one batch ahead on a second stream")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the also_aggr (max / mean) and no-overlap legs after the timed run")
+    ap.add_argument("--extra-steps", type=int, default=5)
     return ap.parse_args()
 
 
@@ -162,12 +164,6 @@ def main():
     from mlgnn.dist import broadcast_parameters
     from mlgnn.optim import FlatAdam
 
-    torch.manual_seed(1234)
-    model = W.ThreeLevelGNN(hidden=args.hidden, num_layers=3, aggr=args.aggr, n_members=args.members).to(dev)
-    broadcast_parameters(model)
-    opt = FlatAdam(model, lr=1e-3)            # Adam over the flat parameter / gradient buffers: one launch per step
-    bucket = opt.bucket
-
     strong = args.global_batch > 0
     if strong and args.global_batch % world != 0:
         raise SystemExit("--global-batch must be a multiple of the number of GPUs")
@@ -179,75 +175,89 @@ def main():
         pool.append(W.collate(ids, args.nodes, args.edges, match, seg, dev))
     torch.cuda.synchronize()
 
-    # The topology work of a step (COO -> CSR, edge attributes into CSR order) runs on a second HIP stream, one
-    # batch ahead of the step that consumes it -- what an input pipeline does -- so its latency-bound kernels
-    # share the GPU with the previous step's HBM-bound ones.  Every step still builds its own CSR inside the timed
-    # region (K steps = K builds; the first one is waited for).  --no-overlap builds it in line instead.
     from mlgnn import CSRGraph
     main_stream = torch.cuda.current_stream()
-    side_stream = torch.cuda.Stream() if not args.no_overlap else None
-    ahead = {}
-
-    def build_topology(i):
-        batch = pool[i % len(pool)]
-        with torch.cuda.stream(side_stream):
-            g = CSRGraph(batch.edge_index, batch.x.shape[0])
-            tables = g.edge_table(batch.edge_attr[:, 0].reshape(-1, 1), 1)      # the key RankOneEdge will look up
-            g.hub_tables("dst"), g.hub_tables("src")                            # long-row tables (csrc/hub.hip)
-            ev = torch.cuda.Event()
-            ev.record(side_stream)
-        ahead[i] = (g, tables, ev)
-
-    def step(i, last=False):
-        batch = pool[i % len(pool)]
-        if side_stream is None:
-            batch.csr = None                   # built inside the model's forward
-        else:
-            if i not in ahead:
-                build_topology(i)
-            g, tables, ev = ahead.pop(i)
-            main_stream.wait_event(ev)
-            hub_tabs = tuple(t for d in ("dst", "src") for t in (g.hub_tables(d) or ())[:3])
-            for t in (g.rowptr, g.col, g.eid, g.rowptr_t, g.col_t, g.pos_t, g.eid_t) + tuple(tables) + hub_tabs:
-                t.record_stream(main_stream)
-            batch.csr = g
-            if not last:
-                build_topology(i + 1)
-        bucket.release()
-        loss = W.training_loss(model, batch)
-        loss.backward()
-        bucket.collect()
-        if ar_events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            bucket.all_reduce_mean()
-            e1.record()
-            ar_events.append((e0, e1))
-        else:
-            bucket.all_reduce_mean()
-        opt.step()
-        return loss
-
-    ar_events = None
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i, last=(i == args.warmup - 1))
-    timer = None if args.no_kernel_timer else ops.KernelTimer()
-    ops.KERNEL_TIMER = timer
-    fence()
-    ar_events = [] if world > 1 else None
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i, last=(i == args.steps - 1))
-    fence()
-    elapsed = time.perf_counter() - t0
-    ops.KERNEL_TIMER = None
-    final_loss = float(loss.detach())
+    def run(aggr, steps, warmup, overlap, use_timer):
+        """``warmup`` untimed + exactly ``steps`` timed training steps of a freshly initialised model with aggregator
+        ``aggr`` -> (seconds, kernel timer summary or None, allreduce events, final loss, bucket)."""
+        torch.manual_seed(1234)
+        model = W.ThreeLevelGNN(hidden=args.hidden, num_layers=3, aggr=aggr, n_members=args.members).to(dev)
+        broadcast_parameters(model)
+        opt = FlatAdam(model, lr=1e-3)            # Adam over the flat parameter / gradient buffers: one launch per step
+        bucket = opt.bucket
+        # The topology work of a step (COO -> CSR, edge attributes into CSR order) runs on a second HIP stream, one
+        # batch ahead of the step that consumes it -- what an input pipeline does -- so its latency-bound kernels
+        # share the GPU with the previous step's HBM-bound ones.  Every step still builds its own CSR inside the timed
+        # region (K steps = K builds; the first one is waited for).  overlap=False builds it in line instead.
+        side_stream = torch.cuda.Stream() if overlap else None
+        ahead = {}
+        ar_events = None
+
+        def build_topology(i):
+            batch = pool[i % len(pool)]
+            with torch.cuda.stream(side_stream):
+                g = CSRGraph(batch.edge_index, batch.x.shape[0])
+                # (any view of the same elements is the key RankOneEdge will look up: mlgnn.graph._same_view)
+                tables = g.edge_table(batch.edge_attr[:, 0].reshape(-1, 1), 1)
+                g.hub_tables("dst"), g.hub_tables("src")                            # long-row tables (csrc/hub.hip)
+                ev = torch.cuda.Event()
+                ev.record(side_stream)
+            ahead[i] = (g, tables, ev)
+
+        def step(i, last=False):
+            batch = pool[i % len(pool)]
+            if side_stream is None:
+                batch.csr = None                   # built inside the model's forward
+            else:
+                if i not in ahead:
+                    build_topology(i)
+                g, tables, ev = ahead.pop(i)
+                main_stream.wait_event(ev)
+                hub_tabs = tuple(t for d in ("dst", "src") for t in (g.hub_tables(d) or ())[:3])
+                for t in (g.rowptr, g.col, g.eid, g.rowptr_t, g.col_t, g.pos_t, g.eid_t) + tuple(tables) + hub_tabs:
+                    t.record_stream(main_stream)
+                batch.csr = g
+                if not last:
+                    build_topology(i + 1)
+            bucket.release()
+            loss = W.training_loss(model, batch)
+            loss.backward()
+            bucket.collect()
+            if ar_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                bucket.all_reduce_mean()
+                e1.record()
+                ar_events.append((e0, e1))
+            else:
+                bucket.all_reduce_mean()
+            opt.step()
+            return loss
+
+        for i in range(warmup):
+            step(i, last=(i == warmup - 1))
+        timer = ops.KernelTimer() if use_timer else None
+        ops.KERNEL_TIMER = timer
+        fence()
+        ar_events = [] if world > 1 else None
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step(warmup + i, last=(i == steps - 1))
+        fence()
+        elapsed = time.perf_counter() - t0
+        ops.KERNEL_TIMER = None
+        for batch in pool:
+            batch.csr = None
+        return elapsed, (timer.summary() if timer is not None else None), ar_events, float(loss.detach()), bucket, model
+
+    elapsed, summ, ar_events, final_loss, bucket, model = run(args.aggr, args.steps, args.warmup, not args.no_overlap,
+                                                               not args.no_kernel_timer)
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -270,35 +280,43 @@ def main():
                        "collective_backend": backend if world > 1 else None,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "allreduce_ms": (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)) if ar_events else None,
-                       "allreduce_bytes": bucket.flat.numel() * 4,
+                       "allreduce_bytes": bucket.flat_all.numel() * 4,      # gradients + one reached flag per parameter
                        "final_loss": final_loss},
         }
-        if timer is not None:
-            summ = timer.summary()
+        blob, tsrc = load_traffic()
+        N_all, E_all = B * args.nodes, B * args.edges
+
+        def kernel_table(summary):
             kernels = {}
-            for name, d in summ.items():
+            for name, d in summary.items():
                 gbs = d["bytes"] / (d["avg_ms"] * 1e-3) / 1e9
                 kernels[name] = {"launches": d["launches"], "avg_ms": d["avg_ms"], "algorithmic_bytes": d["bytes"],
                                  "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
+            return kernels
+
+        def view(kernels, name):
+            """algorithmic (edge-gather, no cache credit: the contract figure), counter-measured and compulsory
+            bytes of one launch, each as a rate and a fraction of the 8 TB/s peak."""
+            k = kernels[name]
+            secs = k["avg_ms"] * 1e-3
+            # counters per aggregator when the profile has them ("csr_aggregate_fwd/max"), else the headline's
+            traffic = None
+            if blob:
+                parts = name.split("/")
+                traffic = blob.get("/".join(parts[:2]), blob.get(parts[0]) if parts[1] == "softmax" else None)
+            # perfect reuse: every node row read once and written once, indices and edge scalars once
+            backward = name.startswith("csr_aggregate_bwd")
+            comp = (3 if backward else 2) * N_all * args.hidden * 4 + E_all * 8 + (N_all + 1) * 4
+            return {"kernel": name, "avg_launch_ms": k["avg_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
+                    "achieved": k["achieved_GBps"], "frac": k["frac"], "traffic": traffic,
+                    "frac_hbm_counter": (traffic / secs / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "compulsory_bytes": comp, "frac_compulsory": comp / secs / 1e9 / HBM_PEAK_GBS}
+
+        if summ is not None:
+            kernels = kernel_table(summ)
             # dominant = the hand-written kernel with the largest total time in the timed region
             dom = max(summ, key=lambda n: summ[n]["total_ms"])
-            blob, tsrc = load_traffic()
-            N_all, E_all = B * args.nodes, B * args.edges
-
-            def view(name):
-                """algorithmic (edge-gather, no cache credit: the contract figure), counter-measured and compulsory
-                bytes of one launch, each as a rate and a fraction of the 8 TB/s peak."""
-                k = kernels[name]
-                secs = k["avg_ms"] * 1e-3
-                traffic = blob.get(name.split("/")[0]) if blob else None
-                # perfect reuse: every node row read once and written once, indices and edge scalars once
-                backward = name.startswith("csr_aggregate_bwd")
-                comp = (3 if backward else 2) * N_all * args.hidden * 4 + E_all * 8 + (N_all + 1) * 4
-                return {"kernel": name, "avg_launch_ms": k["avg_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
-                        "achieved": k["achieved_GBps"], "frac": k["frac"], "traffic": traffic,
-                        "frac_hbm_counter": (traffic / secs / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                        "compulsory_bytes": comp, "frac_compulsory": comp / secs / 1e9 / HBM_PEAK_GBS}
-            v = view(dom)
+            v = view(kernels, dom)
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": v["achieved"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": v["frac"], "traffic": v["traffic"],
                                "frac_hbm_counter": v["frac_hbm_counter"], "compulsory_bytes": v["compulsory_bytes"],
@@ -311,14 +329,32 @@ def main():
                                        "peak is the physical one"}
             other = [n for n in summ if n.startswith("csr_aggregate_") and n != dom]
             if other:
-                out["roofline"]["also"] = [view(n) for n in sorted(other)]
+                out["roofline"]["also"] = [view(kernels, n) for n in sorted(other)]
             if world == 1:
                 ceil = stream_copy_ceiling(dev)
                 out["roofline"]["stream_copy_GBps"] = ceil
                 out["roofline"]["frac_of_stream_copy"] = kernels[dom]["achieved_GBps"] / ceil
             out["kernels"] = kernels
+        if world == 1 and not args.no_extras:
+            # "aggr in {softmax, max, mean} -- report all three, headline = softmax": the same step with
+            # the other aggregators, a few steps each after the timed headline run, same process, same batches
+            del model, bucket
+            out["also_aggr"] = []
+            for aggr in ("softmax", "max", "mean"):
+                if aggr == args.aggr:
+                    continue
+                el, sm, _, _, _, _ = run(aggr, args.extra_steps, 2, not args.no_overlap, True)
+                kt = kernel_table(sm)
+                out["also_aggr"].append({"aggr": aggr, "steps": args.extra_steps, "ms_per_step": el / args.extra_steps * 1e3,
+                                         "value": args.extra_steps * B / el, "unit": "graphs/s",
+                                         "kernels": [view(kt, n) for n in sorted(kt) if n.startswith("csr_aggregate_")]})
+            # the same headline step with the topology built in line (a caller without a second stream)
+            el, _, _, _, _, _ = run(args.aggr, args.extra_steps, 2, args.no_overlap, False)
+            out["no_overlap_ms_per_step" if not args.no_overlap else "overlap_ms_per_step"] = el / args.extra_steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, model.state_dict())
+            torch.manual_seed(1234)
+            out["cpu_baseline"] = cpu_baseline(args, W.ThreeLevelGNN(hidden=args.hidden, num_layers=3, aggr=args.aggr,
+                                                                       n_members=args.members).state_dict())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -492,6 +492,20 @@ int mlgnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
                     float beta2, float eps, float weight_decay, float step_size, float bias2_sqrt,
                     float* workspace, void* stream);
 
+/*
+ * Debug facility (csrc/canary.hip; never on the product path, the entry points above never allocate): a guard-band
+ * device allocator in the shape torch.cuda.memory.CUDAPluggableAllocator binds -- every block sits between two 4 KiB
+ * bands of a byte pattern, the rear one starting at the first byte past the requested size -- and a checker.
+ * mlgnn/_lib.py installs the pair as torch's allocator when MLGNN_CANARY=1 and calls mlgnn_canary_check() after every
+ * C-ABI call: device synchronise, compare all bands of all live and recently freed blocks; returns 0 (intact), 1 (a
+ * band was overwritten: `message` names the block, side and distance; the band is repaired) or -1 (the synchronise
+ * itself failed: a faulting kernel).  mlgnn_canary_stats: out4 = {live blocks, device allocations, reuses, checks}.
+ */
+void* mlgnn_canary_malloc(int64_t size, int device, void* stream);
+void mlgnn_canary_free(void* ptr, int64_t size, int device, void* stream);
+int64_t mlgnn_canary_check(char* message, int64_t message_bytes);
+int64_t mlgnn_canary_stats(int64_t* out4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,10 @@ SIGNATURES = {
     "mlgnn_hub_capacity": (_I64, [_I64, _INT]),
     "mlgnn_hub_scratch_bytes": (_I64, [_I64, _I64]),
     "mlgnn_hub_rows": (_INT, [_P, _I64, _INT, _I64, _P, _P, _P, _P]),
+    "mlgnn_canary_malloc": (_P, [_I64, _INT, _P]),
+    "mlgnn_canary_free": (None, [_P, _I64, _INT, _P]),
+    "mlgnn_canary_check": (_I64, [_c.c_char_p, _I64]),
+    "mlgnn_canary_stats": (_I64, [_c.POINTER(_I64)]),
 }
 
 
@@ -96,6 +100,60 @@ def _load():
 
 
 lib = _load()
+
+# MLGNN_CANARY=1 (debug; tests/README): every device allocation of the process gets guard bands (csrc/canary.hip
+# becomes torch's allocator -- this must happen before the first device allocation) and every C-ABI call is followed by
+# a device synchronise + a comparison of all bands; an out-of-bounds write is reported at the call that made it.
+CANARY = os.environ.get("MLGNN_CANARY", "0") == "1"
+CANARY_CALLS = 0
+
+
+def canary_check(what):
+    """Synchronise and compare every guard band; raises :class:`MlgnnError` naming ``what`` on damage."""
+    buf = ctypes.create_string_buffer(512)
+    rc = lib.mlgnn_canary_check(buf, 512)
+    if rc != 0:
+        raise MlgnnError("MLGNN_CANARY: after %s: %s" % (what, buf.value.decode(errors="replace") or "check failed (%d)" % rc))
+
+
+def canary_stats():
+    out = (_I64 * 4)()
+    lib.mlgnn_canary_stats(out)
+    return dict(live=out[0], device_allocations=out[1], reuses=out[2], checks=out[3], guarded_calls=CANARY_CALLS)
+
+
+class _CanaryLib:
+    """``lib`` with a guard-band check behind every call that takes a stream (the ones that launch kernels)."""
+
+    def __init__(self, inner):
+        self._inner = inner
+
+    def __getattr__(self, name):
+        fn = getattr(self._inner, name)
+        if name.startswith("mlgnn_canary") or name not in SIGNATURES or not SIGNATURES[name][1] \
+                or SIGNATURES[name][0] is not _INT or name.endswith("_supported") or name.endswith("_workgroups"):
+            return fn
+
+        def guarded(*args):
+            global CANARY_CALLS
+            rc = fn(*args)
+            CANARY_CALLS += 1
+            canary_check(name)
+            return rc
+        setattr(self, name, guarded)
+        return guarded
+
+
+def _install_canary():
+    import torch
+    alloc = torch.cuda.memory.CUDAPluggableAllocator(LIB, "mlgnn_canary_malloc", "mlgnn_canary_free")
+    torch.cuda.memory.change_current_allocator(alloc)       # raises if the process has allocated device memory already
+    return alloc
+
+
+if CANARY:
+    _CANARY_ALLOCATOR = _install_canary()
+    lib = _CanaryLib(lib)
 
 
 def check(code, what):

@@ -8,6 +8,8 @@ constructor, ``forward(batch) -> (pred [B,2], pca_feature [B,C,146,3k])`` and ``
 The reference's ``except: pdb.set_trace()`` traps around the layer calls are NOT reproduced:
 errors propagate as exceptions.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -22,8 +24,12 @@ class HeadConv2d(nn.Conv2d):
     as one GEMM on the channel-last view instead of through the convolution library, whose first call per shape
     searches / compiles solvers at run time."""
 
+    # MLGNN_HEAD_CONV2D=1: always the convolution library (tools/abort_repro.py: the configuration in which two full
+    # test runs of round 2 aborted)
+    FORCE_LIBRARY = os.environ.get("MLGNN_HEAD_CONV2D", "0") == "1"
+
     def forward(self, x):
-        if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.dilation == (1, 1)
+        if (not self.FORCE_LIBRARY and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.dilation == (1, 1)
                 and self.groups == 1 and self.padding_mode == "zeros" and x.dim() == 4):
             y = torch.nn.functional.linear(x.permute(0, 2, 3, 1), self.weight[:, :, 0, 0], self.bias)
             return y.permute(0, 3, 1, 2)

@@ -1,0 +1,80 @@
+"""bench.py's own line, produced by fresh child processes (never an exec of this GPU-holding process): the N=1 schema
+the driver parses, and -- when the box has two GPUs -- the N=2 launch exactly as the driver starts it
+(``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2``), whose line must have the N=1 line's
+schema with ``world_size == 2`` and a measured all-reduce.  Reduced sizes: this checks the plumbing, not the rate."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "2", "--warmup", "1", "--graphs-per-gpu", "4", "--nodes", "3000", "--edges", "24000", "--members",
+         "6000", "--extra-steps", "2"]
+CONTRACT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "kernels"}
+ROOFLINE = {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "frac_hbm_counter", "frac_compulsory",
+            "avg_launch_ms", "algorithmic_bytes_per_launch"}
+
+
+def _line(cmd, env=None):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def _keys(d, prefix=""):
+    out = set()
+    for k, v in d.items():
+        out.add(prefix + k)
+        if isinstance(v, dict) and k not in ("kernels", "traffic_source"):
+            out |= _keys(v, prefix + k + ".")
+    return out
+
+
+@pytest.fixture(scope="module")
+def line_n1():
+    return _line([sys.executable, "bench.py", "--gpus", "1", "--cpu-baseline-graphs", "1"] + SMALL)
+
+
+def test_bench_line_n1_schema(line_n1):
+    out = line_n1
+    assert CONTRACT <= set(out) and ROOFLINE <= set(out["roofline"])
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["unit"] == "graphs/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]
+    assert out["config"]["world_size"] == 1 and out["config"]["allreduce_ms"] is None
+    assert out["roofline"]["kernel"].startswith("csr_aggregate_") and 0 < out["roofline"]["frac"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])
+    # all three aggregators in the line, headline = softmax; and the in-line-build figure
+    assert [a["aggr"] for a in out["also_aggr"]] == ["max", "mean"]
+    for a in out["also_aggr"]:
+        names = [k["kernel"] for k in a["kernels"]]
+        assert names == ["csr_aggregate_bwd/%s/rank1" % a["aggr"], "csr_aggregate_fwd/%s/rank1" % a["aggr"]]
+        assert a["ms_per_step"] > 0 and all(k["frac"] > 0 and k["frac_compulsory"] > 0 for k in a["kernels"])
+    assert out["no_overlap_ms_per_step"] > 0
+
+
+def test_bench_two_gpus_as_the_driver_launches_it(line_n1):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the 2-rank RCCL launch of bench.py needs two")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                 "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + SMALL, env)
+    single_only = {"cpu_baseline", "also_aggr", "no_overlap_ms_per_step", "roofline.stream_copy_GBps",
+                   "roofline.frac_of_stream_copy"}
+    want = {k for k in _keys(line_n1) if not any(k == s or k.startswith(s + ".") for s in single_only)}
+    assert _keys(out) == want
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["collective_backend"] == "nccl"
+    assert out["config"]["global_batch"] == 8 and out["config"]["allreduce_ms"] > 0
+    assert abs(out["value"] - 8 * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]

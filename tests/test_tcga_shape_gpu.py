@@ -64,8 +64,9 @@ def test_multilevel_gnn_tcga_shape(name, cfg):
     gb = SimpleNamespace(**{k: v.to(dev) for k, v in vars(batch).items()})
     pred, feat = model(gb)
     assert tuple(feat.shape) == (B, 32, 146, 3 * args.pca_dim)
-    assert_close(feat, feat_ref, 1e-4, name + " pca_feature")
-    assert_close(pred, pred_ref, 1e-4, name + " pred")
+    # RELATIVE 1e-4 on pca_feature / pred, entry by entry
+    assert_close(feat, feat_ref, 1e-4, name + " pca_feature", elementwise=True)
+    assert_close(pred, pred_ref, 1e-4, name + " pred", elementwise=True)
     floss = model.get_feature_loss(feat)
     assert_close(floss, floss_ref, 1e-4, name + " feature loss")
     ((pred * cot.to(dev)).sum() + floss).backward()
@@ -74,4 +75,49 @@ def test_multilevel_gnn_tcga_shape(name, cfg):
             continue
         ref = g_ref[k] if g_ref[k] is not None else torch.zeros_like(sd[k])
         got = p.grad if p.grad is not None else torch.zeros_like(p)
-        assert_close(got, ref, 1e-4, name + " grad " + k)
+        # the per-node embedding scale is an input-side gradient ([15 405, dim], one row per node): entry by entry
+        assert_close(got, ref, 1e-4, name + " grad " + k, elementwise=(k == "node_embedding"))
+
+
+def test_kirc_batch_of_64_properties():
+    """config/kirc.yaml's batch size (64 graphs x 15 405 nodes; the CPU oracle needs minutes per sample at this size):
+    size-independent properties instead -- every sample of the batch equals the same sample run alone (outputs AND the
+    gradient it sends to the shared node embedding adds up), two runs are bitwise equal, all gradients are finite."""
+    from models import get_model
+    gen = torch.Generator().manual_seed(43)
+    B, dev = 64, "cuda:0"
+    torch.manual_seed(8)
+    args = make_args(**KIRC)
+    model = get_model("multilevel_gnn")(args)
+    mask = (torch.rand(25015, generator=gen) > 0.3).to(torch.float32)
+    model.set_pca_params(torch.randn(int(mask.sum()), args.pca_dim, generator=gen) * 0.1, mask)
+    model.set_info_mask(mask[:, None].clone())
+    batch, seg = _synthetic_tcga(B, gen)
+    model.to(dev).eval()
+    model.set_pathway_indexs(seg.to(dev))
+    gb = SimpleNamespace(**{k: v.to(dev) for k, v in vars(batch).items()})
+    cot = torch.randn(B, 2, generator=gen).to(dev)
+
+    def run(b):
+        for p in model.parameters():
+            p.grad = None
+        pred, feat = model(b)
+        ((pred * cot[:pred.shape[0]]).sum() + model.get_feature_loss(feat)).backward()
+        return pred.detach().clone(), feat.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()
+                                                              if p.grad is not None}
+
+    pred, feat, grads = run(gb)
+    assert tuple(feat.shape) == (B, 32, 146, 3 * args.pca_dim) and tuple(pred.shape) == (B, 2)
+    assert all(bool(torch.isfinite(g).all()) for g in grads.values()) and bool(torch.isfinite(pred).all())
+    assert float(grads["node_embedding"].abs().max()) > 0
+    pred2, feat2, grads2 = run(gb)                                   # determinism: no atomics on the path
+    assert torch.equal(pred, pred2) and torch.equal(feat, feat2)
+    assert all(torch.equal(grads[k], grads2[k]) for k in grads)
+    NN = 5135 * 3
+    for i in (7, 63):                                                # batch independence
+        one = SimpleNamespace(x=gb.x[i * NN:(i + 1) * NN], edge_index=gb.edge_index[:, :60000],
+                              edge_attr=gb.edge_attr[:60000], gene_pca_match=gb.gene_pca_match[:1],
+                              raw_indice=gb.raw_indice[:1], age=gb.age[i:i + 1])
+        p1, f1 = model(one)
+        assert_close(f1[0], feat[i], 1e-5, "sample %d alone: pca_feature" % i, elementwise=True)
+        assert_close(p1[0], pred[i], 1e-5, "sample %d alone: pred" % i, elementwise=True)

@@ -30,17 +30,21 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dp_st
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_dp_pmc_$TAG -- $DP > $R/gpurun_out/prof_dp_pmc_$TAG.log 2>&1
 echo "diffpool passes done"
 cd $R
-python3 tools/stress.py --steps 3 --dtype bf16 > gpurun_out/stress_$TAG.log 2>&1 || true
+# from here on a failing optional step must not lose the summaries of the passes that succeeded
+set +e
+python3 tools/stress.py --steps 3 --dtype bf16 > gpurun_out/stress_$TAG.log 2>&1
 python3 - <<PY
-import json, re
 txt = open("gpurun_out/stress_$TAG.log").read()
-m = txt[txt.index("{"):]
-open("profiles/${TAG}_stress_configs4_bf16.json", "w").write(m)
+if "{" in txt:
+    open("profiles/${TAG}_stress_configs4_bf16.json", "w").write(txt[txt.index("{"):])
+else:
+    print("WARNING: no JSON line in gpurun_out/stress_$TAG.log -- profiles/${TAG}_stress_configs4_bf16.json not written")
 PY
 python3 tools/bench_diffpool.py --json profiles/${TAG}_diffpool_configs4.json > gpurun_out/dp_$TAG.log 2>&1
 python3 tools/bench_diffpool.py --dtype fp32 --iters 10 --json profiles/${TAG}_diffpool_configs4_fp32.json > gpurun_out/dp32_$TAG.log 2>&1
 python3 tools/bench_skew.py > gpurun_out/skew_$TAG.log 2>&1
-grep '^{' gpurun_out/skew_$TAG.log | tail -1 > profiles/${TAG}_skew.json
+if grep -q '^{' gpurun_out/skew_$TAG.log; then grep '^{' gpurun_out/skew_$TAG.log | tail -1 > profiles/${TAG}_skew.json
+else echo "WARNING: no JSON line in gpurun_out/skew_$TAG.log -- profiles/${TAG}_skew.json not written"; fi
 python3 tools/summarize_prof.py --stats "gpurun_out/prof_stats_$TAG/**/*kernel_stats.csv" --tag $TAG --commit "$MLGNN_COMMIT" \
   --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline" \
   --pmc-cmd "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one pass each) --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline" \

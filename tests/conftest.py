@@ -37,3 +37,28 @@ def _ensure_native():
 
 
 _ensure_native()
+
+
+@pytest.fixture(autouse=True)
+def _canary_guard(request):
+    """MLGNN_CANARY=1 (debug run of the suite under the guard-band allocator, csrc/canary.hip): the bands are compared
+    after every C-ABI call by the binding; once more at the end of each test, which also covers ATen's kernels."""
+    yield
+    if os.environ.get("MLGNN_CANARY") == "1":
+        import torch
+        if torch.cuda.is_available():
+            from mlgnn import _lib
+            _lib.canary_check("test " + request.node.nodeid)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if os.environ.get("MLGNN_CANARY") == "1":
+        import json
+        import torch
+        if torch.cuda.is_available():
+            from mlgnn import _lib
+            stats = dict(_lib.canary_stats(), exitstatus=int(exitstatus), tests=session.testscollected)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "canary_suite.json"), "w") as fh:
+                json.dump(stats, fh)
+            print("\nMLGNN_CANARY:", json.dumps(stats))

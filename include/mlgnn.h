@@ -379,6 +379,23 @@ int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transposed, const fl
                       float* rstd_out, float* row_max_out, void* c, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
 
 /*
+ * The MLP's second Linear with the NEXT block's pre-conv LayerNorm (+ ReLU) in its epilogue (fp32):
+ *     c [N,J] = relu(gamma xhat + beta) [N,R] * bt[J,R]^T (+ bias) (+ residual)          (= mlgnn_tallgemm_nt, ln_mode 2)
+ *     y [N,J] = relu?(post_gamma (c - mean_row(c)) rstd_row + post_beta),   post_mean / post_rstd [N] = mean, 1/sigma
+ * Replaces: the last Linear of GENConv's MLP (torch_nn.py:54-75) + the residual add and the `norm -> relu` the res+
+ * block applies before the next conv (models/deepergcn.py:236-241; the final norm of :247 with post_relu = 0): the
+ * separate LayerNorm pass (read c, write y) becomes one more store of rows this kernel already holds.  J in {64, 128}
+ * (a wave holds whole result rows), R in {64, 128, 256}, R * J * 4 <= 128 KiB.  Two-pass statistics, biased variance,
+ * eps inside the square root, like nn.LayerNorm.  workspace: mlgnn_tallgemm_workspace_bytes(R, J, fp32) bytes.
+ */
+int mlgnn_tallgemm_lnin_postln_supported(int64_t N, int64_t R, int64_t J);
+int mlgnn_tallgemm_lnin_postln(const float* xhat, const float* bt, const float* bias, const float* residual,
+                               const float* row_max, const float* gamma, const float* beta, const float* post_gamma,
+                               const float* post_beta, float post_eps, int post_relu, float* c, float* y,
+                               float* post_mean, float* post_rstd, void* workspace, int64_t workspace_bytes,
+                               int64_t N, int64_t R, int64_t J, void* stream);
+
+/*
  * The MLP's second Linear run backwards with the ReLU + LayerNorm backward in the epilogue (fp32):
  *     dA = grad_out [N,R] * W [R,J] (w_transposed != 0: W is the Linear's own weight [R,J]; 0: its transpose [J,R]),
  *     gy = dA [gamma xhat + beta > 0],  g = gamma gy,

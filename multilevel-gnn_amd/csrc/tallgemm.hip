@@ -89,6 +89,10 @@ struct TgArgs {
   const float* a; const f16x8* image; const float* bias; const float* res; const float* rowmax; float* c;
   const float* gamma; const float* beta; float* rstd_out; float* rowmax_out; float ln_eps;
   const float* xhat; const float* rstd_in; float* ws;        // LN = 3
+  // POST: the result rows go through a SECOND LayerNorm (+ ReLU) in the epilogue -- the norm + activation the res+
+  // block puts in front of the next conv (deepergcn.py:236-241) -- written to y next to c; mean / 1 sigma to
+  // mean_out / rstd_out (what that LayerNorm's backward needs)
+  const float* pgamma; const float* pbeta; float* y; float* mean_out; float peps; int prelu;
   int N; int R; int J;
 };
 
@@ -110,8 +114,12 @@ template <int JT, int LN> constexpr int tg_block() { return (LN == 3 && JT == 8)
 //     gy = dA [gamma xhat + beta > 0],  g = gamma gy,  c = rstd (g - mean(g) - xhat mean(g xhat)),
 // d gamma / d beta partials per workgroup to ws, max |c| per row to rowmax_out -- so dA [N,J] is never written and
 // read back (1.3 GB per layer at config 1) and the separate LayerNorm backward pass does not exist.
-template <int JT, int KS, int LN>       // 32-column tiles = J / 32, 16-deep k-steps = R / 16
+// POST (with LN = 2, JT <= 4): c = A Bt^T + bias (+ residual) is written as before AND layer-normalised once more,
+//     y = relu?(pgamma (c - mean) rstd + pbeta),
+// the pre-conv norm + ReLU of the NEXT res+ block: its separate pass (read c, write y) becomes one extra store here.
+template <int JT, int KS, int LN, bool POST = false>       // 32-column tiles = J / 32, 16-deep k-steps = R / 16
 __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const TgArgs p) {
+  static_assert(!POST || (LN == 2 && JT <= 4), "POST epilogue: second GEMM of the MLP, whole rows of <= 128 columns");
   constexpr int kTgBlock = tg_block<JT, LN>(), kTgWaves = kTgBlock / kWave;      // (shadow the defaults above)
   extern __shared__ f16x8 wlds[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -133,6 +141,11 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
   float dg[LN == 3 ? JT : 1], db[LN == 3 ? JT : 1];          // LN = 3: this lane's share of d gamma / d beta
 #pragma unroll
   for (int t = 0; t < (LN == 3 ? JT : 1); ++t) { dg[t] = 0.f; db[t] = 0.f; }
+  float pg[POST ? JT : 1], pb[POST ? JT : 1];                  // POST: affine parameters of this lane's output columns
+  if constexpr (POST) {
+#pragma unroll
+    for (int t = 0; t < JT; ++t) { pg[t] = p.pgamma[32 * t + r31]; pb[t] = p.pbeta[32 * t + r31]; }
+  }
   float* kg = reinterpret_cast<float*>(wlds + n_frag);         // [R] gamma then [R] beta, behind the image
   if constexpr (LN == 1) {
 #pragma unroll
@@ -323,6 +336,32 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
           if (r31 == 0) p.rowmax_out[row] = om;
         }
         asm volatile("" ::: "memory");                             // keep the rows apart: gamma / beta are re-read per row
+      } else if constexpr (POST) {
+        float v[JT], sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+          v[t] = fmaf(acc[t][r], us, bias[t]);
+          if (p.res) v[t] += res[t][r];
+          sum += v[t];
+        }
+        if (row < p.N) {
+#pragma unroll
+          for (int t = 0; t < JT; ++t) p.c[(size_t)row * p.J + 32 * t + r31] = v[t];
+        }
+        // two-pass statistics over the row (its J values sit in the 32 lanes sharing h), like layernorm_act_fwd_kernel
+        const float mu = half_sum(sum) * (1.0f / (32 * JT));
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) { v[t] -= mu; q = fmaf(v[t], v[t], q); }
+        const float rs = rsqrtf(half_sum(q) * (1.0f / (32 * JT)) + p.peps);
+        if (row < p.N) {
+#pragma unroll
+          for (int t = 0; t < JT; ++t) {
+            const float yv = fmaf(v[t] * rs, pg[t], pb[t]);
+            p.y[(size_t)row * p.J + 32 * t + r31] = p.prelu ? relu_keep_nan(yv) : yv;
+          }
+          if (r31 == 0) { p.mean_out[row] = mu; p.rstd_out[row] = rs; }
+        }
       } else if (row < p.N) {
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
@@ -386,16 +425,22 @@ extern "C" int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J, int dtyp
   return R * J * 4 + kTgHeader * 16;
 }
 
-extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transposed, const float* bias, const void* residual,
-                                 const float* row_max, int ln_mode, const float* gamma, const float* beta,
-                                 float ln_eps, float* rstd_out, float* row_max_out, void* c, void* workspace,
-                                 int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype,
-                                 void* stream) {
+namespace mlgnn {
+struct TgPost {                 // second LayerNorm of the result rows (nullptr gamma: none)
+  const float* gamma; const float* beta; float eps; int relu; float* y; float* mean; float* rstd;
+};
+}
+
+static int tallgemm_nt_any(const void* a, const void* bt, int bt_transposed, const float* bias, const void* residual,
+                           const float* row_max, int ln_mode, const float* gamma, const float* beta,
+                           float ln_eps, float* rstd_out, float* row_max_out, void* c, void* workspace,
+                           int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, const TgPost* post,
+                           void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || N > INT32_MAX) return MLGNN_E_SHAPE;
   if (N == 0) return 0;
   if (dtype == MLGNN_DTYPE_BF16) {                          // plain product (+ bias, + residual) only
-    if (ln_mode != 0 || bt_transposed) return MLGNN_E_MODE;
+    if (ln_mode != 0 || bt_transposed || post) return MLGNN_E_MODE;
     if (tb_tiles_per_slice(R, J) == 0) return MLGNN_E_SHAPE;
     if (!a || !bt || !c || !workspace) return MLGNN_E_NULL;
     if (workspace_bytes < R * J * 2) return MLGNN_E_WORKSPACE;
@@ -411,6 +456,10 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transpose
   if (ln_mode != 0 && (!gamma || !beta)) return MLGNN_E_NULL;
   if (ln_mode == 1 && (!rstd_out || !row_max_out || residual)) return MLGNN_E_NULL;
   if (ln_mode != 0 && (R < 64 || J < 64)) return MLGNN_E_SHAPE;      // LN modes are instantiated for 64..256 only
+  if (post) {
+    if (ln_mode != 2 || J > 128) return MLGNN_E_MODE;
+    if (!post->gamma || !post->beta || !post->y || !post->mean || !post->rstd) return MLGNN_E_NULL;
+  }
   if (workspace_bytes < R * J * 4 + kTgHeader * 16) return MLGNN_E_WORKSPACE;
   if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bt) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
     return MLGNN_E_ALIGN;
@@ -425,6 +474,11 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transpose
   p.rowmax = row_max; p.c = (float*)c;
   p.gamma = gamma; p.beta = beta; p.rstd_out = rstd_out; p.rowmax_out = row_max_out; p.ln_eps = ln_eps;
   p.xhat = nullptr; p.rstd_in = nullptr; p.ws = nullptr;
+  p.pgamma = nullptr; p.pbeta = nullptr; p.y = nullptr; p.mean_out = nullptr; p.peps = 0.f; p.prelu = 0;
+  if (post) {
+    p.pgamma = post->gamma; p.pbeta = post->beta; p.y = post->y; p.mean_out = post->mean; p.rstd_out = post->rstd;
+    p.peps = post->eps; p.prelu = post->relu;
+  }
   p.N = (int)N; p.R = (int)R; p.J = (int)J;
   const size_t lds = (size_t)R * J * 4 + (ln_mode == 2 ? (size_t)R * 8 : 0);
   const int64_t tiles = (N + 31) / 32;
@@ -432,30 +486,62 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transpose
   if (grid > 256) grid = 256;                      // persistent: one workgroup per CU
   const dim3 g(grid), b(kTgBlock);
   bool launched = false;
-#define MLGNN_TG_LAUNCH(JT_, KS_, LN_)                                                                 \
+#define MLGNN_TG_LAUNCH(JT_, KS_, LN_, POST_)                                                          \
   {                                                                                                   \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, LN_>),         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, LN_, POST_>),  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds + 2048);          \
-    hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, LN_>), g, b, lds, s, p);                             \
+    hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, LN_, POST_>), g, b, lds, s, p);                      \
     launched = true;                                                                                  \
   }
 #define MLGNN_TG_CASE(JT_, KS_)                                                                       \
-  if (!launched && ln_mode == 0 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 0)
+  if (!launched && ln_mode == 0 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 0, false)
 #define MLGNN_TG_CASE_LN(JT_, KS_)                                                                    \
-  if (!launched && ln_mode == 1 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 1)       \
-  if (!launched && ln_mode == 2 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 2)
+  if (!launched && ln_mode == 1 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 1, false)       \
+  if (!launched && ln_mode == 2 && !post && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 2, false)
+#define MLGNN_TG_CASE_POST(JT_, KS_)                                                                  \
+  if (!launched && ln_mode == 2 && post && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 2, true)
 #define MLGNN_TG_ROW(JT_) MLGNN_TG_CASE(JT_, 1) MLGNN_TG_CASE(JT_, 2) MLGNN_TG_CASE(JT_, 4) MLGNN_TG_CASE(JT_, 8)
   MLGNN_TG_ROW(1) MLGNN_TG_ROW(2) MLGNN_TG_ROW(4) MLGNN_TG_ROW(8)
   MLGNN_TG_CASE(1, 16) MLGNN_TG_CASE(2, 16) MLGNN_TG_CASE(4, 16)          // 256 x 256 exceeds the LDS image
   MLGNN_TG_CASE_LN(2, 4) MLGNN_TG_CASE_LN(2, 8) MLGNN_TG_CASE_LN(2, 16)
   MLGNN_TG_CASE_LN(4, 4) MLGNN_TG_CASE_LN(4, 8) MLGNN_TG_CASE_LN(4, 16)
   MLGNN_TG_CASE_LN(8, 4) MLGNN_TG_CASE_LN(8, 8)
+  MLGNN_TG_CASE_POST(2, 4) MLGNN_TG_CASE_POST(2, 8) MLGNN_TG_CASE_POST(2, 16)
+  MLGNN_TG_CASE_POST(4, 4) MLGNN_TG_CASE_POST(4, 8) MLGNN_TG_CASE_POST(4, 16)
 #undef MLGNN_TG_ROW
+#undef MLGNN_TG_CASE_POST
 #undef MLGNN_TG_CASE_LN
 #undef MLGNN_TG_CASE
 #undef MLGNN_TG_LAUNCH
   if (!launched) return MLGNN_E_SHAPE;
   return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transposed, const float* bias, const void* residual,
+                                 const float* row_max, int ln_mode, const float* gamma, const float* beta,
+                                 float ln_eps, float* rstd_out, float* row_max_out, void* c, void* workspace,
+                                 int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype,
+                                 void* stream) {
+  return tallgemm_nt_any(a, bt, bt_transposed, bias, residual, row_max, ln_mode, gamma, beta, ln_eps, rstd_out,
+                         row_max_out, c, workspace, workspace_bytes, N, R, J, dtype, nullptr, stream);
+}
+
+extern "C" int mlgnn_tallgemm_lnin_postln_supported(int64_t N, int64_t R, int64_t J) {
+  const bool ok = (J == 64 || J == 128) && (R == 64 || R == 128 || R == 256) && R * J * 4 <= kTgMaxLds;
+  return (N > 0 && N <= INT32_MAX && ok) ? 1 : 0;
+}
+
+extern "C" int mlgnn_tallgemm_lnin_postln(const float* xhat, const float* bt, const float* bias, const float* residual,
+                                          const float* row_max, const float* gamma, const float* beta,
+                                          const float* post_gamma, const float* post_beta, float post_eps,
+                                          int post_relu, float* c, float* y, float* post_mean, float* post_rstd,
+                                          void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J,
+                                          void* stream) {
+  if (N == 0) return 0;
+  if (!mlgnn_tallgemm_lnin_postln_supported(N, R, J)) return MLGNN_E_SHAPE;
+  TgPost post{post_gamma, post_beta, post_eps, post_relu, y, post_mean, post_rstd};
+  return tallgemm_nt_any(xhat, bt, 0, bias, residual, row_max, 2, gamma, beta, 0.f, nullptr, nullptr, c, workspace,
+                         workspace_bytes, N, R, J, MLGNN_DTYPE_F32, &post, stream);
 }
 
 // ---- dA = go W through ReLU + LayerNorm backward in the epilogue (LN = 3 above) --------------------------------------

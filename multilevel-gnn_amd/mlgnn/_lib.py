@@ -47,6 +47,9 @@ SIGNATURES = {
     "mlgnn_tallgemm_supported": (_INT, [_I64, _I64, _I64, _INT]),
     "mlgnn_tallgemm_workspace_bytes": (_I64, [_I64, _I64, _INT]),
     "mlgnn_tallgemm_nt": (_INT, [_P, _P, _INT, _P, _P, _P, _INT, _P, _P, _F, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
+    "mlgnn_tallgemm_lnin_postln_supported": (_INT, [_I64, _I64, _I64]),
+    "mlgnn_tallgemm_lnin_postln": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _INT, _P, _P, _P, _P, _P, _I64,
+                                          _I64, _I64, _I64, _P]),
     "mlgnn_tallgemm_lnbwd_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_tallgemm_lnbwd_workspace_bytes": (_I64, [_I64, _I64]),
     "mlgnn_tallgemm_lnbwd": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),

@@ -52,6 +52,34 @@ def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None, bt_tr
     return (out, rstd, rmax) if mode == 1 else out
 
 
+def tall_matmul_lnin_postln(xhat, w, bias, residual, row_max, gamma, beta, post):
+    """Second Linear of the fused MLP (``ln = ("in", ...)`` of :func:`tall_matmul_nt`) with a further LayerNorm of the
+    result rows in the epilogue: ``post = (gamma2, beta2, eps2, relu)`` -> ``(out, y, mean2, rstd2)`` with
+    ``y = relu?(LayerNorm(out))`` (csrc/tallgemm.hip POST)."""
+    N, R = xhat.shape
+    J = w.shape[0]
+    xhat, w = xhat.contiguous(), w.contiguous()
+    f32 = dict(dtype=torch.float32, device=xhat.device)
+    out, y = torch.empty((N, J), **f32), torch.empty((N, J), **f32)
+    mean, rstd = torch.empty(N, **f32), torch.empty(N, **f32)
+    nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(R, J, 0))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xhat.device)
+    if residual is not None:
+        residual = residual.contiguous()
+    if bias is not None:
+        bias = bias.float().contiguous()
+    ROW_MAX_STATS["given" if row_max is not None else "computed"] += 1
+    g2, b2, eps2, relu = post
+    rc = _lib.lib.mlgnn_tallgemm_lnin_postln(xhat.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual),
+                                             _lib.ptr(row_max), gamma.contiguous().data_ptr(),
+                                             beta.contiguous().data_ptr(), g2.contiguous().data_ptr(),
+                                             b2.contiguous().data_ptr(), float(eps2), int(bool(relu)), out.data_ptr(),
+                                             y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), nbytes,
+                                             N, R, J, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mlgnn_tallgemm_lnin_postln")
+    return out, y, mean, rstd
+
+
 def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
     """``dA = go [N,R] @ w [R,J]`` (``w``: the Linear's own weight) taken through ReLU + LayerNorm backward in the GEMM's
     epilogue (``csrc/tallgemm.hip`` LN = 3): ``-> (grad_h [N,J], grad_gamma, grad_beta, max |grad_h| per row)`` for a
@@ -156,28 +184,54 @@ class _FusedMLP2(torch.autograd.Function):
     torch_vertex.py:35) -- with the hidden activation written ONCE, layer-normalised by the first GEMM's epilogue;
     the affine map + ReLU are applied by its consumers as they load it (second GEMM, its weight gradient), so the
     LayerNorm pass between the two GEMMs does not exist.  The backward is spelled out: weight gradients on the
-    split-row kernel, input gradients on the tall GEMM, LayerNorm backward on the stored normalised activation."""
+    split-row kernel, input gradients on the tall GEMM, LayerNorm backward on the stored normalised activation.
+
+    ``post = (gamma2, beta2, eps2, relu)``: the block's NEXT step -- the res+ block's ``norm -> relu`` in front of the
+    following conv (deepergcn.py:236-241), or the final norm (:247) -- is computed from the result rows in the second
+    GEMM's epilogue; the op then returns ``(out, y)`` with ``y = relu?(LayerNorm(out))`` and its backward starts with
+    that LayerNorm's backward, which also adds the gradient arriving on ``out`` (the identity branch of the residual
+    block) in the same pass."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, residual, eps):
+    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, residual, eps, post_gamma=None, post_beta=None, post_eps=0.0,
+                post_relu=False):
         from .ops import row_max_of as _rm
         x = x.contiguous()
         xhat, rstd, rmax = tall_matmul_nt(x, w1, b1, None, _rm(x), ln=("out", gamma, beta, eps))
         fuse = residual is not None and w2.shape[0] <= 128
+        ctx.post = post_gamma is not None
+        ctx.flags = (b1 is not None, b2 is not None)
+        # row maxima of the weight-gradient operands (x; the activated hidden layer): their scales in the backward
+        ctx.maxima = (_rm(x), rmax)
+        if ctx.post:
+            out, y, mean2, rstd2 = tall_matmul_lnin_postln(xhat, w2, b2, residual, rmax, gamma, beta,
+                                                           (post_gamma, post_beta, post_eps, post_relu))
+            ctx.post_relu = bool(post_relu)
+            ctx.post_dtype = post_gamma.dtype
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(x, xhat, rstd, w1, w2, gamma, beta, out, mean2, rstd2, post_gamma, post_beta)
+            return out, y
         out = tall_matmul_nt(xhat, w2, b2, residual if fuse else None, rmax, ln=("in", gamma, beta))
         if residual is not None and not fuse:
             out = out + residual
         ctx.save_for_backward(x, xhat, rstd, w1, w2, gamma, beta)
-        ctx.flags = (b1 is not None, b2 is not None)
-        # row maxima of the weight-gradient operands (x; the activated hidden layer): their scales in the backward
-        ctx.maxima = (_rm(x), rmax)
         return out
 
     @staticmethod
-    def backward(ctx, go):
-        from .norm import ln_backward_normalised
+    def backward(ctx, go, go_y=None):
+        from .norm import ln_backward_normalised, ln_backward_saved
         from .ops import row_max_of as _rm
-        x, xhat, rstd, w1, w2, gamma, beta = ctx.saved_tensors
+        gpg = gpb = None
+        if ctx.post:
+            x, xhat, rstd, w1, w2, gamma, beta, out, mean2, rstd2, pg, pb = ctx.saved_tensors
+            if go_y is not None:
+                # LayerNorm (+ ReLU) backward of y, plus the gradient that arrived on `out` itself, in one pass
+                go, gpg, gpb = ln_backward_saved(go_y, out, pg, pb, mean2, rstd2, ctx.post_relu, extra=go)
+                gpg, gpb = gpg.to(ctx.post_dtype), gpb.to(ctx.post_dtype)
+            elif go is None:
+                return (None,) * 13
+        else:
+            x, xhat, rstd, w1, w2, gamma, beta = ctx.saved_tensors
         has_b1, has_b2 = ctx.flags
         go = go.contiguous()
         x_max, act_max = ctx.maxima
@@ -191,7 +245,7 @@ class _FusedMLP2(torch.autograd.Function):
         gw1, gb1 = _wgrad(gh, x, go_max=gh_max, x_max=x_max)
         gx = tall_matmul_nt(gh, w1, row_max=gh_max, bt_transposed=True) if ctx.needs_input_grad[0] else None
         return (gx, gw1, gb1 if has_b1 else None, ggamma, gbeta, gw2, gb2 if has_b2 else None,
-                go if ctx.needs_input_grad[7] else None, None)
+                go if ctx.needs_input_grad[7] else None, None, gpg, gpb, None, None)
 
 
 def fused_mlp2_supported(x, w1, w2):
@@ -206,8 +260,19 @@ def fused_mlp2_supported(x, w1, w2):
             and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], o, h, 0) > 0)
 
 
-def fused_mlp2(x, w1, b1, gamma, beta, eps, w2, b2, residual=None):
-    return _FusedMLP2.apply(x, w1, b1, gamma, beta, w2, b2, residual, float(eps))
+def fused_mlp2(x, w1, b1, gamma, beta, eps, w2, b2, residual=None, post_norm=None):
+    """``post_norm = (weight, bias, eps, relu)``: also return ``relu?(LayerNorm(out))`` -> ``(out, y)``; the caller checks
+    :func:`fused_mlp2_post_supported`."""
+    if post_norm is None:
+        return _FusedMLP2.apply(x, w1, b1, gamma, beta, w2, b2, residual, float(eps))
+    pw, pb, peps, prelu = post_norm
+    return _FusedMLP2.apply(x, w1, b1, gamma, beta, w2, b2, residual, float(eps), pw, pb, float(peps), bool(prelu))
+
+
+def fused_mlp2_post_supported(x, w1, w2, post_weight):
+    """The post-LayerNorm epilogue holds whole result rows of 64 or 128 fp32 columns."""
+    return (fused_mlp2_supported(x, w1, w2) and post_weight is not None and post_weight.dtype == torch.float32
+            and bool(_lib.lib.mlgnn_tallgemm_lnin_postln_supported(x.shape[0], w1.shape[0], w2.shape[0])))
 
 
 def linear(x, weight, bias=None, residual=None):

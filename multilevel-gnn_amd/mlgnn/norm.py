@@ -89,6 +89,31 @@ def _ln_backward(ctx, go, extra):
     return gx, ggb.to(ctx.param_dtype)
 
 
+def ln_backward_saved(go, x, weight, bias, mean, rstd, relu, extra=None):
+    """LayerNorm(+ReLU) backward from the saved input and statistics, outside an autograd node of its own (the fused
+    MLP's post-LayerNorm, :class:`mlgnn.dense._FusedMLP2`): ``-> (grad_x (+ extra), grad_gamma, grad_beta)``; the
+    result carries its row maxima for the GEMMs that consume it."""
+    rows, d = x.shape
+    go = go.contiguous()
+    if extra is not None:
+        extra = extra.contiguous()
+    weight, bias = _f32_params(weight, bias)
+    gx = torch.empty_like(x)
+    ggb = torch.empty((2, d), dtype=torch.float32, device=x.device)
+    dt = _DTYPE_IDS[x.dtype]
+    n = int(_lib.lib.mlgnn_layernorm_bwd_workspace_floats(rows, d, dt))
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    row_max = torch.empty(rows, dtype=torch.float32, device=x.device) if x.dtype == torch.float32 else None
+    rc = _lib.lib.mlgnn_layernorm_act_bwd(go.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                          mean.data_ptr(), rstd.data_ptr(), _lib.ptr(extra), gx.data_ptr(),
+                                          _lib.ptr(row_max), ggb.data_ptr(), ws.data_ptr(), n, None, 1.0, rows, d,
+                                          int(relu), dt, _stream())
+    _lib.check(rc, "mlgnn_layernorm_act_bwd")
+    if row_max is not None:
+        tag_row_max(gx, row_max)
+    return gx, ggb[0], ggb[1]
+
+
 def ln_backward_normalised(go, xhat, weight, bias, rstd, relu=True):
     """LayerNorm(+ReLU) backward when the stored activation is already normalised (``xhat``, ``rstd`` from the
     first GEMM of :class:`mlgnn.dense._FusedMLP2`): ``-> (grad_x, grad_gamma, grad_beta, max |grad_x| per row)``."""

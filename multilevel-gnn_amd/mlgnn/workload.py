@@ -17,7 +17,6 @@ from torch import nn
 
 from .dense import linear
 from .graph import CSRGraph
-from .norm import layer_norm_act, layer_norm_act_fork
 from .ops import RankOneEdge
 from .project import segment_project
 
@@ -111,16 +110,14 @@ class ThreeLevelGNN(nn.Module):
             graph = CSRGraph(batch.edge_index, N)
         h = linear(batch.x, self.node_features_encoder.weight, self.node_features_encoder.bias)
         edge = RankOneEdge(batch.edge_attr[:, 0], self.edge_encoder.weight[:, 0], self.edge_encoder.bias)
-        # res+ block (deepergcn.py:232-247), dropout 0
-        h = self.gcns[0](h, graph, edge)
-        for l in range(1, self.num_layers):
-            n = self.norms[l - 1]
-            # h = conv(relu(norm(h))) + h: the add runs in the conv's last GEMM epilogue, its gradient in the
-            # LayerNorm backward kernel
-            y, identity = layer_norm_act_fork(h, n.weight, n.bias, n.eps, relu=True)
-            h = self.gcns[l](y, graph, edge, residual=identity)
-        n = self.norms[self.num_layers - 1]
-        h = layer_norm_act(h, n.weight, n.bias, n.eps)
+        # res+ block (deepergcn.py:232-247), dropout 0: h = conv(relu(norm(h))) + h.  The add, and the norm (+ ReLU) that
+        # follows -- the next block's input, the final norm after the last conv -- run in the conv's last GEMM epilogue;
+        # the gradient of the identity branch is added inside that LayerNorm's backward
+        L = self.num_layers
+        h, y = self.gcns[0](h, graph, edge, post_norm=(self.norms[0], L > 1))
+        for l in range(1, L):
+            h, y = self.gcns[l](y, graph, edge, residual=h, post_norm=(self.norms[l], l < L - 1))
+        h = y
         # level 1: gene -> pathway projection pooling (multilevel_gnn.py:212-242)
         B = batch.gene_pca_match.shape[0]
         p = segment_project(h, batch.gene_pca_match, batch.raw_indice, self.learnable_pca_params,

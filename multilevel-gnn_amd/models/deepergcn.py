@@ -155,6 +155,28 @@ class DeeperGCN(torch.nn.Module):
         h = F.relu(h) if relu else h
         return self._drop(h) if drop else h
 
+    def _res_plus_unfused(self, h, graph, edge_emb):
+        """res+ stack with the norm / ReLU / dropout passes of their own (dropout active, non-LayerNorm norms)."""
+        L = self.num_layers
+        h = self.gcns[0](h, graph, edge_emb)
+        for layer in range(1, L):
+            m = self.norms[layer - 1]
+            drop = not self.no_inter_drop
+            if not self.no_inter_norm and isinstance(m, nn.LayerNorm) and h.dim() == 2:
+                # the residual add runs in the conv's last GEMM epilogue and its gradient inside the
+                # LayerNorm backward kernel (same values, two elementwise passes fewer); the dropout behind
+                # norm + ReLU is applied by the same kernels
+                h2, identity = layer_norm_act_fork(h, m.weight, m.bias, m.eps, relu=True,
+                                                   dropout_p=self.dropout if (drop and self.training) else 0.0)
+            else:
+                h2 = F.relu(h) if self.no_inter_norm else self._norm(layer - 1, h, relu=True)
+                identity = h
+                if drop:
+                    h2 = self._drop(h2)
+            h = self.gcns[layer](h2, graph, edge_emb, residual=identity)
+        h = self._norm(L - 1, h, drop=not self.no_inter_drop)
+        return h
+
     # ------------------------------------------------------------------ forward
     def forward(self, input_batch):
         x = input_batch.x
@@ -182,23 +204,18 @@ class DeeperGCN(torch.nn.Module):
 
         L = self.num_layers
         if self.block == 'res+':
-            h = self.gcns[0](h, graph, edge_emb)
-            for layer in range(1, L):
-                m = self.norms[layer - 1]
-                drop = not self.no_inter_drop
-                if not self.no_inter_norm and isinstance(m, nn.LayerNorm) and h.dim() == 2:
-                    # the residual add runs in the conv's last GEMM epilogue and its gradient inside the
-                    # LayerNorm backward kernel (same values, two elementwise passes fewer); the dropout behind
-                    # norm + ReLU is applied by the same kernels
-                    h2, identity = layer_norm_act_fork(h, m.weight, m.bias, m.eps, relu=True,
-                                                       dropout_p=self.dropout if (drop and self.training) else 0.0)
-                else:
-                    h2 = F.relu(h) if self.no_inter_norm else self._norm(layer - 1, h, relu=True)
-                    identity = h
-                    if drop:
-                        h2 = self._drop(h2)
-                h = self.gcns[layer](h2, graph, edge_emb, residual=identity)
-            h = self._norm(L - 1, h, drop=not self.no_inter_drop)
+            drop_active = self.training and self.dropout > 0 and not self.no_inter_drop
+            if (not self.no_inter_norm and not drop_active and h.dim() == 2
+                    and all(isinstance(m, nn.LayerNorm) and m.elementwise_affine for m in self.norms)):
+                # every conv also emits the norm (+ ReLU) of its result -- the next block's input, or the final norm --
+                # from its last GEMM's epilogue (mlgnn.dense._FusedMLP2 `post`): no LayerNorm pass of its own; the
+                # residual add runs in the same epilogue and its gradient inside that LayerNorm's backward
+                h, y = self.gcns[0](h, graph, edge_emb, post_norm=(self.norms[0], L > 1))
+                for layer in range(1, L):
+                    h, y = self.gcns[layer](y, graph, edge_emb, residual=h, post_norm=(self.norms[layer], layer < L - 1))
+                h = y
+            else:
+                h = self._res_plus_unfused(h, graph, edge_emb)
         elif self.block == 'res':
             h = self._drop(self._norm(0, self.gcns[0](h, graph, edge_emb), relu=True))
             for layer in range(1, L):

@@ -7,8 +7,8 @@ the reference are molecule-dataset leftovers outside the hot path and are not pr
 """
 from torch import nn
 
-from mlgnn.dense import fused_mlp2, fused_mlp2_supported, linear
-from mlgnn.norm import layer_norm_act
+from mlgnn.dense import fused_mlp2, fused_mlp2_post_supported, fused_mlp2_supported, linear
+from mlgnn.norm import layer_norm_act, layer_norm_act_fork
 
 _ACTS = {
     "relu": lambda inplace, slope, n: nn.ReLU(inplace),
@@ -43,6 +43,13 @@ def _enabled(name):
     return name is not None and isinstance(name, str) and name.lower() != "none"
 
 
+def _post(out, post_norm):
+    """``(identity, relu?(norm(out)))`` as a separate (fork) pass: shapes the fused epilogue does not cover."""
+    pn, relu = post_norm
+    y, identity = layer_norm_act_fork(out, pn.weight, pn.bias, pn.eps, relu=relu)
+    return identity, y
+
+
 class MLP(nn.Sequential):
     """``Linear -> [norm] -> [act] -> [Dropout2d]`` per hop; the last hop is a bare Linear when
     ``last_lin``.  Child indices (and so ``state_dict`` keys) follow the reference's layout."""
@@ -62,18 +69,26 @@ class MLP(nn.Sequential):
                 layers.append(nn.Dropout2d(drop))
         super().__init__(*layers)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, post_norm=None):
         """Same children, same order; a ``LayerNorm`` directly followed by ``ReLU`` runs as ONE
         fused HIP pass (``mlgnn.norm.layer_norm_act``) instead of two ATen passes; ``nn.Linear``
         children use ``mlgnn.dense.linear`` (split-precision MFMA GEMMs); ``residual`` is added in the last
-        Linear's epilogue."""
+        Linear's epilogue.  ``post_norm = (nn.LayerNorm, relu)``: the caller's next step is that norm (+ ReLU) of the
+        result -- returns ``(out, relu?(norm(out)))``, computed in the last GEMM's epilogue when the fused MLP applies."""
         mods = list(self)
         # Linear -> LayerNorm -> ReLU -> Linear (GENConv's MLP): one fused op, no LayerNorm pass in between
         if (len(mods) == 4 and type(mods[0]) is nn.Linear and isinstance(mods[1], nn.LayerNorm)
                 and mods[1].elementwise_affine and isinstance(mods[2], nn.ReLU) and type(mods[3]) is nn.Linear
                 and fused_mlp2_supported(x, mods[0].weight, mods[3].weight)):
-            return fused_mlp2(x, mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias, mods[1].eps,
-                              mods[3].weight, mods[3].bias, residual)
+            if post_norm is not None and fused_mlp2_post_supported(x, mods[0].weight, mods[3].weight, post_norm[0].weight):
+                pn, relu = post_norm
+                return fused_mlp2(x, mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias, mods[1].eps,
+                                  mods[3].weight, mods[3].bias, residual, (pn.weight, pn.bias, pn.eps, relu))
+            out = fused_mlp2(x, mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias, mods[1].eps,
+                             mods[3].weight, mods[3].bias, residual)
+            return out if post_norm is None else _post(out, post_norm)
+        if post_norm is not None:
+            return _post(self.forward(x, residual), post_norm)
         i = 0
         while i < len(mods):
             m = mods[i]

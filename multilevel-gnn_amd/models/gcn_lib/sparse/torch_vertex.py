@@ -41,9 +41,12 @@ class GENConv(GenMessagePassing):
             self.edge_encoder = nn.Linear(edge_feat_dim, in_dim)
         self.pca_only = pca_only
 
-    def forward(self, x, edge_index, edge_attr=None, residual=None):
+    def forward(self, x, edge_index, edge_attr=None, residual=None, post_norm=None):
         """``edge_index``: COO ``[2, E]`` or a prebuilt :class:`mlgnn.CSRGraph`.
         ``residual``: added to the result inside the last Linear's epilogue (the caller's ``conv(...) + h``).
+        ``post_norm = (nn.LayerNorm, relu)``: the caller's next step is ``relu?(norm(result))`` (the res+ block's
+        pre-conv norm, deepergcn.py:236-241) -- returns ``(result, relu?(norm(result)))``, the second value written by
+        the last Linear's epilogue instead of by a pass of its own.
         ``edge_attr``: ``[E, d_e]`` tensor, a :class:`mlgnn.LowRankEdge` (raw attributes kept factored
         through the Linear encoders: no ``[E, d]`` tensor, no edge GEMM) or a :class:`mlgnn.TableEdge`
         (one row of a small table per edge: the edge-type embedding)."""
@@ -66,8 +69,8 @@ class GENConv(GenMessagePassing):
             h = msg_norm_add(flat, self.reduce_messages(flat, graph, edge, self.eps), self.msg_norm.msg_scale)
         if h.shape != x.shape:                    # (a same-shape reshape would drop the row-max tag of the kernel's output)
             h = h.reshape(x.shape)
-        if residual is not None and isinstance(self.feature_encoder, MLP):
-            return self.feature_encoder(h, residual=residual)
+        if isinstance(self.feature_encoder, MLP) and (residual is not None or post_norm is not None):
+            return self.feature_encoder(h, residual=residual, post_norm=post_norm)
         out = self.feature_encoder(h)
         return out if residual is None else out + residual
 

@@ -161,3 +161,58 @@ def test_fused_mlp2_matches_the_unfused_composition(rows, k, hdim, o, res):
     names = ["x", "W1", "b1", "gamma", "beta", "W2", "b2"] + (["residual"] if res else [])
     for name, a, b in zip(names, got, gr):
         assert_close(a, b, 1e-4, "fused mlp grad " + name)
+
+
+@pytest.mark.parametrize("rows,k,hdim,o,res,relu,use", [(9000, 128, 256, 128, True, True, "both"),
+                                                       (8200, 64, 128, 64, False, True, "both"),
+                                                       (20011, 128, 256, 128, True, False, "y"),
+                                                       (8192, 64, 256, 128, True, True, "out"),
+                                                       (8300, 128, 128, 64, False, False, "both")])
+def test_fused_mlp2_with_the_next_norm_in_its_epilogue(rows, k, hdim, o, res, relu, use):
+    """``(out, relu?(LayerNorm(out)))`` from the second GEMM's epilogue (csrc/tallgemm.hip POST): both values and every
+    gradient -- with cotangents on both outputs (a middle res+ block: identity branch + next conv), on ``y`` alone (the
+    final norm after the last conv) and on ``out`` alone -- against the unfused composition on the CPU."""
+    from mlgnn.dense import fused_mlp2, fused_mlp2_post_supported
+    gen = torch.Generator().manual_seed(rows + hdim + 1)
+    x = torch.randn(rows, k, generator=gen, requires_grad=True)
+    w1 = (torch.randn(hdim, k, generator=gen) * 0.2).requires_grad_(True)
+    b1 = torch.randn(hdim, generator=gen).requires_grad_(True)
+    g = (torch.rand(hdim, generator=gen) + 0.5).requires_grad_(True)
+    be = (torch.randn(hdim, generator=gen) * 0.3).requires_grad_(True)
+    w2 = (torch.randn(o, hdim, generator=gen) * 0.1).requires_grad_(True)
+    b2 = torch.randn(o, generator=gen).requires_grad_(True)
+    g2 = (torch.rand(o, generator=gen) + 0.5).requires_grad_(True)
+    be2 = (torch.randn(o, generator=gen) * 0.3).requires_grad_(True)
+    leaves = [x, w1, b1, g, be, w2, b2, g2, be2]
+    if res:
+        leaves.append((torch.randn(rows, o, generator=gen) * 2.0).requires_grad_(True))
+    c_out, c_y = torch.randn(rows, o, generator=gen), torch.randn(rows, o, generator=gen)
+
+    def run(lv, dev):
+        if dev == "cpu":
+            hid = torch.relu(F.layer_norm(F.linear(lv[0], lv[1], lv[2]), (hdim,), lv[3], lv[4], 1e-5))
+            out = F.linear(hid, lv[5], lv[6]) + (lv[9] if res else 0)
+            y = F.layer_norm(out, (o,), lv[7], lv[8], 1e-5)
+            y = torch.relu(y) if relu else y
+        else:
+            assert fused_mlp2_post_supported(lv[0], lv[1], lv[5], lv[7])
+            out, y = fused_mlp2(lv[0], lv[1], lv[2], lv[3], lv[4], 1e-5, lv[5], lv[6], lv[9] if res else None,
+                                (lv[7], lv[8], 1e-5, relu))
+        loss = 0.0
+        if use in ("both", "out"):
+            loss = loss + (out * c_out.to(dev)).sum()
+        if use in ("both", "y"):
+            loss = loss + (y * c_y.to(dev)).sum()
+        return out, y, torch.autograd.grad(loss, lv, allow_unused=True)
+
+    out_r, y_r, gr = run(leaves, "cpu")
+    dl = [t.detach().cuda().requires_grad_(True) for t in leaves]
+    out, y, got = run(dl, "cuda")
+    assert_close(out, out_r, 1e-4, "out", elementwise=True)
+    assert_close(y, y_r, 1e-4, "y", elementwise=True)
+    names = ["x", "W1", "b1", "gamma", "beta", "W2", "b2", "post gamma", "post beta"] + (["residual"] if res else [])
+    for name, a, b in zip(names, got, gr):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, name
+        else:
+            assert_close(a, b, 1e-4, "grad " + name)

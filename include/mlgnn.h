@@ -150,6 +150,10 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
  *   grad_uv  [edge_rank+1,d]  EDGE_RANK1: d loss / d eu (edge_rank rows), then d loss / d ev
  *   learn_t  non-zero: SOFTMAX weights carry gradient (torch_message.py:51-52)
  *   workspace: mlgnn_csr_aggregate_bwd_workspace_floats(N,d,dtype,edge_rank,aggr,learn_t) floats
+ *   grad_shifted [N,d], shift_flag [4 x int32]  optional (both or neither; SOFTMAX without learn_t): the rescaled
+ *            cotangent grad_out * 2^(-aux) and its overflow flag, already written by the producer of grad_out
+ *            (mlgnn_tallgemm_nt_shift); the streaming pre-pass that would compute them is skipped and the workspace
+ *            needs the edge-term partials only (query with aggr = MLGNN_AGGR_SUM)
  */
 int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out, const float* aux,
                             const int32_t* argmax,
@@ -161,7 +165,8 @@ int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out
                             float* workspace, int64_t workspace_floats,
                             int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                             int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev,
-                            float eps, int add_root, int accumulate_efull, const mlgnn_hub_t* hub, void* stream);
+                            float eps, int add_root, int accumulate_efull, const mlgnn_hub_t* hub,
+                            const void* grad_shifted, const int32_t* shift_flag, void* stream);
 
 /*
  * Gene -> pathway learnable-projection pooling.
@@ -377,6 +382,20 @@ int64_t mlgnn_tallgemm_workspace_bytes(int64_t R, int64_t J, int dtype);
 int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transposed, const float* bias, const void* residual,
                       const float* row_max, int ln_mode, const float* gamma, const float* beta, float ln_eps,
                       float* rstd_out, float* row_max_out, void* c, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, void* stream);
+
+/*
+ * Input gradient of a Linear whose INPUT is the output of a softmax aggregation (fp32): the plain product
+ *     c [N,J] = a [N,R] * bt (mlgnn_tallgemm_nt, ln_mode 0, no bias / residual)
+ * plus, from the same epilogue, what that aggregation's backward gathers per edge (csrc/aggregate_bwd.hip):
+ *     grad_shifted[i][j] = c[i][j] * 2^(-lse[i][j])   (0 for nodes without incoming edges: rowptr [N+1] by destination),
+ *     shift_flag[0] = 1 when some |lse| > 60 (the consumer then takes its two-row path), else 0   (4 x int32, zeroed here)
+ * Replaces: the streaming pre-pass of the softmax backward (read grad_out and lse, write grad_shifted) -- a load and a
+ * store of rows this kernel already holds.  Hand both to mlgnn_csr_aggregate_bwd.  J in {64, 128}, R in {64, 128, 256}.
+ */
+int mlgnn_tallgemm_nt_shift_supported(int64_t N, int64_t R, int64_t J);
+int mlgnn_tallgemm_nt_shift(const float* a, const float* bt, int bt_transposed, const float* row_max, const float* lse,
+                            const int32_t* rowptr, float* c, float* grad_shifted, int32_t* shift_flag, void* workspace,
+                            int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream);
 
 /*
  * The MLP's second Linear with the NEXT block's pre-conv LayerNorm (+ ReLU) in its epilogue (fp32):

@@ -263,10 +263,6 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
   }
 }
 
-// |lse| (log2 units) up to which the two factors 2^(t m) <= 2^lse and 2^(-lse) are taken apart: 2^(+-60) leaves
-// fp32 more than 60 binades on either side for the cotangent itself
-constexpr float kMaxLse = 60.0f;
-
 template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool VIRT = false>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
   __shared__ float red[kWavesPerBlock][kWave * VEC];
@@ -444,7 +440,8 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                                        int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
                                        int aggr, int learn_t, float t, float p, const float* t_dev,
                                        const float* p_dev, float eps, int add_root, int accumulate_efull,
-                                       const mlgnn_hub_t* hub, void* stream) {
+                                       const mlgnn_hub_t* hub, const void* grad_shifted, const int32_t* shift_flag,
+                                       void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
@@ -472,7 +469,9 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   }
   // workspace = [edge-term partials: (nblk + kHubBlocks) * (rk+1) * d][softmax one-row path: flag (4 floats), gt [N*d] of T]
   const int64_t part_floats = rk > 0 ? (int64_t)(nblk + kHubBlocks) * (rk + 1) * d : 0;
-  const bool want_shift = ag == A_SOFTMAX && !learn_t;
+  // the shifted cotangent may arrive ready-made from the producer of grad_out (mlgnn_tallgemm_nt_shift)
+  const bool have_shift = ag == A_SOFTMAX && !learn_t && grad_shifted != nullptr && shift_flag != nullptr;
+  const bool want_shift = ag == A_SOFTMAX && !learn_t && !have_shift;
   const bool want_slots = ag == A_MAX && d % 4 == 0;
   const int64_t shift_floats = want_shift ? 4 + (N * d * (bf16 ? 2 : 4) + 3) / 4 : (want_slots ? 4 + (N * d + 3) / 4 : 0);
   if (part_floats + shift_floats > 0 && (!workspace || workspace_floats < part_floats + shift_floats)) return MLGNN_E_WORKSPACE;
@@ -502,6 +501,10 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   hipStream_t s = (hipStream_t)stream;
   a.lpr_log2 = lanes_per_row_log2(d, vec);
   a.gt = nullptr; a.spread = nullptr;
+  if (have_shift) {
+    if (!aligned16(grad_shifted) && vec != 1) return MLGNN_E_ALIGN;
+    a.gt = grad_shifted; a.spread = shift_flag;
+  }
   if (want_shift) {
     float* base = workspace + part_floats;               // 16-byte aligned: part_floats is a multiple of 4 when d % 4 == 0
     if (!rowptr) return MLGNN_E_NULL;

@@ -132,6 +132,11 @@ __device__ __forceinline__ float relu_keep_nan(float y) { return (y < 0.f) ? 0.f
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
+// |lse| (log2 units) up to which the softmax backward takes the two factors 2^(t m) <= 2^lse and 2^(-lse) apart (the
+// shifted cotangent gt = go * 2^(-lse): csrc/aggregate_bwd.hip, and its producer epilogue in csrc/tallgemm.hip):
+// 2^(+-60) leaves fp32 more than 60 binades on either side for the cotangent itself
+constexpr float kMaxLse = 60.0f;
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 

@@ -93,9 +93,20 @@ struct TgArgs {
   // block puts in front of the next conv (deepergcn.py:236-241) -- written to y next to c; mean / 1 sigma to
   // mean_out / rstd_out (what that LayerNorm's backward needs)
   const float* pgamma; const float* pbeta; float* y; float* mean_out; float peps; int prelu;
+  // SHIFT: res holds lse [N,J] of the softmax aggregation whose backward consumes c; y receives c * 2^(-lse)
+  const int* rowptr; int* spread;
   int N; int R; int J;
 };
 
+// k-steps of the A operand in flight ahead of the MFMAs: 4 where the registers allow it, 2 for the instantiations
+// that otherwise spill (8 column tiles with the LayerNorm epilogue, the POST epilogue)
+#ifdef MLGNN_TG_PF
+template <int JT, int KS, int LN, bool POST> constexpr int tg_prefetch() { return MLGNN_TG_PF; }
+#else
+template <int JT, int KS, int LN, bool POST> constexpr int tg_prefetch() {
+  return (LN == 3 && JT == 8) ? 4 : ((POST || (LN == 1 && JT == 8)) ? 2 : 4);
+}
+#endif
 constexpr int kTgBlock = 512;              // 8 waves: two per SIMD share the LDS image and hide each other's loads
 constexpr int kTgWaves = kTgBlock / kWave;
 // LN = 3 at 8 column tiles: 128 accumulator registers + the epilogue's operands do not fit the 256 registers a wave has
@@ -117,9 +128,16 @@ template <int JT, int LN> constexpr int tg_block() { return (LN == 3 && JT == 8)
 // POST (with LN = 2, JT <= 4): c = A Bt^T + bias (+ residual) is written as before AND layer-normalised once more,
 //     y = relu?(pgamma (c - mean) rstd + pbeta),
 // the pre-conv norm + ReLU of the NEXT res+ block: its separate pass (read c, write y) becomes one extra store here.
-template <int JT, int KS, int LN, bool POST = false>       // 32-column tiles = J / 32, 16-deep k-steps = R / 16
+// SHIFT (with LN = 0, JT <= 4): c is the cotangent of a softmax aggregation's output (the input gradient of the Linear
+// behind it); the epilogue also writes the rescaled cotangent that aggregation's backward gathers,
+//     y[i][c] = c[i][c] * 2^(-lse[i][c])      (rows without incoming edges: 0),
+// with lse arriving through the residual slot, and raises *spread when some |lse| > kMaxLse -- the streaming pre-pass
+// of csrc/aggregate_bwd.hip (softmax_shift_kernel: read c and lse, write y) becomes one load and one store here.
+template <int JT, int KS, int LN, bool POST = false, bool SHIFT = false>       // 32-column tiles = J / 32, 16-deep k-steps = R / 16
 __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const TgArgs p) {
   static_assert(!POST || (LN == 2 && JT <= 4), "POST epilogue: second GEMM of the MLP, whole rows of <= 128 columns");
+  static_assert(!SHIFT || (LN == 0 && JT <= 4 && !POST), "SHIFT epilogue: plain product, lse tile in the residual registers");
+  float worst_lse = 0.f;
   constexpr int kTgBlock = tg_block<JT, LN>(), kTgWaves = kTgBlock / kWave;      // (shadow the defaults above)
   extern __shared__ f16x8 wlds[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -222,32 +240,46 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    float4 n0 = *reinterpret_cast<const float4*>(ap);
-    float4 n1 = *reinterpret_cast<const float4*>(ap + 4);
-#pragma unroll 1                                               // keep ONE k-step of A live: a full unroll spills
-    for (int s = 0; s < KS; ++s) {
-      float e[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
-      activate(e, s);
-      if (s + 1 < KS) {
-        n0 = *reinterpret_cast<const float4*>(ap + 16 * (s + 1));
-        n1 = *reinterpret_cast<const float4*>(ap + 16 * (s + 1) + 4);
-      }
-      f16x8 ahi, alo;
+    // k-loop: PF k-steps of A (32 bytes per lane each) are in flight ahead of the one being multiplied -- a k-step's 3 JT
+    // MFMAs take 0.15-0.3 us, a load from HBM 1-2 us, so with one k-step ahead (the first version) every k-step waited
+    // out most of a memory round trip.  The ring is unrolled PF-fold; the outer loop is not (a full unroll spills).
+    // (at most KS / 2: with the whole k range in the ring the loop below unrolls completely and the compiler spills)
+    constexpr int kWant = tg_prefetch<JT, KS, LN, POST>();
+    constexpr int PF = KS == 1 ? 1 : (kWant <= KS / 2 ? kWant : KS / 2);
+    float4 n0[PF], n1[PF];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = e[j] * sa;
-        const _Float16 hh = (_Float16)x;
-        ahi[j] = hh;
-        alo[j] = (_Float16)(x - (float)hh);
-      }
-      const f16x8* wf = wlds + (size_t)(s * JT) * 2 * 64 + lane;
+    for (int i = 0; i < PF; ++i) {
+      n0[i] = *reinterpret_cast<const float4*>(ap + 16 * i);
+      n1[i] = *reinterpret_cast<const float4*>(ap + 16 * i + 4);
+    }
+#pragma unroll 1
+    for (int s0 = 0; s0 < KS; s0 += PF) {
 #pragma unroll
-      for (int t = 0; t < JT; ++t) {
-        const f16x8 bhi = wf[t * 128];
-        const f16x8 blo = wf[t * 128 + 64];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[t], 0, 0, 0);
+      for (int i = 0; i < PF; ++i) {
+        const int s = s0 + i;
+        float e[8] = {n0[i].x, n0[i].y, n0[i].z, n0[i].w, n1[i].x, n1[i].y, n1[i].z, n1[i].w};
+        if (s + PF < KS) {
+          n0[i] = *reinterpret_cast<const float4*>(ap + 16 * (s + PF));
+          n1[i] = *reinterpret_cast<const float4*>(ap + 16 * (s + PF) + 4);
+        }
+        activate(e, s);
+        f16x8 ahi, alo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = e[j] * sa;
+          const _Float16 hh = (_Float16)x;
+          ahi[j] = hh;
+          alo[j] = (_Float16)(x - (float)hh);
+        }
+        const f16x8* wf = wlds + (size_t)(s * JT) * 2 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+          const f16x8 bhi = wf[t * 128];
+          const f16x8 blo = wf[t * 128 + 64];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[t], 0, 0, 0);
+        }
       }
     }
 
@@ -362,6 +394,18 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
           }
           if (r31 == 0) { p.mean_out[row] = mu; p.rstd_out[row] = rs; }
         }
+      } else if constexpr (SHIFT) {
+        if (row < p.N) {
+          const bool live = p.rowptr[row + 1] > p.rowptr[row];   // (nodes without incoming edges are never gathered)
+#pragma unroll
+          for (int t = 0; t < JT; ++t) {
+            const float v = fmaf(acc[t][r], us, bias[t]);
+            const float l = res[t][r];
+            p.c[(size_t)row * p.J + 32 * t + r31] = v;
+            p.y[(size_t)row * p.J + 32 * t + r31] = live ? v * fast_exp2(-l) : 0.f;
+            if (live) worst_lse = fmaxf(worst_lse, fabsf(l));
+          }
+        }
       } else if (row < p.N) {
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
@@ -371,6 +415,11 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
         }
       }
     }
+  }
+  if constexpr (SHIFT) {
+    // (a NaN lse fails the comparison, like in softmax_shift_kernel: the NaN then travels in y itself)
+    for (int off = 1; off < kWave; off <<= 1) worst_lse = fmaxf(worst_lse, __shfl_xor(worst_lse, off));
+    if (lane == 0 && worst_lse > kMaxLse) *p.spread = 1;        // plain store: every writer stores the same value
   }
 
   if constexpr (LN == 3) {
@@ -429,18 +478,21 @@ namespace mlgnn {
 struct TgPost {                 // second LayerNorm of the result rows (nullptr gamma: none)
   const float* gamma; const float* beta; float eps; int relu; float* y; float* mean; float* rstd;
 };
+struct TgShift {                // rescaled cotangent for a softmax aggregation's backward
+  const float* lse; const int* rowptr; float* gt; int* flag;
+};
 }
 
 static int tallgemm_nt_any(const void* a, const void* bt, int bt_transposed, const float* bias, const void* residual,
                            const float* row_max, int ln_mode, const float* gamma, const float* beta,
                            float ln_eps, float* rstd_out, float* row_max_out, void* c, void* workspace,
                            int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype, const TgPost* post,
-                           void* stream) {
+                           const TgShift* shift, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || N > INT32_MAX) return MLGNN_E_SHAPE;
   if (N == 0) return 0;
   if (dtype == MLGNN_DTYPE_BF16) {                          // plain product (+ bias, + residual) only
-    if (ln_mode != 0 || bt_transposed || post) return MLGNN_E_MODE;
+    if (ln_mode != 0 || bt_transposed || post || shift) return MLGNN_E_MODE;
     if (tb_tiles_per_slice(R, J) == 0) return MLGNN_E_SHAPE;
     if (!a || !bt || !c || !workspace) return MLGNN_E_NULL;
     if (workspace_bytes < R * J * 2) return MLGNN_E_WORKSPACE;
@@ -460,10 +512,18 @@ static int tallgemm_nt_any(const void* a, const void* bt, int bt_transposed, con
     if (ln_mode != 2 || J > 128) return MLGNN_E_MODE;
     if (!post->gamma || !post->beta || !post->y || !post->mean || !post->rstd) return MLGNN_E_NULL;
   }
+  if (shift) {
+    if (ln_mode != 0 || post || residual || J > 128) return MLGNN_E_MODE;
+    if (!shift->lse || !shift->rowptr || !shift->gt || !shift->flag) return MLGNN_E_NULL;
+  }
   if (workspace_bytes < R * J * 4 + kTgHeader * 16) return MLGNN_E_WORKSPACE;
   if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bt) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
     return MLGNN_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+  if (shift) {
+    int err0 = (int)hipMemsetAsync(shift->flag, 0, 16, s);
+    if (err0) return err0;
+  }
   const int n_frag_lanes = (int)(R / 16) * (int)(J / 32) * 64;
   hipLaunchKernelGGL(tallgemm_split_weight_kernel, dim3((n_frag_lanes + 255) / 256), dim3(256), 0, s,
                      (const float*)bt, (f16x8*)workspace, (int)J, (int)R, bt_transposed);
@@ -479,6 +539,8 @@ static int tallgemm_nt_any(const void* a, const void* bt, int bt_transposed, con
     p.pgamma = post->gamma; p.pbeta = post->beta; p.y = post->y; p.mean_out = post->mean; p.rstd_out = post->rstd;
     p.peps = post->eps; p.prelu = post->relu;
   }
+  p.rowptr = nullptr; p.spread = nullptr;
+  if (shift) { p.res = shift->lse; p.y = shift->gt; p.rowptr = shift->rowptr; p.spread = shift->flag; }
   p.N = (int)N; p.R = (int)R; p.J = (int)J;
   const size_t lds = (size_t)R * J * 4 + (ln_mode == 2 ? (size_t)R * 8 : 0);
   const int64_t tiles = (N + 31) / 32;
@@ -486,15 +548,18 @@ static int tallgemm_nt_any(const void* a, const void* bt, int bt_transposed, con
   if (grid > 256) grid = 256;                      // persistent: one workgroup per CU
   const dim3 g(grid), b(kTgBlock);
   bool launched = false;
-#define MLGNN_TG_LAUNCH(JT_, KS_, LN_, POST_)                                                          \
+#define MLGNN_TG_LAUNCH2(JT_, KS_, LN_, POST_, SHIFT_)                                                 \
   {                                                                                                   \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, LN_, POST_>),  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, LN_, POST_, SHIFT_>),  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds + 2048);          \
-    hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, LN_, POST_>), g, b, lds, s, p);                      \
+    hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, LN_, POST_, SHIFT_>), g, b, lds, s, p);              \
     launched = true;                                                                                  \
   }
+#define MLGNN_TG_LAUNCH(JT_, KS_, LN_, POST_) MLGNN_TG_LAUNCH2(JT_, KS_, LN_, POST_, false)
 #define MLGNN_TG_CASE(JT_, KS_)                                                                       \
-  if (!launched && ln_mode == 0 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 0, false)
+  if (!launched && ln_mode == 0 && !shift && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 0, false)
+#define MLGNN_TG_CASE_SHIFT(JT_, KS_)                                                                 \
+  if (!launched && shift && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH2(JT_, KS_, 0, false, true)
 #define MLGNN_TG_CASE_LN(JT_, KS_)                                                                    \
   if (!launched && ln_mode == 1 && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 1, false)       \
   if (!launched && ln_mode == 2 && !post && J == 32 * JT_ && R == 16 * KS_) MLGNN_TG_LAUNCH(JT_, KS_, 2, false)
@@ -508,6 +573,10 @@ static int tallgemm_nt_any(const void* a, const void* bt, int bt_transposed, con
   MLGNN_TG_CASE_LN(8, 4) MLGNN_TG_CASE_LN(8, 8)
   MLGNN_TG_CASE_POST(2, 4) MLGNN_TG_CASE_POST(2, 8) MLGNN_TG_CASE_POST(2, 16)
   MLGNN_TG_CASE_POST(4, 4) MLGNN_TG_CASE_POST(4, 8) MLGNN_TG_CASE_POST(4, 16)
+  MLGNN_TG_CASE_SHIFT(2, 4) MLGNN_TG_CASE_SHIFT(2, 8) MLGNN_TG_CASE_SHIFT(2, 16)
+  MLGNN_TG_CASE_SHIFT(4, 4) MLGNN_TG_CASE_SHIFT(4, 8) MLGNN_TG_CASE_SHIFT(4, 16)
+#undef MLGNN_TG_CASE_SHIFT
+#undef MLGNN_TG_LAUNCH2
 #undef MLGNN_TG_ROW
 #undef MLGNN_TG_CASE_POST
 #undef MLGNN_TG_CASE_LN
@@ -523,7 +592,23 @@ extern "C" int mlgnn_tallgemm_nt(const void* a, const void* bt, int bt_transpose
                                  int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, int dtype,
                                  void* stream) {
   return tallgemm_nt_any(a, bt, bt_transposed, bias, residual, row_max, ln_mode, gamma, beta, ln_eps, rstd_out,
-                         row_max_out, c, workspace, workspace_bytes, N, R, J, dtype, nullptr, stream);
+                         row_max_out, c, workspace, workspace_bytes, N, R, J, dtype, nullptr, nullptr, stream);
+}
+
+extern "C" int mlgnn_tallgemm_nt_shift_supported(int64_t N, int64_t R, int64_t J) {
+  const bool ok = (J == 64 || J == 128) && (R == 64 || R == 128 || R == 256) && R * J * 4 <= kTgMaxLds;
+  return (N > 0 && N <= INT32_MAX && ok) ? 1 : 0;
+}
+
+extern "C" int mlgnn_tallgemm_nt_shift(const float* a, const float* bt, int bt_transposed, const float* row_max,
+                                       const float* lse, const int32_t* rowptr, float* c, float* grad_shifted,
+                                       int32_t* shift_flag, void* workspace, int64_t workspace_bytes, int64_t N,
+                                       int64_t R, int64_t J, void* stream) {
+  if (N == 0) return 0;
+  if (!mlgnn_tallgemm_nt_shift_supported(N, R, J)) return MLGNN_E_SHAPE;
+  TgShift shift{lse, rowptr, grad_shifted, shift_flag};
+  return tallgemm_nt_any(a, bt, bt_transposed, nullptr, nullptr, row_max, 0, nullptr, nullptr, 0.f, nullptr, nullptr, c,
+                         workspace, workspace_bytes, N, R, J, MLGNN_DTYPE_F32, nullptr, &shift, stream);
 }
 
 extern "C" int mlgnn_tallgemm_lnin_postln_supported(int64_t N, int64_t R, int64_t J) {
@@ -541,7 +626,7 @@ extern "C" int mlgnn_tallgemm_lnin_postln(const float* xhat, const float* bt, co
   if (!mlgnn_tallgemm_lnin_postln_supported(N, R, J)) return MLGNN_E_SHAPE;
   TgPost post{post_gamma, post_beta, post_eps, post_relu, y, post_mean, post_rstd};
   return tallgemm_nt_any(xhat, bt, 0, bias, residual, row_max, 2, gamma, beta, 0.f, nullptr, nullptr, c, workspace,
-                         workspace_bytes, N, R, J, MLGNN_DTYPE_F32, &post, stream);
+                         workspace_bytes, N, R, J, MLGNN_DTYPE_F32, &post, nullptr, stream);
 }
 
 // ---- dA = go W through ReLU + LayerNorm backward in the epilogue (LN = 3 above) --------------------------------------

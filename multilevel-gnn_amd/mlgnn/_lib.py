@@ -18,7 +18,8 @@ SIGNATURES = {
                                        _I64, _I64, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _P, _P]),
     "mlgnn_csr_aggregate_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                        _P, _P, _P, _P, _I64,
-                                       _I64, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _INT, _P, _P]),
+                                       _I64, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _INT, _P,
+                                       _P, _P, _P]),
     "mlgnn_embedding_bwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -47,6 +48,8 @@ SIGNATURES = {
     "mlgnn_tallgemm_supported": (_INT, [_I64, _I64, _I64, _INT]),
     "mlgnn_tallgemm_workspace_bytes": (_I64, [_I64, _I64, _INT]),
     "mlgnn_tallgemm_nt": (_INT, [_P, _P, _INT, _P, _P, _P, _INT, _P, _P, _F, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
+    "mlgnn_tallgemm_nt_shift_supported": (_INT, [_I64, _I64, _I64]),
+    "mlgnn_tallgemm_nt_shift": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "mlgnn_tallgemm_lnin_postln_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_tallgemm_lnin_postln": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _INT, _P, _P, _P, _P, _P, _I64,
                                           _I64, _I64, _I64, _P]),

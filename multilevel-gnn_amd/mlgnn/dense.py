@@ -80,6 +80,26 @@ def tall_matmul_lnin_postln(xhat, w, bias, residual, row_max, gamma, beta, post)
     return out, y, mean, rstd
 
 
+def tall_matmul_nt_shift(a, w, row_max, lse, rowptr):
+    """Input gradient ``a [N,R] @ w [R,J]`` (``w``: the Linear's own weight) of a Linear that reads the output of a softmax
+    aggregation, with that aggregation's rescaled cotangent from the same epilogue (csrc/tallgemm.hip SHIFT):
+    ``-> (gx, gx * 2^(-lse), flag)``."""
+    N, R = a.shape
+    J = w.shape[1]
+    a, w = a.contiguous(), w.contiguous()
+    gx = torch.empty((N, J), dtype=torch.float32, device=a.device)
+    gt = torch.empty_like(gx)
+    flag = torch.empty(4, dtype=torch.int32, device=a.device)
+    nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(R, J, 0))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+    ROW_MAX_STATS["given" if row_max is not None else "computed"] += 1
+    rc = _lib.lib.mlgnn_tallgemm_nt_shift(a.data_ptr(), w.data_ptr(), 1, _lib.ptr(row_max), lse.data_ptr(),
+                                          rowptr.data_ptr(), gx.data_ptr(), gt.data_ptr(), flag.data_ptr(),
+                                          ws.data_ptr(), nbytes, N, R, J, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mlgnn_tallgemm_nt_shift")
+    return gx, gt, flag
+
+
 def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
     """``dA = go [N,R] @ w [R,J]`` (``w``: the Linear's own weight) taken through ReLU + LayerNorm backward in the GEMM's
     epilogue (``csrc/tallgemm.hip`` LN = 3): ``-> (grad_h [N,J], grad_gamma, grad_beta, max |grad_h| per row)`` for a
@@ -195,7 +215,10 @@ class _FusedMLP2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, gamma, beta, w2, b2, residual, eps, post_gamma=None, post_beta=None, post_eps=0.0,
                 post_relu=False):
-        from .ops import row_max_of as _rm
+        from .ops import row_max_of as _rm, softmax_lse_of
+        # x is the output of a softmax aggregation: its backward wants go * 2^(-lse), which the input-gradient GEMM
+        # below can write next to go
+        ctx.shift_src = softmax_lse_of(x) if x.is_contiguous() else None
         x = x.contiguous()
         xhat, rstd, rmax = tall_matmul_nt(x, w1, b1, None, _rm(x), ln=("out", gamma, beta, eps))
         fuse = residual is not None and w2.shape[0] <= 128
@@ -243,7 +266,15 @@ class _FusedMLP2(torch.autograd.Function):
             gy = tall_matmul_nt(go, w2, row_max=_rm(go), bt_transposed=True)
             gh, ggamma, gbeta, gh_max = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
         gw1, gb1 = _wgrad(gh, x, go_max=gh_max, x_max=x_max)
-        gx = tall_matmul_nt(gh, w1, row_max=gh_max, bt_transposed=True) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            src = ctx.shift_src
+            if src is not None and _lib.lib.mlgnn_tallgemm_nt_shift_supported(gh.shape[0], gh.shape[1], w1.shape[1]):
+                from .ops import tag_shifted
+                gx, gt, flag = tall_matmul_nt_shift(gh, w1, gh_max, src[0], src[1])
+                tag_shifted(gx, gt, flag, src[0])
+            else:
+                gx = tall_matmul_nt(gh, w1, row_max=gh_max, bt_transposed=True)
         return (gx, gw1, gb1 if has_b1 else None, ggamma, gbeta, gw2, gb2 if has_b2 else None,
                 go if ctx.needs_input_grad[7] else None, None, gpg, gpb, None, None)
 

@@ -121,6 +121,38 @@ def tag_row_max(t, row_max):
     return t
 
 
+SHIFT_STATS = {"given": 0, "computed": 0}     # softmax backwards whose rescaled cotangent came from the producer / a pre-pass
+
+
+def tag_softmax_lse(out, lse, rowptr):
+    """Mark ``out`` as the result of a softmax aggregation with log-sum-exp ``lse`` [N,d] over the CSR ``rowptr``: the
+    Linear that consumes it can then emit, from its input-gradient GEMM, the rescaled cotangent this aggregation's
+    backward gathers (:func:`tag_shifted`)."""
+    out._mlgnn_lse = (lse, rowptr, out._version)
+    return out
+
+
+def softmax_lse_of(t):
+    tag = getattr(t, "_mlgnn_lse", None)
+    if tag is not None and tag[2] == t._version and tag[0].shape == t.shape:
+        return tag[0], tag[1]
+    return None
+
+
+def tag_shifted(grad, gt, flag, lse):
+    """Attach ``gt = grad * 2^(-lse)`` and its overflow flag to a cotangent on its way to the aggregation's backward."""
+    grad._mlgnn_gt = (gt, flag, lse.data_ptr(), grad._version)
+    return grad
+
+
+def shifted_of(grad, lse):
+    tag = getattr(grad, "_mlgnn_gt", None)
+    if (tag is not None and tag[3] == grad._version and tag[2] == lse.data_ptr() and tag[0].shape == grad.shape
+            and grad.is_contiguous() and tag[0].dtype == grad.dtype):
+        return tag[0], tag[1]
+    return None
+
+
 def row_max_of(t):
     tag = getattr(t, "_mlgnn_row_max", None)
     if tag is not None and tag[1] == t._version and tag[0].shape[0] == t.shape[0]:
@@ -400,6 +432,9 @@ class _GenAggregate(torch.autograd.Function):
         ctx.cfg = (aggr_id, edge_mode, rank, float(t), float(p), float(eps), bool(learn_t), bool(learn_p), bool(add_root))
         ctx.save_for_backward(x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev)
         ctx.rowmax = rowmax
+        # softmax without a learnable temperature: the backward gathers go * 2^(-lse); let the consumer of `out` know
+        ctx.lse_for_shift = aux if (aggr_id == AGGR_SOFTMAX and not learn_t and aux is not None
+                                    and x.dtype == torch.float32) else None
         return out
 
     @staticmethod
@@ -408,6 +443,9 @@ class _GenAggregate(torch.autograd.Function):
         aggr_id, edge_mode, rank, t, p, eps, learn_t, learn_p, add_root = ctx.cfg
         g = ctx.graph
         N, d = x.shape
+        # the producer of grad_out may already have written the rescaled cotangent the softmax backward gathers
+        # (mlgnn.dense: the input-gradient GEMM of the Linear behind this aggregation, csrc/tallgemm.hip SHIFT)
+        shifted = shifted_of(go, aux) if (aggr_id == AGGR_SOFTMAX and not learn_t and aux is not None) else None
         go = _dev_act(go, "grad_out", like=x)
         dtype_id = _DTYPE_IDS[x.dtype]
         grad_t = grad_p = None
@@ -443,7 +481,9 @@ class _GenAggregate(torch.autograd.Function):
         elif edge_mode == EDGE_FULL:                         # a table without gradient: scratch row space
             ge = torch.empty((g.num_edges, d), dtype=efull.dtype, device=efull.device)
         guv = ws = None
-        ws_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_workspace_floats(N, d, dtype_id, rank, aggr_id, int(learn_t)))
+        ws_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_workspace_floats(N, d, dtype_id, rank,
+                                                                     AGGR_SUM if shifted is not None else aggr_id,
+                                                                     int(learn_t)))
         if ws_n < 0:
             _lib.check(ws_n, "mlgnn_csr_aggregate_bwd_workspace_floats")
         if ws_n > 0:
@@ -460,9 +500,11 @@ class _GenAggregate(torch.autograd.Function):
             _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), eid_t.data_ptr(), _lib.ptr(geid_t),
             gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
             N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, int(learn_t), t, p,
-            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), ge_accumulate, hub, _stream())
+            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), ge_accumulate, hub,
+            _lib.ptr(shifted[0]) if shifted else None, _lib.ptr(shifted[1]) if shifted else None, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         del hub_keep
+        SHIFT_STATS["given" if shifted else "computed"] += int(aggr_id == AGGR_SOFTMAX and not learn_t)
         if sink is not None or te is not None:
             ge = None                                        # reported once, by the fan-out node of the shared term
         if timer is not None:
@@ -516,6 +558,9 @@ def gen_aggregate(x, graph, edge=None, aggr="softmax", t=1.0, p=1.0, eps=1e-7, l
     rm = getattr(out.grad_fn, "rowmax", None) if out.grad_fn is not None else None
     if rm is not None:
         tag_row_max(out, rm)
+    lse = getattr(out.grad_fn, "lse_for_shift", None) if out.grad_fn is not None else None
+    if lse is not None:
+        tag_softmax_lse(out, lse, graph.rowptr)
     return out
 
 
@@ -548,7 +593,8 @@ class _WeightedAggregate(torch.autograd.Function):
         rc = _lib.lib.mlgnn_csr_aggregate_bwd(
             go.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
             g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, None, gx.data_ptr(), None, None, None, 0,
-            N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, 0, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, 0, hub, _stream())
+            N, d, _DTYPE_IDS[go.dtype], msg, EDGE_NONE, 0, aggr_id, 0, 1.0, 1.0, None, None, 0.0, 0, 0, hub, None, None,
+            _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         return gx, None, None, None
 

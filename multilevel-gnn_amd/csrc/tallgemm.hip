@@ -107,6 +107,14 @@ template <int JT, int KS, int LN, bool POST> constexpr int tg_prefetch() {
   return (LN == 3 && JT == 8) ? 4 : ((POST || (LN == 1 && JT == 8)) ? 2 : 4);
 }
 #endif
+// XT: the first k-steps of a wave's NEXT row tile are requested before the epilogue of the current one, so that the
+// memory pipe does not drain at every tile boundary (the epilogue is stores + row statistics: 1-2 us without a load in
+// flight from this wave; with one wave per SIMD -- LN = 3 at 8 column tiles -- from the whole SIMD)
+#ifdef MLGNN_TG_XT
+template <int JT, int KS, int LN, bool POST, bool SHIFT> constexpr bool tg_cross_tile() { return MLGNN_TG_XT; }
+#else
+template <int JT, int KS, int LN, bool POST, bool SHIFT> constexpr bool tg_cross_tile() { return LN == 3 && JT == 8; }
+#endif
 constexpr int kTgBlock = 512;              // 8 waves: two per SIMD share the LDS image and hide each other's loads
 constexpr int kTgWaves = kTgBlock / kWave;
 // LN = 3 at 8 column tiles: 128 accumulator registers + the epilogue's operands do not fit the 256 registers a wave has
@@ -192,6 +200,25 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
   // (1) stream the rows once for the row maxima (nothing is kept -- holding a whole 1 KB row per lane
   // spills); (2) the k-step loop re-reads them (the tile is 16-32 KB: L1 / L2 hits), scales, splits and
   // multiplies, with the next k-step's 32 bytes per lane prefetched.
+  constexpr int kWant = tg_prefetch<JT, KS, LN, POST>();
+  constexpr int PF = KS == 1 ? 1 : (kWant <= KS / 2 ? kWant : KS / 2);
+  constexpr bool XT = tg_cross_tile<JT, KS, LN, POST, SHIFT>();
+  float4 n0[PF], n1[PF];                                       // the ring of k-steps in flight (see the k-loop)
+  float m_ahead = 0.f;
+  auto request = [&](int tile_) {                              // first PF k-steps (+ the row maximum) of a row tile
+    const int arow_ = min(tile_ * 32 + r31, p.N - 1);
+    const float* ap_ = p.a + (size_t)arow_ * R + 8 * h;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      n0[i] = *reinterpret_cast<const float4*>(ap_ + 16 * i);
+      n1[i] = *reinterpret_cast<const float4*>(ap_ + 16 * i + 4);
+    }
+    if (p.rowmax) m_ahead = p.rowmax[arow_];
+  };
+  if constexpr (XT) {
+    const int first = blockIdx.x * kTgWaves + wave;
+    if (first < n_tiles) request(first);
+  }
   for (int tile = blockIdx.x * kTgWaves + wave; tile < n_tiles; tile += t_stride) {
     const int row0 = tile * 32;
     const int arow = min(row0 + r31, p.N - 1);                 // rows past N re-read the last row, never stored
@@ -199,7 +226,7 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
 
     float m = 0.f;
     if (p.rowmax) {                                             // the producer of A already knows max |row|
-      m = p.rowmax[arow];
+      m = XT ? m_ahead : p.rowmax[arow];
     } else {
 #pragma unroll 2
       for (int s = 0; s < KS; ++s) {
@@ -244,13 +271,12 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
     // MFMAs take 0.15-0.3 us, a load from HBM 1-2 us, so with one k-step ahead (the first version) every k-step waited
     // out most of a memory round trip.  The ring is unrolled PF-fold; the outer loop is not (a full unroll spills).
     // (at most KS / 2: with the whole k range in the ring the loop below unrolls completely and the compiler spills)
-    constexpr int kWant = tg_prefetch<JT, KS, LN, POST>();
-    constexpr int PF = KS == 1 ? 1 : (kWant <= KS / 2 ? kWant : KS / 2);
-    float4 n0[PF], n1[PF];
+    if constexpr (!XT) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      n0[i] = *reinterpret_cast<const float4*>(ap + 16 * i);
-      n1[i] = *reinterpret_cast<const float4*>(ap + 16 * i + 4);
+      for (int i = 0; i < PF; ++i) {
+        n0[i] = *reinterpret_cast<const float4*>(ap + 16 * i);
+        n1[i] = *reinterpret_cast<const float4*>(ap + 16 * i + 4);
+      }
     }
 #pragma unroll 1
     for (int s0 = 0; s0 < KS; s0 += PF) {
@@ -282,6 +308,10 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
         }
       }
     }
+
+    // XT: every slot of the ring has been consumed -- refill it with the next tile of this wave (the last tile requests
+    // itself again: cache hits, and the loop stays free of a branch the load counter would have to be flushed for)
+    if constexpr (XT) request(min(tile + t_stride, n_tiles - 1));
 
     // LN = 3: the stored normalised activation at this lane's result positions, kXhRows result rows ahead of their use
     // (32-bit byte offsets from the uniform base: [N, J] fp32 < 4 GiB, checked on the host); the accumulators of the rows

@@ -2,7 +2,8 @@
 import ctypes
 import os
 
-LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmlgnn.so")
+# (MLGNN_LIB: a development override for same-box A/B runs of kernel variants, tools/build_variant.py)
+LIB = os.environ.get("MLGNN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmlgnn.so")
 
 _c = ctypes
 _P = _c.c_void_p

@@ -415,6 +415,35 @@ int mlgnn_tallgemm_lnin_postln(const float* xhat, const float* bt, const float* 
                                int64_t N, int64_t R, int64_t J, void* stream);
 
 /*
+ * Backward of a Linear layer y = x W^T + b over a tall x in ONE pass over the cotangent (fp32):
+ *     dx [N,K] = grad_out [N,M] * W [M,K],   grad_w_b = (grad_out^T x' [M,K], column sums of grad_out [M])
+ * and the epilogue the MLP of a GENConv layer needs behind dx (models/gcn_lib/sparse/torch_nn.py:54-75,
+ * torch_vertex.py:35): the autograd of nn.Linear would stream grad_out and x twice (input and weight gradient).
+ *   epilogue 0 (LayerNorm backward; M = 128, K = 256): x = xhat, the hidden activation stored normalised with its rstd
+ *     [N] (mlgnn_tallgemm_nt ln_mode 1); x' = relu(gamma xhat + beta); dx is taken through ReLU + LayerNorm backward,
+ *         gy = dx [gamma xhat + beta > 0],  g = gamma gy,  dx <- rstd (g - mean_row(g) - xhat mean_row(g xhat)),
+ *     and grad_w_b carries two more rows behind the bias gradient: sum_rows gy xhat [K], sum_rows gy [K]
+ *     (M K + M + 2 K floats);
+ *   epilogue 1 (plain; M = 256, K = 128): x' = x, dx as it is;
+ *   epilogue 2 (shift; M = 256, K = 128): as 1, and grad_shifted [N,K] = dx * 2^(-lse) for the softmax aggregation
+ *     that produced x (lse [N,K] in log2 units, 0 for nodes without incoming edges as mlgnn_csr_aggregate_fwd writes
+ *     it); *shift_flag (int32[4], zeroed here) is raised when some |lse| > 60: what mlgnn_csr_aggregate_bwd takes as
+ *     grad_shifted / shift_flag.
+ * Arithmetic: scaled two-way fp16 split on the fp16 matrix cores (3 * 2^-22 per product for everything within 2^-16 of
+ * an operand's largest magnitude, fp32 accumulation), scales from grad_out_max (row maxima [N], or 256 partial maxima
+ * when grad_out_max_is_parts: the dx_max_parts of the call that produced grad_out) and x_row_max [N] (max |x'| per row).
+ * dx_max_parts [256] or NULL: per-workgroup max |dx|.  N * max(M, K) * 4 < 4 GiB.  Deterministic.
+ * workspace: mlgnn_linear_bwd_workspace_floats floats.
+ */
+int mlgnn_linear_bwd_supported(int64_t N, int64_t M, int64_t K, int epilogue);
+int64_t mlgnn_linear_bwd_workspace_floats(int64_t N, int64_t M, int64_t K, int epilogue);
+int mlgnn_linear_bwd(const float* grad_out, const float* w, const float* x, const float* grad_out_max,
+                     int grad_out_max_is_parts, const float* x_row_max, int epilogue, const float* rstd,
+                     const float* gamma, const float* beta, const float* lse, float* dx, float* grad_shifted,
+                     int32_t* shift_flag, float* grad_w_b, float* dx_max_parts, float* workspace,
+                     int64_t workspace_floats, int64_t N, int64_t M, int64_t K, void* stream);
+
+/*
  * The MLP's second Linear run backwards with the ReLU + LayerNorm backward in the epilogue (fp32):
  *     dA = grad_out [N,R] * W [R,J] (w_transposed != 0: W is the Linear's own weight [R,J]; 0: its transpose [J,R]),
  *     gy = dA [gamma xhat + beta > 0],  g = gamma gy,

@@ -103,9 +103,18 @@ struct TgArgs {
 #ifdef MLGNN_TG_PF
 template <int JT, int KS, int LN, bool POST> constexpr int tg_prefetch() { return MLGNN_TG_PF; }
 #else
+#ifndef MLGNN_TG_PF3
+#define MLGNN_TG_PF3 4
+#endif
+#ifndef MLGNN_TG_PF1
+#define MLGNN_TG_PF1 2
+#endif
 template <int JT, int KS, int LN, bool POST> constexpr int tg_prefetch() {
-  return (LN == 3 && JT == 8) ? 4 : ((POST || (LN == 1 && JT == 8)) ? 2 : 4);
+  return (LN == 3 && JT == 8) ? MLGNN_TG_PF3 : (POST ? 2 : ((LN == 1 && JT == 8) ? MLGNN_TG_PF1 : 4));
 }
+#endif
+#ifndef MLGNN_TG_LN1_LDS
+#define MLGNN_TG_LN1_LDS 0
 #endif
 // XT: the first k-steps of a wave's NEXT row tile are requested before the epilogue of the current one, so that the
 // memory pipe does not drain at every tile boundary (the epilogue is stores + row statistics: 1-2 us without a load in
@@ -173,9 +182,16 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
     for (int t = 0; t < JT; ++t) { pg[t] = p.pgamma[32 * t + r31]; pb[t] = p.pbeta[32 * t + r31]; }
   }
   float* kg = reinterpret_cast<float*>(wlds + n_frag);         // [R] gamma then [R] beta, behind the image
-  if constexpr (LN == 1) {
+  constexpr bool kLn1Lds = LN == 1 && JT == 8 && MLGNN_TG_LN1_LDS;     // gamma / beta / bias of the output columns from LDS
+  if constexpr (LN == 1 && !kLn1Lds) {
 #pragma unroll
     for (int t = 0; t < JT; ++t) { og[t] = p.gamma[32 * t + r31]; ob[t] = p.beta[32 * t + r31]; }
+  }
+  if constexpr (kLn1Lds) {
+    for (int i = threadIdx.x; i < 32 * JT; i += kTgBlock) {
+      kg[i] = p.gamma[i]; kg[32 * JT + i] = p.beta[i]; kg[64 * JT + i] = p.bias ? p.bias[i] : 0.f;
+    }
+    __syncthreads();
   }
   if constexpr (LN == 3) {             // gamma / beta of the OUTPUT columns, read from LDS in the epilogue (registers are short)
     for (int i = threadIdx.x; i < 32 * JT; i += kTgBlock) { kg[i] = p.gamma[i]; kg[32 * JT + i] = p.beta[i]; }
@@ -201,7 +217,10 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
   // spills); (2) the k-step loop re-reads them (the tile is 16-32 KB: L1 / L2 hits), scales, splits and
   // multiplies, with the next k-step's 32 bytes per lane prefetched.
   constexpr int kWant = tg_prefetch<JT, KS, LN, POST>();
-  constexpr int PF = KS == 1 ? 1 : (kWant <= KS / 2 ? kWant : KS / 2);
+  // (two waves per SIMD: at most KS / 2 -- with the whole k range in the ring the k-loop unrolls completely and the
+  // compiler spills; the one-wave-per-SIMD shape has the registers for a whole tile)
+  constexpr int kCap = (tg_block<JT, LN>() == 256) ? KS : KS / 2;
+  constexpr int PF = KS == 1 ? 1 : (kWant <= kCap ? kWant : kCap);
   constexpr bool XT = tg_cross_tile<JT, KS, LN, POST, SHIFT>();
   float4 n0[PF], n1[PF];                                       // the ring of k-steps in flight (see the k-loop)
   float m_ahead = 0.f;
@@ -345,7 +364,10 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
         // statistics like layernorm_act_fwd_kernel, reductions over the 32-lane half (DPP rotations + one shuffle)
         float v[JT], sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < JT; ++t) { v[t] = fmaf(acc[t][r], us, bias[t]); sum += v[t]; }
+        for (int t = 0; t < JT; ++t) {
+          v[t] = fmaf(acc[t][r], us, kLn1Lds ? kg[64 * JT + 32 * t + r31] : bias[t]);
+          sum += v[t];
+        }
         sum = half_sum(sum);
         const float mu = sum * (1.0f / (32 * JT));
         float q = 0.f;
@@ -357,7 +379,8 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
           v[t] *= rs;
-          ym = fmaxf(ym, fmaxf(fmaf(v[t], og[t], ob[t]), 0.f));
+          const float gam = kLn1Lds ? kg[32 * t + r31] : og[t], bet = kLn1Lds ? kg[32 * JT + 32 * t + r31] : ob[t];
+          ym = fmaxf(ym, fmaxf(fmaf(v[t], gam, bet), 0.f));
         }
         ym = half_max(ym);
         if (row < p.N) {
@@ -572,7 +595,7 @@ static int tallgemm_nt_any(const void* a, const void* bt, int bt_transposed, con
   p.rowptr = nullptr; p.spread = nullptr;
   if (shift) { p.res = shift->lse; p.y = shift->gt; p.rowptr = shift->rowptr; p.spread = shift->flag; }
   p.N = (int)N; p.R = (int)R; p.J = (int)J;
-  const size_t lds = (size_t)R * J * 4 + (ln_mode == 2 ? (size_t)R * 8 : 0);
+  const size_t lds = (size_t)R * J * 4 + (ln_mode == 2 ? (size_t)R * 8 : 0) + (ln_mode == 1 ? (size_t)J * 12 : 0);
   const int64_t tiles = (N + 31) / 32;
   int grid = (int)((tiles + kTgWaves - 1) / kTgWaves);
   if (grid > 256) grid = 256;                      // persistent: one workgroup per CU
@@ -581,7 +604,7 @@ static int tallgemm_nt_any(const void* a, const void* bt, int bt_transposed, con
 #define MLGNN_TG_LAUNCH2(JT_, KS_, LN_, POST_, SHIFT_)                                                 \
   {                                                                                                   \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, LN_, POST_, SHIFT_>),  \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds + 2048);          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds + 4096);          \
     hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, LN_, POST_, SHIFT_>), g, b, lds, s, p);              \
     launched = true;                                                                                  \
   }
@@ -710,7 +733,7 @@ extern "C" int mlgnn_tallgemm_lnbwd(const float* go, const float* w, int w_trans
 #define MLGNN_TG_LNBWD(JT_, KS_)                                                                      \
   if (!launched && J == 32 * JT_ && R == 16 * KS_) {                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, 3>),           \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds + 2048);          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds + 4096);          \
     hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, 3>), g, b, lds, s, p);                               \
     launched = true;                                                                                  \
   }

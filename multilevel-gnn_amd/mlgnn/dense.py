@@ -121,6 +121,47 @@ def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
     return gh, ggb[0], ggb[1], rmax
 
 
+LB_LN, LB_PLAIN, LB_SHIFT = 0, 1, 2
+
+
+def linear_backward_supported(N, M, K, epilogue):
+    return bool(_lib.lib.mlgnn_linear_bwd_supported(N, M, K, epilogue))
+
+
+def linear_backward(go, w, x, go_max, x_max, epilogue, rstd=None, gamma=None, beta=None, lse=None,
+                    go_max_is_parts=False):
+    """Input, weight and bias gradient of ``y = x' W^T + b`` from ONE pass over ``go`` [N,M] and ``x`` [N,K]
+    (``csrc/linear_bwd.hip``; ``w`` = the Linear's own weight [M,K]).  ``epilogue``: ``LB_LN`` -- ``x`` is the normalised
+    hidden activation, ``x' = relu(gamma x + beta)``, and ``dx`` comes back already taken through ReLU + LayerNorm
+    backward; ``LB_PLAIN``; ``LB_SHIFT`` -- also ``dx * 2^(-lse)`` for the softmax aggregation that produced ``x``.
+    ``go_max``: row maxima [N] of ``|go|`` or the 256 partial maxima a previous call returned; ``x_max``: row maxima of
+    ``|x'|``.  -> ``dict(dx, gw [M,K], gb [M], parts [256], [ggamma, gbeta], [gt, flag])``."""
+    N, M = go.shape
+    K = x.shape[1]
+    go, w, x = go.contiguous(), w.contiguous(), x.contiguous()
+    f32 = dict(dtype=torch.float32, device=go.device)
+    dx = torch.empty((N, K), **f32)
+    cols = M * K + M + (2 * K if epilogue == LB_LN else 0)
+    gwb = torch.empty(cols, **f32)
+    parts = torch.empty(256, **f32)
+    gt = torch.empty((N, K), **f32) if epilogue == LB_SHIFT else None
+    flag = torch.empty(4, dtype=torch.int32, device=go.device) if epilogue == LB_SHIFT else None
+    n = int(_lib.lib.mlgnn_linear_bwd_workspace_floats(N, M, K, epilogue))
+    _lib.check(min(n, 0), "mlgnn_linear_bwd_workspace_floats")
+    ws = torch.empty(n, **f32)
+    if gamma is not None:
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+    rc = _lib.lib.mlgnn_linear_bwd(go.data_ptr(), w.data_ptr(), x.data_ptr(), go_max.data_ptr(), int(go_max_is_parts),
+                                   x_max.data_ptr(), epilogue, _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta),
+                                   _lib.ptr(lse), dx.data_ptr(), _lib.ptr(gt), _lib.ptr(flag), gwb.data_ptr(),
+                                   parts.data_ptr(), ws.data_ptr(), n, N, M, K, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mlgnn_linear_bwd")
+    out = dict(dx=dx, gw=gwb[:M * K].view(M, K), gb=gwb[M * K:M * K + M], parts=parts, gt=gt, flag=flag)
+    if epilogue == LB_LN:
+        out["ggamma"], out["gbeta"] = gwb[M * K + M:M * K + M + K], gwb[M * K + M + K:]
+    return out
+
+
 def tall_matmul_ln_backward_supported(N, R, J):
     return bool(_lib.lib.mlgnn_tallgemm_lnbwd_supported(N, R, J)) and N * J * 4 < (1 << 32)
 

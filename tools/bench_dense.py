@@ -68,7 +68,15 @@ def main():
         N * (d + 2 * h) * 4)
     add("W1  linear_wgrad gh^T x", lambda: D._wgrad(gh, x, go_max=ghmax, x_max=xmax), N * (d + h) * 4)
     add("B1  tallgemm gh -> gx", lambda: D.tall_matmul_nt(gh, w1, row_max=ghmax, bt_transposed=True), N * (d + h) * 4)
-    tot = sum(r_["ms"] for r_ in rows if not r_["kernel"].startswith(("G2 ", "LNf")))
+    if D.linear_backward_supported(N, d, h, D.LB_LN):
+        lse = r(N, d)
+        add("F2  linear_bwd<LN>: go, xhat -> gh, dW2 (one pass)",
+            lambda: D.linear_backward(go, w2, xhat, gomax, amax, D.LB_LN, rstd=rstd, gamma=gam, beta=bet), N * (d + 2 * h) * 4)
+        add("F1  linear_bwd<shift>: gh, x -> gx, gt, dW1 (one pass)",
+            lambda: D.linear_backward(gh, w1, x, ghmax, xmax, D.LB_SHIFT, lse=lse), N * (h + 4 * d) * 4)
+        add("F1p linear_bwd<plain>: gh, x -> gx, dW1 (one pass)",
+            lambda: D.linear_backward(gh, w1, x, ghmax, xmax, D.LB_PLAIN), N * (h + 2 * d) * 4)
+    tot = sum(r_["ms"] for r_ in rows if not r_["kernel"].startswith(("G2 ", "LNf", "F")))
     print("layer forward + backward with the POST epilogue (G1 G2p | LNb W2 B2 W1 B1): %.3f ms" % tot)
     if a.json:
         json.dump(dict(rows=N, d=d, kernels=rows, layer_ms=tot), open(a.json, "w"), indent=1)

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
   constexpr int UPT = M * 4 / kLbThreads;     // go units (column, row group) per thread
   constexpr int DMA = kXStageB / 1024 / kLbWaves;      // LDS-DMA instructions per wave and stage
   constexpr int kExB = 2 * kBufB + 3 * kXStageB;       // exchange area behind the stages
-  constexpr int kExFloats = 4 * M + 64 + (NM == 2 ? kLbWaves * 512 : 0);
+  constexpr int kTotOff = 4 * M + 64;                  // LB_LN: the per-wave totals of the row sums, [8 waves][64]
+  constexpr int kExFloats = 4 * M + 64 + (NM == 2 ? kLbWaves * 512 : kLbWaves * 64);
   constexpr int kRsB = kExB + kExFloats * 4;           // LB_LN: rstd of a stage's rows, [3 stages][8 waves][64] floats
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -213,7 +214,10 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
     lb_pow2_scale(m, sw, iw);
     __syncthreads();
   }
-  const float ux = ia * iw, uw = ia * ix;      // un-scaling of dX and of dW
+  // (wave-uniform values the compiler cannot see as uniform: keep them in scalar registers)
+  auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  sa = uniform(sa); sx = uniform(sx); sw = uniform(sw);
+  const float ux = uniform(ia * iw), uw = uniform(ia * ix);      // un-scaling of dX and of dW
 
   // ---- W[:, strip] as B fragments of the dX product: lane (r31, h) of k-step s holds W[m0 + 16 s + 8 h + j][col] ----
   f16x8 wh[KS], wl[KS];
@@ -360,6 +364,7 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
       }
       fetch_go(row_of(i + 1));
       dma_x(row_of(i + 2), (i + 2) % 3);
+      __builtin_amdgcn_sched_barrier(0);
 
       // -- x values of this lane: x[r0 + rho(r, h)][col], r = 0..15 (accumulator order)
       float xv[16];
@@ -414,6 +419,7 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
           accw[t] = cw;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
       // -- dX tile = go[32 rows, m range] W[m range, strip]: A fragments through the transposing read (lane = row)
       f32x16 accx;
 #pragma unroll
@@ -448,16 +454,13 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
 #undef LB_DX
       }
 
+      __builtin_amdgcn_sched_barrier(0);
       // ---- epilogue ---------------------------------------------------------------------------------------------------
       if constexpr (EPI == LB_LN) {
         float g[16];
-        float* mine = ex + wave * 64 + (lane >> 4) * 16;
         const bool odd_row = (lane & 16) != 0;
-        // (the rstd copy of this stage was requested at the top of the iteration, before the loads of the stages ahead)
-        lb_wait_vm<8 * UPT + DMA>();                   // (only the loads of the stages ahead may still be out)
-        const uint32_t ars = lds0 + kRsB + (uint32_t)(((i % 3) * kLbWaves + wave) * 256 + 16 * h);
-        i32x4 rs0_ = lds_read_b128<0>(ars), rs1_ = lds_read_b128<32>(ars), rs2_ = lds_read_b128<64>(ars),
-              rs3_ = lds_read_b128<96>(ars);          // (tied to the wait below as they are: a copy could be read early)
+        const int r_mine = lane & 15;
+        float mine = 0.f;                              // the row sum this lane hands in: row r_mine of its 16-lane row
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bool live = full || r0 + lb_rho(r, h) < p.N;
@@ -466,17 +469,24 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
           dgam = fmaf(gy, xv[r], dgam);
           dbet += gy;
           g[r] = gy * gam;
-          // sums over the 32 lanes of the half: the two 16-lane rows are folded by ONE exchange -- even rows keep g
-          // and send g xhat, odd rows the other way round, so that even rows end up with sum g and odd rows with
-          // sum g xhat -- then a rotation all-reduce inside the rows
+          // sums over the 32 lanes of the half: the two 16-lane rows are folded by ONE exchange -- even rows keep g and
+          // send g xhat, odd rows the other way round, so that even rows end up with sum g and odd rows with
+          // sum g xhat -- then a rotation all-reduce inside the rows (no exec masking in this loop: the 16 chains are
+          // independent and interleave)
           const float gx = g[r] * xv[r];
           const float recv = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(
               __builtin_bit_cast(int, odd_row ? g[r] : gx), 0x401f));          // lane ^ 16
           float u = (odd_row ? gx : g[r]) + recv;
           u += lb_row_ror<8>(u); u += lb_row_ror<4>(u); u += lb_row_ror<2>(u); u += lb_row_ror<1>(u);
-          // row16 = lane >> 4: (sum g, h = 0), (sum g xhat, h = 0), (sum g, h = 1), (sum g xhat, h = 1); 16 rows each
-          if ((lane & 15) == 0) mine[r] = u;
+          mine = (r_mine == r) ? u : mine;
         }
+        // value index = lane: row16 = lane >> 4 is (sum g, h = 0), (sum g xhat, h = 0), (sum g, h = 1), (sum g xhat, h = 1)
+        ex[wave * 64 + lane] = mine;
+        // (the rstd copy of this stage was requested at the top of the iteration, before the loads of the stages ahead)
+        lb_wait_vm<8 * UPT + DMA>();                   // (only the loads of the stages ahead may still be out)
+        const uint32_t ars = lds0 + kRsB + (uint32_t)(((i % 3) * kLbWaves + wave) * 256 + 16 * h);
+        i32x4 rs0_ = lds_read_b128<0>(ars), rs1_ = lds_read_b128<32>(ars), rs2_ = lds_read_b128<64>(ars),
+              rs3_ = lds_read_b128<96>(ars);          // (tied to the wait below as they are: a copy could be read early)
         lgkm_landed<0>(rs0_, rs1_, rs2_, rs3_);      // (and the partial sums above are in LDS)
         float rs[16];
 #pragma unroll
@@ -540,6 +550,8 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
           for (int q = 0; q < 8; ++q) keep[q] = 0.f;          // (not instantiated: every plain shape splits the m range)
         }
         if constexpr (EPI == LB_SHIFT) vm_landed<8 * UPT + DMA>(lse8);      // (only this iteration's loads ahead may be out)
+        else asm volatile("" : "+v"(keep[0]), "+v"(keep[1]), "+v"(keep[2]), "+v"(keep[3]), "+v"(keep[4]), "+v"(keep[5]),
+                          "+v"(keep[6]), "+v"(keep[7])::"memory");        // (the same fence for the scheduler)
         float v[8], gt[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -574,6 +586,7 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
       }
 
       // ---- the next stage of go into the other plane buffer; x of the next stage has to have landed ------------------
+      __builtin_amdgcn_sched_barrier(0);
       // the go registers of stage i + 1: behind them only this iteration's LDS-DMAs and stores (a ragged stage may
       // have skipped stores: it waits for everything)
       if (full) {
@@ -647,7 +660,8 @@ __global__ __launch_bounds__(256) void lb_rowmax_parts_kernel(const float* __res
 
 template <int M, int K>
 constexpr int lb_lds_bytes() {
-  return 2 * (2 * 4 * (M + 4) * 16) + 3 * (kLbStage * K * 4) + (4 * M + 64) * 4 + (M == 256 ? kLbWaves * 512 * 4 : 0) +
+  return 2 * (2 * 4 * (M + 4) * 16) + 3 * (kLbStage * K * 4) + (4 * M + 64) * 4 +
+         (M == 256 ? kLbWaves * 512 * 4 : kLbWaves * 64 * 4) +
          3 * kLbWaves * 256;
 }
 

@@ -122,6 +122,8 @@ def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
 
 
 LB_LN, LB_PLAIN, LB_SHIFT = 0, 1, 2
+_ONE_PASS = os.environ.get("MLGNN_ONE_PASS_BWD", "1") == "1"      # (0: the two-kernel backward of each Linear, for A/B runs)
+LINEAR_BWD_STATS = {"ln": 0, "shift": 0}
 
 
 def linear_backward_supported(N, M, K, epilogue):
@@ -299,23 +301,44 @@ class _FusedMLP2(torch.autograd.Function):
         has_b1, has_b2 = ctx.flags
         go = go.contiguous()
         x_max, act_max = ctx.maxima
-        gw2, gb2 = _wgrad(go, xhat, gamma.contiguous(), beta.contiguous(), go_max=_rm(go), x_max=act_max)   # go^T relu(gamma xhat + beta)
-        if tall_matmul_ln_backward_supported(go.shape[0], go.shape[1], w2.shape[1]):
-            # dA = go W2 never reaches memory: ReLU + LayerNorm backward run in the product's epilogue
-            gh, ggamma, gbeta, gh_max = tall_matmul_ln_backward(go, w2, xhat, rstd, gamma, beta, _rm(go))
+        N = go.shape[0]
+        gh_parts = None
+        if (_ONE_PASS and _rm(go) is not None and act_max is not None
+                and linear_backward_supported(N, w2.shape[0], w2.shape[1], LB_LN)):
+            # second Linear: dW2, db2 and dA = go W2 from ONE pass over go and xhat, dA taken through ReLU + LayerNorm
+            # backward in the same kernel (csrc/linear_bwd.hip)
+            r2 = linear_backward(go, w2, xhat, _rm(go), act_max, LB_LN, rstd=rstd, gamma=gamma, beta=beta)
+            gh, gw2, gb2, ggamma, gbeta, gh_parts, gh_max = r2["dx"], r2["gw"], r2["gb"], r2["ggamma"], r2["gbeta"], r2["parts"], None
+            LINEAR_BWD_STATS["ln"] += 1
         else:
-            gy = tall_matmul_nt(go, w2, row_max=_rm(go), bt_transposed=True)
-            gh, ggamma, gbeta, gh_max = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
-        gw1, gb1 = _wgrad(gh, x, go_max=gh_max, x_max=x_max)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            src = ctx.shift_src
-            if src is not None and _lib.lib.mlgnn_tallgemm_nt_shift_supported(gh.shape[0], gh.shape[1], w1.shape[1]):
-                from .ops import tag_shifted
-                gx, gt, flag = tall_matmul_nt_shift(gh, w1, gh_max, src[0], src[1])
-                tag_shifted(gx, gt, flag, src[0])
+            gw2, gb2 = _wgrad(go, xhat, gamma.contiguous(), beta.contiguous(), go_max=_rm(go), x_max=act_max)   # go^T relu(gamma xhat + beta)
+            if tall_matmul_ln_backward_supported(go.shape[0], go.shape[1], w2.shape[1]):
+                # dA = go W2 never reaches memory: ReLU + LayerNorm backward run in the product's epilogue
+                gh, ggamma, gbeta, gh_max = tall_matmul_ln_backward(go, w2, xhat, rstd, gamma, beta, _rm(go))
             else:
-                gx = tall_matmul_nt(gh, w1, row_max=gh_max, bt_transposed=True)
+                gy = tall_matmul_nt(go, w2, row_max=_rm(go), bt_transposed=True)
+                gh, ggamma, gbeta, gh_max = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
+        src = ctx.shift_src if ctx.needs_input_grad[0] else None
+        gx = None
+        if (_ONE_PASS and src is not None and x_max is not None and (gh_parts is not None or gh_max is not None)
+                and linear_backward_supported(N, w1.shape[0], w1.shape[1], LB_SHIFT)):
+            # first Linear: dW1, db1, the input gradient and the rescaled cotangent of the softmax aggregation behind
+            # it from one pass over gh and x
+            from .ops import tag_shifted
+            r1 = linear_backward(gh, w1, x, gh_parts if gh_parts is not None else gh_max, x_max, LB_SHIFT, lse=src[0],
+                                 go_max_is_parts=gh_parts is not None)
+            gx, gw1, gb1 = r1["dx"], r1["gw"], r1["gb"]
+            tag_shifted(gx, r1["gt"], r1["flag"], src[0])
+            LINEAR_BWD_STATS["shift"] += 1
+        else:
+            gw1, gb1 = _wgrad(gh, x, go_max=gh_max, x_max=x_max)
+            if ctx.needs_input_grad[0]:
+                if src is not None and _lib.lib.mlgnn_tallgemm_nt_shift_supported(gh.shape[0], gh.shape[1], w1.shape[1]):
+                    from .ops import tag_shifted
+                    gx, gt, flag = tall_matmul_nt_shift(gh, w1, gh_max, src[0], src[1])
+                    tag_shifted(gx, gt, flag, src[0])
+                else:
+                    gx = tall_matmul_nt(gh, w1, row_max=gh_max, bt_transposed=True)
         return (gx, gw1, gb1 if has_b1 else None, ggamma, gbeta, gw2, gb2 if has_b2 else None,
                 go if ctx.needs_input_grad[7] else None, None, gpg, gpb, None, None)
 

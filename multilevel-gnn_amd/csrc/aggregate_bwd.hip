@@ -409,7 +409,46 @@ __global__ __launch_bounds__(kRedCols * kRedSlices) void reduce_partials_kernel(
   }
 }
 
+// Wide tables (the [M K] weight-gradient partials of csrc/linear_bwd.hip / wgrad.hip: 256 slabs x 33 000 columns):
+// 16-byte loads, 1 KB of a slab row per workgroup pass (the narrow kernel reads 128-byte pieces), 4 row slices of 64
+// column quads, slices folded in order.
+constexpr int kRedWQuads = 64, kRedWSlices = 4;
+__global__ __launch_bounds__(kRedWQuads * kRedWSlices) void reduce_partials_wide_kernel(const float4* __restrict__ ws,
+                                                                                       float4* __restrict__ out,
+                                                                                       int nblk, int quads) {
+  __shared__ float4 part[kRedWSlices][kRedWQuads];
+  const int ql = threadIdx.x % kRedWQuads;
+  const int slice = threadIdx.x / kRedWQuads;
+  const int q = blockIdx.x * kRedWQuads + ql;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < quads) {
+#pragma unroll 4
+    for (int b = slice; b < nblk; b += kRedWSlices) {
+      const float4 v = ws[(size_t)b * quads + q];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[slice][ql] = s;
+  __syncthreads();
+  if (slice == 0 && q < quads) {
+    float4 t = part[0][ql];
+#pragma unroll
+    for (int k = 1; k < kRedWSlices; ++k) {
+      const float4 v = part[k][ql];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    out[q] = t;
+  }
+}
+
 void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream) {
+  if (cols >= 4096 && cols % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const int quads = cols / 4;
+    hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((quads + kRedWQuads - 1) / kRedWQuads),
+                       dim3(kRedWQuads * kRedWSlices), 0, stream, reinterpret_cast<const float4*>(ws),
+                       reinterpret_cast<float4*>(out), nblk, quads);
+    return;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + kRedCols - 1) / kRedCols), dim3(kRedCols * kRedSlices),
                      0, stream, ws, out, nblk, cols);
 }

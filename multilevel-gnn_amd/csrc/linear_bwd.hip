@@ -642,8 +642,13 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
 
 // row maxima [n] -> kLbParts partial maxima (slices), one or two arrays per launch
 __global__ __launch_bounds__(256) void lb_rowmax_parts_kernel(const float* __restrict__ a, float* __restrict__ pa,
-                                                             const float* __restrict__ b, float* __restrict__ pb, int n) {
+                                                             const float* __restrict__ b, float* __restrict__ pb, int n,
+                                                             int* __restrict__ zero4, float* __restrict__ zero_parts) {
   __shared__ float red[2][4];
+  // (what the main kernel expects cleared -- the shift flag, the unused tail of the max table -- is cleared here
+  // instead of by memset launches of their own)
+  if (blockIdx.x == 0 && threadIdx.x < 4 && zero4) zero4[threadIdx.x] = 0;
+  if (threadIdx.x == 0 && zero_parts) zero_parts[blockIdx.x] = 0.f;
   const int per = (n + kLbParts - 1) / kLbParts;
   const int lo = blockIdx.x * per, hi = min(n, lo + per);
   float ma = 0.f, mb = 0.f;
@@ -705,19 +710,12 @@ extern "C" int mlgnn_linear_bwd(const float* go, const float* w, const float* x,
   hipStream_t s = (hipStream_t)stream;
   const int cols = (int)(M * K + M + (epilogue == LB_LN ? 2 * K : 0));
   float* parts = workspace + (int64_t)kLbParts * cols;           // [go | x | (unused)]
-  hipLaunchKernelGGL(lb_rowmax_parts_kernel, dim3(kLbParts), dim3(256), 0, s, go_max_is_parts ? nullptr : go_max, parts,
-                     x_row_max, parts + kLbParts, (int)N);
   const int64_t stages = (N + kLbStage - 1) / kLbStage;
   const int grid = (int)(stages < kLbParts ? stages : kLbParts);
+  hipLaunchKernelGGL(lb_rowmax_parts_kernel, dim3(kLbParts), dim3(256), 0, s, go_max_is_parts ? nullptr : go_max, parts,
+                     x_row_max, parts + kLbParts, (int)N, epilogue == LB_SHIFT ? shift_flag : nullptr,
+                     (dx_max_parts && grid < kLbParts) ? dx_max_parts : nullptr);
   int err;
-  if (dx_max_parts && grid < kLbParts) {
-    err = (int)hipMemsetAsync(dx_max_parts, 0, kLbParts * sizeof(float), s);
-    if (err) return err;
-  }
-  if (epilogue == LB_SHIFT) {
-    err = (int)hipMemsetAsync(shift_flag, 0, 16, s);
-    if (err) return err;
-  }
   LbArgs a;
   a.go = go; a.w = w; a.x = x; a.go_parts = go_max_is_parts ? go_max : parts; a.x_parts = parts + kLbParts;
   a.dx = dx; a.ws = workspace; a.out_parts = dx_max_parts;

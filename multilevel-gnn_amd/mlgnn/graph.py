@@ -40,6 +40,46 @@ class CSRGraph:
         self._table_cache = None
         self._hub = {}
 
+    # ---- topology cache --------------------------------------------------------------------------------------------
+    # The reference's loader hands the SAME gene-gene topology to every sample of a fold
+    # (dataloader/multiloader.py:687-691): a training loop that passes the same edge_index tensor again (or, with
+    # ``content=True``, an equal one) gets the CSR it built the first time.
+    _CACHE = []                    # [(edge_index, version, num_nodes, content key or None, graph)], most recent first
+    CACHE_SIZE = 8
+    CACHE_STATS = {"hit": 0, "miss": 0}
+
+    @classmethod
+    def from_cache(cls, edge_index, num_nodes, content=False):
+        """The CSR of ``edge_index`` from a small most-recently-used cache.  A hit is the same tensor (or another view
+        of the same elements) at the same version -- no device work, no synchronisation.  ``content=True`` also matches
+        a DIFFERENT tensor with equal contents through a 128-bit checksum computed on the device (one pass over the
+        index list and one 16-byte read back: a host synchronisation per lookup, still far cheaper than a build); for
+        loaders that collate a fresh but identical ``edge_index`` per batch."""
+        N = int(num_nodes)
+        for k, ent in enumerate(cls._CACHE):
+            if ent[2] == N and ent[1] == edge_index._version and _same_view(ent[0], edge_index):
+                cls.CACHE_STATS["hit"] += 1
+                cls._CACHE.insert(0, cls._CACHE.pop(k))
+                return ent[4]
+        key = None
+        if content:
+            key = _content_key(edge_index)
+            for k, ent in enumerate(cls._CACHE):
+                if ent[2] == N and ent[3] == key and ent[0].shape == edge_index.shape:
+                    cls.CACHE_STATS["hit"] += 1
+                    cls._CACHE.insert(0, cls._CACHE.pop(k))
+                    return ent[4]
+        cls.CACHE_STATS["miss"] += 1
+        graph = cls(edge_index, N)
+        # (the entry holds the tensor: its storage cannot be recycled under the cache)
+        cls._CACHE.insert(0, (edge_index, edge_index._version, N, key, graph))
+        del cls._CACHE[cls.CACHE_SIZE:]
+        return graph
+
+    @classmethod
+    def clear_cache(cls):
+        del cls._CACHE[:]
+
     def hub_tables(self, direction):
         """Chunk tables of the long rows of one direction (``"dst"``: by-destination CSR, forward; ``"src"``:
         transposed CSR, backward), built on the device on first use: ``(vrows, hubs, counts, capacity)`` or ``None``
@@ -193,6 +233,15 @@ class CSRGraph:
                 hit = (by_dst, by_dst[self.pos_t.long()].contiguous())
             self._table_cache = (src, src._version, width, hit)      # holds `src`: see edge_scalar
         return hit
+
+
+def _content_key(edge_index):
+    """(sum of the entries, position-weighted sum) in wrapping int64 arithmetic + the shape: equal index lists give equal
+    keys, and two different lists of one shape collide with probability ~2^-64 per word."""
+    flat = edge_index.reshape(-1).to(torch.int64)
+    w = torch.arange(1, flat.numel() + 1, dtype=torch.int64, device=flat.device) * 0x9E3779B97F4A7C15 % (1 << 62) | 1
+    pair = torch.stack([flat.sum(), (flat * w).sum()])
+    return tuple(int(v) for v in pair.tolist()) + tuple(edge_index.shape)
 
 
 def _same_view(held, t):

@@ -54,9 +54,11 @@ _MEMBERSHIP_CACHE = []
 def membership_tables(gene_pca_match, raw_indice, nodes_per_graph, n_segments, n_rows, match_mask=True):
     """The table is a per-fold constant in the reference's data; batches hand in the same tensors
     again and again, so the last few results are kept (tensor identity + version)."""
+    from .graph import _same_view
     key = (nodes_per_graph, n_segments, n_rows, bool(match_mask), gene_pca_match._version, raw_indice._version)
     for ent in _MEMBERSHIP_CACHE:
-        if ent[0] is gene_pca_match and ent[1] is raw_indice and ent[2] == key:
+        # (any view of the same elements: a loader that expands ONE per-fold table to every batch hits)
+        if _same_view(ent[0], gene_pca_match) and _same_view(ent[1], raw_indice) and ent[2] == key:
             return ent[3]
     m = Membership(gene_pca_match, raw_indice, nodes_per_graph, n_segments, n_rows, match_mask)
     _MEMBERSHIP_CACHE.insert(0, (gene_pca_match, raw_indice, key, m))

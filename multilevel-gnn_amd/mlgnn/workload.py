@@ -48,6 +48,15 @@ def membership(n_nodes, n_members, seed=7):
     return match, seg
 
 
+def _rows(table, B, device):
+    """The per-fold membership table as the ``[B, G]`` rows a batch carries.  A table that already lives on the target
+    device is expanded (every batch then views the SAME storage, as a loader holding one table per fold would, and
+    :func:`mlgnn.project.membership_tables` recognises it); otherwise each batch gets its own copy."""
+    if table.device == torch.device(device):
+        return table[None, :].expand(B, -1)
+    return table[None, :].repeat(B, 1)
+
+
 def collate(graph_ids, n_nodes, n_edges, match, seg, device="cpu"):
     """PyG-style collate: block-diagonal batch with ``edge_index`` offset by the cumulative node
     count, ``batch`` vector, per-graph ``gene_pca_match``/``raw_indice`` rows (not offset)."""
@@ -63,7 +72,7 @@ def collate(graph_ids, n_nodes, n_edges, match, seg, device="cpu"):
     b = SimpleNamespace(
         x=torch.cat(xs), edge_index=torch.cat(eis, dim=1), edge_attr=torch.cat(eas),
         batch=torch.arange(B).repeat_interleave(n_nodes), y=labels.reshape(-1),
-        gene_pca_match=match[None, :].repeat(B, 1), raw_indice=seg[None, :].repeat(B, 1),
+        gene_pca_match=_rows(match, B, device), raw_indice=_rows(seg, B, device),
         num_graphs=B, nodes_per_graph=n_nodes)
     for k, v in list(vars(b).items()):
         if torch.is_tensor(v):

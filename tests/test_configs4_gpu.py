@@ -9,6 +9,8 @@ fp32 accumulation) as a tested configuration.
 The 4096-node DiffPool of the same config is tests/test_diffpool_large_gpu.py.  Tolerances are bf16-sized and say so."""
 from types import SimpleNamespace
 
+import os
+
 import pytest
 import torch
 
@@ -131,4 +133,5 @@ def test_configs4_four_layer_training_step_and_28_layer_forward():
     with torch.no_grad():
         o28 = deep(batch)
     assert bool(torch.isfinite(o28.float()).all()) and abs(float(o28.float().sum()) - 1.0) < 2e-2
-    assert torch.cuda.max_memory_allocated() < 40e9
+    if os.environ.get("MLGNN_CANARY") != "1":          # (the guard-band allocator of a canary run keeps no statistics)
+        assert torch.cuda.max_memory_allocated() < 40e9

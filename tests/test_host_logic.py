@@ -216,3 +216,42 @@ def test_head_conv_1x1_equals_conv2d():
     assert torch.allclose(c.bias.grad, r.bias.grad, atol=1e-4)
     c3 = HeadConv2d(4, 4, 3, padding=1)
     assert torch.equal(c3(x[:, :4]), torch.nn.functional.conv2d(x[:, :4], c3.weight, c3.bias, padding=1))
+
+
+def test_topology_cache_identity_view_and_content():
+    """CSRGraph.from_cache: the same tensor (or an equal view) hits without any work, an in-place edit misses, an equal
+    COPY hits only with content=True (dataloader/multiloader.py:687-691: one topology per fold)."""
+    from mlgnn import CSRGraph
+    CSRGraph.clear_cache()
+    gen = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, 50, (2, 400), generator=gen)
+    g0 = CSRGraph.from_cache(ei, 50)
+    assert CSRGraph.from_cache(ei, 50) is g0
+    assert CSRGraph.from_cache(ei[:, :], 50) is g0                       # another view of the same elements
+    assert CSRGraph.from_cache(ei, 51) is not g0                         # a different node count is a different graph
+    copy = ei.clone()
+    g1 = CSRGraph.from_cache(copy, 50)
+    assert g1 is not g0 and torch.equal(g1.col, g0.col)                  # identity cache: an equal copy is built again
+    CSRGraph.clear_cache()
+    g2 = CSRGraph.from_cache(ei, 50, content=True)
+    assert CSRGraph.from_cache(ei.clone(), 50, content=True) is g2       # equal contents, different tensor
+    other = ei.clone()
+    other[0, 7] = (other[0, 7] + 1) % 50
+    assert CSRGraph.from_cache(other, 50, content=True) is not g2
+    ei[1, 3] = (ei[1, 3] + 1) % 50                                       # in-place edit: the version moved on
+    assert CSRGraph.from_cache(ei, 50) is not g2
+    CSRGraph.clear_cache()
+
+
+def test_membership_cache_hits_for_views_of_one_table():
+    """Every batch of a fold views ONE membership table: the grouped index tables are built once."""
+    from mlgnn import project
+    del project._MEMBERSHIP_CACHE[:]
+    gen = torch.Generator().manual_seed(5)
+    match = torch.randint(0, 30, (200,), generator=gen)
+    seg = torch.sort(torch.randint(0, 12, (200,), generator=gen))[0]
+    a = project.membership_tables(match[None, :].expand(4, -1), seg[None, :].expand(4, -1), 30, 12, 120)
+    b = project.membership_tables(match[None, :].expand(4, -1), seg[None, :].expand(4, -1), 30, 12, 120)
+    assert a is b
+    c = project.membership_tables(match[None, :].repeat(4, 1), seg[None, :].repeat(4, 1), 30, 12, 120)
+    assert c is not a and torch.equal(c.seg_mem, a.seg_mem) and torch.equal(c.node_ptr, a.node_ptr)

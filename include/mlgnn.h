@@ -514,7 +514,9 @@ int mlgnn_gemm_bf16_nt(const void* const* a, const void* const* b, const int64_t
  *
  * Backward: grad_x [K,C], grad_adj_out [K,K] (grad_dtype) = cotangents of x_out / adj_out; grad_link, grad_ent = the
  * scalar cotangents of stats[0] / stats[1] ON THE DEVICE (scalar_dtype; no host sync); stats = the forward's;
- * outputs grad_z [N,C], grad_logits [N,K] in logits_dtype.  adj is treated as a constant (no adjacency gradient);
+ * outputs grad_z [N,C], grad_logits [N,K] in logits_dtype; grad_adj [N,N] (logits_dtype) or NULL: the adjacency
+ * gradient  S (dA' - cI) S^T + c adj,  c = grad_link / (numel ||adj - S S^T||)  -- two more products; the next pooling
+ * level's adjacency is this level's adj_out (models/diff_pooling.py:116-127).
  * adj_symmetric non-zero promises adj = adj^T and saves the product adj^T S (one third of the backward).
  * workspace: mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, adj_symmetric) bytes.
  */
@@ -530,8 +532,8 @@ int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logit
                              const void* s_soft, const void* saved, const void* grad_x,
                              const void* grad_adj_out, int grad_dtype, const void* grad_link,
                              const void* grad_ent, int scalar_dtype, const float* stats, void* grad_z,
-                             void* grad_logits, int adj_symmetric, void* workspace, int64_t workspace_bytes,
-                             int64_t N, int64_t K, int64_t C, void* stream);
+                             void* grad_logits, void* grad_adj, int adj_symmetric, void* workspace,
+                             int64_t workspace_bytes, int64_t N, int64_t K, int64_t C, void* stream);
 
 /*
  * Optimizer step on one flat fp32 buffer: global-norm gradient clipping + Adam with L2 weight decay, two launches.

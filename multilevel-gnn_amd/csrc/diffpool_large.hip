@@ -431,6 +431,7 @@ extern "C" int64_t mlgnn_diffpool_large_bwd_workspace_bytes(int64_t N, int64_t K
   const int tiles_z = (int)((N / kGemmTile) * (C / kGemmTile));
   o += dpl_align((size_t)dpl_splits(tiles_z, (int)(K / kGemmBK)) * N * C * 4);   // dZ slabs
   if (!adj_symmetric) o += dpl_align((size_t)N * N * 2) + dpl_align((size_t)N * K * 2);   // A^T, T2
+  o += dpl_align((size_t)N * K * 2);                            // P = S~ (dA' - cI) of the adjacency gradient
   return (int64_t)o;
 }
 
@@ -438,8 +439,8 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
                                         const void* s_soft, const void* saved, const void* grad_x,
                                         const void* grad_adj_out, int grad_dtype, const void* grad_link,
                                         const void* grad_ent, int scalar_dtype, const float* stats, void* grad_z,
-                                        void* grad_logits, int adj_symmetric, void* workspace, int64_t workspace_bytes,
-                                        int64_t N, int64_t K, int64_t C, void* stream) {
+                                        void* grad_logits, void* grad_adj, int adj_symmetric, void* workspace,
+                                        int64_t workspace_bytes, int64_t N, int64_t K, int64_t C, void* stream) {
   if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
   if (!z || !adj || !s_logits || !s_soft || !saved || !grad_x || !grad_adj_out || !grad_link || !grad_ent || !stats ||
       !grad_z || !grad_logits || !workspace) return MLGNN_E_NULL;
@@ -526,6 +527,25 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
     // dZ takes the dtype of z = the dtype of the logits
     DPL_CHECK(slab_reduce_launch(slab, splits_z, n, c, c, grad_z, C, logits_dtype == MLGNN_DTYPE_F32, nullptr, 0, nullptr,
                                  kDplPartials, st));
+  }
+  // dA = S~ dA' S~^T  (through A' = S^T A S)  +  c (A - S~ S~^T)  (through the link term)
+  //    = P S~^T + c A,   P = S~ (dA' - cI)   -- two products, the second with the `+ c A` in its epilogue (c read on
+  // the device).  The adjacency of the next pooling level is this level's A' (models/diff_pooling.py:116-127).
+  if (grad_adj) {
+    uint16_t* P = (uint16_t*)take((size_t)N * K * 2);
+    GemmDesc d{};
+    d.nseg = 1;
+    d.seg[0] = GemmSeg{S, b2, K, K, k};                       // S~ [N,K] x (dA'^T - cI)[K,K]^T = S~ (dA' - cI)
+    d.M = n; d.N = k; d.splits = 1;
+    d.c = P; d.ldc = K; d.c_f32 = 0;
+    DPL_CHECK(gemm_nt_launch(d, st));
+    GemmDesc e{};
+    e.nseg = 1;
+    e.seg[0] = GemmSeg{P, S, K, K, k};                        // P [N,K] x S~[N,K]^T
+    e.M = n; e.N = n; e.splits = 1;
+    e.c = grad_adj; e.ldc = N; e.c_f32 = logits_dtype == MLGNN_DTYPE_F32;
+    e.aux = adj; e.ldaux = N; e.aux_f32 = 0; e.alpha = 0.f; e.alpha_dev = coef;
+    DPL_CHECK(gemm_nt_launch(e, st));
   }
   return (int)hipGetLastError();
 }

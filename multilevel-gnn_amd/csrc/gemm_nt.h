@@ -27,6 +27,7 @@ struct GemmDesc {
   void* c; int64_t ldc; int c_f32;                    // C [M,N], bf16 or fp32
   uint16_t* ct; int64_t ldct;                         // C^T [N,M], bf16
   const void* aux; int64_t ldaux; int aux_f32; float alpha;   // C = acc + alpha * aux[M,N]
+  const float* alpha_dev;                                     // non-NULL: alpha is read from the device instead
   const uint16_t* dot; int64_t lddot; float* dot_partial;     // dot_partial[workgroup] = sum_ij dot[i][j] * acc[i][j]
 };
 

@@ -264,9 +264,10 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
     if (threadIdx.x == 0) p.d.dot_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
   }
   if (p.d.aux) {
+    const float alpha = p.d.alpha_dev ? *p.d.alpha_dev : p.d.alpha;
     MLGNN_FOR_ACC(
         const size_t at = (size_t)row * p.d.ldaux + col;
-        v += p.d.alpha * (p.d.aux_f32 ? reinterpret_cast<const float*>(p.d.aux)[at]
+        v += alpha * (p.d.aux_f32 ? reinterpret_cast<const float*>(p.d.aux)[at]
                                                    : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.d.aux)[at]));)
   }
   if (p.d.c) {

@@ -530,14 +530,13 @@ class _DiffPoolLarge(torch.autograd.Function):
         _lib.check(rc, "mlgnn_diffpool_large_fwd")
         ctx.save_for_backward(zb, ab, s, S, ws, stats)
         ctx.cfg = (bool(adj_symmetric), z.dtype)
+        ctx.adj_dtype = adj.dtype
         return x_out, a_out, scal[0], scal[1]
 
     @staticmethod
     def backward(ctx, gx, ga, g_link, g_ent):
         zb, ab, s, S, ws, stats = ctx.saved_tensors
         sym, z_dtype = ctx.cfg
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("the large DiffPool path treats the adjacency as a constant (no gradient)")
         N, C = zb.shape
         K = S.shape[1]
         dev = zb.device
@@ -547,13 +546,17 @@ class _DiffPoolLarge(torch.autograd.Function):
             g_link, g_ent = g_link.float(), g_ent.float()
         gz = torch.empty((N, C), dtype=s.dtype, device=dev)
         gs = torch.empty((N, K), dtype=s.dtype, device=dev)
+        # the adjacency of a second pooling level is the first level's S^T A S (diff_pooling.py:116-127): its gradient
+        # is two more products of the same chain
+        gadj = torch.empty((N, N), dtype=s.dtype, device=dev) if ctx.needs_input_grad[1] else None
         wb = torch.empty(int(_lib.lib.mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, int(sym))), dtype=torch.uint8, device=dev)
         rc = _lib.lib.mlgnn_diffpool_large_bwd(zb.data_ptr(), ab.data_ptr(), s.data_ptr(), _dt(s), S.data_ptr(), ws.data_ptr(),
                                                gx.data_ptr(), ga.data_ptr(), _dt(gx), g_link.data_ptr(), g_ent.data_ptr(),
-                                               _dt(g_link), stats.data_ptr(), gz.data_ptr(), gs.data_ptr(), int(sym), wb.data_ptr(), wb.numel(), N, K, C,
+                                               _dt(g_link), stats.data_ptr(), gz.data_ptr(), gs.data_ptr(), _lib.ptr(gadj),
+                                               int(sym), wb.data_ptr(), wb.numel(), N, K, C,
                                                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_diffpool_large_bwd")
-        return gz.to(z_dtype), None, gs, None
+        return gz.to(z_dtype), (gadj.to(ctx.adj_dtype) if gadj is not None else None), gs, None
 
 
 def _dt(t):
@@ -611,8 +614,6 @@ class _DiffPoolLargeFP32(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gx, ga, g_link, g_ent):
         z, adj, S, T, G, norm = ctx.saved_tensors
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("the large DiffPool path treats the adjacency as a constant (no gradient)")
         N, C = z.shape
         K = S.shape[1]
         c = g_link / (adj.numel() * norm)
@@ -628,14 +629,18 @@ class _DiffPoolLargeFP32(torch.autograd.Function):
         gs = S * (dS - (dS * S).sum(dim=-1, keepdim=True))
         tiles = (N // 128) * (C // 128)
         gz = _matmul_nt_3term(Sp, gx.float().t().contiguous(), splits=max(1, min(256 // tiles, 3 * K // 64)))
-        return gz, None, gs, None
+        gadj = None
+        if ctx.needs_input_grad[1]:
+            # dA = S (dA' - cI) S^T + c A   (through A' = S^T A S and through the link term)
+            P = _matmul_nt_3term(Sp, (ga.t() - c * eye).contiguous())
+            gadj = _matmul_nt_3term(P, Sp) + c * adj
+        return gz, gadj, gs, None
 
 
 def diff_pool_large_supported(z, adj, s):
     B, N, C = z.shape
     same = z.dtype == s.dtype == adj.dtype and z.dtype in (torch.bfloat16, torch.float32)
-    return (z.is_cuda and same and not adj.requires_grad
-            and bool(_lib.lib.mlgnn_diffpool_large_supported(N, s.shape[2], C)))
+    return z.is_cuda and same and bool(_lib.lib.mlgnn_diffpool_large_supported(N, s.shape[2], C))
 
 
 def _diff_pool_large(z, adj, s, adj_symmetric=False):

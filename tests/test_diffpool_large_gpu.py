@@ -206,3 +206,76 @@ def test_fp32_path_matches_fp64_oracle_to_1e4(N, K, C):
     for got, ref, name in ((zc.grad, zd.grad, "grad z"), (sc.grad, sd.grad, "grad logits")):
         err = float((got.double() - ref).abs().max())
         assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (name, err)
+
+
+# ---- adjacency gradient: the second pooling level's adjacency is the first level's S^T A S ---------------------------
+
+@pytest.mark.parametrize("N,K,C", SIZES)
+def test_adjacency_gradient_bf16(N, K, C):
+    """dA = S (dA' - cI) S^T + c A against autograd of the fp64 oracle (models/diff_pooling.py:116-127 feeds A' of
+    level i to level i+1 as its adjacency): norm-wise within the bf16 bound, like the other gradients."""
+    from mlgnn.dense import dense_diff_pool
+    z, a, s = _inputs(N, K, C, 7)
+    zd, ad, sd = z.double().requires_grad_(True), a.double().requires_grad_(True), s.double().requires_grad_(True)
+    rx, ra, rl, re = OP.dense_diff_pool(zd, ad, sd)
+    g = torch.Generator().manual_seed(8)
+    wx, wa = torch.randn(K, C, generator=g).double(), torch.randn(K, K, generator=g).double() / K
+    (rx[0] * wx).sum().add((ra[0] * wa).sum()).add(rl * 3e4).add(re * 2.0).backward()
+    zc, ac, sc = z.cuda().requires_grad_(True), a.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+    x, ao, link, ent = dense_diff_pool(zc, ac, sc)
+    ((x[0].float() * wx.float().cuda()).sum() + (ao[0].float() * wa.float().cuda()).sum() + link.float() * 3e4
+     + ent.float() * 2.0).backward()
+    assert ac.grad is not None and ac.grad.shape == (N, N) and ac.grad.dtype == torch.bfloat16
+    for got, ref, name in ((ac.grad, ad.grad, "grad adj"), (zc.grad, zd.grad, "grad z"), (sc.grad, sd.grad, "grad logits")):
+        err = float(torch.linalg.norm(got.double().cpu() - ref)) / float(torch.linalg.norm(ref))
+        assert err <= 2.0 ** -6, (name, err)
+
+
+@pytest.mark.parametrize("N,K,C", SIZES)
+def test_adjacency_gradient_fp32(N, K, C):
+    from mlgnn.dense import dense_diff_pool
+    g = torch.Generator().manual_seed(31)
+    dev = "cuda:0"
+    z = torch.randn(N, C, generator=g)
+    a = torch.rand(N, N, generator=g) + torch.eye(N)
+    s = torch.randn(N, K, generator=g) * 2.0
+    zd, ad, sd = (t.double().to(dev).requires_grad_(True) for t in (z, a, s))
+    rx, ra, rl, re = OP.dense_diff_pool(zd, ad, sd)
+    wx, wa = torch.randn(K, C, generator=g).double().to(dev), (torch.randn(K, K, generator=g) / K).double().to(dev)
+    ((rx[0] * wx).sum() + (ra[0] * wa).sum() + rl * 3e4 + re * 2.0).backward()
+    zc, ac, sc = (t.to(dev).requires_grad_(True) for t in (z, a, s))
+    x, ao, link, ent = dense_diff_pool(zc, ac, sc)
+    ((x[0] * wx.float()).sum() + (ao[0] * wa.float()).sum() + link * 3e4 + ent * 2.0).backward()
+    err = float((ac.grad.double() - ad.grad).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ad.grad.abs().max())), err
+
+
+def test_two_level_chain_gradients_through_both_levels():
+    """4096 -> 1024 -> 256 (BASELINE configs[4]): level 2 takes level 1's (x', A') -- both levels stay on the
+    matrix-core chain, the gradient of level 1's inputs passes through level 2's adjacency gradient.  fp32 inputs,
+    fp64 oracle on the device, 1e-4 like the single-level fp32 test."""
+    from mlgnn.dense import dense_diff_pool
+    g = torch.Generator().manual_seed(41)
+    dev = "cuda:0"
+    N, K1, K2, C = 4096, 1024, 256, 256
+    z = torch.randn(N, C, generator=g)
+    a = torch.rand(N, N, generator=g) + torch.eye(N)
+    s1 = torch.randn(N, K1, generator=g) * 2.0
+    s2 = torch.randn(K1, K2, generator=g) * 2.0
+    zd, sd1, sd2 = (t.double().to(dev).requires_grad_(True) for t in (z, s1, s2))
+    ad = a.double().to(dev)
+    x1, a1, l1, e1 = OP.dense_diff_pool(zd, ad, sd1)
+    x2, a2, l2, e2 = OP.dense_diff_pool(x1[0], a1[0], sd2)
+    wx, wa = torch.randn(K2, C, generator=g).double().to(dev), (torch.randn(K2, K2, generator=g) / K2).double().to(dev)
+    ((x2[0] * wx).sum() + (a2[0] * wa).sum() + (l1 + l2) * 3e4 + (e1 + e2) * 2.0).backward()
+    zc, sc1, sc2 = (t.to(dev).requires_grad_(True) for t in (z, s1, s2))
+    y1, b1, m1, f1 = dense_diff_pool(zc, a.to(dev), sc1)
+    assert b1.requires_grad
+    y2, b2, m2, f2 = dense_diff_pool(y1[0], b1[0], sc2)
+    ((y2[0] * wx.float()).sum() + (b2[0] * wa.float()).sum() + (m1 + m2) * 3e4 + (f1 + f2) * 2.0).backward()
+    for got, ref, name in ((y2[0], x2[0].detach(), "x''"), (b2[0], a2[0].detach(), "A''")):
+        err = float((got.detach().double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert err <= 1e-4, (name, err)
+    for got, ref, name in ((zc.grad, zd.grad, "grad z"), (sc1.grad, sd1.grad, "grad logits 1"), (sc2.grad, sd2.grad, "grad logits 2")):
+        err = float((got.double() - ref).abs().max())
+        assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (name, err)

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
   }
   float gam = 0.f, bet = 0.f;
   if constexpr (EPI == LB_LN) { gam = p.gamma[col]; bet = p.beta[col]; }
+  const bool shift = EPI != LB_SHIFT || p.gt != nullptr;      // LB_SHIFT without lse / gt: the plain epilogue
 
   // ---- go units of this thread: (column, row group) ---------------------------------------------------------------
   auto ucol = [&](int q) { return (tid + q * kLbThreads) % M; };
@@ -349,7 +350,12 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
                                            (lds_void_t*)(smem + kRsB + ((i % 3) * kLbWaves + wave) * 256), 16, 0, 0);
       }
       if constexpr (EPI == LB_SHIFT) {
-        if (full) {
+        if (!shift) {
+          // plain epilogue through the same instantiation (a separate one without these loads makes the register
+          // allocator spill the weight fragments inside the loop): eight loads of one cached word instead
+#pragma unroll
+          for (int q = 0; q < 8; ++q) lse8[q] = glb_load_f32<0>(p.go_parts, 0u);
+        } else if (full) {
           const float* base = p.lse + (size_t)r0 * K;
           const uint32_t o0 = (uint32_t)((16 * mh + 4 * h) * K + col) * 4u, o1 = o0 + 8u * K * 4u;
           lse8[0] = glb_load_f32<0>(base, o0); lse8[1] = glb_load_f32<K * 4>(base, o0);
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
           if constexpr (EPI == LB_SHIFT) {
             // (a node without incoming edges is never gathered, and the forward writes lse = 0 for it)
             gt[q] = v[q] * fast_exp2(-lse8[q]);
-            worst = fmaxf(worst, fabsf(lse8[q]));
+            if (shift) worst = fmaxf(worst, fabsf(lse8[q]));
           }
         }
         char* out = reinterpret_cast<char*>(p.dx + (size_t)r0 * K);
@@ -568,10 +574,12 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
         const uint32_t o0 = (uint32_t)((16 * mh + 4 * h) * K + col) * 4u;
         if (full) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const uint32_t o = o0 + (uint32_t)(((q & 3) + 8 * (q >> 2)) * K * 4);
-            *reinterpret_cast<float*>(out + o) = v[q];
-            if constexpr (EPI == LB_SHIFT) *reinterpret_cast<float*>(out_t + o) = gt[q];
+          for (int q = 0; q < 8; ++q)
+            *reinterpret_cast<float*>(out + (o0 + (uint32_t)(((q & 3) + 8 * (q >> 2)) * K * 4))) = v[q];
+          if (EPI == LB_SHIFT && shift) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              *reinterpret_cast<float*>(out_t + (o0 + (uint32_t)(((q & 3) + 8 * (q >> 2)) * K * 4))) = gt[q];
           }
         } else {
 #pragma unroll
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
             if (r0 + lb_rho(8 * mh + q, h) < p.N) {
               const uint32_t o = o0 + (uint32_t)(((q & 3) + 8 * (q >> 2)) * K * 4);
               *reinterpret_cast<float*>(out + o) = v[q];
-              if constexpr (EPI == LB_SHIFT) *reinterpret_cast<float*>(out_t + o) = gt[q];
+              if (EPI == LB_SHIFT && shift) *reinterpret_cast<float*>(out_t + o) = gt[q];
             }
           }
         }
@@ -589,16 +597,21 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
       __builtin_amdgcn_sched_barrier(0);
       // the go registers of stage i + 1: behind them only this iteration's LDS-DMAs and stores (a ragged stage may
       // have skipped stores: it waits for everything)
-      if (full) {
+      if (full && shift) {
 #pragma unroll
         for (int q = 0; q < UPT; ++q) vm_landed<DMA + E_S>(gr[q]);
+      } else if (full) {
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) vm_landed<DMA + (EPI == LB_SHIFT ? 8 : E_S)>(gr[q]);      // (no gt stores)
       } else {
 #pragma unroll
         for (int q = 0; q < UPT; ++q) vm_landed<0>(gr[q]);
       }
       commit_go(buf ^ 1, row_of(i + 1), i + 1 < n);
       // x of stage i + 1 (requested one iteration ago): everything older than this iteration's own operations
-      if (full) lb_wait_vm<kVmPerIter>(); else lb_wait_vm<0>();
+      if (full && shift) lb_wait_vm<kVmPerIter>();
+      else if (full) lb_wait_vm<kVmPerIter - (EPI == LB_SHIFT ? 8 : 0)>();
+      else lb_wait_vm<0>();
       LB_WAIT_LGKM(0);                              // (the plane writes above)
       __builtin_amdgcn_s_barrier();
     }
@@ -636,7 +649,7 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
   }
   if constexpr (EPI == LB_SHIFT) {
     // (a NaN lse fails the comparison, like in softmax_shift_kernel: the NaN then travels in gt itself)
-    if (lane == 0 && worst > kMaxLse) *p.spread = 1;            // plain store: every writer stores the same value
+    if (shift && lane == 0 && worst > kMaxLse) *p.spread = 1;   // plain store: every writer stores the same value
   }
 }
 
@@ -729,9 +742,9 @@ extern "C" int mlgnn_linear_bwd(const float* go, const float* w, const float* x,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                        \
     hipLaunchKernelGGL((linear_bwd_kernel<M_, K_, EPI_>), dim3(grid), dim3(kLbThreads), lds_bytes, s, a);    \
   }
+  if (epilogue == LB_PLAIN) { a.lse = nullptr; a.gt = nullptr; a.spread = nullptr; }
   if (epilogue == LB_LN) MLGNN_LB_LAUNCH(128, 256, LB_LN)
-  else if (epilogue == LB_SHIFT) MLGNN_LB_LAUNCH(256, 128, LB_SHIFT)
-  else MLGNN_LB_LAUNCH(256, 128, LB_PLAIN)
+  else MLGNN_LB_LAUNCH(256, 128, LB_SHIFT)              // (plain = the same instantiation without lse / grad_shifted)
 #undef MLGNN_LB_LAUNCH
   err = (int)hipGetLastError();
   if (err) return err;

@@ -123,7 +123,7 @@ def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
 
 LB_LN, LB_PLAIN, LB_SHIFT = 0, 1, 2
 _ONE_PASS = os.environ.get("MLGNN_ONE_PASS_BWD", "1") == "1"      # (0: the two-kernel backward of each Linear, for A/B runs)
-LINEAR_BWD_STATS = {"ln": 0, "shift": 0}
+LINEAR_BWD_STATS = {"ln": 0, "shift": 0, "plain": 0}
 
 
 def linear_backward_supported(N, M, K, epilogue):
@@ -320,16 +320,18 @@ class _FusedMLP2(torch.autograd.Function):
                 gh, ggamma, gbeta, gh_max = ln_backward_normalised(gy, xhat, gamma, beta, rstd, relu=True)
         src = ctx.shift_src if ctx.needs_input_grad[0] else None
         gx = None
-        if (_ONE_PASS and src is not None and x_max is not None and (gh_parts is not None or gh_max is not None)
+        if (_ONE_PASS and x_max is not None and (gh_parts is not None or gh_max is not None)
                 and linear_backward_supported(N, w1.shape[0], w1.shape[1], LB_SHIFT)):
-            # first Linear: dW1, db1, the input gradient and the rescaled cotangent of the softmax aggregation behind
-            # it from one pass over gh and x
+            # first Linear: dW1, db1, the input gradient and -- behind a softmax aggregation -- its rescaled cotangent
+            # from one pass over gh and x
             from .ops import tag_shifted
-            r1 = linear_backward(gh, w1, x, gh_parts if gh_parts is not None else gh_max, x_max, LB_SHIFT, lse=src[0],
-                                 go_max_is_parts=gh_parts is not None)
+            epi = LB_SHIFT if src is not None else LB_PLAIN
+            r1 = linear_backward(gh, w1, x, gh_parts if gh_parts is not None else gh_max, x_max, epi,
+                                 lse=src[0] if src is not None else None, go_max_is_parts=gh_parts is not None)
             gx, gw1, gb1 = r1["dx"], r1["gw"], r1["gb"]
-            tag_shifted(gx, r1["gt"], r1["flag"], src[0])
-            LINEAR_BWD_STATS["shift"] += 1
+            if src is not None:
+                tag_shifted(gx, r1["gt"], r1["flag"], src[0])
+            LINEAR_BWD_STATS["shift" if src is not None else "plain"] += 1
         else:
             gw1, gb1 = _wgrad(gh, x, go_max=gh_max, x_max=x_max)
             if ctx.needs_input_grad[0]:

@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import _DTYPE_IDS, row_max_of
+from .ops import _DTYPE_IDS, f32_cached, row_max_of
 
 DIFFPOOL_EPS = 1e-15
 WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bottleneck
@@ -32,7 +32,7 @@ def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None, bt_tr
     if residual is not None:
         residual = residual.contiguous()
     if bias is not None:
-        bias = bias.float().contiguous()                 # [J]; the kernels add it in fp32
+        bias = f32_cached(bias)                          # [J]; the kernels add it in fp32
     if a.dtype == torch.float32:
         ROW_MAX_STATS["given" if row_max is not None else "computed"] += 1
     mode, gamma, beta, eps, rstd, rmax = 0, None, None, 0.0, None, None
@@ -67,7 +67,7 @@ def tall_matmul_lnin_postln(xhat, w, bias, residual, row_max, gamma, beta, post)
     if residual is not None:
         residual = residual.contiguous()
     if bias is not None:
-        bias = bias.float().contiguous()
+        bias = f32_cached(bias)
     ROW_MAX_STATS["given" if row_max is not None else "computed"] += 1
     g2, b2, eps2, relu = post
     rc = _lib.lib.mlgnn_tallgemm_lnin_postln(xhat.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual),

@@ -24,7 +24,8 @@ def fused_supported(x):
 
 def _f32_params(weight, bias):
     """gamma / beta as the kernels take them: fp32, contiguous (a bf16 model keeps bf16 parameters: [d] casts)."""
-    return weight.float().contiguous(), bias.float().contiguous()
+    from .ops import f32_cached
+    return f32_cached(weight), f32_cached(bias)
 
 
 def _keep_mask(x, p):

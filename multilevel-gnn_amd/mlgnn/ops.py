@@ -153,6 +153,21 @@ def shifted_of(grad, lse):
     return None
 
 
+def f32_cached(t):
+    """``t`` as a contiguous fp32 tensor for a kernel argument (LayerNorm gamma / beta, a bias: the kernels read their
+    [d]-sized parameters in fp32).  The copy of a non-fp32 parameter is kept on the tensor until its version changes, so
+    a bf16 model casts each parameter once per optimizer step instead of once per use (forward and backward: ~20 tiny
+    launches per layer at BASELINE configs[4]).  Only for use inside autograd Functions (the copy is detached)."""
+    if t.dtype == torch.float32:
+        return t.contiguous()
+    tag = getattr(t, "_mlgnn_f32", None)
+    if tag is not None and tag[0] == t._version:
+        return tag[1]
+    c = t.detach().float().contiguous()
+    t._mlgnn_f32 = (t._version, c)
+    return c
+
+
 def row_max_of(t):
     tag = getattr(t, "_mlgnn_row_max", None)
     if tag is not None and tag[1] == t._version and tag[0].shape[0] == t.shape[0]:

@@ -10,7 +10,7 @@
 # 4. hub-row benchmark -> profiles/<tag>_skew.json
 # The program always follows `rocprofv3 ... --` directly (no wrapper process).  Outputs: gpurun_out/prof_*_<tag>/.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 export MLGNN_COMMIT=${2:-unknown}
 R=$(pwd)
 BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
@@ -42,6 +42,7 @@ else:
 PY
 python3 tools/bench_diffpool.py --json profiles/${TAG}_diffpool_configs4.json > gpurun_out/dp_$TAG.log 2>&1
 python3 tools/bench_diffpool.py --dtype fp32 --iters 10 --json profiles/${TAG}_diffpool_configs4_fp32.json > gpurun_out/dp32_$TAG.log 2>&1
+python3 tools/bench_dense.py --iters 30 --json profiles/${TAG}_dense_kernels.json > gpurun_out/dense_$TAG.log 2>&1
 python3 tools/bench_skew.py > gpurun_out/skew_$TAG.log 2>&1
 if grep -q '^{' gpurun_out/skew_$TAG.log; then grep '^{' gpurun_out/skew_$TAG.log | tail -1 > profiles/${TAG}_skew.json
 else echo "WARNING: no JSON line in gpurun_out/skew_$TAG.log -- profiles/${TAG}_skew.json not written"; fi

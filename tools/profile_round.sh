@@ -60,4 +60,7 @@ python3 bench.py > gpurun_out/bench_$TAG.log 2>&1
 tail -1 gpurun_out/bench_$TAG.log > profiles/${TAG}_bench.json
 # keep only the CSVs the summaries came from (the traces are large)
 find gpurun_out -name "*kernel_trace.csv" -delete
-ls -la profiles/
+# gpurun brings back gpurun_out/ only: a copy of what this run wrote under profiles/ travels in it
+mkdir -p gpurun_out/profiles_$TAG
+cp profiles/${TAG}_* profiles/traffic.json gpurun_out/profiles_$TAG/
+ls -la gpurun_out/profiles_$TAG/

@@ -398,6 +398,17 @@ int mlgnn_tallgemm_nt_shift(const float* a, const float* bt, int bt_transposed, 
                             int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream);
 
 /*
+ * The same for bf16 storage (BASELINE configs[4]): c [N,J] = a [N,R] * bt [J,R]^T (bf16, fp32 accumulation) and
+ * grad_shifted = c * 2^(-lse) (bf16, from the rounded c: bitwise what the streaming pre-pass would write), lse [N,J]
+ * fp32 in log2 units (0 for nodes without incoming edges, as mlgnn_csr_aggregate_fwd writes it); shift_flag as above.
+ * Shapes: those of mlgnn_tallgemm_nt with MLGNN_DTYPE_BF16; workspace: mlgnn_tallgemm_workspace_bytes(R, J, bf16).
+ */
+int mlgnn_tallgemm_bf16_shift_supported(int64_t N, int64_t R, int64_t J);
+int mlgnn_tallgemm_bf16_shift(const void* a, const void* bt, const float* lse, void* c, void* grad_shifted,
+                              int32_t* shift_flag, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R,
+                              int64_t J, void* stream);
+
+/*
  * The MLP's second Linear with the NEXT block's pre-conv LayerNorm (+ ReLU) in its epilogue (fp32):
  *     c [N,J] = relu(gamma xhat + beta) [N,R] * bt[J,R]^T (+ bias) (+ residual)          (= mlgnn_tallgemm_nt, ln_mode 2)
  *     y [N,J] = relu?(post_gamma (c - mean_row(c)) rstd_row + post_beta),   post_mean / post_rstd [N] = mean, 1/sigma

@@ -502,7 +502,8 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
 // bf16 storage: csrc/tallgemm_bf16.hip
 int tb_tiles_per_slice(int64_t R, int64_t J);
 int tallgemm_bf16(const void* a, const void* bt, const float* bias, const void* residual, void* c, void* workspace,
-                  int64_t N, int64_t R, int64_t J, hipStream_t s);
+                  int64_t N, int64_t R, int64_t J, hipStream_t s, const float* lse = nullptr, void* gt = nullptr,
+                  int* spread = nullptr);
 
 static bool tg_dims_ok(int64_t R, int64_t J) {
   const bool j_ok = (J == 32 || J == 64 || J == 128 || J == 256);

@@ -50,6 +50,9 @@ __global__ __launch_bounds__(256) void tallgemm_bf16_pack_kernel(const uint4* __
 
 struct TbArgs {
   const uint4* a; const uint4* image; const float* bias; const uint16_t* res; uint16_t* c;
+  // SHIFT (input gradient of a Linear behind a softmax aggregation): gt = c * 2^(-lse) next to c, from the rounded c
+  // (bitwise what the streaming pre-pass of csrc/aggregate_bwd.hip would produce); *spread raised when |lse| > kMaxLse
+  const float* lse; uint16_t* gt; int* spread;
   int N; int R; int J;
 };
 
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
 #pragma unroll
   for (int t = 0; t < JT; ++t) bias[t] = p.bias ? p.bias[j0 + tb_col<JT>(t, r31)] : 0.f;
 
+  float worst = 0.f;
   const int n_tiles = (p.N + 31) / 32;
   const int row_u4 = p.R / 8;                                   // uint4 per row of A
   for (int tile = blockIdx.x * kTbWaves + wave; tile < n_tiles; tile += gridDim.x * kTbWaves) {
@@ -132,7 +136,13 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
       if constexpr (JT == 1) {
         float v = acc[0][r] + bias[0];
         if (p.res) v += bf16_to_f32((uint16_t)resw[0][r]);
-        p.c[base + r31] = f32_to_bf16(v);
+        const uint16_t cb = f32_to_bf16(v);
+        p.c[base + r31] = cb;
+        if (p.lse) {
+          const float l = p.lse[base + r31];
+          p.gt[base + r31] = f32_to_bf16(bf16_to_f32(cb) * fast_exp2(-l));
+          worst = fmaxf(worst, fabsf(l));
+        }
       } else {
 #pragma unroll
         for (int u = 0; u < JT / 2; ++u) {
@@ -143,10 +153,22 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
             v0 += __builtin_bit_cast(float, w << 16);
             v1 += __builtin_bit_cast(float, w & 0xffff0000u);
           }
-          *reinterpret_cast<uint32_t*>(p.c + at) = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+          const uint16_t c0 = f32_to_bf16(v0), c1 = f32_to_bf16(v1);
+          *reinterpret_cast<uint32_t*>(p.c + at) = (uint32_t)c0 | ((uint32_t)c1 << 16);
+          if (p.lse) {
+            const float2 l = *reinterpret_cast<const float2*>(p.lse + at);
+            const float g0 = bf16_to_f32(c0) * fast_exp2(-l.x), g1 = bf16_to_f32(c1) * fast_exp2(-l.y);
+            *reinterpret_cast<uint32_t*>(p.gt + at) = (uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16);
+            worst = fmaxf(worst, fmaxf(fabsf(l.x), fabsf(l.y)));
+          }
         }
       }
     }
+  }
+  if (p.lse) {
+    // (a NaN lse fails the comparison, like in softmax_shift_kernel: the NaN then travels in gt itself)
+    for (int off = 1; off < kWave; off <<= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
+    if (lane == 0 && worst > kMaxLse) *p.spread = 1;              // plain store: every writer stores the same value
   }
 }
 
@@ -159,7 +181,7 @@ int tb_tiles_per_slice(int64_t R, int64_t J) {
 }
 
 int tallgemm_bf16(const void* a, const void* bt, const float* bias, const void* residual, void* c, void* workspace,
-                  int64_t N, int64_t R, int64_t J, hipStream_t s) {
+                  int64_t N, int64_t R, int64_t J, hipStream_t s, const float* lse, void* gt, int* spread) {
   const int jt = tb_tiles_per_slice(R, J);
   if (jt == 0) return MLGNN_E_SHAPE;
   const int ksteps = (int)(R / 16), slices = (int)(J / (32 * jt));
@@ -167,6 +189,7 @@ int tallgemm_bf16(const void* a, const void* bt, const float* bias, const void* 
   TbArgs p;
   p.a = (const uint4*)a; p.image = (const uint4*)workspace; p.bias = bias; p.res = (const uint16_t*)residual;
   p.c = (uint16_t*)c; p.N = (int)N; p.R = (int)R; p.J = (int)J;
+  p.lse = lse; p.gt = (uint16_t*)gt; p.spread = spread;
   const size_t lds = (size_t)ksteps * jt * 64 * 16;
   const int64_t tiles = (N + 31) / 32;
   int gx = (int)((tiles + kTbWaves - 1) / kTbWaves);
@@ -190,3 +213,27 @@ int tallgemm_bf16(const void* a, const void* bt, const float* bias, const void* 
 }
 
 }  // namespace mlgnn
+
+using namespace mlgnn;
+
+extern "C" int mlgnn_tallgemm_bf16_shift_supported(int64_t N, int64_t R, int64_t J) {
+  return (N > 0 && N <= INT32_MAX && tb_tiles_per_slice(R, J) > 0 && N * J * 4 < ((int64_t)1 << 40)) ? 1 : 0;
+}
+
+extern "C" int mlgnn_tallgemm_bf16_shift(const void* a, const void* bt, const float* lse, void* c, void* grad_shifted,
+                                         int32_t* shift_flag, void* workspace, int64_t workspace_bytes, int64_t N,
+                                         int64_t R, int64_t J, void* stream) {
+  if (N == 0) return 0;
+  if (!mlgnn_tallgemm_bf16_shift_supported(N, R, J)) return MLGNN_E_SHAPE;
+  if (!a || !bt || !lse || !c || !grad_shifted || !shift_flag || !workspace) return MLGNN_E_NULL;
+  if (workspace_bytes < R * J * 2) return MLGNN_E_WORKSPACE;
+  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bt) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0 ||
+      ((reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(grad_shifted)) & 3) != 0 ||
+      (reinterpret_cast<uintptr_t>(lse) & 7) != 0)
+    return MLGNN_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  int err = (int)hipMemsetAsync(shift_flag, 0, 16, s);
+  if (err) return err;
+  return tallgemm_bf16(a, bt, nullptr, nullptr, c, workspace, N, R, J, s, lse, grad_shifted, shift_flag);
+}
+

@@ -29,6 +29,8 @@ SIGNATURES = {
     "mlgnn_layernorm_act_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I64, _I64, _F, _INT, _INT, _P]),
     "mlgnn_layernorm_act_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _F, _I64, _I64, _INT, _INT, _P]),
     "mlgnn_linear_wgrad_workspace_floats": (_I64, [_I64, _I64, _I64, _INT]),
+    "mlgnn_tallgemm_bf16_shift_supported": (_INT, [_I64, _I64, _I64]),
+    "mlgnn_tallgemm_bf16_shift": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "mlgnn_linear_bwd_supported": (_INT, [_I64, _I64, _I64, _INT]),
     "mlgnn_linear_bwd_workspace_floats": (_I64, [_I64, _I64, _I64, _INT]),
     "mlgnn_linear_bwd": (_INT, [_P, _P, _P, _P, _INT, _P, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64,

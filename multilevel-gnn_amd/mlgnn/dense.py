@@ -100,6 +100,25 @@ def tall_matmul_nt_shift(a, w, row_max, lse, rowptr):
     return gx, gt, flag
 
 
+def tall_matmul_bf16_shift(go, weight, lse):
+    """bf16 storage: input gradient ``go [N,M] @ weight [M,K]`` of a Linear that reads the output of a softmax aggregation,
+    with that aggregation's rescaled cotangent from the same epilogue (csrc/tallgemm_bf16.hip SHIFT):
+    ``-> (gx, gx * 2^(-lse), flag)``."""
+    N, M = go.shape
+    K = weight.shape[1]
+    go, bt = go.contiguous(), weight.t().contiguous()             # [K, M]: the contraction index contiguous
+    gx = torch.empty((N, K), dtype=torch.bfloat16, device=go.device)
+    gt = torch.empty_like(gx)
+    flag = torch.empty(4, dtype=torch.int32, device=go.device)
+    nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(M, K, 1))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
+    rc = _lib.lib.mlgnn_tallgemm_bf16_shift(go.data_ptr(), bt.data_ptr(), lse.data_ptr(), gx.data_ptr(), gt.data_ptr(),
+                                            flag.data_ptr(), ws.data_ptr(), nbytes, N, M, K,
+                                            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mlgnn_tallgemm_bf16_shift")
+    return gx, gt, flag
+
+
 def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
     """``dA = go [N,R] @ w [R,J]`` (``w``: the Linear's own weight) taken through ReLU + LayerNorm backward in the GEMM's
     epilogue (``csrc/tallgemm.hip`` LN = 3): ``-> (grad_h [N,J], grad_gamma, grad_beta, max |grad_h| per row)`` for a
@@ -122,6 +141,10 @@ def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
 
 
 LB_LN, LB_PLAIN, LB_SHIFT = 0, 1, 2
+# bf16: the rescaled cotangent from the input-gradient GEMM's epilogue (csrc/tallgemm_bf16.hip SHIFT) instead of the
+# streaming pre-pass.  Off by default: at BASELINE configs[4] the epilogue's dependent lse loads cost more than the
+# pre-pass they replace (65.9 vs 64.7 ms per step in a same-box A/B); the fp32 path folds it into linear_bwd.
+_BF16_SHIFT = os.environ.get("MLGNN_BF16_SHIFT", "0") == "1"
 _ONE_PASS = os.environ.get("MLGNN_ONE_PASS_BWD", "1") == "1"      # (0: the two-kernel backward of each Linear, for A/B runs)
 LINEAR_BWD_STATS = {"ln": 0, "shift": 0, "plain": 0}
 
@@ -204,8 +227,12 @@ class _TallLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
+        from .ops import softmax_lse_of
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        # bf16: x is the output of a softmax aggregation -> its backward wants go * 2^(-lse), which the input-gradient
+        # GEMM below can write next to go (the fp32 path does this inside the fused MLP)
+        ctx.shift_src = softmax_lse_of(x) if (x.dtype == torch.bfloat16 and x.is_contiguous()) else None
         ctx.x_max = row_max_of(x) if x.dtype == torch.float32 else None
         if tall_matmul_supported(x.shape[0], x.shape[1], weight.shape[0], x.dtype):
             # fp32: the kernel holds the residual tile in registers (<= 128 columns); bf16: any width
@@ -226,7 +253,13 @@ class _TallLinear(torch.autograd.Function):
         M = weight.shape[0]
         gx = None
         if ctx.needs_input_grad[0]:
-            if tall_matmul_supported(N, M, K, go.dtype):
+            src = ctx.shift_src
+            if (_BF16_SHIFT and src is not None and go.dtype == torch.bfloat16 and src[0].shape == (N, K)
+                    and _lib.lib.mlgnn_tallgemm_bf16_shift_supported(N, M, K)):
+                from .ops import tag_shifted
+                gx, gt, flag = tall_matmul_bf16_shift(go, weight, src[0])
+                tag_shifted(gx, gt, flag, src[0])
+            elif tall_matmul_supported(N, M, K, go.dtype):
                 gx = tall_matmul_nt(go, weight, row_max=row_max_of(go), bt_transposed=True)     # go [N,M] @ W [M,K]
             else:
                 gx = go.matmul(weight)

@@ -448,8 +448,7 @@ class _GenAggregate(torch.autograd.Function):
         ctx.save_for_backward(x, out, aux, aux2, argmax, eu, ev, efull, t_dev, p_dev)
         ctx.rowmax = rowmax
         # softmax without a learnable temperature: the backward gathers go * 2^(-lse); let the consumer of `out` know
-        ctx.lse_for_shift = aux if (aggr_id == AGGR_SOFTMAX and not learn_t and aux is not None
-                                    and x.dtype == torch.float32) else None
+        ctx.lse_for_shift = aux if (aggr_id == AGGR_SOFTMAX and not learn_t and aux is not None) else None
         return out
 
     @staticmethod

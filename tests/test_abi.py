@@ -106,3 +106,29 @@ def test_argument_errors_of_the_dense_and_embedding_entry_points():
     # embedding gradient
     emb = lambda T, d, dtype=F32: lib.mlgnn_embedding_bwd(None, None, None, None, T, d, dtype, None)
     assert emb(0, 128) == 0 and emb(10, 128) == -1 and emb(10, 130) == -2 and emb(10, 128, BF16) == -4
+
+
+def test_argument_errors_of_the_one_pass_linear_backward():
+    """mlgnn_linear_bwd / mlgnn_tallgemm_bf16_shift: shapes, epilogues, NULL operands and workspace sizes are checked
+    before anything is launched (no GPU needed)."""
+    from mlgnn import _lib
+    lib = _lib.lib
+    LN, PLAIN, SHIFT = 0, 1, 2
+    assert lib.mlgnn_linear_bwd_supported(640000, 128, 256, LN) == 1
+    assert lib.mlgnn_linear_bwd_supported(640000, 256, 128, SHIFT) == 1 and lib.mlgnn_linear_bwd_supported(640000, 256, 128, PLAIN) == 1
+    assert lib.mlgnn_linear_bwd_supported(640000, 256, 128, LN) == 0            # the LayerNorm epilogue: 128 -> 256 only
+    assert lib.mlgnn_linear_bwd_supported(640000, 128, 128, PLAIN) == 0 and lib.mlgnn_linear_bwd_supported(0, 128, 256, LN) == 0
+    assert lib.mlgnn_linear_bwd_supported(640000, 128, 256, 7) == 0
+    assert lib.mlgnn_linear_bwd_supported(5000000, 128, 256, LN) == 0           # 32-bit byte offsets: N K 4 < 4 GiB
+    assert lib.mlgnn_linear_bwd_workspace_floats(1000, 128, 256, LN) == 256 * (128 * 256 + 128 + 512) + 768
+    assert lib.mlgnn_linear_bwd_workspace_floats(1000, 256, 128, SHIFT) == 256 * (256 * 128 + 256) + 768
+    assert lib.mlgnn_linear_bwd_workspace_floats(1000, 100, 256, LN) == -2
+    call = lambda epi, M, K, ws=1 << 30: lib.mlgnn_linear_bwd(None, None, None, None, 0, None, epi, None, None, None, None,
+                                                              None, None, None, None, None, None, ws, 1000, M, K, None)
+    assert call(LN, 128, 256) == -1 and call(SHIFT, 256, 128) == -1             # NULL operands
+    assert call(LN, 256, 128) == -2 and call(5, 128, 256) == -3
+    # bf16 input gradient + rescaled cotangent
+    assert lib.mlgnn_tallgemm_bf16_shift_supported(1000, 512, 256) == 1
+    assert lib.mlgnn_tallgemm_bf16_shift_supported(1000, 40, 64) == 0 and lib.mlgnn_tallgemm_bf16_shift_supported(0, 512, 256) == 0
+    sh = lambda N, R, J, ws=1 << 20: lib.mlgnn_tallgemm_bf16_shift(None, None, None, None, None, None, None, ws, N, R, J, None)
+    assert sh(0, 512, 256) == 0 and sh(1000, 512, 256) == -1 and sh(1000, 40, 64) == -2

@@ -307,3 +307,24 @@ def test_bf16_pooled_levels_run_on_the_native_kernels():
     assert_close(ox.float(), rx, 2.0 ** -7, "bf16 small DiffPool x")
     assert_close(oa.float(), ra, 2.0 ** -7, "bf16 small DiffPool adj")
     assert abs(float(ol) - float(rl)) <= 2.0 ** -7 * float(rl) and abs(float(oe) - float(re)) <= 2.0 ** -7 * abs(float(re))
+
+
+@pytest.mark.parametrize("N,M,K", [(4099, 512, 256), (33, 128, 64), (9000, 256, 128)])
+def test_bf16_input_gradient_with_shifted_cotangent(N, M, K):
+    """csrc/tallgemm_bf16.hip SHIFT: the input gradient of a Linear behind a softmax aggregation and that aggregation's
+    rescaled cotangent from one epilogue -- c bitwise equal to the plain product, gt = bf16(c * 2^(-lse)) from the
+    rounded c (what the streaming pre-pass of csrc/aggregate_bwd.hip computes), the flag raised past |lse| = 60."""
+    from mlgnn import dense as D
+    g = torch.Generator(device="cuda:0").manual_seed(N)
+    go = torch.randn(N, M, device="cuda:0", generator=g).bfloat16()
+    w = (torch.randn(M, K, device="cuda:0", generator=g) * 0.1).bfloat16()
+    lse = torch.randn(N, K, device="cuda:0", generator=g) * 6.0
+    gx, gt, flag = D.tall_matmul_bf16_shift(go, w, lse)
+    plain = D.tall_matmul_nt(go, w, bt_transposed=True)
+    assert torch.equal(gx, plain)
+    want = (gx.float() * torch.exp2(-lse)).bfloat16()
+    assert torch.equal(gt, want)
+    assert int(flag[0]) == 0
+    lse[N // 2, 3] = -61.0
+    _, _, flag = D.tall_matmul_bf16_shift(go, w, lse)
+    assert int(flag[0]) == 1

@@ -45,21 +45,32 @@ class FlatGradBucket:
             p.grad = None
 
     def collect(self):
-        src, dst = [], []
+        # runs of consecutive parameters with a fresh gradient tensor are concatenated straight into their slice of
+        # the flat buffer: ONE launch per run (`torch.cat(..., out=)`, public API) -- one launch in all when every
+        # parameter was reached, as in every shipped model
+        run, run_start, off = [], 0, 0
+
+        def flush(end):
+            if run:
+                torch.cat([g.reshape(-1) for g in run], out=self.flat[run_start:end])
+                del run[:]
+
         for i, (p, v) in enumerate(zip(self.params, self.views)):
+            n = p.numel()
             self.reached[i] = p.grad is not None
-            if p.grad is None:
-                v.zero_()                          # parameter not reached by this backward: zero in the flat buffer
-            elif p.grad.data_ptr() != v.data_ptr():
-                src.append(p.grad)
-                dst.append(v)
-        if src:
-            multi_copy = getattr(torch, "_foreach_copy_", None)      # one multi-tensor launch where torch has the op
-            if multi_copy is not None:
-                multi_copy(dst, src)
+            fresh = p.grad is not None and p.grad.data_ptr() != v.data_ptr()
+            if fresh and p.grad.dtype == self.flat.dtype:
+                if not run:
+                    run_start = off
+                run.append(p.grad)
             else:
-                for d, s in zip(dst, src):
-                    d.copy_(s)
+                flush(off)
+                if p.grad is None:
+                    v.zero_()                      # parameter not reached by this backward: zero in the flat buffer
+                elif fresh:
+                    v.copy_(p.grad)                # (a gradient of another dtype: converting copy)
+            off += n
+        flush(off)
         for p, v in zip(self.params, self.views):
             p.grad = v
         key = tuple(self.reached)

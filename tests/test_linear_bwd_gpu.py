@@ -114,3 +114,37 @@ def test_chained_partial_maxima():
     b = D.linear_backward(a["dx"], w1, x, a["parts"], x.abs().amax(1), D.LB_PLAIN, go_max_is_parts=True)
     c = D.linear_backward(a["dx"], w1, x, a["dx"].abs().amax(1), x.abs().amax(1), D.LB_PLAIN)
     assert torch.equal(b["dx"], c["dx"]) and torch.equal(b["gw"], c["gw"])
+
+
+def test_repeatable_under_a_competing_stream():
+    """The kernel's software pipeline waits by hand (counted s_waitcnt on LDS-DMAs and asm loads, bare barriers): a
+    mis-counted wait would read an LDS stage before it has landed -- timing dependent, so it shows as outputs that
+    differ between identical calls.  40 calls of each epilogue with a second stream hammering memory next to them."""
+    from mlgnn import dense as D
+    N = 200 * 1024 + 5
+    go, xhat, w2, g = _inputs(N, 128, 256, 77)
+    rstd = torch.rand(N, device=DEV, generator=g) + 0.5
+    gamma = torch.rand(256, device=DEV, generator=g) + 0.5
+    beta = torch.randn(256, device=DEV, generator=g) * 0.3
+    act = _act(gamma, xhat, beta)
+    gomax, amax = go.abs().amax(1), act.abs().amax(1)
+    gh, x, w1, _ = _inputs(N, 256, 128, 78)
+    lse = torch.randn(N, 128, device=DEV, generator=g) * 4.0
+    ghmax, xmax = gh.abs().amax(1), x.abs().amax(1)
+    side = torch.cuda.Stream()
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    ref = None
+    for it in range(40):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                junk.fill_(it & 255)
+        a = D.linear_backward(go, w2, xhat, gomax, amax, D.LB_LN, rstd=rstd, gamma=gamma, beta=beta)
+        b = D.linear_backward(gh, w1, x, ghmax, xmax, D.LB_SHIFT, lse=lse)
+        if ref is None:
+            ref = (a, b)
+            continue
+        for k in ("dx", "gw", "gb", "ggamma", "gbeta", "parts"):
+            assert torch.equal(a[k], ref[0][k]), (it, "LN", k)
+        for k in ("dx", "gw", "gb", "gt", "parts"):
+            assert torch.equal(b[k], ref[1][k]), (it, "SHIFT", k)
+    torch.cuda.synchronize()

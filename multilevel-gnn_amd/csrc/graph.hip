@@ -28,14 +28,29 @@ __device__ __forceinline__ int checked_id(int64_t v, int N, int* bad) {
   return (int)v;
 }
 
-// The histogram and placement passes keep their atomics in LDS.  A workgroup takes a chunk of kCsrChunk
+// The histogram and placement passes keep their atomics in LDS.  A workgroup takes a chunk of `per` * 1024
 // consecutive edges; in a block-diagonal batch their endpoints fall into one graph, i.e. into a window of a few
 // thousand consecutive rows, so the workgroup counts into an LDS window of kCsrWindow rows starting at the
 // chunk's smallest id and touches global memory with one COALESCED atomic per window row (a scattered global
 // atomic per edge runs at ~2.5e10/s on this chip: 0.75 ms for the two histograms of 10 M edges).  Ids outside
 // the window (unsorted edge lists) fall back to per-edge global atomics: slower, same result.
-constexpr int kCsrThreads = 1024, kCsrPerThread = 32, kCsrChunk = kCsrThreads * kCsrPerThread;
+//
+// Launch shape (round 3): ONE 64 KB window per workgroup and <= 64 VGPRs, so two 1024-thread workgroups share a CU;
+// the chunk length is chosen on the host so that the whole edge list is one resident round of about 2 x 256
+// workgroups (the earlier fixed 32768-edge chunks gave 312 workgroups at one per CU: a full round and a 22 % one).
+// Chunks are dealt to the XCDs in contiguous runs (workgroups b, b + 8, ... share an XCD and its L2): the scattered
+// 4-byte writes of the placement then fall, per XCD, into the 640 KB window of the graph that XCD is working on, and
+// a cache line is completed by ONE L2 before it is written back (with interleaved chunks every line of `out` was
+// assembled from partial writes of up to eight L2s: 5 x the bytes of the array reached HBM).
+constexpr int kCsrThreads = 1024, kCsrMaxPer = 20;
 constexpr int kCsrWindow = 16384;
+constexpr int kCsrTargetBlocks = 512;                  // two per CU
+
+// chunk a workgroup works on: XCD x owns chunks [x * nb / 8, (x + 1) * nb / 8) in order
+__device__ __forceinline__ int csr_chunk_of_block() {
+  const int nb = gridDim.x, q = nb / kXcds, r = nb % kXcds, xcd = blockIdx.x % kXcds;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blockIdx.x / kXcds;
+}
 
 __device__ __forceinline__ int block_min(int v, int* slot) {
   if (threadIdx.x == 0) *slot = INT32_MAX;
@@ -47,78 +62,96 @@ __device__ __forceinline__ int block_min(int v, int* slot) {
   return *slot;
 }
 
-// pass 1: clamp + narrow the endpoints, degree histograms of both
-__global__ __launch_bounds__(kCsrThreads) void csr_count_kernel(const int64_t* __restrict__ src64,
-                                                                const int64_t* __restrict__ dst64,
-                                                                int* __restrict__ src32, int* __restrict__ dst32,
-                                                                int* __restrict__ cnt_dst, int* __restrict__ cnt_src,
-                                                                int64_t n, int N, int* bad) {
-  __shared__ int hd[kCsrWindow], hs[kCsrWindow];
-  __shared__ int slot_d, slot_s;
-  const int64_t e0 = (int64_t)blockIdx.x * kCsrChunk;
-  int kd[kCsrPerThread], ks[kCsrPerThread];
-  int md = INT32_MAX, ms = INT32_MAX;
+// degree histogram of one endpoint list of the chunk: clamp + narrow to int32, count in the LDS window, flush
+__device__ __forceinline__ void csr_count_side(const int64_t* __restrict__ in64, int* __restrict__ out32,
+                                               int* __restrict__ cnt, int64_t e0, int64_t n, int per, int N, int* bad,
+                                               int* h, int* slot) {
+  int k[kCsrMaxPer];
+  int mk = INT32_MAX;
+  // (64-bit loads in groups of 5: twenty of them in flight would take 40 of the 64 registers)
+  const int64_t first = e0 + threadIdx.x;
+  const int64_t left = n - first;
+  const int lim = (int)(left < (int64_t)per * kCsrThreads ? (left < 0 ? 0 : left) : (int64_t)per * kCsrThreads);
+  const int64_t* __restrict__ in = in64 + first;
+  int* __restrict__ out = out32 + first;
 #pragma unroll
-  for (int q = 0; q < kCsrPerThread; ++q) {
-    const int64_t i = e0 + threadIdx.x + (int64_t)q * kCsrThreads;
-    kd[q] = -1; ks[q] = -1;
-    if (i < n) {
-      ks[q] = checked_id(src64[i], N, bad); kd[q] = checked_id(dst64[i], N, bad);
-      src32[i] = ks[q]; dst32[i] = kd[q];
-      md = min(md, kd[q]); ms = min(ms, ks[q]);
+  for (int g = 0; g < kCsrMaxPer; g += 5) {
+    int64_t raw[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) raw[q] = ((g + q) * kCsrThreads < lim) ? in[(g + q) * kCsrThreads] : -1;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      k[g + q] = -1;
+      if ((g + q) * kCsrThreads < lim) {
+        k[g + q] = checked_id(raw[q], N, bad);
+        out[(g + q) * kCsrThreads] = k[g + q];
+        mk = min(mk, k[g + q]);
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  for (int i = threadIdx.x; i < kCsrWindow; i += kCsrThreads) { hd[i] = 0; hs[i] = 0; }
-  const int base_d = block_min(md, &slot_d), base_s = block_min(ms, &slot_s);     // (barriers inside)
+  for (int i = threadIdx.x; i < kCsrWindow / 4; i += kCsrThreads) reinterpret_cast<int4*>(h)[i] = make_int4(0, 0, 0, 0);
+  const int base = block_min(mk, slot);                                           // (barriers inside)
 #pragma unroll
-  for (int q = 0; q < kCsrPerThread; ++q) {
-    if (kd[q] < 0) continue;
-    const int od = kd[q] - base_d, os = ks[q] - base_s;
-    if (od < kCsrWindow) atomicAdd(hd + od, 1); else atomicAdd(cnt_dst + kd[q], 1);
-    if (os < kCsrWindow) atomicAdd(hs + os, 1); else atomicAdd(cnt_src + ks[q], 1);
+  for (int q = 0; q < kCsrMaxPer; ++q) {
+    if (q >= per || k[q] < 0) continue;
+    const int o = k[q] - base;
+    if (o < kCsrWindow) atomicAdd(h + o, 1); else atomicAdd(cnt + k[q], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kCsrWindow; i += kCsrThreads) {
-    if (hd[i]) atomicAdd(cnt_dst + base_d + i, hd[i]);
-    if (hs[i]) atomicAdd(cnt_src + base_s + i, hs[i]);
-  }
+  for (int i = threadIdx.x; i < kCsrWindow; i += kCsrThreads)
+    if (h[i]) atomicAdd(cnt + base + i, h[i]);
+  __syncthreads();
+}
+
+// pass 1: clamp + narrow the endpoints, degree histograms of both (one after the other through the same window)
+__global__ __launch_bounds__(kCsrThreads, 8) void csr_count_kernel(const int64_t* __restrict__ src64,
+                                                                   const int64_t* __restrict__ dst64,
+                                                                   int* __restrict__ src32, int* __restrict__ dst32,
+                                                                   int* __restrict__ cnt_dst, int* __restrict__ cnt_src,
+                                                                   int64_t n, int per, int N, int* bad) {
+  __shared__ __attribute__((aligned(16))) int h[kCsrWindow];
+  __shared__ int slot;
+  const int64_t e0 = (int64_t)csr_chunk_of_block() * per * kCsrThreads;
+  csr_count_side(dst64, dst32, cnt_dst, e0, n, per, N, bad, h, &slot);
+  csr_count_side(src64, src32, cnt_src, e0, n, per, N, bad, h, &slot);
 }
 
 // pass 2: element i (value = i) goes to the next free slot of row key[i].  The workgroup reserves, per window
-// row, a contiguous range of the row with ONE global atomic and hands its slots out with LDS atomics.
-__global__ __launch_bounds__(kCsrThreads) void csr_place_kernel(const int* __restrict__ key,
-                                                                const int* __restrict__ rowptr,
-                                                                int* __restrict__ cursor, int* __restrict__ out,
-                                                                int64_t n) {
-  __shared__ int h[kCsrWindow], hb[kCsrWindow];
+// row, a contiguous range of the row with ONE global atomic and hands its slots out with LDS atomics: h[] holds the
+// chunk's count of the row, then the next free slot of the reserved range.
+__global__ __launch_bounds__(kCsrThreads, 8) void csr_place_kernel(const int* __restrict__ key,
+                                                                   const int* __restrict__ rowptr,
+                                                                   int* __restrict__ cursor, int* __restrict__ out,
+                                                                   int64_t n, int per) {
+  __shared__ __attribute__((aligned(16))) int h[kCsrWindow];
   __shared__ int slot;
-  const int64_t e0 = (int64_t)blockIdx.x * kCsrChunk;
-  int k[kCsrPerThread];
+  const int64_t e0 = (int64_t)csr_chunk_of_block() * per * kCsrThreads;
+  int k[kCsrMaxPer];
   int mk = INT32_MAX;
 #pragma unroll
-  for (int q = 0; q < kCsrPerThread; ++q) {
+  for (int q = 0; q < kCsrMaxPer; ++q) {
     const int64_t i = e0 + threadIdx.x + (int64_t)q * kCsrThreads;
-    k[q] = i < n ? key[i] : -1;
+    k[q] = (q < per && i < n) ? key[i] : -1;
     if (k[q] >= 0) mk = min(mk, k[q]);
   }
-  for (int i = threadIdx.x; i < kCsrWindow; i += kCsrThreads) h[i] = 0;
+  for (int i = threadIdx.x; i < kCsrWindow / 4; i += kCsrThreads) reinterpret_cast<int4*>(h)[i] = make_int4(0, 0, 0, 0);
   const int base = block_min(mk, &slot);
 #pragma unroll
-  for (int q = 0; q < kCsrPerThread; ++q)
-    if (k[q] >= 0 && k[q] - base < kCsrWindow) atomicAdd(h + (k[q] - base), 1);
+  for (int q = 0; q < kCsrMaxPer; ++q)
+    if (q < per && k[q] >= 0 && k[q] - base < kCsrWindow) atomicAdd(h + (k[q] - base), 1);
   __syncthreads();
   for (int i = threadIdx.x; i < kCsrWindow; i += kCsrThreads) {
     const int c = h[i];
-    if (c) hb[i] = rowptr[base + i] + atomicAdd(cursor + base + i, c);
-    h[i] = 0;
+    if (c) h[i] = rowptr[base + i] + atomicAdd(cursor + base + i, c);
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < kCsrPerThread; ++q) {
-    if (k[q] < 0) continue;
+  for (int q = 0; q < kCsrMaxPer; ++q) {
+    if (q >= per || k[q] < 0) continue;
     const int64_t i = e0 + threadIdx.x + (int64_t)q * kCsrThreads;
     const int o = k[q] - base;
-    const int where = o < kCsrWindow ? hb[o] + atomicAdd(h + o, 1) : rowptr[k[q]] + atomicAdd(cursor + k[q], 1);
+    const int where = o < kCsrWindow ? atomicAdd(h + o, 1) : rowptr[k[q]] + atomicAdd(cursor + k[q], 1);
     out[where] = (int)i;
   }
 }
@@ -154,35 +187,62 @@ __device__ __forceinline__ void emit(const RowOut& o, int slot, int v, int row) 
 }
 
 // pass 3: sort every row of `data` (unique keys) in place and emit the dependent arrays; rows longer than 64
-// are appended to long_rows
+// are appended to long_rows.  A wavefront takes 2 * kSortPairs consecutive rows: their row pointers are one load, and
+// when all of them hold at most 32 edges (two rows per wavefront, one per 32-lane half) the loads of the pairs, their
+// sorting networks and the gathers of the dependent arrays are issued pair after pair before the first result is
+// needed -- the kernel is a chain of three dependent memory round trips per row (row pointer -> keys -> gathered
+// values) and ran 2.5 x over its traffic bound with one pair per wavefront.
+constexpr int kSortPairs = 4;
+constexpr int kSortRows = 2 * kSortPairs;
+
 template <bool BY_SRC>
 __global__ __launch_bounds__(kBlock) void csr_sort_rows_kernel(const int* __restrict__ rowptr, int* __restrict__ data,
                                                                int N, int* __restrict__ long_rows,
                                                                int* __restrict__ long_count, const RowOut o) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int pair = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-  const int r0 = 2 * pair;
+  const int r0 = (blockIdx.x * kWavesPerBlock + threadIdx.x / kWave) * kSortRows;
   if (r0 >= N) return;
-  const int b0 = rowptr[r0], e0 = rowptr[r0 + 1];
-  const int e1 = (r0 + 1 < N) ? rowptr[r0 + 2] : e0;
-  const int d0 = e0 - b0, d1 = e1 - e0;
-  if (max(d0, d1) <= 32) {                       // two rows per wavefront, one per 32-lane half
+  const int rp = rowptr[min(r0 + min(lane, kSortRows), N)];          // rows past N: empty
+  const int deg_l = __shfl_down(rp, 1) - rp;
+  const bool small = __builtin_amdgcn_ballot_w64(lane < kSortRows && deg_l > 32) == 0;
+  if (small) {
     const int half = lane >> 5, l = lane & 31;
-    const int beg = half ? e0 : b0, deg = half ? d1 : d0;
-    int v = l < deg ? data[beg + l] : INT32_MAX;
-    v = wave_sort<32>(v, lane);                  // partners stay inside the half (xor with < 32)
-    if (l < deg) { data[beg + l] = v; emit<BY_SRC>(o, beg + l, v, r0 + half); }
+    int v[kSortPairs], beg[kSortPairs], dg[kSortPairs];
+#pragma unroll
+    for (int p = 0; p < kSortPairs; ++p) {
+      beg[p] = __shfl(rp, 2 * p + half);
+      dg[p] = __shfl(rp, 2 * p + half + 1) - beg[p];
+      v[p] = l < dg[p] ? data[beg[p] + l] : INT32_MAX;
+    }
+#pragma unroll
+    for (int p = 0; p < kSortPairs; ++p) v[p] = wave_sort<32>(v[p], lane);     // partners stay inside the half
+    int g0[kSortPairs], g1[kSortPairs];
+#pragma unroll
+    for (int p = 0; p < kSortPairs; ++p) {
+      g0[p] = 0; g1[p] = 0;
+      if (l < dg[p]) {
+        if constexpr (!BY_SRC) g0[p] = o.src32[v[p]];
+        else { g0[p] = o.rowkey[v[p]]; g1[p] = o.eid[v[p]]; }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kSortPairs; ++p) {
+      if (l >= dg[p]) continue;
+      const int slot = beg[p] + l;
+      data[slot] = v[p];
+      if constexpr (!BY_SRC) { o.col[slot] = g0[p]; o.rowkey[slot] = r0 + 2 * p + half; }
+      else { o.col_t[slot] = g0[p]; o.eid_t[slot] = g1[p]; }
+    }
     return;
   }
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    const int beg = which ? e0 : b0, deg = which ? d1 : d0;
+  for (int w = 0; w < kSortRows && r0 + w < N; ++w) {
+    const int beg = __shfl(rp, w), deg = __shfl(rp, w + 1) - beg;
     if (deg <= kWave) {
       int v = lane < deg ? data[beg + lane] : INT32_MAX;
       v = wave_sort<kWave>(v, lane);
-      if (lane < deg) { data[beg + lane] = v; emit<BY_SRC>(o, beg + lane, v, r0 + which); }
+      if (lane < deg) { data[beg + lane] = v; emit<BY_SRC>(o, beg + lane, v, r0 + w); }
     } else if (lane == 0) {
-      long_rows[atomicAdd(long_count, 1)] = r0 + which;
+      long_rows[atomicAdd(long_count, 1)] = r0 + w;
     }
   }
 }
@@ -247,6 +307,24 @@ __global__ void edge_table_kernel(const float* __restrict__ attr, int64_t stride
   }
 }
 
+// one scalar per edge (the rank-1 edge term of BASELINE configs[1]): four edges per thread, 16-byte index loads and
+// table stores, the eight gathers of a thread in flight together.  n4 = n / 4 groups; the tail runs on the kernel above.
+__global__ __launch_bounds__(256) void edge_table_w1_kernel(const float* __restrict__ attr, int64_t stride,
+                                                            const int4* __restrict__ eid, const int4* __restrict__ eid_t,
+                                                            float4* __restrict__ by_dst, float4* __restrict__ by_src,
+                                                            int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int4 e = eid[i], t = eid_t[i];
+  float4 a, b;
+  a.x = attr[(int64_t)e.x * stride]; a.y = attr[(int64_t)e.y * stride];
+  a.z = attr[(int64_t)e.z * stride]; a.w = attr[(int64_t)e.w * stride];
+  b.x = attr[(int64_t)t.x * stride]; b.y = attr[(int64_t)t.y * stride];
+  b.z = attr[(int64_t)t.z * stride]; b.w = attr[(int64_t)t.w * stride];
+  by_dst[i] = a;
+  by_src[i] = b;
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static size_t scan_temp_bytes(int64_t n) {
@@ -257,7 +335,8 @@ static size_t scan_temp_bytes(int64_t n) {
 
 // workspace layout (256-byte aligned pieces)
 struct CsrWs {
-  int *src32, *dst32, *rowkey, *cnt_dst, *cnt_src, *long_rows, *long_count;
+  int *src32, *dst32, *rowkey, *cnt_dst, *cnt_src, *cur_dst, *cur_src, *long_rows, *long_rows_t, *long_count;
+  size_t zero_bytes;                       // cnt_dst .. long_count: cleared by ONE fill at the start of a build
   void* scan_temp; size_t scan_bytes; size_t total;
 };
 static CsrWs csr_ws(void* workspace, int64_t N, int64_t E) {
@@ -267,14 +346,25 @@ static CsrWs csr_ws(void* workspace, int64_t N, int64_t E) {
   w.src32 = (int*)p; p += e4;
   w.dst32 = (int*)p; p += e4;
   w.rowkey = (int*)p; p += e4;                  // destination row of every by-destination slot
-  w.cnt_dst = (int*)p; p += n4;                 // histogram, then reused as the placement cursor
+  w.long_rows = (int*)p; p += n4;               // (written before they are read: not cleared)
+  w.long_rows_t = (int*)p; p += n4;
+  w.cnt_dst = (int*)p; p += n4;                 // degree histograms
   w.cnt_src = (int*)p; p += n4;
-  w.long_rows = (int*)p; p += n4;
-  w.long_count = (int*)p; p += 256;
+  w.cur_dst = (int*)p; p += n4;                 // placement cursors
+  w.cur_src = (int*)p; p += n4;
+  w.long_count = (int*)p; p += 256;             // [0]: by destination, [1]: by source
+  w.zero_bytes = (size_t)(p - (char*)w.cnt_dst);
   w.scan_bytes = scan_temp_bytes(N + 1);
   w.scan_temp = p; p += align256(w.scan_bytes);
   w.total = (size_t)(p - (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255)) + 256;
   return w;
+}
+
+// edges per thread of the count / placement workgroups: the whole list in about kCsrTargetBlocks chunks
+static int csr_per_thread(int64_t E) {
+  const int64_t target = (E + kCsrTargetBlocks - 1) / kCsrTargetBlocks;
+  const int64_t per = (target + kCsrThreads - 1) / kCsrThreads;
+  return (int)(per < 1 ? 1 : per > kCsrMaxPer ? kCsrMaxPer : per);
 }
 
 }  // namespace mlgnn
@@ -293,7 +383,6 @@ extern "C" int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
   if (N < 0 || E < 0 || N > INT32_MAX - 1 || E > INT32_MAX) return MLGNN_E_SHAPE;
   if (!rowptr || !rowptr_t) return MLGNN_E_NULL;
   hipStream_t s = (hipStream_t)stream;
-  const int threads = 256;
   if (bad_ids) (void)hipMemsetAsync(bad_ids, 0, 4, s);
   if (E == 0) {
     (void)hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 4, s);
@@ -304,16 +393,16 @@ extern "C" int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
   if (N == 0) return MLGNN_E_SHAPE;                               // edges without nodes
   const CsrWs w = csr_ws(workspace, N, E);
   if (workspace_bytes < (int64_t)w.total) return MLGNN_E_WORKSPACE;
-  const unsigned gC = (unsigned)((E + kCsrChunk - 1) / kCsrChunk);
-  const unsigned gRows = (unsigned)(((N + 1) / 2 + kWavesPerBlock - 1) / kWavesPerBlock);
-  const size_t n4 = (size_t)(N + 1) * 4;
+  const int per = csr_per_thread(E);
+  const int64_t chunk = (int64_t)per * kCsrThreads;
+  const unsigned gC = (unsigned)((E + chunk - 1) / chunk);
+  const unsigned gRows = (unsigned)(((N + kSortRows - 1) / kSortRows + kWavesPerBlock - 1) / kWavesPerBlock);
   hipError_t err;
-  (void)threads;
 
   // ---- degrees and row pointers ---------------------------------------------------------------------
-  (void)hipMemsetAsync(w.cnt_dst, 0, (size_t)((char*)w.long_count - (char*)w.cnt_dst) + 4, s);   // cnt_dst .. long_count
+  (void)hipMemsetAsync(w.cnt_dst, 0, w.zero_bytes, s);            // histograms, cursors, long-row counters
   hipLaunchKernelGGL(csr_count_kernel, dim3(gC), dim3(kCsrThreads), 0, s, edge_index, edge_index + E, w.src32,
-                     w.dst32, w.cnt_dst, w.cnt_src, E, (int)N, bad_ids);
+                     w.dst32, w.cnt_dst, w.cnt_src, E, per, (int)N, bad_ids);
   size_t sb = w.scan_bytes;
   err = hipcub::DeviceScan::ExclusiveSum(w.scan_temp, sb, w.cnt_dst, rowptr, (int)(N + 1), s);
   if (err != hipSuccess) return (int)err;
@@ -323,21 +412,18 @@ extern "C" int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
   RowOut o;
   o.src32 = w.src32; o.col = col; o.rowkey = w.rowkey; o.eid = eid; o.col_t = col_t; o.eid_t = eid_t;
   // ---- by destination: slot by arrival, rows sorted by COO position ---------------------------------------
-  (void)hipMemsetAsync(w.cnt_dst, 0, n4, s);
-  hipLaunchKernelGGL(csr_place_kernel, dim3(gC), dim3(kCsrThreads), 0, s, w.dst32, rowptr, w.cnt_dst, eid, E);
+  hipLaunchKernelGGL(csr_place_kernel, dim3(gC), dim3(kCsrThreads), 0, s, w.dst32, rowptr, w.cur_dst, eid, E, per);
   hipLaunchKernelGGL(csr_sort_rows_kernel<false>, dim3(gRows), dim3(kBlock), 0, s, rowptr, eid, (int)N, w.long_rows,
                      w.long_count, o);
   hipLaunchKernelGGL(csr_sort_long_rows_kernel<false>, dim3(256), dim3(kBlock), 0, s, rowptr, eid, w.long_rows,
                      w.long_count, o);
 
   // ---- by source: the by-destination slots p = 0..E-1 keyed by their source col[p], rows sorted by p ---------
-  (void)hipMemsetAsync(w.cnt_src, 0, n4, s);
-  (void)hipMemsetAsync(w.long_count, 0, 4, s);
-  hipLaunchKernelGGL(csr_place_kernel, dim3(gC), dim3(kCsrThreads), 0, s, col, rowptr_t, w.cnt_src, pos_t, E);
-  hipLaunchKernelGGL(csr_sort_rows_kernel<true>, dim3(gRows), dim3(kBlock), 0, s, rowptr_t, pos_t, (int)N, w.long_rows,
-                     w.long_count, o);
-  hipLaunchKernelGGL(csr_sort_long_rows_kernel<true>, dim3(256), dim3(kBlock), 0, s, rowptr_t, pos_t, w.long_rows,
-                     w.long_count, o);
+  hipLaunchKernelGGL(csr_place_kernel, dim3(gC), dim3(kCsrThreads), 0, s, col, rowptr_t, w.cur_src, pos_t, E, per);
+  hipLaunchKernelGGL(csr_sort_rows_kernel<true>, dim3(gRows), dim3(kBlock), 0, s, rowptr_t, pos_t, (int)N, w.long_rows_t,
+                     w.long_count + 1, o);
+  hipLaunchKernelGGL(csr_sort_long_rows_kernel<true>, dim3(256), dim3(kBlock), 0, s, rowptr_t, pos_t, w.long_rows_t,
+                     w.long_count + 1, o);
   return (int)hipGetLastError();
 }
 
@@ -348,7 +434,17 @@ extern "C" int mlgnn_edge_table_to_csr(const float* attr, int64_t row_stride, in
   if (E == 0) return 0;
   if (!attr || !eid || !eid_t || !by_dst || !by_src) return MLGNN_E_NULL;
   const int threads = 256;
-  hipLaunchKernelGGL(edge_table_kernel, dim3((unsigned)((E + threads - 1) / threads)), dim3(threads), 0,
-                     (hipStream_t)stream, attr, row_stride, (int)r, (int)width, eid, eid_t, by_dst, by_src, E);
+  hipStream_t s = (hipStream_t)stream;
+  int64_t done = 0;
+  if (width == 1 && (((uintptr_t)eid | (uintptr_t)eid_t | (uintptr_t)by_dst | (uintptr_t)by_src) & 15) == 0 && E >= 4) {
+    const int64_t n4 = E / 4;
+    hipLaunchKernelGGL(edge_table_w1_kernel, dim3((unsigned)((n4 + threads - 1) / threads)), dim3(threads), 0, s, attr,
+                       row_stride, (const int4*)eid, (const int4*)eid_t, (float4*)by_dst, (float4*)by_src, n4);
+    done = n4 * 4;
+  }
+  if (done < E)
+    hipLaunchKernelGGL(edge_table_kernel, dim3((unsigned)((E - done + threads - 1) / threads)), dim3(threads), 0, s, attr,
+                       row_stride, (int)r, (int)width, eid + done, eid_t + done, by_dst + done * width,
+                       by_src + done * width, E - done);
   return (int)hipGetLastError();
 }

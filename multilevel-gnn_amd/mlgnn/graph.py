@@ -133,7 +133,7 @@ class CSRGraph:
         self.col_t, self.pos_t, self.eid_t = torch.empty(E, **i32), torch.empty(E, **i32), torch.empty(E, **i32)
         nbytes = int(_lib.lib.mlgnn_coo_to_csr_workspace_bytes(N, E))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        self._bad_ids = torch.zeros(1, **i32)
+        self._bad_ids = torch.empty(1, **i32)               # cleared by the build itself
         rc = _lib.lib.mlgnn_coo_to_csr(ei.data_ptr(), E, N, self.rowptr.data_ptr(), _lib.ptr(self.col),
                                        _lib.ptr(self.eid), self.rowptr_t.data_ptr(), _lib.ptr(self.col_t),
                                        _lib.ptr(self.pos_t), _lib.ptr(self.eid_t), self._bad_ids.data_ptr(),

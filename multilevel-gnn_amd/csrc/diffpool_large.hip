@@ -28,145 +28,43 @@
 
 namespace mlgnn {
 
-// columns [0, n_a) -> ca, [n_a, n_b) -> cb (bf16, + sum of squares), [n_b, N) -> cc; cc == nullptr: two ranges
-int slab_reduce_launch(const float* slab, int splits, int M, int N, int n_a, void* ca, int64_t lda, int ca_f32,
-                       uint16_t* cb, int64_t ldb, float* sq_partial, int blocks, hipStream_t s, int n_b = 0,
-                       void* cc = nullptr, int64_t ldc = 0, int cc_f32 = 0);
-
 constexpr float kDplEps = 1e-15f;
-constexpr int kDplPartials = 1024;       // workgroups of the streaming reductions (= partial sums each)
+constexpr int kDplPartials = 1024;       // workgroups of the split-K reduce (= partial sums of ||S^T S||^2)
+constexpr int kDplSqBlocks = 256;        // workgroups (= partial sums) of ||A||_F^2
+constexpr int kProRows = 32;             // rows of the logits one softmax workgroup owns
+constexpr int kProCols = 128;            // columns per transposed write-out
+constexpr int kProPitch = kProCols + 2;  // LDS pitch of the staging image (bf16 elements)
 
-// ---- row softmax: logits [N,K] (fp32 or bf16) -> S~ bf16 [N,K]; per-workgroup entropy partial ------------------
 template <typename T>
 __device__ __forceinline__ float dpl_load(const T* p, size_t i) {
   if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(p)[i];
   else return bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
 }
-
-template <typename T>
-__global__ __launch_bounds__(256) void dpl_softmax_kernel(const T* __restrict__ logits, uint16_t* __restrict__ s_out,
-                                                          float* __restrict__ ent_partial, int N, int K) {
-  __shared__ float wsum[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ent = 0.f;
-  for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
-    const T* lr = logits + (size_t)row * K;
-    float mx = -3.0e38f;
-    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, dpl_load(lr, k));
+__device__ __forceinline__ float dpl_load_dt(const void* p, size_t i, int f32) {
+  return f32 ? reinterpret_cast<const float*>(p)[i] : bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+}
+__device__ __forceinline__ uint32_t dpl_pack2(float a, float b) {
+  return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+__device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float sum = 0.f;
-    for (int k = lane; k < K; k += 64) sum += __expf(dpl_load(lr, k) - mx);
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-    const float inv = 1.0f / sum;
-    for (int k = lane; k < K; k += 64) {
-      const float s = __expf(dpl_load(lr, k) - mx) * inv;
-      ent -= s * __logf(s + kDplEps);
-      s_out[(size_t)row * K + k] = f32_to_bf16(s);
-    }
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) ent += __shfl_xor(ent, o);
-  if (lane == 0) wsum[wave] = ent;
-  __syncthreads();
-  if (threadIdx.x == 0) ent_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
 }
 
-// K = 512 * CH: 16-byte loads, the row stays in registers (CH x 8 values per lane), 16-byte stores
-template <int CH>
-__global__ __launch_bounds__(256) void dpl_softmax_vec_kernel(const uint16_t* __restrict__ logits, uint16_t* __restrict__ s_out,
-                                                              float* __restrict__ ent_partial, int N) {
-  __shared__ float wsum[4];
-  constexpr int K = 512 * CH;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ent = 0.f;
-  for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
-    float v[CH][8];
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      load_t<bf16_t, 8>(v[c], reinterpret_cast<const bf16_t*>(logits + (size_t)row * K + c * 512 + lane * 8));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[c][j]);
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[c][j] = __expf(v[c][j] - mx);
-        sum += v[c][j];
-      }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[c][j] *= inv;
-        ent -= v[c][j] * __logf(v[c][j] + kDplEps);
-      }
-      store_t<bf16_t, 8>(reinterpret_cast<bf16_t*>(s_out + (size_t)row * K + c * 512 + lane * 8), v[c]);
-    }
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) ent += __shfl_xor(ent, o);
-  if (lane == 0) wsum[wave] = ent;
-  __syncthreads();
-  if (threadIdx.x == 0) ent_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-}
-
-// dlogits = S (ds - <ds, S>),  ds = dS + c_ent * d/dS(-S log(S + eps)),   S recomputed in fp32 from the logits
-template <typename T>
-__global__ __launch_bounds__(256) void dpl_softmax_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ ds_in,
-                                                              const float* __restrict__ coef, T* __restrict__ dlogits,
-                                                              int N, int K) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float c_ent = coef[1];
-  for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
-    const T* lr = logits + (size_t)row * K;
-    const float* dr = ds_in + (size_t)row * K;
-    float mx = -3.0e38f;
-    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, dpl_load(lr, k));
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float sum = 0.f;
-    for (int k = lane; k < K; k += 64) sum += __expf(dpl_load(lr, k) - mx);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-    const float inv = 1.0f / sum;
-    float dot = 0.f;
-    for (int k = lane; k < K; k += 64) {
-      const float s = __expf(dpl_load(lr, k) - mx) * inv;
-      const float g = dr[k] - c_ent * (__logf(s + kDplEps) + s / (s + kDplEps));
-      dot += g * s;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
-    for (int k = lane; k < K; k += 64) {
-      const float s = __expf(dpl_load(lr, k) - mx) * inv;
-      const float g = dr[k] - c_ent * (__logf(s + kDplEps) + s / (s + kDplEps));
-      const float v = s * (g - dot);
-      if constexpr (sizeof(T) == 4) reinterpret_cast<float*>(dlogits)[(size_t)row * K + k] = v;
-      else reinterpret_cast<uint16_t*>(dlogits)[(size_t)row * K + k] = f32_to_bf16(v);
-    }
-  }
-}
-
-// ---- bf16 transpose through LDS: in [R,C] (leading dimension ld_in) -> out [C,R] (ld_out); R, C % 64 == 0 -------
-__global__ __launch_bounds__(256) void dpl_transpose_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                            int64_t ld_in, int64_t ld_out, int tiles_c) {
-  __shared__ uint16_t tile[64][66];
-  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
-  const int r0 = tr * 64, c0 = tc * 64;
+// 64 x 64 bf16 tile transpose through LDS: in [.., ld_in] -> out [.., ld_out]; 256 threads; tile = [64][66]
+__device__ __forceinline__ void dpl_transpose_tile(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                   int64_t ld_in, int64_t ld_out, int r0, int c0, uint16_t (*tile)[66],
+                                                   int tid) {
   // 64 rows x 128 B: 8 lanes per row, 16 bytes each; 256 threads = 32 rows per pass
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    const int r = pass * 32 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+    const int r = pass * 32 + (tid >> 3), ch = tid & 7;
     const uint4 v = *reinterpret_cast<const uint4*>(in + (size_t)(r0 + r) * ld_in + c0 + ch * 8);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -178,7 +76,7 @@ __global__ __launch_bounds__(256) void dpl_transpose_kernel(const uint16_t* __re
   __syncthreads();
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    const int c = pass * 32 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+    const int c = pass * 32 + (tid >> 3), ch = tid & 7;
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = (uint32_t)tile[ch * 8 + 2 * i][c] | ((uint32_t)tile[ch * 8 + 2 * i + 1][c] << 16);
@@ -186,24 +84,259 @@ __global__ __launch_bounds__(256) void dpl_transpose_kernel(const uint16_t* __re
   }
 }
 
-// ---- sum of squares of a bf16 matrix (contiguous, n % 8 == 0) -> one partial per workgroup ------------------------
-__global__ __launch_bounds__(256) void dpl_sumsq_kernel(const uint4* __restrict__ x, int64_t n8, float* __restrict__ partial) {
-  __shared__ float wsum[4];
+// sum of squares of a bf16 matrix (contiguous, n8 groups of 8) over workgroup `b` of `nb`
+__device__ __forceinline__ float dpl_sumsq_part(const uint4* __restrict__ x, int64_t n8, int b, int nb) {
   float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)b * blockDim.x + threadIdx.x; i < n8; i += (int64_t)nb * blockDim.x) {
     const uint4 v = x[i];
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float a = __builtin_bit_cast(float, w[j] << 16), b = __builtin_bit_cast(float, w[j] & 0xffff0000u);
-      acc += a * a + b * b;
+      const float a = __builtin_bit_cast(float, w[j] << 16), c = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+      acc += a * a + c * c;
     }
   }
+  return acc;
+}
+
+// ---- forward prologue: ONE launch, workgroups by role ------------------------------------------------------------
+//   [0, nb_sm)           32 rows of the logits each: S~ = bf16(softmax) written as S [N,K] AND as S^T [K,N] (128-column
+//                        slabs staged in LDS, 64-byte runs of S^T per column), entropy partial from the fp32 softmax
+//   [nb_sm, +nb_zt)      64 x 64 tiles of Z -> Z^T
+//   [.., +nb_sq)         ||A||_F^2 partials
+// (round 2 ran these as four launches: softmax, two transposes, sum of squares.)
+struct DplProArgs {
+  const void* logits; uint16_t* S; uint16_t* St; float* ent_partial;
+  const uint16_t* z; uint16_t* Zt;
+  const uint4* adj; int64_t adj_n8; float* a2_partial;
+  int N, K, C, nb_sm, nb_zt, nb_sq;
+};
+
+constexpr int kProThreads = 1024;        // 16 wavefronts: two rows of the softmax each
+constexpr int kProWaves = kProThreads / 64;
+constexpr int kProRowsPerWave = kProRows / kProWaves;
+
+constexpr int kProWide = 512, kProWidePitch = kProWide + 8;      // CH > 0: 512-column slabs, rows held in registers
+
+// CH = K / 512 in {1, 2, 4}: the two rows of a wavefront stay in registers (one read of the logits, 16-byte accesses,
+// K / 512 slabs of 512 columns); CH = 0: any K (multiple of 128), rows re-read from the cache, 128-column slabs.
+template <typename T, int CH>
+__global__ __launch_bounds__(kProThreads) void dpl_prologue_kernel(const DplProArgs p) {
+  constexpr int kLdsElems = 4 * 64 * 66 + 64;
+  static_assert(kLdsElems >= kProRows * kProWidePitch && kLdsElems >= kProRows * kProPitch, "staging image");
+  __shared__ __attribute__((aligned(16))) uint16_t lds_all[kLdsElems];
+  uint16_t (*lds)[64 * 66] = reinterpret_cast<uint16_t(*)[64 * 66]>(lds_all);    // four transpose tiles
+  __shared__ float wsum[kProWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  if (b >= p.nb_sm + p.nb_zt) {
+    float acc = wave_sum(dpl_sumsq_part(p.adj, p.adj_n8, b - p.nb_sm - p.nb_zt, p.nb_sq));
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+      for (int i = 0; i < kProWaves; ++i) tot += wsum[i];
+      p.a2_partial[b - p.nb_sm - p.nb_zt] = tot;
+    }
+    return;
+  }
+  if (b >= p.nb_sm) {
+    // four 64 x 64 tiles of Z per workgroup, one per group of 256 threads (a group past the last tile repeats it)
+    const int tiles_c = p.C / 64, tiles = (p.N / 64) * tiles_c;
+    const int t = min((b - p.nb_sm) * 4 + (int)(threadIdx.x >> 8), tiles - 1);
+    dpl_transpose_tile(p.z, p.Zt, p.C, p.N, (t / tiles_c) * 64, (t % tiles_c) * 64,
+                       reinterpret_cast<uint16_t(*)[66]>(lds[threadIdx.x >> 8]), threadIdx.x & 255);
+    return;
+  }
+  const T* logits = static_cast<const T*>(p.logits);
+  const int K = p.K;
+  const int row0 = b * kProRows + wave * kProRowsPerWave;
+  if constexpr (CH > 0) {
+    float v[kProRowsPerWave][CH][8];
+    float ent = 0.f;
+#pragma unroll
+    for (int j = 0; j < kProRowsPerWave; ++j) {
+      const T* lr = logits + (size_t)(row0 + j) * K;
+      float m = -3.0e38f;
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        load_t<T, 8>(v[j][q], lr + q * kProWide + lane * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = fmaxf(m, v[j][q][i]);
+      }
+      m = wave_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < CH; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[j][q][i] = __expf(v[j][q][i] - m);
+          sum += v[j][q][i];
+        }
+      const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+      for (int q = 0; q < CH; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[j][q][i] *= inv;
+          ent -= v[j][q][i] * __logf(v[j][q][i] + kDplEps);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+#pragma unroll
+      for (int j = 0; j < kProRowsPerWave; ++j) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = dpl_pack2(v[j][q][2 * i], v[j][q][2 * i + 1]);
+        const uint4 pk = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(p.S + (size_t)(row0 + j) * K + q * kProWide + lane * 8) = pk;
+        *reinterpret_cast<uint4*>(lds_all + (wave * kProRowsPerWave + j) * kProWidePitch + lane * 8) = pk;
+      }
+      __syncthreads();
+      {
+        // 512 columns x 32 rows: thread -> (column, 16 rows) = one 32-byte run of S^T
+        const int col = threadIdx.x >> 1, half = threadIdx.x & 1;
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = half * 16 + 2 * i;
+          w[i] = (uint32_t)lds_all[r * kProWidePitch + col] | ((uint32_t)lds_all[(r + 1) * kProWidePitch + col] << 16);
+        }
+        uint16_t* dst = p.St + (size_t)(q * kProWide + col) * p.N + b * kProRows + half * 16;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+      }
+      if (q + 1 < CH) __syncthreads();
+    }
+    ent = wave_sum(ent);
+    if (lane == 0) wsum[wave] = ent;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int i = 0; i < kProWaves; ++i) tot += wsum[i];
+      p.ent_partial[b] = tot;
+    }
+    return;
+  }
+  float mx[kProRowsPerWave], inv[kProRowsPerWave];
+#pragma unroll
+  for (int j = 0; j < kProRowsPerWave; ++j) {
+    const T* lr = logits + (size_t)(row0 + j) * K;
+    float m = -3.0e38f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float v[8];
+      load_t<T, 8>(v, lr + k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float v[8];
+      load_t<T, 8>(v, lr + k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += __expf(v[i] - m);
+    }
+    sum = wave_sum(sum);
+    mx[j] = m;
+    inv[j] = 1.0f / sum;
+  }
+  float ent = 0.f;
+  uint16_t* img = lds[0];
+  for (int c0 = 0; c0 < K; c0 += kProCols) {
+#pragma unroll
+    for (int j = 0; j < kProRowsPerWave; ++j) {
+      const size_t at = (size_t)(row0 + j) * K + c0 + lane * 2;
+      const float s0 = __expf(dpl_load(logits, at) - mx[j]) * inv[j];
+      const float s1 = __expf(dpl_load(logits, at + 1) - mx[j]) * inv[j];
+      ent -= s0 * __logf(s0 + kDplEps) + s1 * __logf(s1 + kDplEps);
+      const uint32_t w = dpl_pack2(s0, s1);
+      *reinterpret_cast<uint32_t*>(p.S + at) = w;
+      *reinterpret_cast<uint32_t*>(img + (wave * kProRowsPerWave + j) * kProPitch + lane * 2) = w;
+    }
+    __syncthreads();
+    {
+      // 128 columns x 32 rows: thread -> (column, 4 rows) = one 8-byte run of S^T
+      const int col = threadIdx.x >> 3, part = threadIdx.x & 7;
+      uint32_t w[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = part * 4 + 2 * i;
+        w[i] = (uint32_t)img[r * kProPitch + col] | ((uint32_t)img[(r + 1) * kProPitch + col] << 16);
+      }
+      *reinterpret_cast<uint2*>(p.St + (size_t)(c0 + col) * p.N + b * kProRows + part * 4) = make_uint2(w[0], w[1]);
+    }
+    __syncthreads();
+  }
+  ent = wave_sum(ent);
+  if (lane == 0) wsum[wave] = ent;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < kProWaves; ++i) tot += wsum[i];
+    p.ent_partial[b] = tot;
+  }
+}
+
+// dlogits = S (ds - <ds, S>),  ds = dS + c_ent * d/dS(-S log(S + eps)),   S recomputed in fp32 from the logits.
+// One wavefront per row, 8 consecutive elements per lane and pass (16-byte loads of the bf16 logits, 2 x 16 of dS);
+// the four passes over a row re-read it from the cache.
+template <typename T>
+__global__ __launch_bounds__(256) void dpl_softmax_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ ds_in,
+                                                              const float* __restrict__ coef, T* __restrict__ dlogits,
+                                                              int N, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float c_ent = coef[1];
+  for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
+    const T* lr = logits + (size_t)row * K;
+    const float* dr = ds_in + (size_t)row * K;
+    float mx = -3.0e38f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float v[8];
+      load_t<T, 8>(v, lr + k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float v[8];
+      load_t<T, 8>(v, lr + k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += __expf(v[i] - mx);
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float dot = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float v[8], d[8];
+      load_t<T, 8>(v, lr + k);
+      load_vec<8>(d, dr + k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float s = __expf(v[i] - mx) * inv;
+        const float g = d[i] - c_ent * (__logf(s + kDplEps) + s / (s + kDplEps));
+        dot += g * s;
+      }
+    }
+    dot = wave_sum(dot);
+    for (int k = lane * 8; k < K; k += 512) {
+      float v[8], d[8], o[8];
+      load_t<T, 8>(v, lr + k);
+      load_vec<8>(d, dr + k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float s = __expf(v[i] - mx) * inv;
+        const float g = d[i] - c_ent * (__logf(s + kDplEps) + s / (s + kDplEps));
+        o[i] = s * (g - dot);
+      }
+      store_t<T, 8>(dlogits + (size_t)row * K + k, o);
+    }
+  }
 }
 
 // ---- forward scalars: stats = {link, ent, ||A - S S^T||_F} from the partial sums, fixed order ---------------------
@@ -218,16 +351,14 @@ struct DplFinalArgs {
 __device__ float dpl_block_sum(const float* p, int n, float* sh) {
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) acc += p[i];
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  acc = wave_sum(acc);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__global__ __launch_bounds__(256) void dpl_final_kernel(const DplFinalArgs p) {
-  __shared__ float sh[4];
+__device__ void dpl_final(const DplFinalArgs& p, float* sh) {
   const float a2 = dpl_block_sum(p.a2, p.n_a2, sh);
   const float dot = dpl_block_sum(p.dot, p.n_dot, sh);
   const float g2 = dpl_block_sum(p.g2, p.n_g2, sh);
@@ -248,40 +379,146 @@ __global__ __launch_bounds__(256) void dpl_final_kernel(const DplFinalArgs p) {
   }
 }
 
-// ---- backward operand preparation ----------------------------------------------------------------------------------
-// ga [K,K] (fp32 or bf16), G [K,K] bf16, coef[0] = c  ->  b1 = ga - cI,  b2 = ga^T - cI,  b3 = 2c G   (bf16 [K,K])
-// coef = { grad_link / (numel(adj) * ||adj - S S^T||_F),  grad_ent / N }  from the scalar cotangents (device)
-template <typename T>
-__global__ void dpl_coef_kernel(const T* g_link, const T* g_ent, const float* stats, float* coef, float inv_numel, float inv_rows) {
-  coef[0] = dpl_load(g_link, 0) * inv_numel / stats[2];
-  coef[1] = dpl_load(g_ent, 0) * inv_rows;
+__global__ __launch_bounds__(256) void dpl_final_kernel(const DplFinalArgs p) {
+  __shared__ float sh[4];
+  dpl_final(p, sh);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void dpl_prep_ga_kernel(const T* __restrict__ ga, const uint16_t* __restrict__ G,
-                                                          const float* __restrict__ coef, uint16_t* __restrict__ b1,
-                                                          uint16_t* __restrict__ b2, uint16_t* __restrict__ b3, int K) {
-  const float c = coef[0];
-  const int64_t n = (int64_t)K * K;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int r = (int)(i / K), q = (int)(i % K);
-    const float d = r == q ? c : 0.f;
-    b1[i] = f32_to_bf16(dpl_load(ga, i) - d);
-    b2[i] = f32_to_bf16(dpl_load(ga, (size_t)q * K + r) - d);
-    b3[i] = f32_to_bf16(2.f * c * bf16_to_f32(G[i]));
+// ---- split-K reduce of [A' | G | X'] -------------------------------------------------------------------------------
+// out[i] = sum_z slab[z][i]  in a fixed order; columns [0, n_a) of every row go to `ca` (bf16 or fp32, leading
+// dimension lda), columns [n_a, n_b) to `cb` (bf16, leading dimension ldb) with their squares summed per workgroup
+// into sq_partial (||.||_F^2 of that column range), columns [n_b, N) to `cc`.
+// (Measured and not kept: the forward scalars computed by the workgroup that finishes last, found through a completion
+// counter.  The device-scope release in front of the counter writes back the XCD's whole L2 on this part -- 1024
+// workgroups doing that took the reduce from 6 to 34 us; the separate one-workgroup launch costs 5.)
+struct SlabReduceArgs {
+  const float* slab; int splits; int M, N, n_a, n_b;
+  void* ca; int64_t lda; int ca_f32;
+  uint16_t* cb; int64_t ldb; float* sq_partial;
+  void* cc; int64_t ldc; int cc_f32;
+};
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs p) {
+  __shared__ float wsum[4];
+  const int per_row = p.N / 4;
+  const int64_t total = (int64_t)p.M * per_row;
+  float sq = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / per_row), col = (int)(i % per_row) * 4;
+    float4 s = reinterpret_cast<const float4*>(p.slab)[i];
+    for (int z = 1; z < p.splits; ++z) {
+      const float4 v = reinterpret_cast<const float4*>(p.slab + (size_t)z * p.M * p.N)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (col < p.n_a || col >= p.n_b) {
+      const bool first = col < p.n_a;
+      void* dst = first ? p.ca : p.cc;
+      const size_t at = first ? (size_t)row * p.lda + col : (size_t)row * p.ldc + (col - p.n_b);
+      if (first ? p.ca_f32 : p.cc_f32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + at) = s;
+      } else {
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + at) = make_uint2(dpl_pack2(s.x, s.y), dpl_pack2(s.z, s.w));
+      }
+    } else {
+      sq += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+      *reinterpret_cast<uint2*>(p.cb + (size_t)row * p.ldb + (col - p.n_a)) = make_uint2(dpl_pack2(s.x, s.y), dpl_pack2(s.z, s.w));
+    }
   }
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) p.sq_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-// gx [K,C] (fp32 or bf16) -> bf16 copy
-template <typename T>
-__global__ __launch_bounds__(256) void dpl_to_bf16_kernel(const T* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = f32_to_bf16(dpl_load(x, i));
-}
+// ---- backward operand preparation: ONE launch, workgroups by role --------------------------------------------------
+// coef = { c = grad_link / (numel(adj) * ||adj - S S^T||_F),  grad_ent / N }  from the scalar cotangents (device)
+//   [0, nb_ga)        64 x 64 tiles of  b1 = ga - cI,  b2 = ga^T - cI (the transposed tile through LDS),  b3 = 2c G
+//   [nb_ga, +nb_gx)   64 x 64 tiles of gx [K,C] -> bf16 copy and its transpose [C,K]
+//   [.., +nb_at)      64 x 64 tiles of A -> A^T (only when adj is not promised symmetric)
+// (round 2: coef, prep_ga, to_bf16 and one or two transposes as separate launches.)
+struct DplPrepArgs {
+  const void* g_link; const void* g_ent; int scal_f32; const float* stats; float* coef; float inv_numel, inv_rows;
+  const void* ga; const void* gx; int g_f32; const uint16_t* G;
+  uint16_t *b1, *b2, *b3, *gxb, *gxt;
+  const uint16_t* adj; uint16_t* At;
+  int N, K, C, nb_ga, nb_gx, nb_at;
+};
 
-int dpl_transpose(const uint16_t* in, uint16_t* out, int R, int C, int64_t ld_in, int64_t ld_out, hipStream_t s) {
-  if (R % 64 || C % 64) return MLGNN_E_SHAPE;
-  hipLaunchKernelGGL(dpl_transpose_kernel, dim3((R / 64) * (C / 64)), dim3(256), 0, s, in, out, ld_in, ld_out, C / 64);
-  return (int)hipGetLastError();
+__global__ __launch_bounds__(256) void dpl_prep_kernel(const DplPrepArgs p) {
+  __shared__ __attribute__((aligned(16))) float ldsf[64 * 65];
+  const int b = blockIdx.x;
+  const float c = dpl_load_dt(p.g_link, 0, p.scal_f32) * p.inv_numel / p.stats[2];
+  if (b == 0 && threadIdx.x == 0) {
+    p.coef[0] = c;
+    p.coef[1] = dpl_load_dt(p.g_ent, 0, p.scal_f32) * p.inv_rows;
+  }
+  // tile roles: thread -> (row r = pass * 32 + tid / 8, 8 consecutive columns ch * 8 ..) as in dpl_transpose_tile
+  const int trow = threadIdx.x >> 3, ch = threadIdx.x & 7;
+  if (b < p.nb_ga) {
+    const int tiles = p.K / 64, tr = b / tiles, tc = b % tiles;
+    // the source tile of ga^T: rows of block tc, columns of block tr
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = pass * 32 + trow;
+      float v[8];
+      const size_t at = (size_t)(tc * 64 + r) * p.K + tr * 64 + ch * 8;
+      if (p.g_f32) load_vec<8>(v, reinterpret_cast<const float*>(p.ga) + at);
+      else load_t<bf16_t, 8>(v, reinterpret_cast<const bf16_t*>(p.ga) + at);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ldsf[r * 65 + ch * 8 + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = pass * 32 + trow;
+      const int row = tr * 64 + r, col = tc * 64 + ch * 8;
+      const size_t at = (size_t)row * p.K + col;
+      float v[8], g[8], o1[8], o2[8], o3[8];
+      if (p.g_f32) load_vec<8>(v, reinterpret_cast<const float*>(p.ga) + at);
+      else load_t<bf16_t, 8>(v, reinterpret_cast<const bf16_t*>(p.ga) + at);
+      load_t<bf16_t, 8>(g, reinterpret_cast<const bf16_t*>(p.G) + at);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = row == col + i ? c : 0.f;
+        o1[i] = v[i] - d;
+        o2[i] = ldsf[(ch * 8 + i) * 65 + r] - d;
+        o3[i] = 2.f * c * g[i];
+      }
+      store_t<bf16_t, 8>(reinterpret_cast<bf16_t*>(p.b1) + at, o1);
+      store_t<bf16_t, 8>(reinterpret_cast<bf16_t*>(p.b2) + at, o2);
+      store_t<bf16_t, 8>(reinterpret_cast<bf16_t*>(p.b3) + at, o3);
+    }
+    return;
+  }
+  if (b < p.nb_ga + p.nb_gx) {
+    const int t = b - p.nb_ga, tiles_c = p.C / 64, r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    uint16_t* tile = reinterpret_cast<uint16_t*>(ldsf);                // [64][66]
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = pass * 32 + trow;
+      const size_t at = (size_t)(r0 + r) * p.C + c0 + ch * 8;
+      float v[8];
+      if (p.g_f32) load_vec<8>(v, reinterpret_cast<const float*>(p.gx) + at);
+      else load_t<bf16_t, 8>(v, reinterpret_cast<const bf16_t*>(p.gx) + at);
+      store_t<bf16_t, 8>(reinterpret_cast<bf16_t*>(p.gxb) + at, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tile[r * 66 + ch * 8 + i] = f32_to_bf16(v[i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int cc = pass * 32 + trow;                                 // column of the tile = row of the transpose
+      uint32_t w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        w[i] = (uint32_t)tile[(ch * 8 + 2 * i) * 66 + cc] | ((uint32_t)tile[(ch * 8 + 2 * i + 1) * 66 + cc] << 16);
+      *reinterpret_cast<uint4*>(p.gxt + (size_t)(c0 + cc) * p.K + r0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return;
+  }
+  const int t = b - p.nb_ga - p.nb_gx, tiles_c = p.N / 64;
+  dpl_transpose_tile(p.adj, p.At, p.N, p.N, (t / tiles_c) * 64, (t % tiles_c) * 64, reinterpret_cast<uint16_t(*)[66]>(ldsf),
+                     threadIdx.x);
 }
 
 inline size_t dpl_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -349,6 +586,8 @@ extern "C" int64_t mlgnn_diffpool_large_saved_bytes(int64_t N, int64_t K, int64_
   return (int64_t)dpl_layout(N, K, C).scratch;
 }
 
+// Forward: FIVE launches -- prologue (softmax + S^T, Z^T, ||A||^2), T = A S~, [A' | G | X'] split along K, its reduce,
+// the scalars.
 extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
                                         void* s_out, void* x_out, void* adj_out, void* scal_out, int out_dtype,
                                         float* stats, void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int64_t C,
@@ -359,7 +598,7 @@ extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const vo
       (out_dtype != MLGNN_DTYPE_F32 && out_dtype != MLGNN_DTYPE_BF16)) return MLGNN_E_DTYPE;
   const DplLayout L = dpl_layout(N, K, C);
   if (workspace_bytes < (int64_t)L.total) return MLGNN_E_WORKSPACE;
-  if (((uintptr_t)z | (uintptr_t)adj | (uintptr_t)s_out | (uintptr_t)workspace) & 15) return MLGNN_E_ALIGN;
+  if (((uintptr_t)z | (uintptr_t)adj | (uintptr_t)s_out | (uintptr_t)workspace | (uintptr_t)s_logits) & 15) return MLGNN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
   uint16_t* stack = (uint16_t*)(ws + L.stack);
@@ -376,24 +615,29 @@ extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const vo
   uint16_t* S = (uint16_t*)s_out;
   const int n = (int)N, k = (int)K, c = (int)C;
 
-  // 1. S~ = softmax(logits), entropy partials; S~^T and Z^T into the stacked operand
-  const int sm_blocks = (int)((N + 3) / 4 < kDplPartials ? (N + 3) / 4 : kDplPartials);
-  const bool vec = logits_dtype == MLGNN_DTYPE_BF16 && ((uintptr_t)s_logits & 15) == 0;
-  if (logits_dtype == MLGNN_DTYPE_F32)
-    hipLaunchKernelGGL(dpl_softmax_kernel<float>, dim3(sm_blocks), dim3(256), 0, st, (const float*)s_logits, S, p_ent, n, k);
-  else if (vec && k == 512)
-    hipLaunchKernelGGL(dpl_softmax_vec_kernel<1>, dim3(sm_blocks), dim3(256), 0, st, (const uint16_t*)s_logits, S, p_ent, n);
-  else if (vec && k == 1024)
-    hipLaunchKernelGGL(dpl_softmax_vec_kernel<2>, dim3(sm_blocks), dim3(256), 0, st, (const uint16_t*)s_logits, S, p_ent, n);
-  else if (vec && k == 2048)
-    hipLaunchKernelGGL(dpl_softmax_vec_kernel<4>, dim3(sm_blocks), dim3(256), 0, st, (const uint16_t*)s_logits, S, p_ent, n);
-  else
-    hipLaunchKernelGGL(dpl_softmax_kernel<bf16_t>, dim3(sm_blocks), dim3(256), 0, st, (const bf16_t*)s_logits, S, p_ent, n, k);
-  DPL_CHECK(dpl_transpose(S, St, n, k, K, N, st));
-  DPL_CHECK(dpl_transpose((const uint16_t*)z, Zt, n, c, C, N, st));
-  // 2. ||A||_F^2
-  hipLaunchKernelGGL(dpl_sumsq_kernel, dim3(kDplPartials), dim3(256), 0, st, (const uint4*)adj, (int64_t)N * N / 8, p_a2);
-  // 3. T = A S~ (and T^T, <S~, T>)
+  // 1. S~ = softmax(logits) as S and S^T, entropy partials; Z^T; ||A||_F^2 partials
+  DplProArgs pro;
+  pro.logits = s_logits; pro.S = S; pro.St = St; pro.ent_partial = p_ent;
+  pro.z = (const uint16_t*)z; pro.Zt = Zt;
+  pro.adj = (const uint4*)adj; pro.adj_n8 = (int64_t)N * N / 8; pro.a2_partial = p_a2;
+  pro.N = n; pro.K = k; pro.C = c;
+  pro.nb_sm = n / kProRows; pro.nb_zt = ((n / 64) * (c / 64) + 3) / 4; pro.nb_sq = kDplSqBlocks;
+  const dim3 pro_grid(pro.nb_sm + pro.nb_zt + pro.nb_sq);
+  {
+    const bool f32 = logits_dtype == MLGNN_DTYPE_F32;
+    const dim3 blk(kProThreads);
+#define DPL_PRO(CH)                                                                                   \
+  do {                                                                                                \
+    if (f32) hipLaunchKernelGGL((dpl_prologue_kernel<float, CH>), pro_grid, blk, 0, st, pro);        \
+    else hipLaunchKernelGGL((dpl_prologue_kernel<bf16_t, CH>), pro_grid, blk, 0, st, pro);           \
+  } while (0)
+    if (k == 512) DPL_PRO(1);
+    else if (k == 1024) DPL_PRO(2);
+    else if (k == 2048) DPL_PRO(4);
+    else DPL_PRO(0);
+#undef DPL_PRO
+  }
+  // 2. T = A S~ (and T^T, <S~, T>)
   {
     GemmDesc d{};
     d.nseg = 1;
@@ -404,18 +648,22 @@ extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const vo
     d.dot = S; d.lddot = K; d.dot_partial = p_dot;
     DPL_CHECK(gemm_nt_launch(d, st));
   }
-  // 4. [A' | G | X'] = S~^T [T | S~ | Z]: one product over the whole stack (T^T, S~^T, Z^T are its rows), one reduce
-  {
+  // 3. [A' | G | X'] = S~^T [T | S~ | Z]: one product over the whole stack (T^T, S~^T, Z^T are its rows), one reduce
+    {
     GemmDesc d{};
     d.nseg = 1;
     d.seg[0] = GemmSeg{St, Tt, N, N, n};
     d.M = k; d.N = 2 * k + c; d.splits = L.splits_ag; d.slab = slab;
     DPL_CHECK(gemm_nt_launch(d, st));
-    DPL_CHECK(slab_reduce_launch(slab, L.splits_ag, k, 2 * k + c, k, adj_out, K, out_dtype == MLGNN_DTYPE_F32, G, K, p_g2,
-                                 kDplPartials, st, 2 * k, x_out, C, out_dtype == MLGNN_DTYPE_F32));
+    SlabReduceArgs r{};
+    r.slab = slab; r.splits = L.splits_ag; r.M = k; r.N = 2 * k + c; r.n_a = k; r.n_b = 2 * k;
+    r.ca = adj_out; r.lda = K; r.ca_f32 = out_dtype == MLGNN_DTYPE_F32;
+    r.cb = G; r.ldb = K; r.sq_partial = p_g2;
+    r.cc = x_out; r.ldc = C; r.cc_f32 = out_dtype == MLGNN_DTYPE_F32;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(kDplPartials), dim3(256), 0, st, r);
   }
-  // 6. link / entropy
-  DplFinalArgs f{p_a2, kDplPartials, p_dot, (int)((N / kGemmTile) * (K / kGemmTile)), p_g2, kDplPartials, p_ent, sm_blocks,
+  // 4. link / entropy from the partial sums
+  DplFinalArgs f{p_a2, kDplSqBlocks, p_dot, (int)((N / kGemmTile) * (K / kGemmTile)), p_g2, kDplPartials, p_ent, pro.nb_sm,
                  stats, scal_out, out_dtype == MLGNN_DTYPE_F32, (float)(1.0 / ((double)N * (double)N)), (float)(1.0 / (double)N)};
   hipLaunchKernelGGL(dpl_final_kernel, dim3(1), dim3(256), 0, st, f);
   return (int)hipGetLastError();
@@ -428,13 +676,13 @@ extern "C" int64_t mlgnn_diffpool_large_bwd_workspace_bytes(int64_t N, int64_t K
   o += 3 * dpl_align((size_t)K * K * 2);                        // b1, b2, b3
   o += 2 * dpl_align((size_t)K * C * 2);                        // gx bf16, its transpose
   o += dpl_align((size_t)N * K * 4);                            // dS fp32
-  const int tiles_z = (int)((N / kGemmTile) * (C / kGemmTile));
-  o += dpl_align((size_t)dpl_splits(tiles_z, (int)(K / kGemmBK)) * N * C * 4);   // dZ slabs
   if (!adj_symmetric) o += dpl_align((size_t)N * N * 2) + dpl_align((size_t)N * K * 2);   // A^T, T2
   o += dpl_align((size_t)N * K * 2);                            // P = S~ (dA' - cI) of the adjacency gradient
   return (int64_t)o;
 }
 
+// Backward: FOUR launches when adj is promised symmetric (operand preparation, the four-term dS product, softmax
+// backward, dZ), one more product (T2 = A^T S~) otherwise, two more for the adjacency gradient.
 extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
                                         const void* s_soft, const void* saved, const void* grad_x,
                                         const void* grad_adj_out, int grad_dtype, const void* grad_link,
@@ -448,6 +696,8 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
   if ((logits_dtype != MLGNN_DTYPE_F32 && logits_dtype != MLGNN_DTYPE_BF16) ||
       (grad_dtype != MLGNN_DTYPE_F32 && grad_dtype != MLGNN_DTYPE_BF16)) return MLGNN_E_DTYPE;
   if (workspace_bytes < mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, adj_symmetric)) return MLGNN_E_WORKSPACE;
+  if (((uintptr_t)s_logits | (uintptr_t)grad_logits | (uintptr_t)workspace | (uintptr_t)adj | (uintptr_t)grad_x |
+       (uintptr_t)grad_adj_out | (uintptr_t)grad_z) & 15) return MLGNN_E_ALIGN;
   const DplLayout L = dpl_layout(N, K, C);
   hipStream_t st = (hipStream_t)stream;
   const unsigned char* sv = (const unsigned char*)saved;
@@ -461,26 +711,32 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
   size_t o = 0;
   auto take = [&](size_t bytes) { unsigned char* p = ws + o; o += dpl_align(bytes); return p; };
   float* coef = (float*)take(16);
-  {
-    const float inv_numel = (float)(1.0 / ((double)N * (double)N)), inv_rows = (float)(1.0 / (double)N);
-    if (scalar_dtype == MLGNN_DTYPE_F32)
-      hipLaunchKernelGGL(dpl_coef_kernel<float>, dim3(1), dim3(1), 0, st, (const float*)grad_link, (const float*)grad_ent, stats, coef, inv_numel, inv_rows);
-    else
-      hipLaunchKernelGGL(dpl_coef_kernel<bf16_t>, dim3(1), dim3(1), 0, st, (const bf16_t*)grad_link, (const bf16_t*)grad_ent, stats, coef, inv_numel, inv_rows);
-  }
   uint16_t* b1 = (uint16_t*)take((size_t)K * K * 2);
   uint16_t* b2 = (uint16_t*)take((size_t)K * K * 2);
   uint16_t* b3 = (uint16_t*)take((size_t)K * K * 2);
   uint16_t* gxb = (uint16_t*)take((size_t)K * C * 2);
   uint16_t* gxt = (uint16_t*)take((size_t)K * C * 2);
   float* dS = (float*)take((size_t)N * K * 4);
-  const int splits_z = dpl_splits((int)((N / kGemmTile) * (C / kGemmTile)), (int)(K / kGemmBK));
-  float* slab = (float*)take((size_t)splits_z * N * C * 4);
+  uint16_t* At = nullptr;
+  uint16_t* t2 = nullptr;
+  if (!adj_symmetric) {
+    At = (uint16_t*)take((size_t)N * N * 2);
+    t2 = (uint16_t*)take((size_t)N * K * 2);
+  }
+  // 1. operands derived from the incoming gradients (+ A^T)
+  {
+    DplPrepArgs q;
+    q.g_link = grad_link; q.g_ent = grad_ent; q.scal_f32 = scalar_dtype == MLGNN_DTYPE_F32; q.stats = stats; q.coef = coef;
+    q.inv_numel = (float)(1.0 / ((double)N * (double)N)); q.inv_rows = (float)(1.0 / (double)N);
+    q.ga = grad_adj_out; q.gx = grad_x; q.g_f32 = grad_dtype == MLGNN_DTYPE_F32; q.G = G;
+    q.b1 = b1; q.b2 = b2; q.b3 = b3; q.gxb = gxb; q.gxt = gxt;
+    q.adj = (const uint16_t*)adj; q.At = At;
+    q.N = n; q.K = k; q.C = c;
+    q.nb_ga = (k / 64) * (k / 64); q.nb_gx = (k / 64) * (c / 64); q.nb_at = At ? (n / 64) * (n / 64) : 0;
+    hipLaunchKernelGGL(dpl_prep_kernel, dim3(q.nb_ga + q.nb_gx + q.nb_at), dim3(256), 0, st, q);
+  }
   const uint16_t* T2 = T;
   if (!adj_symmetric) {
-    uint16_t* At = (uint16_t*)take((size_t)N * N * 2);
-    uint16_t* t2 = (uint16_t*)take((size_t)N * K * 2);
-    DPL_CHECK(dpl_transpose((const uint16_t*)adj, At, n, n, N, N, st));
     GemmDesc d{};
     d.nseg = 1;
     d.seg[0] = GemmSeg{At, St, N, N, n};
@@ -489,15 +745,6 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
     DPL_CHECK(gemm_nt_launch(d, st));
     T2 = t2;
   }
-  // operands derived from the incoming gradients
-  if (grad_dtype == MLGNN_DTYPE_F32) {
-    hipLaunchKernelGGL(dpl_prep_ga_kernel<float>, dim3(1024), dim3(256), 0, st, (const float*)grad_adj_out, G, coef, b1, b2, b3, k);
-    hipLaunchKernelGGL(dpl_to_bf16_kernel<float>, dim3(256), dim3(256), 0, st, (const float*)grad_x, gxb, (int64_t)K * C);
-  } else {
-    hipLaunchKernelGGL(dpl_prep_ga_kernel<bf16_t>, dim3(1024), dim3(256), 0, st, (const bf16_t*)grad_adj_out, G, coef, b1, b2, b3, k);
-    hipLaunchKernelGGL(dpl_to_bf16_kernel<bf16_t>, dim3(256), dim3(256), 0, st, (const bf16_t*)grad_x, gxb, (int64_t)K * C);
-  }
-  DPL_CHECK(dpl_transpose(gxb, gxt, k, c, C, K, st));
   // dS = Z gx^T + T (ga - cI)^T + T2 (ga^T - cI)^T + S~ (2cG)^T    (one product over the concatenated contraction range)
   {
     GemmDesc d{};
@@ -510,23 +757,23 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
     d.c = dS; d.ldc = K; d.c_f32 = 1;
     DPL_CHECK(gemm_nt_launch(d, st));
   }
-  const int sm_blocks = (int)((N + 3) / 4 < kDplPartials ? (N + 3) / 4 : kDplPartials);
+  const int sm_blocks = (int)((N + 3) / 4 < 1024 ? (N + 3) / 4 : 1024);
   if (logits_dtype == MLGNN_DTYPE_F32)
     hipLaunchKernelGGL(dpl_softmax_bwd_kernel<float>, dim3(sm_blocks), dim3(256), 0, st, (const float*)s_logits, dS, coef,
                        (float*)grad_logits, n, k);
   else
     hipLaunchKernelGGL(dpl_softmax_bwd_kernel<bf16_t>, dim3(sm_blocks), dim3(256), 0, st, (const bf16_t*)s_logits, dS, coef,
                        (bf16_t*)grad_logits, n, k);
-  // dZ = S~ gx
+  // dZ = S~ gx, written in the dtype of z (= the dtype of the logits).  One workgroup per output tile: at
+  // 4096 x 256 x 1024 that is 64 workgroups for 16 K-steps -- a split along K with its slabs and reduce launch
+  // (round 2) took longer than the quarter-filled chip does.
   {
     GemmDesc d{};
     d.nseg = 1;
     d.seg[0] = GemmSeg{S, gxt, K, K, k};
-    d.M = n; d.N = c; d.splits = splits_z; d.slab = slab;
+    d.M = n; d.N = c; d.splits = 1;
+    d.c = grad_z; d.ldc = C; d.c_f32 = logits_dtype == MLGNN_DTYPE_F32;
     DPL_CHECK(gemm_nt_launch(d, st));
-    // dZ takes the dtype of z = the dtype of the logits
-    DPL_CHECK(slab_reduce_launch(slab, splits_z, n, c, c, grad_z, C, logits_dtype == MLGNN_DTYPE_F32, nullptr, 0, nullptr,
-                                 kDplPartials, st));
   }
   // dA = S~ dA' S~^T  (through A' = S^T A S)  +  c (A - S~ S~^T)  (through the link term)
   //    = P S~^T + c A,   P = S~ (dA' - cI)   -- two products, the second with the `+ c A` in its epilogue (c read on

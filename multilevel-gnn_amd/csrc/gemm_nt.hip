@@ -300,57 +300,6 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
 #undef MLGNN_FOR_ACC
 }
 
-// out[i] = sum_z slab[z][i]  in a fixed order; columns [0, n_a) of every row go to `ca` (bf16 or fp32, leading
-// dimension lda), columns [n_a, N) to `cb` (bf16, leading dimension ldb) with their squares summed per workgroup
-// into sq_partial (||.||_F^2 of that column range).
-struct SlabReduceArgs {
-  const float* slab; int splits; int M, N, n_a, n_b;
-  void* ca; int64_t lda; int ca_f32;
-  uint16_t* cb; int64_t ldb; float* sq_partial;
-  void* cc; int64_t ldc; int cc_f32;
-};
-
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs p) {
-  __shared__ float wsum[4];
-  const int per_row = p.N / 4;
-  const int64_t total = (int64_t)p.M * per_row;
-  float sq = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int row = (int)(i / per_row), col = (int)(i % per_row) * 4;
-    float4 s = reinterpret_cast<const float4*>(p.slab)[i];
-    for (int z = 1; z < p.splits; ++z) {
-      const float4 v = reinterpret_cast<const float4*>(p.slab + (size_t)z * p.M * p.N)[i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    if (col < p.n_a || col >= p.n_b) {
-      const bool first = col < p.n_a;
-      void* dst = first ? p.ca : p.cc;
-      const size_t at = first ? (size_t)row * p.lda + col : (size_t)row * p.ldc + (col - p.n_b);
-      if (first ? p.ca_f32 : p.cc_f32) {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + at) = s;
-      } else {
-        uint2 w;
-        w.x = (uint32_t)f32_to_bf16(s.x) | ((uint32_t)f32_to_bf16(s.y) << 16);
-        w.y = (uint32_t)f32_to_bf16(s.z) | ((uint32_t)f32_to_bf16(s.w) << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + at) = w;
-      }
-    } else {
-      sq += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
-      uint2 w;
-      w.x = (uint32_t)f32_to_bf16(s.x) | ((uint32_t)f32_to_bf16(s.y) << 16);
-      w.y = (uint32_t)f32_to_bf16(s.z) | ((uint32_t)f32_to_bf16(s.w) << 16);
-      *reinterpret_cast<uint2*>(p.cb + (size_t)row * p.ldb + (col - p.n_a)) = w;
-    }
-  }
-  if (p.sq_partial) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
-    __syncthreads();
-    if (threadIdx.x == 0) p.sq_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-  }
-}
-
 int gemm_nt_workgroups(const GemmDesc& d) { return (d.M / kGemmTile) * (d.N / kGemmTile) * (d.splits > 0 ? d.splits : 1); }
 
 int gemm_nt_launch(const GemmDesc& d, hipStream_t s) {
@@ -380,16 +329,6 @@ int gemm_nt_launch(const GemmDesc& d, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_nt_kernel<kStages>), dim3(gemm_nt_workgroups(d)), dim3(kGThreads), lds, s, p);
-  return (int)hipGetLastError();
-}
-
-int slab_reduce_launch(const float* slab, int splits, int M, int N, int n_a, void* ca, int64_t lda, int ca_f32,
-                       uint16_t* cb, int64_t ldb, float* sq_partial, int blocks, hipStream_t s, int n_b, void* cc,
-                       int64_t ldc, int cc_f32) {
-  if (!cc) n_b = N;                                    // two ranges: [0, n_a) -> ca, [n_a, N) -> cb
-  if (N % 4 || n_a % 4 || n_b % 4 || lda % 4 || (cb && ldb % 4) || (cc && ldc % 4) || n_b < n_a || n_b > N) return MLGNN_E_SHAPE;
-  SlabReduceArgs p{slab, splits, M, N, n_a, n_b, ca, lda, ca_f32, cb, ldb, sq_partial, cc, ldc, cc_f32};
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
   return (int)hipGetLastError();
 }
 

@@ -682,17 +682,20 @@ def _diff_pool_large(z, adj, s, adj_symmetric=False):
     """Batch loop around the one-graph product chain; losses are combined as the reference does
     (one Frobenius norm over the whole batch, entropy averaged over all nodes)."""
     B = z.shape[0]
+    fn = _DiffPoolLarge if z.dtype == torch.bfloat16 else _DiffPoolLargeFP32
+    if B == 1:
+        # views, not selects: the backward of `z[0]` would allocate and fill a full-size zero tensor per operand
+        N, C = z.shape[1], z.shape[2]
+        x, a, link, ent = fn.apply(z.reshape(N, C), adj.reshape(N, N), s.reshape(N, -1), adj_symmetric)
+        return x.unsqueeze(0), a.unsqueeze(0), link, ent
     xs, as_, l2, es = [], [], [], []
     for b in range(B):
         a_b = adj[b if adj.shape[0] == B and B > 1 else 0]
-        fn = _DiffPoolLarge if z.dtype == torch.bfloat16 else _DiffPoolLargeFP32
         x, a, link, ent = fn.apply(z[b], a_b.contiguous(), s[b], adj_symmetric)
         xs.append(x)
         as_.append(a)
         l2.append((link.float() * a_b.numel()) ** 2)
         es.append(ent.float())
-    if B == 1:
-        return xs[0].unsqueeze(0), as_[0].unsqueeze(0), link, ent
     link = torch.sqrt(torch.stack(l2).sum()) / adj.numel()
     return torch.stack(xs), torch.stack(as_), link.to(z.dtype), torch.stack(es).mean().to(z.dtype)
 

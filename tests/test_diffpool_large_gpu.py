@@ -16,7 +16,8 @@ from oracle import primitives as OP
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [(256, 128, 128), (512, 256, 128), (1024, 384, 256)]
+# K = 512 / 1024 / 2048 take the register-resident softmax of the forward prologue, other widths the generic one
+SIZES = [(256, 128, 128), (512, 256, 128), (1024, 384, 256), (512, 512, 128), (256, 2048, 128), (384, 1024, 128)]
 
 
 def _inputs(N, K, C, seed, symmetric=False):
@@ -101,9 +102,14 @@ def test_forward_backward_vs_oracle(N, K, C):
     soft = torch.softmax(sd.detach(), -1)
     bound_x = soft.t() @ zd.detach().abs()
     bound_a = soft.t() @ ad.abs() @ soft
-    tol = 2.0 ** -7                                       # three bf16 roundings, worst case
+    # worst case per factor: S~ is within ONE bf16 ulp of the exact softmax (2^-8: the fast exponential may flip the
+    # rounding, see test_kernel_arithmetic_given_rounded_softmax), T and the output are correctly rounded (2^-9 each).
+    # X' = S~^T Z: 2^-8 + 2^-9 < 2^-7.  A' = S~^T (A S~) carries S~ twice: 2 * 2^-8 + 2 * 2^-9 = 3 * 2^-8 -- reached
+    # when a column of S is dominated by one node (few nodes, many clusters: the 256 x 2048 case), where the errors of
+    # the dominant entries do not average out.
+    tol = 2.0 ** -7
     assert ((x[0].double().cpu() - rx[0].detach()).abs() <= tol * bound_x).all()
-    assert ((ao[0].double().cpu() - ra[0].detach()).abs() <= tol * bound_a).all()
+    assert ((ao[0].double().cpu() - ra[0].detach()).abs() <= 3 * 2.0 ** -8 * bound_a).all()
     assert abs(float(link) - float(rl)) <= 2.0 ** -7 * float(rl)
     assert abs(float(ent) - float(re)) <= 2.0 ** -7 * abs(float(re))
     ((x[0].float() * wx.float().cuda()).sum() + (ao[0].float() * wa.float().cuda()).sum() + link.float() * 3e4

@@ -169,6 +169,48 @@ int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out
                             const void* grad_shifted, const int32_t* shift_flag, void* stream);
 
 /*
+ * The same backward when x was  y = relu?(LayerNorm(h))  -- the res+ block's norm + ReLU in front of the conv,
+ * models/deepergcn.py:236-241 -- and this aggregation (with add_root) is what consumes y: the row epilogue, which
+ * holds the finished row of d loss / d y, takes it through that LayerNorm's backward, so
+ *     grad_x [N,d]          receives  d loss / d h  (+ grad_extra)  instead of d loss / d y
+ *     grad_gamma_beta [2,d] receives  d loss / d gamma, d loss / d beta of the LayerNorm
+ *     row_max [N] or NULL   max |grad_x| per row (what the GEMMs that consume grad_x scale their operand by)
+ * and the separate LayerNorm-backward pass over [N,d] (mlgnn_layernorm_act_bwd) does not run.
+ *   h [N,d], mean [N], rstd [N], gamma [d], beta [d]: the LayerNorm's input, statistics and affine parameters
+ *   grad_extra [N,d] or NULL: gradient arriving on h along the block's identity branch (deepergcn.py:241), added here
+ *   workspace: mlgnn_csr_aggregate_bwd_ln_workspace_floats(N, d) floats
+ * fp32, d = 4 * 2^k <= 256 (one channel chunk per lane group), no long-row split (hub NULL or cap 0), no learn_t:
+ * MLGNN_E_MODE otherwise, and the caller runs the two passes.
+ */
+typedef struct mlgnn_ln_fold {
+  const float* h;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+  const float* grad_extra;
+  float* row_max;
+  float* grad_gamma_beta;
+  float* workspace;
+  int64_t workspace_floats;
+  int32_t relu;
+} mlgnn_ln_fold_t;
+int64_t mlgnn_csr_aggregate_bwd_ln_workspace_floats(int64_t N, int64_t d);
+int mlgnn_csr_aggregate_bwd_ln(const void* grad_out, const void* x, const void* out, const float* aux,
+                               const int32_t* argmax,
+                               const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
+                               const int32_t* rowptr,
+                               const float* ew_t, const float* eu, const float* ev,
+                               const void* efull, const int32_t* eid_t, const int32_t* geid_t,
+                               void* grad_x, void* grad_efull, float* grad_uv,
+                               float* workspace, int64_t workspace_floats,
+                               int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
+                               int aggr, int learn_t, float t, float p, const float* t_dev, const float* p_dev,
+                               float eps, int add_root, int accumulate_efull, const mlgnn_hub_t* hub,
+                               const void* grad_shifted, const int32_t* shift_flag, const mlgnn_ln_fold_t* ln,
+                               void* stream);
+
+/*
  * Gene -> pathway learnable-projection pooling.
  * Replaces: models/multilevel_gnn.py:212-239 (advanced-index gather, repeat, mul, permute,
  * Tensor.scatter_reduce('sum')):

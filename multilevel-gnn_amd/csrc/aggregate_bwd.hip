@@ -20,6 +20,11 @@ struct BwdArgs {                      // go / x / out / efull / gx / ge are T; a
   int N; int d; int lpr_log2; int mean; int learn_t; int add_root; int ge_accumulate;
   float t; float p; float eps;
   int cap; const int* vrows; const int* vcount;             // long source rows, as in FwdArgs (csrc/hub.hip)
+  // LNB: x was y = relu?(LayerNorm(h)) -- the res+ block's pre-conv norm (deepergcn.py:236-241) -- and the row epilogue
+  // takes the finished grad_y row through that LayerNorm's backward: gx receives d loss / d h (+ ln_extra, the gradient
+  // arriving on h along the block's identity branch); per-workgroup [2, d] partials of d gamma / d beta go to ln_ws
+  const float* ln_h; const float* ln_mean; const float* ln_rstd; const float* ln_gamma; const float* ln_beta;
+  const float* ln_extra; float* ln_rowmax; float* ln_ws; int ln_relu;
 };
 
 // VEC one-byte winner slots -> ints
@@ -44,8 +49,9 @@ __device__ __forceinline__ void load_slots(int (&r)[VEC], const uint8_t* p) {
 // edge gathers ONE row (gt) instead of two (go, lse): half the gather traffic, and no per-edge scalar either.
 // SHIFT with max: the winning edge of (i, c) is looked up as a 1-byte slot inside row i (max_slot_kernel) instead of
 // the 4-byte by-destination position the forward wrote -- the second gathered row shrinks from 4 d to d bytes.
-template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool SHIFT, bool VIRT>
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool SHIFT, bool VIRT, bool LNB = false>
 __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (*red)[kWave * VEC]) {
+  static_assert(!LNB || (sizeof(T) == 4 && !VIRT && !LEARN_T), "LayerNorm-backward epilogue: fp32 rows of the main launch");
   constexpr int RK = rank_of<MODE>();
   constexpr int ES = edge_scalars<MODE>();
   constexpr int ESA = ES > 0 ? ES : 1;
@@ -90,6 +96,96 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
       }
     }
 
+    // LNB (one channel chunk: d == lpr * VEC, checked on the host).  The epilogue's arithmetic is the same for every
+    // lane group, and after the merge below every group holds the finished row -- so a finished row is only PARKED with
+    // one group (group `slot`), and the epilogue runs once per `groups` rows with each group working on its own row:
+    // 1/groups of the instructions and shuffle trips per row (this kernel is bound by instruction issue; an epilogue
+    // per row cost as much as the LayerNorm pass it replaces).  Only the parked row stays in registers between rows
+    // (this kernel runs four waves per SIMD at <= 128 registers): the LayerNorm operands are requested at the flush,
+    // the d gamma / d beta sums of the rows a lane owned live in LDS (`red`, a slot per lane and channel).
+    const float inv_d = 1.0f / (float)a.d;
+    int slot = 0, keep_r = -1;
+    float keep[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) keep[i] = 0.f;
+    float* lds_dg = &red[wave][0] + lane * VEC;                   // [kWave * VEC] per wave: this lane's d gamma ...
+    float* lds_db = lds_dg + kWavesPerBlock * kWave * VEC;        // ... and d beta sums (second half of `red`)
+    if constexpr (LNB) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { lds_dg[i] = 0.f; lds_db[i] = 0.f; }
+    }
+    // the LayerNorm operands of the rows a flush will work on, requested when the LAST row of a group of `groups`
+    // starts (every lane group for the row parked with it, the last group for the row about to be walked), so that
+    // they arrive behind that row's edges
+    float lh[VEC], le[VEC], lroot[VEC], lmu = 0.f, lrs = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { lh[i] = 0.f; le[i] = 0.f; lroot[i] = 0.f; }
+    // (read once, next to a gather that lives on its L2 hit rate: non-temporal)
+    auto stream4 = [](float (&dst)[VEC], const float* src) {
+      if constexpr (VEC == 4) {
+        using f4 = __attribute__((ext_vector_type(4))) float;
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src));
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      } else {
+        load_vec<VEC>(dst, src);
+      }
+    };
+    auto ln_request = [&](int kr) {
+      stream4(lh, a.ln_h + (size_t)kr * a.d + c0);
+      lmu = a.ln_mean[kr]; lrs = a.ln_rstd[kr];
+      if (a.ln_extra) stream4(le, a.ln_extra + (size_t)kr * a.d + c0);
+      if (a.add_root) stream4(lroot, reinterpret_cast<const float*>(GO) + (size_t)kr * a.d + c0);
+    };
+    auto ln_flush = [&](bool requested) {
+      const bool wr = keep_r >= 0;
+      const int kr = max(keep_r, 0);
+      if (!requested) ln_request(kr);
+      float lng[VEC], lnb[VEC], ldg[VEC], ldb[VEC];
+      load_vec<VEC>(lng, a.ln_gamma + c0);
+      load_vec<VEC>(lnb, a.ln_beta + c0);
+      load_vec<VEC>(ldg, lds_dg);
+      load_vec<VEC>(ldb, lds_db);
+      float xh[VEC], gg[VEC], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        xh[i] = (lh[i] - lmu) * lrs;
+        const float y = fmaf(xh[i], lng[i], lnb[i]);
+        const float gy = (wr && !(a.ln_relu && !(y > 0.f))) ? keep[i] + lroot[i] : 0.f;
+        ldg[i] = fmaf(gy, xh[i], ldg[i]);
+        ldb[i] += gy;
+        gg[i] = gy * lng[i];
+        s1 += gg[i];
+        s2 = fmaf(gg[i], xh[i], s2);
+      }
+      store_vec<VEC>(lds_dg, ldg);
+      store_vec<VEC>(lds_db, ldb);
+      // d = 128: a lane group is a 32-lane half -- rotations inside the rows of 16 lanes as DPP modifiers, one
+      // crossbar trip for the last step (common.h); the shuffle ladder (five trips per sum) otherwise
+      if (a.lpr_log2 == 5) { s1 = half_sum(s1); s2 = half_sum(s2); }
+      else for (int off = 1; off < lpr; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+      s1 *= inv_d; s2 *= inv_d;
+      float o[VEC], om = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        o[i] = wr ? fmaf(lrs, gg[i] - s1 - xh[i] * s2, le[i]) : 0.f;
+        om = fmaxf(om, fabsf(o[i]));
+      }
+      if (a.ln_rowmax) {
+        if (a.lpr_log2 == 5) om = half_max(om);
+        else for (int off = 1; off < lpr; off <<= 1) om = fmaxf(om, __shfl_xor(om, off));
+        if (wr && cl == 0) a.ln_rowmax[kr] = om;
+      }
+      if constexpr (VEC == 4) {
+        if (wr) {
+          using f4 = __attribute__((ext_vector_type(4))) float;
+          const f4 v = {o[0], o[1], o[2], o[3]};
+          __builtin_nontemporal_store(v, reinterpret_cast<f4*>(reinterpret_cast<float*>(GX) + (size_t)kr * a.d + c0));
+        }
+      }
+      keep_r = -1;
+      slot = 0;
+    };
+
     for (int r = walk.first; r < walk.r_end; r += walk.stride) {
       // xr: the source node whose features this row of edges belongs to (VIRT: a chunk of a long row, csrc/hub.hip)
       const int xr = VIRT ? a.vrows[3 * r] : r;
@@ -102,7 +198,9 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
       float xjv[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) xjv[i] = xj[i] + ev[i];
-
+      if constexpr (LNB) {
+        if (slot == groups - 1) ln_request(sub == slot ? r : max(keep_r, 0));
+      }
       for (int base = beg; base < end; base += kWave) {
         const int cnt = min(kWave, end - base);
         uint32_t my_off = 0;
@@ -222,6 +320,14 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
       for (int off = lpr; off < kWave; off <<= 1)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) gx[i] += __shfl_xor(gx[i], off);
+      if constexpr (LNB) {
+        if (sub == slot) {
+          keep_r = r;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) keep[i] = gx[i];
+        }
+        if (++slot == groups) ln_flush(true);
+      } else
       if (sub == 0 && cact) {
         if (a.add_root && !VIRT) {    // identity branch of h = x + m (once per real row: the main launch)
           float gr[VEC];
@@ -234,6 +340,22 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
       }
     }
 
+    if constexpr (LNB) {
+      if (slot > 0) ln_flush(false);               // rows still parked when the walk ends
+    }
+    if constexpr (LNB) {
+      // d gamma / d beta: every lane holds (in LDS) the sums of the rows its group owned -> groups -> waves -> one
+      // [2, d] partial per workgroup
+      __syncthreads();
+      for (int c = threadIdx.x; c < 2 * a.d; c += kBlock) {
+        const int which = c / a.d, ch = c % a.d;
+        const float* src = &red[0][0] + which * (kWavesPerBlock * kWave * VEC);
+        float sum = 0.f;
+        for (int w = 0; w < kWavesPerBlock; ++w)
+          for (int g2 = 0; g2 < groups; ++g2) sum += src[w * (kWave * VEC) + (g2 * lpr) * VEC + ch];
+        a.ln_ws[((size_t)blockIdx.x * 2 + which) * a.d + ch] = sum;
+      }
+    }
     if constexpr (RK > 0) {
       // per-workgroup partial of d loss/d U [RK,d] and d loss/d v [d]  ->  ws[block][RK+1][d]; summed by a second launch
       for (int off = lpr; off < kWave; off <<= 1)
@@ -263,22 +385,23 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
   }
 }
 
-template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool VIRT = false>
-__global__ __launch_bounds__(kBlock) void csr_aggregate_bwd_kernel(const BwdArgs a) {
-  __shared__ float red[kWavesPerBlock][kWave * VEC];
+// (LNB: four waves per SIMD asked for -- the parked row puts the softmax instantiation two registers past 128)
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool VIRT = false, bool LNB = false>
+__global__ __launch_bounds__(kBlock, LNB ? 4 : 1) void csr_aggregate_bwd_kernel(const BwdArgs a) {
+  __shared__ float red[LNB ? 2 * kWavesPerBlock : kWavesPerBlock][kWave * VEC];     // LNB: + the d gamma / d beta slots
   if constexpr (AGGR == A_SOFTMAX && !LEARN_T) {
     // *a.spread != 0: softmax_shift_kernel met a node with |lse| > kMaxLse in some channel; the two-row path
     // stays as the fallback for such inputs (never seen in practice: lse = log2 sum_e 2^(t m_e))
     const bool shift_ok = a.gt != nullptr && *a.spread == 0;
-    if (shift_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT>(a, red);
-    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT>(a, red);
+    if (shift_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT, LNB>(a, red);
+    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT, LNB>(a, red);
   } else if constexpr (AGGR == A_MAX) {
     // *a.spread != 0: some node has more than 254 incoming edges, its slots do not fit a byte
     const bool slots_ok = a.slot8 != nullptr && *a.spread == 0;
-    if (slots_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT>(a, red);
-    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT>(a, red);
+    if (slots_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT, LNB>(a, red);
+    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT, LNB>(a, red);
   } else {
-    csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT>(a, red);
+    csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT, LNB>(a, red);
   }
 }
 
@@ -468,7 +591,7 @@ static int num_cus() {
   return n;
 }
 
-extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out, const float* aux,
+static int csr_aggregate_bwd_impl(const void* grad_out, const void* x, const void* out, const float* aux,
                                        const int32_t* argmax,
                                        const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
                                        const int32_t* rowptr,
@@ -480,7 +603,7 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
                                        int aggr, int learn_t, float t, float p, const float* t_dev,
                                        const float* p_dev, float eps, int add_root, int accumulate_efull,
                                        const mlgnn_hub_t* hub, const void* grad_shifted, const int32_t* shift_flag,
-                                       void* stream) {
+                                       const mlgnn_ln_fold_t* ln, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
   if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
@@ -539,6 +662,19 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
   int launched_blocks = nblk;
   hipStream_t s = (hipStream_t)stream;
   a.lpr_log2 = lanes_per_row_log2(d, vec);
+  a.ln_h = nullptr; a.ln_mean = a.ln_rstd = a.ln_gamma = a.ln_beta = a.ln_extra = nullptr;
+  a.ln_rowmax = nullptr; a.ln_ws = nullptr; a.ln_relu = 0;
+  if (ln) {
+    // the epilogue holds whole fp32 rows in one lane group; long rows (whose gradient is finished by the combine
+    // launch) and the d/dt path keep the separate LayerNorm backward
+    if (bf16 || vec != 4 || d != ((int64_t)4 << a.lpr_log2) || split || learn_t) return MLGNN_E_MODE;
+    if (!ln->h || !ln->mean || !ln->rstd || !ln->gamma || !ln->beta || !ln->grad_gamma_beta || !ln->workspace) return MLGNN_E_NULL;
+    if (ln->workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
+    if (!aligned16(ln->h) || !aligned16(ln->gamma) || !aligned16(ln->beta) || (ln->grad_extra && !aligned16(ln->grad_extra)))
+      return MLGNN_E_ALIGN;
+    a.ln_h = ln->h; a.ln_mean = ln->mean; a.ln_rstd = ln->rstd; a.ln_gamma = ln->gamma; a.ln_beta = ln->beta;
+    a.ln_extra = ln->grad_extra; a.ln_rowmax = ln->row_max; a.ln_ws = ln->workspace; a.ln_relu = ln->relu;
+  }
   a.gt = nullptr; a.spread = nullptr;
   if (have_shift) {
     if (!aligned16(grad_shifted) && vec != 1) return MLGNN_E_ALIGN;
@@ -608,6 +744,9 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
           if (fixed_grid > 0) g = fixed_grid; else launched_blocks = g;
           hipLaunchKernelGGL(kernel, dim3(g), block, 0, s, args);
         };
+        if constexpr (std::is_same<T, float>::value && VEC == 4 && !VIRT) {
+          if (ln) { go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false, VIRT, true>, IC<2>{}); return; }
+        }
         if (kCanLearn && lt) go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, kCanLearn, VIRT>, BC<true>{});
         else go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false, VIRT>, BC<false>{});
       };
@@ -637,5 +776,53 @@ extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, cons
     launch_reduce_partials(workspace, grad_uv, total_blocks, (rk + 1) * (int)d, s);
     err = (int)hipGetLastError();
   }
+  if (ln && !err) {
+    launch_reduce_partials(ln->workspace, ln->grad_gamma_beta, launched_blocks, 2 * (int)d, s);
+    err = (int)hipGetLastError();
+  }
   return err;
+}
+
+extern "C" int mlgnn_csr_aggregate_bwd(const void* grad_out, const void* x, const void* out, const float* aux,
+                                       const int32_t* argmax,
+                                       const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
+                                       const int32_t* rowptr,
+                                       const float* ew_t, const float* eu, const float* ev,
+                                       const void* efull, const int32_t* eid_t, const int32_t* geid_t,
+                                       void* grad_x, void* grad_efull, float* grad_uv,
+                                       float* workspace, int64_t workspace_floats,
+                                       int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
+                                       int aggr, int learn_t, float t, float p, const float* t_dev,
+                                       const float* p_dev, float eps, int add_root, int accumulate_efull,
+                                       const mlgnn_hub_t* hub, const void* grad_shifted, const int32_t* shift_flag,
+                                       void* stream) {
+  return csr_aggregate_bwd_impl(grad_out, x, out, aux, argmax, rowptr_t, col_t, pos_t, rowptr, ew_t, eu, ev, efull, eid_t,
+                                geid_t, grad_x, grad_efull, grad_uv, workspace, workspace_floats, N, d, dtype, msg, edge_mode,
+                                edge_rank, aggr, learn_t, t, p, t_dev, p_dev, eps, add_root, accumulate_efull, hub,
+                                grad_shifted, shift_flag, nullptr, stream);
+}
+
+extern "C" int64_t mlgnn_csr_aggregate_bwd_ln_workspace_floats(int64_t N, int64_t d) {
+  if (N < 0 || d <= 0 || N > INT32_MAX) return MLGNN_E_SHAPE;
+  return (int64_t)grid_for_rows(N) * 2 * d;
+}
+
+extern "C" int mlgnn_csr_aggregate_bwd_ln(const void* grad_out, const void* x, const void* out, const float* aux,
+                                          const int32_t* argmax,
+                                          const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
+                                          const int32_t* rowptr,
+                                          const float* ew_t, const float* eu, const float* ev,
+                                          const void* efull, const int32_t* eid_t, const int32_t* geid_t,
+                                          void* grad_x, void* grad_efull, float* grad_uv,
+                                          float* workspace, int64_t workspace_floats,
+                                          int64_t N, int64_t d, int dtype, int msg, int edge_mode, int edge_rank,
+                                          int aggr, int learn_t, float t, float p, const float* t_dev,
+                                          const float* p_dev, float eps, int add_root, int accumulate_efull,
+                                          const mlgnn_hub_t* hub, const void* grad_shifted, const int32_t* shift_flag,
+                                          const mlgnn_ln_fold_t* ln, void* stream) {
+  if (!ln) return MLGNN_E_NULL;
+  return csr_aggregate_bwd_impl(grad_out, x, out, aux, argmax, rowptr_t, col_t, pos_t, rowptr, ew_t, eu, ev, efull, eid_t,
+                                geid_t, grad_x, grad_efull, grad_uv, workspace, workspace_floats, N, d, dtype, msg, edge_mode,
+                                edge_rank, aggr, learn_t, t, p, t_dev, p_dev, eps, add_root, accumulate_efull, hub,
+                                grad_shifted, shift_flag, ln, stream);
 }

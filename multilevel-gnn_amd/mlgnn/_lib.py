@@ -21,6 +21,11 @@ SIGNATURES = {
                                        _P, _P, _P, _P, _I64,
                                        _I64, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _INT, _P,
                                        _P, _P, _P]),
+    "mlgnn_csr_aggregate_bwd_ln_workspace_floats": (_I64, [_I64, _I64]),
+    "mlgnn_csr_aggregate_bwd_ln": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                          _P, _P, _P, _P, _I64,
+                                          _I64, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _INT, _P,
+                                          _P, _P, _P, _P]),
     "mlgnn_embedding_bwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -90,6 +95,12 @@ class HubStruct(_c.Structure):
     """``mlgnn_hub_t`` (include/mlgnn.h)."""
     _fields_ = [("cap", _c.c_int32), ("capacity", _c.c_int32), ("vrows", _P), ("hubs", _P), ("counts", _P),
                 ("tmp", _P), ("tmp_bytes", _I64)]
+
+
+class LnFoldStruct(_c.Structure):
+    """``mlgnn_ln_fold_t`` (include/mlgnn.h)."""
+    _fields_ = [("h", _P), ("mean", _P), ("rstd", _P), ("gamma", _P), ("beta", _P), ("grad_extra", _P), ("row_max", _P),
+                ("grad_gamma_beta", _P), ("workspace", _P), ("workspace_floats", _I64), ("relu", _c.c_int32)]
 
 
 ERRORS = {-1: "MLGNN_E_NULL", -2: "MLGNN_E_SHAPE", -3: "MLGNN_E_MODE", -4: "MLGNN_E_DTYPE",

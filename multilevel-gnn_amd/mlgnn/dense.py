@@ -291,10 +291,14 @@ class _FusedMLP2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, gamma, beta, w2, b2, residual, eps, post_gamma=None, post_beta=None, post_eps=0.0,
                 post_relu=False):
-        from .ops import row_max_of as _rm, softmax_lse_of
+        from .ops import LN_FOLD, PostLN, row_max_of as _rm, softmax_lse_of
         # x is the output of a softmax aggregation: its backward wants go * 2^(-lse), which the input-gradient GEMM
         # below can write next to go
         ctx.shift_src = softmax_lse_of(x) if x.is_contiguous() else None
+        # the residual is the `h` of an earlier op's (h, relu(LayerNorm(h))): its gradient can ride that LayerNorm's
+        # backward instead of being returned (mlgnn.ops.PostLN)
+        ctx.res_tag = getattr(residual, "_mlgnn_post_ln_of", None) if (LN_FOLD and residual is not None) else None
+        ctx.post_tag = None
         x = x.contiguous()
         xhat, rstd, rmax = tall_matmul_nt(x, w1, b1, None, _rm(x), ln=("out", gamma, beta, eps))
         fuse = residual is not None and w2.shape[0] <= 128
@@ -309,6 +313,9 @@ class _FusedMLP2(torch.autograd.Function):
             ctx.post_dtype = post_gamma.dtype
             ctx.set_materialize_grads(False)
             ctx.save_for_backward(x, xhat, rstd, w1, w2, gamma, beta, out, mean2, rstd2, post_gamma, post_beta)
+            if LN_FOLD and post_gamma.dtype == torch.float32:
+                # (detached alias of `out`: the tag is held by this node, and `out` itself points back to it)
+                ctx.post_tag = PostLN(out.detach(), mean2, rstd2, post_gamma.detach(), post_beta.detach(), post_relu)
             return out, y
         out = tall_matmul_nt(xhat, w2, b2, residual if fuse else None, rmax, ln=("in", gamma, beta))
         if residual is not None and not fuse:
@@ -320,15 +327,41 @@ class _FusedMLP2(torch.autograd.Function):
     def backward(ctx, go, go_y=None):
         from .norm import ln_backward_normalised, ln_backward_saved
         from .ops import row_max_of as _rm
+        from .ops import tag_row_max
         gpg = gpb = None
         if ctx.post:
             x, xhat, rstd, w1, w2, gamma, beta, out, mean2, rstd2, pg, pb = ctx.saved_tensors
+            # what the consumers of (out, y) left in the side channel (mlgnn.ops.PostLN): the aggregation that read y
+            # may already have taken its gradient through this LayerNorm's backward, and the op that added `out` as its
+            # residual may have parked that branch's gradient there
+            tag, folded, pending = ctx.post_tag, None, None
+            if tag is not None:
+                folded, tag.folded = tag.folded, None
+                if tag.extra is not None and not (folded is not None and tag.extra_used):
+                    pending = tag.extra
+                tag.extra, tag.extra_used = None, False
+            g_out = rmax = None
+            if folded is not None:
+                g_out, gpg, gpb, rmax = folded
             if go_y is not None:
-                # LayerNorm (+ ReLU) backward of y, plus the gradient that arrived on `out` itself, in one pass
-                go, gpg, gpb = ln_backward_saved(go_y, out, pg, pb, mean2, rstd2, ctx.post_relu, extra=go)
-                gpg, gpb = gpg.to(ctx.post_dtype), gpb.to(ctx.post_dtype)
-            elif go is None:
+                # LayerNorm (+ ReLU) backward of y, plus a gradient that arrived on `out` itself, in one pass
+                ex, go = go, None
+                if ex is None and pending is not None:
+                    ex, pending = pending, None
+                g2, gpg2, gpb2 = ln_backward_saved(go_y, out, pg, pb, mean2, rstd2, ctx.post_relu, extra=ex)
+                if g_out is None:
+                    g_out, gpg, gpb = g2, gpg2, gpb2
+                else:
+                    g_out, gpg, gpb, rmax = g_out + g2, gpg + gpg2, gpb + gpb2, None
+            for t in (go, pending):
+                if t is not None:
+                    g_out, rmax = (t, None) if g_out is None else (g_out + t, None)
+            if g_out is None:
                 return (None,) * 13
+            if rmax is not None:
+                tag_row_max(g_out, rmax)
+            go = g_out
+            gpg, gpb = (gpg.to(ctx.post_dtype), gpb.to(ctx.post_dtype)) if gpg is not None else (None, None)
         else:
             x, xhat, rstd, w1, w2, gamma, beta = ctx.saved_tensors
         has_b1, has_b2 = ctx.flags
@@ -374,8 +407,11 @@ class _FusedMLP2(torch.autograd.Function):
                     tag_shifted(gx, gt, flag, src[0])
                 else:
                     gx = tall_matmul_nt(gh, w1, row_max=gh_max, bt_transposed=True)
+        g_res = go if ctx.needs_input_grad[7] else None
+        if g_res is not None and ctx.res_tag is not None:
+            ctx.res_tag.extra, g_res = g_res, None           # added by the LayerNorm backward of the residual's producer
         return (gx, gw1, gb1 if has_b1 else None, ggamma, gbeta, gw2, gb2 if has_b2 else None,
-                go if ctx.needs_input_grad[7] else None, None, gpg, gpb, None, None)
+                g_res, None, gpg, gpb, None, None)
 
 
 def fused_mlp2_supported(x, w1, w2):
@@ -396,7 +432,12 @@ def fused_mlp2(x, w1, b1, gamma, beta, eps, w2, b2, residual=None, post_norm=Non
     if post_norm is None:
         return _FusedMLP2.apply(x, w1, b1, gamma, beta, w2, b2, residual, float(eps))
     pw, pb, peps, prelu = post_norm
-    return _FusedMLP2.apply(x, w1, b1, gamma, beta, w2, b2, residual, float(eps), pw, pb, float(peps), bool(prelu))
+    out, y = _FusedMLP2.apply(x, w1, b1, gamma, beta, w2, b2, residual, float(eps), pw, pb, float(peps), bool(prelu))
+    tag = getattr(out.grad_fn, "post_tag", None) if out.grad_fn is not None else None
+    if tag is not None:
+        from .ops import tag_post_ln
+        tag_post_ln(y, out, tag)
+    return out, y
 
 
 def fused_mlp2_post_supported(x, w1, w2, post_weight):

@@ -87,6 +87,13 @@ class CSRGraph:
         if HUB_CAP <= 0 or not self.rowptr.is_cuda or self.num_edges == 0:
             return None
         hit = self._hub.get(direction)
+        if hit is None and not self._hub:
+            # first use: both directions at once -- the backward's tables are then known hub-free (on the host, through
+            # the asynchronous count copy) by the time the backward asks, and its kernels may use the epilogues that
+            # need a row to be finished by ONE wavefront (mlgnn_csr_aggregate_bwd_ln)
+            self._hub[direction] = None
+            self.hub_tables("src" if direction == "dst" else "dst")
+            del self._hub[direction]
         if hit is None:
             from . import _lib
             cap_rows = int(_lib.lib.mlgnn_hub_capacity(self.num_edges, HUB_CAP))

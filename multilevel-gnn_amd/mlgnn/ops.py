@@ -3,6 +3,9 @@
 PyTorch owns memory and the autograd graph; every numeric step of the aggregation itself runs in
 libmlgnn.so.  All functions require CUDA(HIP) fp32 tensors and raise otherwise -- no CPU path.
 """
+import ctypes
+import os
+
 import torch
 
 from . import _lib
@@ -151,6 +154,46 @@ def shifted_of(grad, lse):
             and grad.is_contiguous() and tag[0].dtype == grad.dtype):
         return tag[0], tag[1]
     return None
+
+
+class PostLN:
+    """Side channel between the three nodes around a res+ block's pre-conv ``y = relu?(LayerNorm(h))``
+    (deepergcn.py:236-241) when ``y`` was written by the previous conv's last GEMM (:class:`mlgnn.dense._FusedMLP2`):
+
+    * the aggregation that consumes ``y`` takes the finished ``d loss / d y`` rows through the LayerNorm's backward in
+      its own row epilogue (``mlgnn_csr_aggregate_bwd_ln``), returns NO gradient for ``y`` and leaves
+      ``folded = (d loss / d h, d gamma, d beta, row maxima)`` here;
+    * the op that adds ``h`` as its residual (the same block's MLP) leaves the gradient of that identity branch in
+      ``extra`` instead of returning it, so that the epilogue above adds it in the same pass (``extra_used``);
+    * the producer of ``(h, y)`` picks both up in its backward -- and still runs the separate LayerNorm backward on
+      whatever gradient reaches ``y`` from other consumers.
+    Every field is consumed (reset) by the backward that reads it."""
+
+    def __init__(self, h, mean, rstd, gamma, beta, relu):
+        self.h, self.mean, self.rstd, self.gamma, self.beta, self.relu = h, mean, rstd, gamma, beta, bool(relu)
+        self.extra = None
+        self.extra_used = False
+        self.folded = None
+
+
+# Off by default.  Measured at BASELINE configs[1] (same-box A/B, bench.py): the epilogue costs the aggregation backward
+# 0.13-0.27 ms per launch (per row / per pair of rows, operands prefetched or not, non-temporal or not) against the
+# 0.21 ms LayerNorm-backward launch it removes -- that kernel is bound by instruction issue and by the L2 hit rate of
+# its gather, and the epilogue adds to both; the step moved by -0.1 ... +0.1 ms.  MLGNN_LN_FOLD=1 turns it on.
+LN_FOLD = os.environ.get("MLGNN_LN_FOLD", "0") == "1"
+LN_FOLD_STATS = {"folded": 0, "separate": 0}
+
+
+if os.environ.get("MLGNN_PRINT_STATS", "0") == "1":          # development: which paths a run took
+    import atexit
+    import sys
+    atexit.register(lambda: print("mlgnn stats: ln_fold %r" % (LN_FOLD_STATS,), file=sys.stderr))
+
+
+def tag_post_ln(y, h, tag):
+    y._mlgnn_post_ln = tag
+    h._mlgnn_post_ln_of = tag
+    return y
 
 
 def f32_cached(t):
@@ -383,9 +426,14 @@ class _GenAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eu, ev, efull, t_par, p_par, graph, ew_pair, aggr_id, t, p, eps, learn_t, learn_p, add_root,
                 table_edge=None):
+        post_ln = getattr(x, "_mlgnn_post_ln", None)
         x = _dev_act(x, "x")
         dtype_id = _DTYPE_IDS[x.dtype]
         N, d = x.shape
+        # x = relu?(LayerNorm(h)) written by the previous conv's GEMM: its backward can run in this op's row epilogue
+        ctx.post_ln = post_ln if (LN_FOLD and post_ln is not None and add_root and not learn_t and not learn_p
+                                  and x.dtype == torch.float32 and d in (16, 32, 64, 128, 256)
+                                  and aggr_id != AGGR_POWER and post_ln.h.shape == x.shape) else None
         if graph.num_nodes != N:
             raise ValueError("graph/feature size mismatch")
         edge_mode = EDGE_RANK1 if eu is not None else (EDGE_FULL if efull is not None else EDGE_NONE)
@@ -508,15 +556,44 @@ class _GenAggregate(torch.autograd.Function):
         timer = KERNEL_TIMER
         t0 = timer.start() if timer is not None else None
         hub, hub_keep = g.hub_arg("src", d)
-        rc = _lib.lib.mlgnn_csr_aggregate_bwd(
-            go_k.data_ptr(), x.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(argmax),
-            g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(), g.rowptr.data_ptr(),
-            _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), eid_t.data_ptr(), _lib.ptr(geid_t),
-            gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
-            N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, int(learn_t), t, p,
-            _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), ge_accumulate, hub,
-            _lib.ptr(shifted[0]) if shifted else None, _lib.ptr(shifted[1]) if shifted else None, _stream())
-        _lib.check(rc, "mlgnn_csr_aggregate_bwd")
+        tag = ctx.post_ln if (hub is None and ctx.needs_input_grad[0]) else None
+        if tag is not None:
+            # d loss / d y goes through the LayerNorm backward of y = relu?(LayerNorm(h)) in the row epilogue; gx is then
+            # d loss / d h (+ the identity-branch gradient the block's MLP left in tag.extra)
+            f32 = dict(dtype=torch.float32, device=x.device)
+            ln_n = int(_lib.lib.mlgnn_csr_aggregate_bwd_ln_workspace_floats(N, d))
+            ln_ws, ggb, row_max = torch.empty(ln_n, **f32), torch.empty((2, d), **f32), torch.empty(N, **f32)
+            extra = tag.extra if (tag.extra is not None and tag.extra.dtype == torch.float32
+                                  and tag.extra.shape == x.shape and tag.extra.is_contiguous()) else None
+            gamma, beta = f32_cached(tag.gamma), f32_cached(tag.beta)
+            st = _lib.LnFoldStruct(tag.h.data_ptr(), tag.mean.data_ptr(), tag.rstd.data_ptr(), gamma.data_ptr(),
+                                   beta.data_ptr(), _lib.ptr(extra), row_max.data_ptr(), ggb.data_ptr(), ln_ws.data_ptr(),
+                                   ln_n, int(tag.relu))
+            rc = _lib.lib.mlgnn_csr_aggregate_bwd_ln(
+                go_k.data_ptr(), x.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(argmax),
+                g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(), g.rowptr.data_ptr(),
+                _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), eid_t.data_ptr(), _lib.ptr(geid_t),
+                gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
+                N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, int(learn_t), t, p,
+                _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), ge_accumulate, None,
+                _lib.ptr(shifted[0]) if shifted else None, _lib.ptr(shifted[1]) if shifted else None,
+                ctypes.byref(st), _stream())
+            _lib.check(rc, "mlgnn_csr_aggregate_bwd_ln")
+            tag.folded = (gx, ggb[0], ggb[1], row_max)
+            tag.extra_used = extra is not None
+            LN_FOLD_STATS["folded"] += 1
+            gx = None                                        # nothing reaches y through autograd: see PostLN
+        else:
+            LN_FOLD_STATS["separate"] += int(ctx.post_ln is not None)
+            rc = _lib.lib.mlgnn_csr_aggregate_bwd(
+                go_k.data_ptr(), x.data_ptr(), out.data_ptr(), _lib.ptr(aux), _lib.ptr(argmax),
+                g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(), g.rowptr.data_ptr(),
+                _lib.ptr(ew_t), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(efull), eid_t.data_ptr(), _lib.ptr(geid_t),
+                gx.data_ptr(), _lib.ptr(ge), _lib.ptr(guv), _lib.ptr(ws), ws_n,
+                N, d, dtype_id, MSG_GEN, edge_mode, rank, aggr_id, int(learn_t), t, p,
+                _lib.ptr(t_dev), _lib.ptr(p_dev), eps, int(add_root), ge_accumulate, hub,
+                _lib.ptr(shifted[0]) if shifted else None, _lib.ptr(shifted[1]) if shifted else None, _stream())
+            _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         del hub_keep
         SHIFT_STATS["given" if shifted else "computed"] += int(aggr_id == AGGR_SOFTMAX and not learn_t)
         if sink is not None or te is not None:

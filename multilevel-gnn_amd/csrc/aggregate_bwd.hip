@@ -336,7 +336,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
           for (int i = 0; i < VEC; ++i) gx[i] += gr[i];
         }
         if constexpr (VIRT) store_vec<VEC>(reinterpret_cast<float*>(a.gx) + (size_t)r * a.d + c0, gx);   // chunk partial: fp32
-        else store_t<T, VEC>(GX + (size_t)r * a.d + c0, gx);
+        else store_t<T, VEC>(GX + (size_t)r * a.d + c0, gx);     // (non-temporal measured here: 0.75 -> 0.85 ms per launch)
       }
     }
 

@@ -320,10 +320,10 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
           for (int i = 0; i < VEC; ++i) o[i] += xr[i];
         }
         if constexpr (VIRT) store_vec<VEC>(reinterpret_cast<float*>(a.out) + off, o);   // chunk partials stay fp32 (hub.hip)
-        else store_t<T, VEC>(OUT + off, o);
+        else store_t_stream<T, VEC>(OUT + off, o);
         if (AGGR == A_MAX && a.argmax) store_vec<VEC>(a.argmax + off, am);
-        if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_vec<VEC>(a.aux + off, ax);
-        if (SECOND && a.aux2) store_vec<VEC>(a.aux2 + off, ax2);
+        if ((AGGR == A_SOFTMAX || AGGR == A_POWER) && a.aux) store_t_stream<float, VEC>(a.aux + off, ax);
+        if (SECOND && a.aux2) store_t_stream<float, VEC>(a.aux2 + off, ax2);
         if (a.rowmax) {   // max |row| of the result for the consumer GEMM's per-row scaling.  Only requested when
                           // d == lpr * VEC: every lane of group 0 is in this branch, so the shuffles are defined
           float om = 0.f;

@@ -108,6 +108,33 @@ __device__ __forceinline__ void store_t(T* __restrict__ p, const float (&r)[VEC]
   }
 }
 
+// Streaming (written once, not read again by this kernel) 16-byte stores with the non-temporal hint, for kernels whose
+// speed hangs on the L2 hit rate of a gather running next to the stream (the CSR aggregations).  MLGNN_NT_STORES=0
+// compiles them as plain stores (same-box A/B through tools/build_variant.py).
+#ifndef MLGNN_NT_STORES
+#define MLGNN_NT_STORES 1
+#endif
+template <typename T, int VEC>
+__device__ __forceinline__ void store_t_stream(T* __restrict__ p, const float (&r)[VEC]) {
+#if MLGNN_NT_STORES
+  using u4 = __attribute__((ext_vector_type(4))) uint32_t;
+  if constexpr (sizeof(T) == 4 && VEC == 4) {
+    const u4 v = {__builtin_bit_cast(uint32_t, r[0]), __builtin_bit_cast(uint32_t, r[1]),
+                  __builtin_bit_cast(uint32_t, r[2]), __builtin_bit_cast(uint32_t, r[3])};
+    __builtin_nontemporal_store(v, reinterpret_cast<u4*>(p));
+  } else if constexpr (sizeof(T) == 2 && VEC == 8) {
+    u4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (uint32_t)f32_to_bf16(r[2 * i]) | ((uint32_t)f32_to_bf16(r[2 * i + 1]) << 16);
+    __builtin_nontemporal_store(v, reinterpret_cast<u4*>(p));
+  } else {
+    store_t<T, VEC>(p, r);
+  }
+#else
+  store_t<T, VEC>(p, r);
+#endif
+}
+
 // All-reduce over the 32-lane half of a wavefront without the LDS crossbar: rotations inside each row of 16 lanes
 // are DPP modifiers of the VALU op (row_ror:8/4/2/1), only the last step (row <-> row) is a ds_bpermute.  For
 // epilogues that reduce many values per lane (a `__shfl_xor` ladder is five crossbar trips per value).

@@ -25,6 +25,20 @@ def test_device_csr_matches_host(N, E):
         assert torch.equal(a, b), f
 
 
+def test_headline_batch_shape_matches_host():
+    """64 graphs x 10 000 nodes / 160 000 edges as one block-diagonal edge list (BASELINE configs[1]): the chunk length
+    of the count / placement workgroups is at its cap here (20 edges per thread, ~500 workgroups in XCD-contiguous runs)."""
+    from mlgnn import CSRGraph
+    gen = torch.Generator().manual_seed(4)
+    B, n, e = 64, 10000, 160000
+    ei = torch.randint(0, n, (2, B, e), generator=gen) + (torch.arange(B) * n)[None, :, None]
+    ei = ei.reshape(2, B * e)
+    host = CSRGraph(ei, B * n)
+    dev = CSRGraph(ei.to("cuda:0"), B * n)
+    for f in FIELDS:
+        assert torch.equal(getattr(host, f), getattr(dev, f).cpu()), f
+
+
 @pytest.mark.parametrize("N,E,hub_in,hub_out", [(3000, 60000, 33, 64), (3000, 60000, 65, 700), (2000, 90000, 4096, 4097),
                                                (500, 70000, 20000, 15000), (64, 30000, 0, 0)])
 def test_long_rows(N, E, hub_in, hub_out):
@@ -84,3 +98,16 @@ def test_edge_table_device_gather_matches_host(r, width):
     assert torch.equal(s2.cpu()[:, 0], wide.cpu()[:, 2][g.eid_t.cpu().long()])
     d3, _ = g.edge_table(attr.double().cuda(), width)
     assert torch.equal(d3.cpu(), ref_dst)
+
+
+def test_edge_table_one_column_tail():
+    """One column, an edge count that is not a multiple of four: the 16-byte path plus its scalar tail."""
+    from mlgnn import CSRGraph
+    gen = torch.Generator().manual_seed(2)
+    N, E = 300, 4099
+    ei = torch.randint(0, N, (2, E), generator=gen)
+    attr = torch.rand(E, 1, generator=gen)
+    g = CSRGraph(ei.cuda(), N)
+    by_dst, by_src = g.edge_table(attr.cuda(), 1)
+    assert torch.equal(by_dst.cpu(), attr[g.eid.cpu().long()])
+    assert torch.equal(by_src.cpu(), attr[g.eid_t.cpu().long()])

@@ -552,7 +552,7 @@ int mlgnn_gemm_bf16_nt(const void* const* a, const void* const* b, const int64_t
 
 /*
  * dense_diff_pool for LARGE pooled graphs on the bf16 matrix cores (BASELINE configs[4]: N = 4096 nodes, K = 1024
- * clusters, C = 256 channels), one pooled graph per call.
+ * clusters, C = 256 channels); the shapes below are those of ONE pooled graph, a batch is described at the end.
  * Replaces: torch_geometric.nn.dense_diff_pool as called from DiffPoolLayer.forward (models/diff_pooling.py:59-65):
  *   S = softmax(s_logits, -1);  x_out = S^T z;  adj_out = S^T adj S;
  *   stats[0] = ||adj - S S^T||_F / numel(adj);  stats[1] = mean_n(sum_k -S log(S + 1e-15));  stats[2] = ||adj - S S^T||_F
@@ -572,6 +572,14 @@ int mlgnn_gemm_bf16_nt(const void* const* a, const void* const* b, const int64_t
  * level's adjacency is this level's adj_out (models/diff_pooling.py:116-127).
  * adj_symmetric non-zero promises adj = adj^T and saves the product adj^T S (one third of the backward).
  * workspace: mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, adj_symmetric) bytes.
+ *
+ * A batch: B >= 1 pooled graphs of one shape run as ONE grouped launch per step of the chain (grid.y = graph), not a
+ * host loop: z [B,N,C], s_logits / s_out [B,N,K], x_out [B,K,C], adj_out [B,K,K]; adj [B,N,N] when adj_batched, else
+ * ONE [N,N] adjacency shared by the batch (PyG broadcasts a 2-D adj).  stats / scal_out are the batch's scalars as the
+ * reference computes them on a batched call: ONE Frobenius norm over all graphs divided by numel(adj) of the ARGUMENT
+ * (N*N for a shared adjacency), the entropy averaged over all B*N nodes.  workspace (and `saved`): B consecutive blocks
+ * of the per-graph size.  Backward: grad_x [B,K,C], grad_adj_out [B,K,K], grad_z [B,N,C], grad_logits [B,N,K];
+ * grad_adj [B,N,N] -- one block per graph also for a shared adjacency, whose gradient is their sum (the caller's).
  */
 int mlgnn_diffpool_large_supported(int64_t N, int64_t K, int64_t C);
 int64_t mlgnn_diffpool_large_workspace_bytes(int64_t N, int64_t K, int64_t C);
@@ -579,14 +587,15 @@ int64_t mlgnn_diffpool_large_saved_bytes(int64_t N, int64_t K, int64_t C);
 int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
                              void* s_out, void* x_out, void* adj_out, void* scal_out, int out_dtype,
                              float* stats, void* workspace, int64_t workspace_bytes, int64_t N, int64_t K,
-                             int64_t C, void* stream);
+                             int64_t C, int64_t B, int adj_batched, void* stream);
 int64_t mlgnn_diffpool_large_bwd_workspace_bytes(int64_t N, int64_t K, int64_t C, int adj_symmetric);
 int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
                              const void* s_soft, const void* saved, const void* grad_x,
                              const void* grad_adj_out, int grad_dtype, const void* grad_link,
                              const void* grad_ent, int scalar_dtype, const float* stats, void* grad_z,
                              void* grad_logits, void* grad_adj, int adj_symmetric, void* workspace,
-                             int64_t workspace_bytes, int64_t N, int64_t K, int64_t C, void* stream);
+                             int64_t workspace_bytes, int64_t N, int64_t K, int64_t C, int64_t B, int adj_batched,
+                             void* stream);
 
 /*
  * Optimizer step on one flat fp32 buffer: global-norm gradient clipping + Adam with L2 weight decay, two launches.

@@ -110,6 +110,9 @@ struct DplProArgs {
   const uint16_t* z; uint16_t* Zt;
   const uint4* adj; int64_t adj_n8; float* a2_partial;
   int N, K, C, nb_sm, nb_zt, nb_sq;
+  // grouped launch: graph blockIdx.y of the batch; strides in elements of each pointer's type (ws: bytes between the
+  // per-graph workspaces that hold St, Zt and the partial sums); adj_batch graphs have an adjacency of their own
+  int64_t s_rowsK, s_z, s_adj8, ws_stride; int adj_batch;
 };
 
 constexpr int kProThreads = 1024;        // 16 wavefronts: two rows of the softmax each
@@ -121,7 +124,7 @@ constexpr int kProWide = 512, kProWidePitch = kProWide + 8;      // CH > 0: 512-
 // CH = K / 512 in {1, 2, 4}: the two rows of a wavefront stay in registers (one read of the logits, 16-byte accesses,
 // K / 512 slabs of 512 columns); CH = 0: any K (multiple of 128), rows re-read from the cache, 128-column slabs.
 template <typename T, int CH>
-__global__ __launch_bounds__(kProThreads) void dpl_prologue_kernel(const DplProArgs p) {
+__global__ __launch_bounds__(kProThreads) void dpl_prologue_kernel(const DplProArgs p_in) {
   constexpr int kLdsElems = 4 * 64 * 66 + 64;
   static_assert(kLdsElems >= kProRows * kProWidePitch && kLdsElems >= kProRows * kProPitch, "staging image");
   __shared__ __attribute__((aligned(16))) uint16_t lds_all[kLdsElems];
@@ -129,6 +132,19 @@ __global__ __launch_bounds__(kProThreads) void dpl_prologue_kernel(const DplProA
   __shared__ float wsum[kProWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x;
+  DplProArgs p = p_in;
+  {
+    const int64_t bz = blockIdx.y;
+    p.logits = static_cast<const T*>(p.logits) + bz * p.s_rowsK;
+    p.S += bz * p.s_rowsK;
+    p.St += bz * (p.ws_stride / 2);
+    p.Zt += bz * (p.ws_stride / 2);
+    p.z += bz * p.s_z;
+    p.adj += bz * p.s_adj8;
+    p.ent_partial += bz * (p.ws_stride / 4);
+    p.a2_partial += bz * (p.ws_stride / 4);
+    if (b >= p.nb_sm + p.nb_zt && bz >= p.adj_batch) return;        // a shared adjacency is summed once
+  }
   if (b >= p.nb_sm + p.nb_zt) {
     float acc = wave_sum(dpl_sumsq_part(p.adj, p.adj_n8, b - p.nb_sm - p.nb_zt, p.nb_sq));
     if (lane == 0) wsum[wave] = acc;
@@ -288,9 +304,12 @@ __global__ __launch_bounds__(kProThreads) void dpl_prologue_kernel(const DplProA
 template <typename T>
 __global__ __launch_bounds__(256) void dpl_softmax_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ ds_in,
                                                               const float* __restrict__ coef, T* __restrict__ dlogits,
-                                                              int N, int K) {
+                                                              int N, int K, int64_t ds_stride) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float c_ent = coef[1];
+  logits += (size_t)blockIdx.y * N * K;                             // graph of a grouped launch
+  dlogits += (size_t)blockIdx.y * N * K;
+  ds_in += (size_t)blockIdx.y * ds_stride;
   for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
     const T* lr = logits + (size_t)row * K;
     const float* dr = ds_in + (size_t)row * K;
@@ -346,6 +365,9 @@ struct DplFinalArgs {
   const float* g2; int n_g2;          // ||S^T S||_F^2 partials
   const float* ent; int n_ent;        // entropy partials
   float* stats; void* scal_out; int scal_f32; float inv_numel; float inv_rows;
+  // a batch: the partial sums of graph b sit ws_floats further on (a2: only the first adj_batch graphs have their own);
+  // the reference takes ONE Frobenius norm over the whole batch and the mean entropy over all its nodes
+  int batch, adj_batch; int64_t ws_floats;
 };
 
 __device__ float dpl_block_sum(const float* p, int n, float* sh) {
@@ -359,12 +381,16 @@ __device__ float dpl_block_sum(const float* p, int n, float* sh) {
 }
 
 __device__ void dpl_final(const DplFinalArgs& p, float* sh) {
-  const float a2 = dpl_block_sum(p.a2, p.n_a2, sh);
-  const float dot = dpl_block_sum(p.dot, p.n_dot, sh);
-  const float g2 = dpl_block_sum(p.g2, p.n_g2, sh);
-  const float ent = dpl_block_sum(p.ent, p.n_ent, sh);
+  float sq = 0.f, ent = 0.f;
+  for (int b = 0; b < p.batch; ++b) {
+    const int64_t o = (int64_t)b * p.ws_floats;
+    const float a2 = dpl_block_sum(p.a2 + (b < p.adj_batch ? o : 0), p.n_a2, sh);
+    const float dot = dpl_block_sum(p.dot + o, p.n_dot, sh);
+    const float g2 = dpl_block_sum(p.g2 + o, p.n_g2, sh);
+    ent += dpl_block_sum(p.ent + o, p.n_ent, sh);
+    sq += fmaxf(a2 - 2.f * dot + g2, 0.f);
+  }
   if (threadIdx.x == 0) {
-    const float sq = fmaxf(a2 - 2.f * dot + g2, 0.f);
     const float norm = sqrtf(sq);
     p.stats[0] = norm * p.inv_numel;
     p.stats[1] = ent * p.inv_rows;
@@ -396,9 +422,19 @@ struct SlabReduceArgs {
   void* ca; int64_t lda; int ca_f32;
   uint16_t* cb; int64_t ldb; float* sq_partial;
   void* cc; int64_t ldc; int cc_f32;
+  int64_t s_ca, s_cc, ws_stride;       // grouped launch: element strides of ca / cc, bytes between per-graph workspaces
 };
 
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs p) {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs p_in) {
+  SlabReduceArgs p = p_in;
+  {
+    const int64_t bz = blockIdx.y;
+    p.slab += bz * (p.ws_stride / 4);
+    p.cb += bz * (p.ws_stride / 2);
+    p.sq_partial += bz * (p.ws_stride / 4);
+    p.ca = p.ca_f32 ? (void*)(static_cast<float*>(p.ca) + bz * p.s_ca) : (void*)(static_cast<uint16_t*>(p.ca) + bz * p.s_ca);
+    p.cc = p.cc_f32 ? (void*)(static_cast<float*>(p.cc) + bz * p.s_cc) : (void*)(static_cast<uint16_t*>(p.cc) + bz * p.s_cc);
+  }
   __shared__ float wsum[4];
   const int per_row = p.N / 4;
   const int64_t total = (int64_t)p.M * per_row;
@@ -442,13 +478,27 @@ struct DplPrepArgs {
   uint16_t *b1, *b2, *b3, *gxb, *gxt;
   const uint16_t* adj; uint16_t* At;
   int N, K, C, nb_ga, nb_gx, nb_at;
+  // grouped launch: bytes between the per-graph forward (G) / backward (b1 .. At) workspaces; element stride of adj
+  int64_t fws_stride, bws_stride, s_adj;
 };
 
-__global__ __launch_bounds__(256) void dpl_prep_kernel(const DplPrepArgs p) {
+__global__ __launch_bounds__(256) void dpl_prep_kernel(const DplPrepArgs p_in) {
   __shared__ __attribute__((aligned(16))) float ldsf[64 * 65];
   const int b = blockIdx.x;
+  DplPrepArgs p = p_in;
+  {
+    const int64_t bz = blockIdx.y;
+    const int64_t kk = (int64_t)p.K * p.K, kc = (int64_t)p.K * p.C;
+    p.ga = p.g_f32 ? (const void*)(static_cast<const float*>(p.ga) + bz * kk) : (const void*)(static_cast<const uint16_t*>(p.ga) + bz * kk);
+    p.gx = p.g_f32 ? (const void*)(static_cast<const float*>(p.gx) + bz * kc) : (const void*)(static_cast<const uint16_t*>(p.gx) + bz * kc);
+    p.G += bz * (p.fws_stride / 2);
+    const int64_t o = bz * (p.bws_stride / 2);
+    p.b1 += o; p.b2 += o; p.b3 += o; p.gxb += o; p.gxt += o;
+    p.adj += bz * p.s_adj;
+    if (p.At) p.At += o;
+  }
   const float c = dpl_load_dt(p.g_link, 0, p.scal_f32) * p.inv_numel / p.stats[2];
-  if (b == 0 && threadIdx.x == 0) {
+  if (b == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     p.coef[0] = c;
     p.coef[1] = dpl_load_dt(p.g_ent, 0, p.scal_f32) * p.inv_rows;
   }
@@ -586,21 +636,26 @@ extern "C" int64_t mlgnn_diffpool_large_saved_bytes(int64_t N, int64_t K, int64_
   return (int64_t)dpl_layout(N, K, C).scratch;
 }
 
-// Forward: FIVE launches -- prologue (softmax + S^T, Z^T, ||A||^2), T = A S~, [A' | G | X'] split along K, its reduce,
-// the scalars.
+// Forward: FIVE launches for a whole batch of B pooled graphs of one shape (grid.y = graph) -- prologue (softmax + S^T,
+// Z^T, ||A||^2), T = A S~, [A' | G | X'] split along K, its reduce, the scalars (ONE Frobenius norm over the batch and
+// the mean entropy over all its nodes, as the reference computes them on a batched call).
+// z [B,N,C], s_logits / s_out [B,N,K], adj [B,N,N] (adj_batched) or [N,N] shared by the batch, x_out [B,K,C],
+// adj_out [B,K,K]; workspace: B consecutive blocks of mlgnn_diffpool_large_workspace_bytes(N, K, C) bytes.
 extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
                                         void* s_out, void* x_out, void* adj_out, void* scal_out, int out_dtype,
                                         float* stats, void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int64_t C,
-                                        void* stream) {
-  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+                                        int64_t B, int adj_batched, void* stream) {
+  if (!dpl_supported(N, K, C) || B < 1 || B > 65535) return MLGNN_E_SHAPE;
   if (!z || !adj || !s_logits || !s_out || !x_out || !adj_out || !scal_out || !stats || !workspace) return MLGNN_E_NULL;
   if ((logits_dtype != MLGNN_DTYPE_F32 && logits_dtype != MLGNN_DTYPE_BF16) ||
       (out_dtype != MLGNN_DTYPE_F32 && out_dtype != MLGNN_DTYPE_BF16)) return MLGNN_E_DTYPE;
   const DplLayout L = dpl_layout(N, K, C);
-  if (workspace_bytes < (int64_t)L.total) return MLGNN_E_WORKSPACE;
+  if (workspace_bytes < (int64_t)L.total * B) return MLGNN_E_WORKSPACE;
   if (((uintptr_t)z | (uintptr_t)adj | (uintptr_t)s_out | (uintptr_t)workspace | (uintptr_t)s_logits) & 15) return MLGNN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
+  const int64_t WS = (int64_t)L.total;                // bytes between the per-graph workspaces (a multiple of 256)
+  const int batch = (int)B, adj_batch = adj_batched ? (int)B : 1;
   uint16_t* stack = (uint16_t*)(ws + L.stack);
   uint16_t* Tt = stack;                               // [K,N]
   uint16_t* St = stack + (size_t)K * N;               // [K,N]
@@ -622,7 +677,8 @@ extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const vo
   pro.adj = (const uint4*)adj; pro.adj_n8 = (int64_t)N * N / 8; pro.a2_partial = p_a2;
   pro.N = n; pro.K = k; pro.C = c;
   pro.nb_sm = n / kProRows; pro.nb_zt = ((n / 64) * (c / 64) + 3) / 4; pro.nb_sq = kDplSqBlocks;
-  const dim3 pro_grid(pro.nb_sm + pro.nb_zt + pro.nb_sq);
+  pro.s_rowsK = N * K; pro.s_z = N * C; pro.s_adj8 = adj_batched ? N * N / 8 : 0; pro.ws_stride = WS; pro.adj_batch = adj_batch;
+  const dim3 pro_grid(pro.nb_sm + pro.nb_zt + pro.nb_sq, batch);
   {
     const bool f32 = logits_dtype == MLGNN_DTYPE_F32;
     const dim3 blk(kProThreads);
@@ -641,30 +697,34 @@ extern "C" int mlgnn_diffpool_large_fwd(const void* z, const void* adj, const vo
   {
     GemmDesc d{};
     d.nseg = 1;
-    d.seg[0] = GemmSeg{(const uint16_t*)adj, St, N, N, n};
+    d.seg[0] = GemmSeg{(const uint16_t*)adj, St, N, N, n, adj_batched ? N * N : 0, WS / 2};
     d.M = n; d.N = k; d.splits = 1;
     d.c = T; d.ldc = K; d.c_f32 = 0;
     d.ct = Tt; d.ldct = N;
     d.dot = S; d.lddot = K; d.dot_partial = p_dot;
+    d.batch = batch; d.s_c = WS / 2; d.s_ct = WS / 2; d.s_dot = N * K; d.s_part = WS / 4;
     DPL_CHECK(gemm_nt_launch(d, st));
   }
   // 3. [A' | G | X'] = S~^T [T | S~ | Z]: one product over the whole stack (T^T, S~^T, Z^T are its rows), one reduce
-    {
+  {
     GemmDesc d{};
     d.nseg = 1;
-    d.seg[0] = GemmSeg{St, Tt, N, N, n};
+    d.seg[0] = GemmSeg{St, Tt, N, N, n, WS / 2, WS / 2};
     d.M = k; d.N = 2 * k + c; d.splits = L.splits_ag; d.slab = slab;
+    d.batch = batch; d.s_slab = WS / 4;
     DPL_CHECK(gemm_nt_launch(d, st));
     SlabReduceArgs r{};
     r.slab = slab; r.splits = L.splits_ag; r.M = k; r.N = 2 * k + c; r.n_a = k; r.n_b = 2 * k;
     r.ca = adj_out; r.lda = K; r.ca_f32 = out_dtype == MLGNN_DTYPE_F32;
     r.cb = G; r.ldb = K; r.sq_partial = p_g2;
     r.cc = x_out; r.ldc = C; r.cc_f32 = out_dtype == MLGNN_DTYPE_F32;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(kDplPartials), dim3(256), 0, st, r);
+    r.s_ca = K * K; r.s_cc = K * C; r.ws_stride = WS;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(kDplPartials, batch), dim3(256), 0, st, r);
   }
-  // 4. link / entropy from the partial sums
+  // 4. link / entropy from the partial sums of the whole batch; numel(adj) is the ARGUMENT's element count
   DplFinalArgs f{p_a2, kDplSqBlocks, p_dot, (int)((N / kGemmTile) * (K / kGemmTile)), p_g2, kDplPartials, p_ent, pro.nb_sm,
-                 stats, scal_out, out_dtype == MLGNN_DTYPE_F32, (float)(1.0 / ((double)N * (double)N)), (float)(1.0 / (double)N)};
+                 stats, scal_out, out_dtype == MLGNN_DTYPE_F32, (float)(1.0 / ((double)adj_batch * (double)N * (double)N)),
+                 (float)(1.0 / ((double)B * (double)N)), batch, adj_batch, WS / 4};
   hipLaunchKernelGGL(dpl_final_kernel, dim3(1), dim3(256), 0, st, f);
   return (int)hipGetLastError();
 }
@@ -681,24 +741,31 @@ extern "C" int64_t mlgnn_diffpool_large_bwd_workspace_bytes(int64_t N, int64_t K
   return (int64_t)o;
 }
 
-// Backward: FOUR launches when adj is promised symmetric (operand preparation, the four-term dS product, softmax
-// backward, dZ), one more product (T2 = A^T S~) otherwise, two more for the adjacency gradient.
+// Backward: FOUR launches for the whole batch when adj is promised symmetric (operand preparation, the four-term dS
+// product, softmax backward, dZ), one more product (T2 = A^T S~) otherwise, two more for the adjacency gradient.
+// grad_x [B,K,C], grad_adj_out [B,K,K], grad_z [B,N,C], grad_logits [B,N,K], grad_adj [B,N,N] or NULL (one [N,N] block per
+// graph also for a shared adjacency: the caller sums them); saved / workspace: B consecutive per-graph blocks.
 extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logits, int logits_dtype,
                                         const void* s_soft, const void* saved, const void* grad_x,
                                         const void* grad_adj_out, int grad_dtype, const void* grad_link,
                                         const void* grad_ent, int scalar_dtype, const float* stats, void* grad_z,
                                         void* grad_logits, void* grad_adj, int adj_symmetric, void* workspace,
-                                        int64_t workspace_bytes, int64_t N, int64_t K, int64_t C, void* stream) {
-  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+                                        int64_t workspace_bytes, int64_t N, int64_t K, int64_t C, int64_t B, int adj_batched,
+                                        void* stream) {
+  if (!dpl_supported(N, K, C) || B < 1 || B > 65535) return MLGNN_E_SHAPE;
   if (!z || !adj || !s_logits || !s_soft || !saved || !grad_x || !grad_adj_out || !grad_link || !grad_ent || !stats ||
       !grad_z || !grad_logits || !workspace) return MLGNN_E_NULL;
   if (scalar_dtype != MLGNN_DTYPE_F32 && scalar_dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if ((logits_dtype != MLGNN_DTYPE_F32 && logits_dtype != MLGNN_DTYPE_BF16) ||
       (grad_dtype != MLGNN_DTYPE_F32 && grad_dtype != MLGNN_DTYPE_BF16)) return MLGNN_E_DTYPE;
-  if (workspace_bytes < mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, adj_symmetric)) return MLGNN_E_WORKSPACE;
+  const int64_t W = mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, adj_symmetric);
+  if (workspace_bytes < W * B) return MLGNN_E_WORKSPACE;
   if (((uintptr_t)s_logits | (uintptr_t)grad_logits | (uintptr_t)workspace | (uintptr_t)adj | (uintptr_t)grad_x |
        (uintptr_t)grad_adj_out | (uintptr_t)grad_z) & 15) return MLGNN_E_ALIGN;
   const DplLayout L = dpl_layout(N, K, C);
+  const int64_t WS = (int64_t)L.total;
+  const int batch = (int)B;
+  const int64_t s_adj = adj_batched ? N * N : 0;
   hipStream_t st = (hipStream_t)stream;
   const unsigned char* sv = (const unsigned char*)saved;
   const uint16_t* stack = (const uint16_t*)(sv + L.stack);
@@ -710,7 +777,7 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
   unsigned char* ws = (unsigned char*)workspace;
   size_t o = 0;
   auto take = [&](size_t bytes) { unsigned char* p = ws + o; o += dpl_align(bytes); return p; };
-  float* coef = (float*)take(16);
+  float* coef = (float*)take(16);                     // (the first graph's block; one pair of coefficients for the batch)
   uint16_t* b1 = (uint16_t*)take((size_t)K * K * 2);
   uint16_t* b2 = (uint16_t*)take((size_t)K * K * 2);
   uint16_t* b3 = (uint16_t*)take((size_t)K * K * 2);
@@ -723,56 +790,62 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
     At = (uint16_t*)take((size_t)N * N * 2);
     t2 = (uint16_t*)take((size_t)N * K * 2);
   }
+  const int adj_batch = adj_batched ? batch : 1;
   // 1. operands derived from the incoming gradients (+ A^T)
   {
     DplPrepArgs q;
     q.g_link = grad_link; q.g_ent = grad_ent; q.scal_f32 = scalar_dtype == MLGNN_DTYPE_F32; q.stats = stats; q.coef = coef;
-    q.inv_numel = (float)(1.0 / ((double)N * (double)N)); q.inv_rows = (float)(1.0 / (double)N);
+    q.inv_numel = (float)(1.0 / ((double)adj_batch * (double)N * (double)N)); q.inv_rows = (float)(1.0 / ((double)B * (double)N));
     q.ga = grad_adj_out; q.gx = grad_x; q.g_f32 = grad_dtype == MLGNN_DTYPE_F32; q.G = G;
     q.b1 = b1; q.b2 = b2; q.b3 = b3; q.gxb = gxb; q.gxt = gxt;
     q.adj = (const uint16_t*)adj; q.At = At;
     q.N = n; q.K = k; q.C = c;
     q.nb_ga = (k / 64) * (k / 64); q.nb_gx = (k / 64) * (c / 64); q.nb_at = At ? (n / 64) * (n / 64) : 0;
-    hipLaunchKernelGGL(dpl_prep_kernel, dim3(q.nb_ga + q.nb_gx + q.nb_at), dim3(256), 0, st, q);
+    q.fws_stride = WS; q.bws_stride = W; q.s_adj = s_adj;
+    hipLaunchKernelGGL(dpl_prep_kernel, dim3(q.nb_ga + q.nb_gx + q.nb_at, batch), dim3(256), 0, st, q);
   }
   const uint16_t* T2 = T;
+  int64_t s_T2 = WS / 2;
   if (!adj_symmetric) {
     GemmDesc d{};
     d.nseg = 1;
-    d.seg[0] = GemmSeg{At, St, N, N, n};
+    d.seg[0] = GemmSeg{At, St, N, N, n, W / 2, WS / 2};
     d.M = n; d.N = k; d.splits = 1;
     d.c = t2; d.ldc = K; d.c_f32 = 0;
+    d.batch = batch; d.s_c = W / 2;
     DPL_CHECK(gemm_nt_launch(d, st));
-    T2 = t2;
+    T2 = t2; s_T2 = W / 2;
   }
   // dS = Z gx^T + T (ga - cI)^T + T2 (ga^T - cI)^T + S~ (2cG)^T    (one product over the concatenated contraction range)
   {
     GemmDesc d{};
     d.nseg = 4;
-    d.seg[0] = GemmSeg{(const uint16_t*)z, gxb, C, C, c};
-    d.seg[1] = GemmSeg{T, b1, K, K, k};
-    d.seg[2] = GemmSeg{T2, b2, K, K, k};
-    d.seg[3] = GemmSeg{S, b3, K, K, k};
+    d.seg[0] = GemmSeg{(const uint16_t*)z, gxb, C, C, c, N * C, W / 2};
+    d.seg[1] = GemmSeg{T, b1, K, K, k, WS / 2, W / 2};
+    d.seg[2] = GemmSeg{T2, b2, K, K, k, s_T2, W / 2};
+    d.seg[3] = GemmSeg{S, b3, K, K, k, N * K, W / 2};
     d.M = n; d.N = k; d.splits = 1;
     d.c = dS; d.ldc = K; d.c_f32 = 1;
+    d.batch = batch; d.s_c = W / 4;
     DPL_CHECK(gemm_nt_launch(d, st));
   }
   const int sm_blocks = (int)((N + 3) / 4 < 1024 ? (N + 3) / 4 : 1024);
   if (logits_dtype == MLGNN_DTYPE_F32)
-    hipLaunchKernelGGL(dpl_softmax_bwd_kernel<float>, dim3(sm_blocks), dim3(256), 0, st, (const float*)s_logits, dS, coef,
-                       (float*)grad_logits, n, k);
+    hipLaunchKernelGGL(dpl_softmax_bwd_kernel<float>, dim3(sm_blocks, batch), dim3(256), 0, st, (const float*)s_logits, dS, coef,
+                       (float*)grad_logits, n, k, W / 4);
   else
-    hipLaunchKernelGGL(dpl_softmax_bwd_kernel<bf16_t>, dim3(sm_blocks), dim3(256), 0, st, (const bf16_t*)s_logits, dS, coef,
-                       (bf16_t*)grad_logits, n, k);
+    hipLaunchKernelGGL(dpl_softmax_bwd_kernel<bf16_t>, dim3(sm_blocks, batch), dim3(256), 0, st, (const bf16_t*)s_logits, dS,
+                       coef, (bf16_t*)grad_logits, n, k, W / 4);
   // dZ = S~ gx, written in the dtype of z (= the dtype of the logits).  One workgroup per output tile: at
   // 4096 x 256 x 1024 that is 64 workgroups for 16 K-steps -- a split along K with its slabs and reduce launch
   // (round 2) took longer than the quarter-filled chip does.
   {
     GemmDesc d{};
     d.nseg = 1;
-    d.seg[0] = GemmSeg{S, gxt, K, K, k};
+    d.seg[0] = GemmSeg{S, gxt, K, K, k, N * K, W / 2};
     d.M = n; d.N = c; d.splits = 1;
     d.c = grad_z; d.ldc = C; d.c_f32 = logits_dtype == MLGNN_DTYPE_F32;
+    d.batch = batch; d.s_c = N * C;
     DPL_CHECK(gemm_nt_launch(d, st));
   }
   // dA = S~ dA' S~^T  (through A' = S^T A S)  +  c (A - S~ S~^T)  (through the link term)
@@ -782,16 +855,18 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
     uint16_t* P = (uint16_t*)take((size_t)N * K * 2);
     GemmDesc d{};
     d.nseg = 1;
-    d.seg[0] = GemmSeg{S, b2, K, K, k};                       // S~ [N,K] x (dA'^T - cI)[K,K]^T = S~ (dA' - cI)
+    d.seg[0] = GemmSeg{S, b2, K, K, k, N * K, W / 2};         // S~ [N,K] x (dA'^T - cI)[K,K]^T = S~ (dA' - cI)
     d.M = n; d.N = k; d.splits = 1;
     d.c = P; d.ldc = K; d.c_f32 = 0;
+    d.batch = batch; d.s_c = W / 2;
     DPL_CHECK(gemm_nt_launch(d, st));
     GemmDesc e{};
     e.nseg = 1;
-    e.seg[0] = GemmSeg{P, S, K, K, k};                        // P [N,K] x S~[N,K]^T
+    e.seg[0] = GemmSeg{P, S, K, K, k, W / 2, N * K};          // P [N,K] x S~[N,K]^T
     e.M = n; e.N = n; e.splits = 1;
     e.c = grad_adj; e.ldc = N; e.c_f32 = logits_dtype == MLGNN_DTYPE_F32;
     e.aux = adj; e.ldaux = N; e.aux_f32 = 0; e.alpha = 0.f; e.alpha_dev = coef;
+    e.batch = batch; e.s_c = N * N; e.s_aux = s_adj;
     DPL_CHECK(gemm_nt_launch(e, st));
   }
   return (int)hipGetLastError();

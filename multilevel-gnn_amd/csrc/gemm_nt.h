@@ -15,6 +15,7 @@ struct GemmSeg {
   const uint16_t* b;
   int64_t lda, ldb;
   int K;
+  int64_t sa, sb;            // grouped launch: element offset of operand A / B from one problem of the batch to the next
 };
 
 struct GemmDesc {
@@ -29,6 +30,10 @@ struct GemmDesc {
   const void* aux; int64_t ldaux; int aux_f32; float alpha;   // C = acc + alpha * aux[M,N]
   const float* alpha_dev;                                     // non-NULL: alpha is read from the device instead
   const uint16_t* dot; int64_t lddot; float* dot_partial;     // dot_partial[workgroup] = sum_ij dot[i][j] * acc[i][j]
+  // grouped launch (B > 1 pooled graphs of one shape, models/diff_pooling.py:59-65 on a batch): `batch` problems run as
+  // grid.y of ONE launch; every pointer above advances by its stride (in elements of its own type; 0 = shared)
+  int batch;
+  int64_t s_slab, s_c, s_ct, s_aux, s_dot, s_part;
 };
 
 // number of workgroups (= dot partials) a descriptor launches

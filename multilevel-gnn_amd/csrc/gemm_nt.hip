@@ -107,6 +107,7 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
   const int t_begin = (int)((int64_t)p.ktiles * split / p.d.splits);
   const int t_end = (int)((int64_t)p.ktiles * (split + 1) / p.d.splits);
   const int T = t_end - t_begin;
+  const int64_t bz = blockIdx.y;                                  // problem of a grouped launch
 
   if (wave >= kGConsumers) {
     // ================= loader waves: nothing but LDS-DMA issue, so that a full memory queue never holds up an MFMA
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
     int64_t step_a, step_b;                                       // 32 rows
     auto enter_segment = [&](int s, int k_tile) {
       const GemmSeg& g = p.d.seg[s];
-      pa = g.a + (int64_t)(m0 + row0) * g.lda + (int64_t)k_tile * kGemmBK + chunk0 * 8;
-      pb = g.b + (int64_t)(n0 + row0) * g.ldb + (int64_t)k_tile * kGemmBK + chunk0 * 8;
+      pa = g.a + bz * g.sa + (int64_t)(m0 + row0) * g.lda + (int64_t)k_tile * kGemmBK + chunk0 * 8;
+      pb = g.b + bz * g.sb + (int64_t)(n0 + row0) * g.ldb + (int64_t)k_tile * kGemmBK + chunk0 * 8;
       step_a = 32 * g.lda;
       step_b = 32 * g.ldb;
       seg_left = g.K / kGemmBK - k_tile;
@@ -248,33 +249,34 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
   }
 
   if (p.d.slab) {
-    float* slab = p.d.slab + (size_t)split * p.d.M * p.d.N;
+    float* slab = p.d.slab + bz * p.d.s_slab + (size_t)split * p.d.M * p.d.N;
     MLGNN_FOR_ACC(slab[(size_t)row * p.d.N + col] = v;)
     return;
   }
   if (p.d.dot || p.d.ct) __syncthreads();                         // every wave has read its last fragments: LDS is free
   if (p.d.dot) {
     float part = 0.f;
-    MLGNN_FOR_ACC(part += v * bf16_to_f32(p.d.dot[(size_t)row * p.d.lddot + col]);)
+    const uint16_t* dotp = p.d.dot + bz * p.d.s_dot;
+    MLGNN_FOR_ACC(part += v * bf16_to_f32(dotp[(size_t)row * p.d.lddot + col]);)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
     float* wsum = reinterpret_cast<float*>(smem + 40960);        // behind the transposed staging image
     if (lane == 0) wsum[wave] = part;
     __syncthreads();
-    if (threadIdx.x == 0) p.d.dot_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (threadIdx.x == 0) p.d.dot_partial[bz * p.d.s_part + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
   }
   if (p.d.aux) {
     const float alpha = p.d.alpha_dev ? *p.d.alpha_dev : p.d.alpha;
     MLGNN_FOR_ACC(
-        const size_t at = (size_t)row * p.d.ldaux + col;
+        const size_t at = (size_t)(bz * p.d.s_aux) + (size_t)row * p.d.ldaux + col;
         v += alpha * (p.d.aux_f32 ? reinterpret_cast<const float*>(p.d.aux)[at]
                                                    : bf16_to_f32(reinterpret_cast<const uint16_t*>(p.d.aux)[at]));)
   }
   if (p.d.c) {
     if (p.d.c_f32) {
-      MLGNN_FOR_ACC(reinterpret_cast<float*>(p.d.c)[(size_t)row * p.d.ldc + col] = v;)
+      MLGNN_FOR_ACC(reinterpret_cast<float*>(p.d.c)[(size_t)(bz * p.d.s_c) + (size_t)row * p.d.ldc + col] = v;)
     } else {
-      MLGNN_FOR_ACC(reinterpret_cast<uint16_t*>(p.d.c)[(size_t)row * p.d.ldc + col] = f32_to_bf16(v);)
+      MLGNN_FOR_ACC(reinterpret_cast<uint16_t*>(p.d.c)[(size_t)(bz * p.d.s_c) + (size_t)row * p.d.ldc + col] = f32_to_bf16(v);)
     }
   }
   if (p.d.ct) {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_kernel(const GemmArgs p) {
     for (int pass = 0; pass < 8; ++pass) {
       const int n = pass * 16 + (threadIdx.x >> 4), ch = threadIdx.x & 15;
       const uint4 v = *reinterpret_cast<const uint4*>(img + n * kGCtPitch + ch * 16);
-      *reinterpret_cast<uint4*>(p.d.ct + (size_t)(n0 + n) * p.d.ldct + m0 + ch * 8) = v;
+      *reinterpret_cast<uint4*>(p.d.ct + bz * p.d.s_ct + (size_t)(n0 + n) * p.d.ldct + m0 + ch * 8) = v;
     }
   }
 #undef MLGNN_FOR_ACC
@@ -328,7 +330,13 @@ int gemm_nt_launch(const GemmDesc& d, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<kStages>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<kStages>), dim3(gemm_nt_workgroups(d)), dim3(kGThreads), lds, s, p);
+  if (d.batch > 1) {          // every problem's operands and results must keep the 16-byte alignment checked above
+    for (int i = 0; i < d.nseg; ++i)
+      if (d.seg[i].sa % 8 || d.seg[i].sb % 8) return MLGNN_E_ALIGN;
+    if (d.s_ct % 8) return MLGNN_E_ALIGN;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<kStages>), dim3(gemm_nt_workgroups(d), d.batch > 1 ? d.batch : 1), dim3(kGThreads), lds,
+                     s, p);
   return (int)hipGetLastError();
 }
 

@@ -75,10 +75,10 @@ SIGNATURES = {
     "mlgnn_diffpool_large_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_diffpool_large_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "mlgnn_diffpool_large_saved_bytes": (_I64, [_I64, _I64, _I64]),
-    "mlgnn_diffpool_large_fwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_diffpool_large_fwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_diffpool_large_bwd_workspace_bytes": (_I64, [_I64, _I64, _I64, _INT]),
     "mlgnn_diffpool_large_bwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _I64,
-                                        _I64, _I64, _I64, _P]),
+                                        _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_adam_workspace_floats": (_I64, []),
     "mlgnn_adam_step": (_INT, [_P, _P, _P, _P, _I64, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
     "mlgnn_hub_capacity": (_I64, [_I64, _INT]),

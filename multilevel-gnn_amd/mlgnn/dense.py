@@ -581,58 +581,65 @@ class _DiffPoolFused(torch.autograd.Function):
 
 
 class _DiffPoolLarge(torch.autograd.Function):
-    """One pooled graph past the fused small-graph kernel (BASELINE configs[4]: 4096 nodes, 1024 clusters): the chain of
-    large bf16 products on the matrix cores, ``mlgnn_diffpool_large_fwd`` / ``_bwd`` (csrc/diffpool_large.hip)."""
+    """Pooled graphs past the fused small-graph kernel (BASELINE configs[4]: 4096 nodes, 1024 clusters): the chain of
+    large bf16 products on the matrix cores, ``mlgnn_diffpool_large_fwd`` / ``_bwd`` (csrc/diffpool_large.hip).  A batch
+    ``z [B,N,C]``, ``s [B,N,K]``, ``adj [B,N,N]`` or ``[1,N,N]`` (shared) runs as one grouped launch per step of the chain."""
 
     @staticmethod
     def forward(ctx, z, adj, s, adj_symmetric):
-        N, C = z.shape
-        K = s.shape[1]
+        B, N, C = z.shape
+        K = s.shape[2]
         dev = z.device
         zb = z.contiguous() if z.dtype == torch.bfloat16 else z.to(torch.bfloat16).contiguous()
         ab = adj.contiguous() if adj.dtype == torch.bfloat16 else adj.to(torch.bfloat16).contiguous()
         s = s.contiguous()
         out_dtype = z.dtype
-        S = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
-        x_out = torch.empty((K, C), dtype=out_dtype, device=dev)
-        a_out = torch.empty((K, K), dtype=out_dtype, device=dev)
+        adj_batched = int(adj.shape[0] == B and B > 1)
+        S = torch.empty((B, N, K), dtype=torch.bfloat16, device=dev)
+        x_out = torch.empty((B, K, C), dtype=out_dtype, device=dev)
+        a_out = torch.empty((B, K, K), dtype=out_dtype, device=dev)
         stats = torch.empty(3, dtype=torch.float32, device=dev)
         scal = torch.empty(2, dtype=out_dtype, device=dev)
-        ws = torch.empty(int(_lib.lib.mlgnn_diffpool_large_workspace_bytes(N, K, C)), dtype=torch.uint8, device=dev)
+        ws = torch.empty(B * int(_lib.lib.mlgnn_diffpool_large_workspace_bytes(N, K, C)), dtype=torch.uint8, device=dev)
         rc = _lib.lib.mlgnn_diffpool_large_fwd(zb.data_ptr(), ab.data_ptr(), s.data_ptr(), _dt(s), S.data_ptr(),
                                                x_out.data_ptr(), a_out.data_ptr(), scal.data_ptr(), _dt(x_out),
-                                               stats.data_ptr(), ws.data_ptr(), ws.numel(), N, K, C,
+                                               stats.data_ptr(), ws.data_ptr(), ws.numel(), N, K, C, B, adj_batched,
                                                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_diffpool_large_fwd")
         ctx.save_for_backward(zb, ab, s, S, ws, stats)
-        ctx.cfg = (bool(adj_symmetric), z.dtype)
-        ctx.adj_dtype = adj.dtype
+        ctx.cfg = (bool(adj_symmetric), z.dtype, adj_batched)
+        ctx.adj_dtype, ctx.adj_shape = adj.dtype, adj.shape
         return x_out, a_out, scal[0], scal[1]
 
     @staticmethod
     def backward(ctx, gx, ga, g_link, g_ent):
         zb, ab, s, S, ws, stats = ctx.saved_tensors
-        sym, z_dtype = ctx.cfg
-        N, C = zb.shape
-        K = S.shape[1]
+        sym, z_dtype, adj_batched = ctx.cfg
+        B, N, C = zb.shape
+        K = S.shape[2]
         dev = zb.device
         gdt = torch.float32 if gx.dtype == torch.float32 else torch.bfloat16
         gx, ga = gx.to(gdt).contiguous(), ga.to(gdt).contiguous()
         if g_link.dtype != g_ent.dtype or g_link.dtype not in (torch.float32, torch.bfloat16):
             g_link, g_ent = g_link.float(), g_ent.float()
-        gz = torch.empty((N, C), dtype=s.dtype, device=dev)
-        gs = torch.empty((N, K), dtype=s.dtype, device=dev)
+        gz = torch.empty((B, N, C), dtype=s.dtype, device=dev)
+        gs = torch.empty((B, N, K), dtype=s.dtype, device=dev)
         # the adjacency of a second pooling level is the first level's S^T A S (diff_pooling.py:116-127): its gradient
         # is two more products of the same chain
-        gadj = torch.empty((N, N), dtype=s.dtype, device=dev) if ctx.needs_input_grad[1] else None
-        wb = torch.empty(int(_lib.lib.mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, int(sym))), dtype=torch.uint8, device=dev)
+        gadj = torch.empty((B, N, N), dtype=s.dtype, device=dev) if ctx.needs_input_grad[1] else None
+        wb = torch.empty(B * int(_lib.lib.mlgnn_diffpool_large_bwd_workspace_bytes(N, K, C, int(sym))), dtype=torch.uint8,
+                         device=dev)
         rc = _lib.lib.mlgnn_diffpool_large_bwd(zb.data_ptr(), ab.data_ptr(), s.data_ptr(), _dt(s), S.data_ptr(), ws.data_ptr(),
                                                gx.data_ptr(), ga.data_ptr(), _dt(gx), g_link.data_ptr(), g_ent.data_ptr(),
                                                _dt(g_link), stats.data_ptr(), gz.data_ptr(), gs.data_ptr(), _lib.ptr(gadj),
-                                               int(sym), wb.data_ptr(), wb.numel(), N, K, C,
+                                               int(sym), wb.data_ptr(), wb.numel(), N, K, C, B, adj_batched,
                                                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_diffpool_large_bwd")
-        return gz.to(z_dtype), (gadj.to(ctx.adj_dtype) if gadj is not None else None), gs, None
+        if gadj is not None:
+            if not adj_batched and B > 1:
+                gadj = gadj.float().sum(0, keepdim=True)         # shared adjacency: the sum over the graphs that read it
+            gadj = gadj.to(ctx.adj_dtype).reshape(ctx.adj_shape)
+        return gz.to(z_dtype), gadj, gs, None
 
 
 def _dt(t):
@@ -720,10 +727,13 @@ def diff_pool_large_supported(z, adj, s):
 
 
 def _diff_pool_large(z, adj, s, adj_symmetric=False):
-    """Batch loop around the one-graph product chain; losses are combined as the reference does
-    (one Frobenius norm over the whole batch, entropy averaged over all nodes)."""
+    """bf16: the whole batch through the grouped launches of the C entry points.  fp32: a batch loop around the one-graph
+    three-term chain; losses are combined as the reference does (one Frobenius norm over the whole batch, entropy
+    averaged over all nodes)."""
     B = z.shape[0]
-    fn = _DiffPoolLarge if z.dtype == torch.bfloat16 else _DiffPoolLargeFP32
+    if z.dtype == torch.bfloat16:
+        return _DiffPoolLarge.apply(z, adj, s, adj_symmetric)        # the whole batch as grouped launches
+    fn = _DiffPoolLargeFP32
     if B == 1:
         # views, not selects: the backward of `z[0]` would allocate and fill a full-size zero tensor per operand
         N, C = z.shape[1], z.shape[2]

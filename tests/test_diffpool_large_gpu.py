@@ -49,7 +49,7 @@ def _raw_forward(z, a, s, out_dtype=torch.float32):
     ws = torch.empty(int(_lib.lib.mlgnn_diffpool_large_workspace_bytes(N, K, C)), dtype=torch.uint8, device=dev)
     rc = _lib.lib.mlgnn_diffpool_large_fwd(z.data_ptr(), a.data_ptr(), s.data_ptr(), 1, S.data_ptr(), x.data_ptr(),
                                            ao.data_ptr(), scal.data_ptr(), 0 if out_dtype == torch.float32 else 1, stats.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), N, K, C, torch.cuda.current_stream().cuda_stream)
+                                           ws.data_ptr(), ws.numel(), N, K, C, 1, 0, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_diffpool_large_fwd")
     off_t = _align((2 * K + C) * N * 2)
     stack = ws[:(2 * K + C) * N * 2].view(torch.bfloat16).view(2 * K + C, N)
@@ -151,6 +151,38 @@ def test_batched_and_reproducible():
     assert abs(float(l1) - float(rl)) <= 2.0 ** -7 * float(rl)
     assert abs(float(e1) - float(re)) <= 2.0 ** -7 * abs(float(re))
     assert float((x1.double().cpu() - rx).abs().max()) <= 2.0 ** -6 * float(rx.abs().max())
+
+
+@pytest.mark.parametrize("shared_adj", [False, True])
+def test_batch_is_one_grouped_launch_with_the_references_batch_semantics(shared_adj):
+    """B = 3 pooled graphs through the grouped launches (grid.y = graph): every graph's outputs are bitwise those of a
+    call on that graph alone, the scalars are the batch's (ONE Frobenius norm over the batch / numel of the adj ARGUMENT,
+    entropy over all nodes) and every gradient -- z, logits, and the adjacency (summed over the batch when it is shared)
+    -- matches the fp64 oracle on the batched call norm-wise within the bf16 bound."""
+    from mlgnn.dense import dense_diff_pool
+    N, K, C, B = 256, 128, 128, 3
+    zs, as_, ss = zip(*[_inputs(N, K, C, 40 + b) for b in range(B)])
+    z, s = torch.stack(zs), torch.stack(ss)
+    a = as_[0][None] if shared_adj else torch.stack(as_)
+    zd, ad, sd = z.double().requires_grad_(True), a.double().requires_grad_(True), s.double().requires_grad_(True)
+    rx, ra, rl, re = OP.dense_diff_pool(zd, ad, sd)
+    g = torch.Generator().manual_seed(8)
+    wx, wa = torch.randn(B, K, C, generator=g).double(), torch.randn(B, K, K, generator=g).double() / K
+    ((rx * wx).sum() + (ra * wa).sum() + rl * 3e4 + re * 2.0).backward()
+    zc, ac, sc = z.cuda().requires_grad_(True), a.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+    x, ao, link, ent = dense_diff_pool(zc, ac, sc)
+    assert x.shape == (B, K, C) and ao.shape == (B, K, K)
+    for b in range(B):
+        xb, ab_, _, _ = dense_diff_pool(z[b:b + 1].cuda(), a[0 if shared_adj else b][None].cuda(), s[b:b + 1].cuda())
+        assert torch.equal(x[b], xb[0]) and torch.equal(ao[b], ab_[0])
+    assert abs(float(link) - float(rl)) <= 2.0 ** -7 * float(rl)
+    assert abs(float(ent) - float(re)) <= 2.0 ** -7 * abs(float(re))
+    ((x.float() * wx.float().cuda()).sum() + (ao.float() * wa.float().cuda()).sum() + link.float() * 3e4
+     + ent.float() * 2.0).backward()
+    assert ac.grad.shape == a.shape
+    for got, ref, name in ((ac.grad, ad.grad, "grad adj"), (zc.grad, zd.grad, "grad z"), (sc.grad, sd.grad, "grad logits")):
+        err = float(torch.linalg.norm(got.double().cpu() - ref)) / float(torch.linalg.norm(ref))
+        assert err <= 2.0 ** -6, (name, err)
 
 
 def test_configs4_size_properties():

@@ -27,6 +27,7 @@ def main():
     dp = load(tag + "_diffpool_configs4.json")
     dp32 = load(tag + "_diffpool_configs4_fp32.json")
     stress = load(tag + "_stress_configs4_bf16.json")
+    csr = load(tag + "_csr_build.json")
 
     def stat(name):
         """(calls, avg ms) of the first stats row whose kernel name contains `name`."""
@@ -95,14 +96,19 @@ def main():
                         % (tag, k["F2"]["ms"], k["F1"]["ms"], k["W2"]["ms"], k["B2"]["ms"], k["W1"]["ms"], k["B1"]["ms"]))
     if dp:
         m = dp["matrix_core_chain"]
-        head.append("  configs[4] DiffPool 4096 / 1024 / 256 bf16 (`profiles/%s_diffpool_configs4.json`): forward %.3f ms, forward + "
-                    "backward %.3f ms (operator alone %.3f ms)" % (tag, m["fwd_ms"], m["fwd_bwd_ms"], m["fwd_bwd_op_ms"]))
+        head.append("  configs[4] DiffPool 4096 / 1024 / 256 bf16 (`profiles/%s_diffpool_configs4.json`): forward %.3f ms (%.0f %% of the "
+                    "dense bf16 peak on the executed FLOP), forward + backward %.3f ms (operator alone %.3f ms, %.3f with a symmetric "
+                    "adjacency)" % (tag, m["fwd_ms"], 100 * m["fwd_MFMA_utilisation_executed"], m["fwd_bwd_ms"], m["fwd_bwd_op_ms"],
+                                    m["fwd_bwd_op_ms_adj_symmetric"]))
         if dp32:
             m32 = dp32["matrix_core_chain"]
             head.append("; fp32 inputs (three-term products): %.3f / %.3f ms" % (m32["fwd_ms"], m32["fwd_bwd_ms"]))
         head.append(".")
     if stress:
         head.append("  configs[4] stress step (bf16, 28 layers, `profiles/%s_stress_configs4_bf16.json`): %.1f ms." % (tag, stress["step_ms"]))
+    if csr:
+        head.append("  Topology build of a configs[1] batch on its own (`profiles/%s_csr_build.json`): %.2f ms."
+                    % (tag, csr["csr_build_plus_edge_table_ms"]))
     headline = "".join(head)
 
     for fname in ("DESIGN.md", "README.md"):

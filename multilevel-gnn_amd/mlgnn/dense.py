@@ -198,7 +198,7 @@ def tall_matmul_supported(N, R, J, dtype=torch.float32):
 _WGRAD_EXACT = os.environ.get("MLGNN_WGRAD_EXACT", "0") == "1"        # always the exact three-way bf16 split
 
 
-def _wgrad(go, x, x_gamma=None, x_beta=None, go_max=None, x_max=None):
+def _wgrad(go, x, x_gamma=None, x_beta=None, go_max=None, x_max=None, out_dtype=None):
     """``(go^T x' [M,K], colsum go [M])`` with ``x' = x`` or ``relu(x_gamma x + x_beta)`` (``csrc/wgrad.hip``).
     ``go_max`` / ``x_max``: ``max |row|`` of ``go`` and of ``x'`` ([N] fp32, the side outputs of the kernels that produced
     them); when both are given (fp32) the kernel uses the scaled two-way fp16 split -- half the MFMAs of the exact
@@ -216,6 +216,8 @@ def _wgrad(go, x, x_gamma=None, x_beta=None, go_max=None, x_max=None):
                                      _lib.ptr(x_max), out.data_ptr(), ws.data_ptr(), n, N, M, K, dt,
                                      torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_linear_wgrad")
+    if out_dtype is not None and out_dtype != torch.float32:
+        out = out.to(out_dtype)                      # weight and bias gradient of a bf16 model: ONE converting copy
     return out[:M * K].view(M, K), out[M * K:]
 
 
@@ -266,8 +268,8 @@ class _TallLinear(torch.autograd.Function):
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if x.dtype == torch.float32 or _lib.lib.mlgnn_linear_wgrad_workspace_floats(N, M, K, _DTYPE_IDS[x.dtype]) > 0:
-                gw, gb = _wgrad(go, x, go_max=row_max_of(go), x_max=ctx.x_max)
-                gw, gb = gw.to(x.dtype), (gb.to(x.dtype) if ctx.has_bias else None)
+                gw, gb = _wgrad(go, x, go_max=row_max_of(go), x_max=ctx.x_max, out_dtype=x.dtype)
+                gb = gb if ctx.has_bias else None
             else:                                    # bf16 widths the transposed-read kernel does not tile
                 gw = go.t().mm(x)
                 gb = go.sum(0) if ctx.has_bias else None

@@ -211,6 +211,21 @@ int mlgnn_csr_aggregate_bwd_ln(const void* grad_out, const void* x, const void* 
                                void* stream);
 
 /*
+ * Backward prologue of the `power` aggregator (models/gcn_lib/sparse/torch_message.py:66-76): what
+ * mlgnn_csr_aggregate_bwd expects as grad_out for MLGNN_AGGR_POWER,
+ *     q = grad_out * mu_c^(1/p - 1) * [1e-7 <= mu <= 10] / max(deg, 1),   mu = aux of the forward, mu_c = clamp(mu, 1e-7, 10),
+ * and, when grad_p is non-NULL (learnable p; needs out and aux2 of the forward and the workspace),
+ *     grad_p[0] = sum grad_out * out * (-ln(mu_c) / p^2 + [in range] * aux2 / (p * mu_c)),
+ * in one streaming pass (fixed-order partial sums).  p: immediate, or read from p_dev (device, no host sync).
+ * grad_out, out, q: [N,d] in `dtype`; mu, aux2: [N,d] fp32; rowptr: by-destination row pointer (in-degree).
+ */
+int64_t mlgnn_power_bwd_prologue_workspace_floats(void);
+int mlgnn_power_bwd_prologue(const void* grad_out, const float* mu, const int32_t* rowptr, const void* out,
+                             const float* aux2, float p, const float* p_dev, void* q, float* grad_p,
+                             float* workspace, int64_t workspace_floats, int64_t N, int64_t d, int dtype,
+                             void* stream);
+
+/*
  * Gene -> pathway learnable-projection pooling.
  * Replaces: models/multilevel_gnn.py:212-239 (advanced-index gather, repeat, mul, permute,
  * Tensor.scatter_reduce('sum')):

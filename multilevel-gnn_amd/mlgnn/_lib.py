@@ -26,6 +26,8 @@ SIGNATURES = {
                                           _P, _P, _P, _P, _I64,
                                           _I64, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _F, _INT, _INT, _P,
                                           _P, _P, _P, _P]),
+    "mlgnn_power_bwd_prologue_workspace_floats": (_I64, []),
+    "mlgnn_power_bwd_prologue": (_INT, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_embedding_bwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,

@@ -513,14 +513,17 @@ class _GenAggregate(torch.autograd.Function):
         grad_t = grad_p = None
         go_k = go
         if aggr_id == AGGR_POWER:
-            pv = p_dev if p_dev is not None else p
-            muc = aux.clamp(POW_LO, POW_HI)
-            inr = ((aux >= POW_LO) & (aux <= POW_HI)).to(torch.float32)
-            go_k = (go.float() * torch.pow(muc, 1.0 / pv - 1.0) * inr / g.in_degree.clamp(min=1)[:, None])
-            go_k = go_k.to(x.dtype).contiguous()
+            # the cotangent through the outer power and the mean (and d loss / dp): one streaming pass (csrc/power.hip)
+            go_k = torch.empty_like(go)
+            gp = torch.empty(1, dtype=torch.float32, device=x.device) if learn_p else None
+            pw_n = int(_lib.lib.mlgnn_power_bwd_prologue_workspace_floats())
+            pw_ws = torch.empty(pw_n, dtype=torch.float32, device=x.device) if learn_p else None
+            rc = _lib.lib.mlgnn_power_bwd_prologue(go.data_ptr(), aux.data_ptr(), g.rowptr.data_ptr(), _lib.ptr(out if learn_p else None),
+                                                   _lib.ptr(aux2 if learn_p else None), float(p), _lib.ptr(p_dev), go_k.data_ptr(),
+                                                   _lib.ptr(gp), _lib.ptr(pw_ws), pw_n, N, d, dtype_id, _stream())
+            _lib.check(rc, "mlgnn_power_bwd_prologue")
             if learn_p:
-                grad_p = (go.float() * out.float() * (-torch.log(muc) / (pv * pv) + inr * aux2 / (pv * muc))).sum().reshape(1)
-                grad_p = grad_p.to(p_dev.dtype)
+                grad_p = gp.to(p_dev.dtype)
         if aggr_id == AGGR_SOFTMAX and learn_t:
             grad_t = (go.float() * (aux2 - out.float() * out.float())).sum().reshape(1).to(t_dev.dtype)
         gx = torch.empty_like(x)

@@ -50,13 +50,41 @@ __device__ __forceinline__ void ds_degrees(const float* ab, int n, float* deg, f
   }
 }
 
+// LDS images are sized by the ACTUAL (padded) widths of the call (dynamic shared memory, odd row strides so that row and
+// transposed reads stay conflict free): a 32-channel conv needs 42 KB forward / 44 KB backward instead of the 125 / 106 KB
+// of the largest supported shape, and two 16-wave workgroups then share a CU -- the 384 pooled graphs of a
+// BASELINE configs[1] batch run as one resident round instead of two.
+struct DsLds { int so, sx, np; };
+__host__ __device__ inline DsLds ds_lds(int n, int C, int O) {
+  DsLds l;
+  l.np = (n + 15) & ~15;
+  l.so = ((O + 15) & ~15) + 1;
+  l.sx = C + 1 + (C & 1);                      // odd
+  return l;
+}
+inline size_t ds_fwd_lds_bytes(int n, int C, int O) {
+  const DsLds l = ds_lds(n, C, O);
+  return ((size_t)l.np * l.so + (size_t)l.np * l.sx + l.np) * 4;
+}
+inline size_t ds_bwd_lds_bytes(int n, int C, int O, bool adj_grad) {
+  const DsLds l = ds_lds(n, C, O);
+  size_t f = (size_t)2 * l.np * l.so + 2 * l.np;
+  if (adj_grad) f += (size_t)l.np * l.so + (size_t)l.np * (l.np + 1);
+  return f * 4;
+}
+
 __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p) {
-  __shared__ float P[kDsMaxN][kDsSO];          // x W_rel^T, then the un-normalised output
-  __shared__ float X[kDsMaxN][kDsMaxC + 1];    // the pooled graph's features, staged once (both products read them)
-  __shared__ float deg[kDsMaxN];
+  extern __shared__ __attribute__((aligned(16))) float ds_smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid / kWave;
   const int n = p.n, C = p.C, O = p.O;
+  const DsLds L = ds_lds(n, C, O);
+  const int SO = L.so, SX = L.sx;
+  float* Pm_ = ds_smem;                        // [NP][SO]  x W_rel^T, then the un-normalised output
+  float* Xm_ = Pm_ + (size_t)L.np * SO;        // [NP][SX]  the pooled graph's features, staged once (both products read them)
+  float* deg = Xm_ + (size_t)L.np * SX;        // [NP]
+#define P(r, c) Pm_[(r) * SO + (c)]
+#define X(r, c) Xm_[(r) * SX + (c)]
   const float* xb = p.x + (size_t)b * n * C;
   const float* ab = p.adj + (p.adj_batched ? (size_t)b * n * n : 0);
   const int NP = (n + 15) & ~15, OP = (O + 15) & ~15;
@@ -66,17 +94,17 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
   ds_degrees(ab, n, deg, nullptr);
   for (int idx = tid; idx < NP * C; idx += kDsBlock) {               // coalesced; rows past n are zero
     const int r = idx / C, c = idx % C;
-    X[r][c] = r < n ? xb[idx] : 0.f;
+    X(r, c) = r < n ? xb[idx] : 0.f;
   }
   __syncthreads();
   // ---- P = x W_rel^T  [n, O] ----------------------------------------------------------------------
   for (int t = wave; t < Nt * Ot; t += kDsWaves) {
     const int i0 = (t / Ot) * 16, j0 = (t % Ot) * 16;
     const f32x4 acc = tile_gemm(C,
-        [&](int i, int k) { return k < C ? X[i0 + i][k] : 0.f; },
+        [&](int i, int k) { return k < C ? X(i0 + i, k) : 0.f; },
         [&](int k, int j) { return (j0 + j < O && k < C) ? p.w_rel[(size_t)(j0 + j) * C + k] : 0.f; });
 #pragma unroll
-    for (int r = 0; r < 4; ++r) P[i0 + lq * 4 + r][j0 + l15] = acc[r];
+    for (int r = 0; r < 4; ++r) P(i0 + lq * 4 + r, j0 + l15) = acc[r];
   }
   __syncthreads();
   // ---- out = (A P) / deg + x W_root^T + b: every wave owns whole tiles, written back after a barrier -----
@@ -86,9 +114,9 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
     const int i0 = (t / Ot) * 16, j0 = (t % Ot) * 16;
     f32x4 acc = tile_gemm(n,
         [&](int i, int k) { return (i0 + i < n && k < n) ? ab[(size_t)(i0 + i) * n + k] : 0.f; },
-        [&](int k, int j) { return k < n ? P[k][j0 + j] : 0.f; });
+        [&](int k, int j) { return k < n ? P(k, j0 + j) : 0.f; });
     const f32x4 root = tile_gemm(C,
-        [&](int i, int k) { return k < C ? X[i0 + i][k] : 0.f; },
+        [&](int i, int k) { return k < C ? X(i0 + i, k) : 0.f; },
         [&](int k, int j) { return (j0 + j < O && k < C) ? p.w_root[(size_t)(j0 + j) * C + k] : 0.f; });
     const float bj = (p.bias && j0 + l15 < O) ? p.bias[j0 + l15] : 0.f;
 #pragma unroll
@@ -103,12 +131,12 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
   for (int t = wave; t < Nt * Ot; t += kDsWaves, ++nk) {
     const int i0 = (t / Ot) * 16, j0 = (t % Ot) * 16;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) P[i0 + lq * 4 + r][j0 + l15] = keep[nk][r];
+    for (int r = 0; r < 4; ++r) P(i0 + lq * 4 + r, j0 + l15) = keep[nk][r];
   }
   __syncthreads();
   // ---- row normalisation and store ----------------------------------------------------------------
   for (int r = wave; r < n; r += kDsWaves) {
-    const float v = lane < O ? P[r][lane] : 0.f;              // O <= 64: one lane per output channel
+    const float v = lane < O ? P(r, lane) : 0.f;              // O <= 64: one lane per output channel
     float ss = v * v;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
@@ -117,16 +145,26 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
     if (lane == 0) p.rinv[(size_t)b * n + r] = ri;
   }
 }
+#undef P
+#undef X
 
 __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p) {
-  __shared__ float G[kDsMaxN][kDsSO];           // g = d loss / d out
-  __shared__ float GP[kDsMaxN][kDsSO];          // gP = A^T (g / deg)
-  __shared__ float Pm[kDsMaxNAdj][kDsSO];       // P = x W_rel^T        (adjacency gradient only)
-  __shared__ float M[kDsMaxNAdj][kDsMaxNAdj + 1];   // <g_i, P_j>        (adjacency gradient only)
-  __shared__ float deg[kDsMaxN], raw[kDsMaxN];
+  extern __shared__ __attribute__((aligned(16))) float ds_smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid / kWave;
   const int n = p.n, C = p.C, O = p.O;
+  const DsLds L = ds_lds(n, C, O);
+  const int SO = L.so, SM = L.np + 1;
+  float* G_ = ds_smem;                          // [NP][SO]  g = d loss / d out
+  float* GP_ = G_ + (size_t)L.np * SO;          // [NP][SO]  gP = A^T (g / deg)
+  float* deg = GP_ + (size_t)L.np * SO;         // [NP]
+  float* raw = deg + L.np;                      // [NP]
+  float* Pm_ = raw + L.np;                      // [NP][SO]  P = x W_rel^T        (adjacency gradient only)
+  float* M_ = Pm_ + (size_t)L.np * SO;          // [NP][NP+1] <g_i, P_j>          (adjacency gradient only)
+#define G(r, c) G_[(r) * SO + (c)]
+#define GP(r, c) GP_[(r) * SO + (c)]
+#define Pm(r, c) Pm_[(r) * SO + (c)]
+#define M(r, c) M_[(r) * SM + (c)]
   const float* xb = p.x + (size_t)b * n * C;
   const float* ab = p.adj + (p.adj_batched ? (size_t)b * n * n : 0);
   const float* gyb = p.gy + (size_t)b * n * O;
@@ -145,7 +183,7 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
     for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
     const float ri = r < n ? p.rinv_in[(size_t)b * n + r] : 0.f;
     const float g = p.normalize ? (gv - yv * dot) * ri : gv;
-    if (lane < OP) G[r][lane] = (r < n && lane < O) ? g : 0.f;
+    if (lane < OP) G(r, lane) = (r < n && lane < O) ? g : 0.f;
   }
   __syncthreads();
   // ---- gP = A^T (g / deg)  [n, O] ---------------------------------------------------------------------
@@ -153,9 +191,9 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
     const int i0 = (t / Ot) * 16, j0 = (t % Ot) * 16;
     const f32x4 acc = tile_gemm(n,
         [&](int i, int k) { return (i0 + i < n && k < n) ? ab[(size_t)k * n + i0 + i] : 0.f; },
-        [&](int k, int j) { return k < n ? G[k][j0 + j] / deg[k] : 0.f; });
+        [&](int k, int j) { return k < n ? G(k, j0 + j) / deg[k] : 0.f; });
 #pragma unroll
-    for (int r = 0; r < 4; ++r) GP[i0 + lq * 4 + r][j0 + l15] = acc[r];
+    for (int r = 0; r < 4; ++r) GP(i0 + lq * 4 + r, j0 + l15) = acc[r];
   }
   __syncthreads();
   // ---- gx = gP W_rel + g W_root  [n, C] ------------------------------------------------------------------
@@ -163,10 +201,10 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
   for (int t = wave; t < Nt * Ct; t += kDsWaves) {
     const int i0 = (t / Ct) * 16, c0 = (t % Ct) * 16;
     f32x4 acc = tile_gemm(O,
-        [&](int i, int k) { return k < O ? GP[i0 + i][k] : 0.f; },
+        [&](int i, int k) { return k < O ? GP(i0 + i, k) : 0.f; },
         [&](int k, int j) { return (k < O && c0 + j < C) ? p.w_rel[(size_t)k * C + c0 + j] : 0.f; });
     const f32x4 t2 = tile_gemm(O,
-        [&](int i, int k) { return k < O ? G[i0 + i][k] : 0.f; },
+        [&](int i, int k) { return k < O ? G(i0 + i, k) : 0.f; },
         [&](int k, int j) { return (k < O && c0 + j < C) ? p.w_root[(size_t)k * C + c0 + j] : 0.f; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -179,9 +217,9 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
   for (int t = wave; t < 2 * Ot * Ct; t += kDsWaves) {
     const int which = t / (Ot * Ct), tt = t % (Ot * Ct);
     const int o0 = (tt / Ct) * 16, c0 = (tt % Ct) * 16;
-    float (*src)[kDsSO] = which == 0 ? GP : G;
+    const float* src = which == 0 ? GP_ : G_;
     const f32x4 acc = tile_gemm(n,
-        [&](int i, int k) { return k < n ? src[k][o0 + i] : 0.f; },
+        [&](int i, int k) { return k < n ? src[k * SO + o0 + i] : 0.f; },
         [&](int k, int j) { return (k < n && c0 + j < C) ? xb[(size_t)k * C + c0 + j] : 0.f; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -191,7 +229,7 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
   }
   for (int o = tid; o < O; o += kDsBlock) {
     float s = 0.f;
-    for (int r = 0; r < n; ++r) s += G[r][o];
+    for (int r = 0; r < n; ++r) s += G(r, o);
     wsb[(size_t)2 * O * C + o] = s;
   }
   // ---- adjacency gradient (n <= 48) ---------------------------------------------------------------------------
@@ -202,28 +240,32 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
           [&](int i, int k) { return (i0 + i < n && k < C) ? xb[(size_t)(i0 + i) * C + k] : 0.f; },
           [&](int k, int j) { return (j0 + j < O && k < C) ? p.w_rel[(size_t)(j0 + j) * C + k] : 0.f; });
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Pm[i0 + lq * 4 + r][j0 + l15] = acc[r];
+      for (int r = 0; r < 4; ++r) Pm(i0 + lq * 4 + r, j0 + l15) = acc[r];
     }
     __syncthreads();
     for (int t = wave; t < Nt * Nt; t += kDsWaves) {            // M = g P^T
       const int i0 = (t / Nt) * 16, j0 = (t % Nt) * 16;
       const f32x4 acc = tile_gemm(O,
-          [&](int i, int k) { return k < O ? G[i0 + i][k] : 0.f; },
-          [&](int k, int j) { return k < O ? Pm[j0 + j][k] : 0.f; });
+          [&](int i, int k) { return k < O ? G(i0 + i, k) : 0.f; },
+          [&](int k, int j) { return k < O ? Pm(j0 + j, k) : 0.f; });
 #pragma unroll
-      for (int r = 0; r < 4; ++r) M[i0 + lq * 4 + r][j0 + l15] = acc[r];
+      for (int r = 0; r < 4; ++r) M(i0 + lq * 4 + r, j0 + l15) = acc[r];
     }
     __syncthreads();
     float* gab = p.gadj + (size_t)b * n * n;
     for (int r = wave; r < n; r += kDsWaves) {
-      float c = lane < n ? ab[(size_t)r * n + lane] * M[r][lane] : 0.f;      // n <= 48 < 64 lanes
+      float c = lane < n ? ab[(size_t)r * n + lane] * M(r, lane) : 0.f;      // n <= 48 < 64 lanes
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
       const float ci = raw[r] > 1.0f ? c / deg[r] : 0.f;                     // clamp(rowsum, 1) passes gradient above 1
-      if (lane < n) gab[(size_t)r * n + lane] = (M[r][lane] - ci) / deg[r];
+      if (lane < n) gab[(size_t)r * n + lane] = (M(r, lane) - ci) / deg[r];
     }
   }
 }
+#undef G
+#undef GP
+#undef Pm
+#undef M
 
 static bool ds_dims_ok(int64_t n, int64_t C, int64_t O) {
   return n >= 1 && n <= kDsMaxN && C >= 1 && C <= kDsMaxC && O >= 1 && O <= kDsMaxO;
@@ -253,7 +295,14 @@ extern "C" int mlgnn_dense_sage_fwd(const void* x, const void* adj, const void* 
   a.x = (const float*)x; a.adj = (const float*)adj; a.w_rel = (const float*)w_rel; a.w_root = (const float*)w_root;
   a.bias = bias; a.y_out = (float*)y; a.rinv = rinv;
   a.n = (int)n; a.C = (int)C; a.O = (int)O; a.adj_batched = adj_batched; a.normalize = normalize;
-  hipLaunchKernelGGL(dense_sage_fwd_kernel, dim3((unsigned)B), dim3(kDsBlock), 0, (hipStream_t)stream, a);
+  const size_t lds = ds_fwd_lds_bytes((int)n, (int)C, (int)O);
+  static size_t fwd_attr = 0;                   // (idempotent: a race only repeats the call)
+  if (lds > fwd_attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_sage_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ds_fwd_lds_bytes(kDsMaxN, kDsMaxC, kDsMaxO));
+    fwd_attr = ds_fwd_lds_bytes(kDsMaxN, kDsMaxC, kDsMaxO);
+  }
+  hipLaunchKernelGGL(dense_sage_fwd_kernel, dim3((unsigned)B), dim3(kDsBlock), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -276,7 +325,15 @@ extern "C" int mlgnn_dense_sage_bwd(const void* grad_y, const void* y, const flo
   a.gy = (const float*)grad_y; a.y = (const float*)y; a.rinv_in = rinv;
   a.gx = (float*)grad_x; a.gadj = (float*)grad_adj; a.ws = workspace; a.ws_cols = cols;
   a.n = (int)n; a.C = (int)C; a.O = (int)O; a.adj_batched = adj_batched; a.normalize = normalize;
-  hipLaunchKernelGGL(dense_sage_bwd_kernel, dim3((unsigned)B), dim3(kDsBlock), 0, s, a);
+  const size_t lds = ds_bwd_lds_bytes((int)n, (int)C, (int)O, grad_adj != nullptr);
+  static size_t bwd_attr = 0;
+  if (lds > bwd_attr) {
+    const size_t most = ds_bwd_lds_bytes(kDsMaxN, kDsMaxC, kDsMaxO, false) > ds_bwd_lds_bytes(kDsMaxNAdj, kDsMaxC, kDsMaxO, true)
+                            ? ds_bwd_lds_bytes(kDsMaxN, kDsMaxC, kDsMaxO, false) : ds_bwd_lds_bytes(kDsMaxNAdj, kDsMaxC, kDsMaxO, true);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_sage_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
+    bwd_attr = most;
+  }
+  hipLaunchKernelGGL(dense_sage_bwd_kernel, dim3((unsigned)B), dim3(kDsBlock), lds, s, a);
   int err = (int)hipGetLastError();
   if (err) return err;
   launch_reduce_partials(workspace, grad_w, (int)B, cols, s);

@@ -28,15 +28,32 @@ constexpr int kDsBlock = 1024, kDsWaves = kDsBlock / kWave;
 constexpr int kDsSO = kDsMaxO + 1;            // odd LDS strides: row and transposed reads stay conflict free
 constexpr float kDsNormEps = 1e-12f;          // F.normalize eps
 
-struct DsArgs {
-  const float* x; const float* adj; const float* w_rel; const float* w_root; const float* bias;
-  const float* gy; const float* y; const float* rinv_in;
-  float* y_out; float* rinv; float* gx; float* gadj; float* ws;
+struct DsArgs {                    // x, adj, weights, gy, y, y_out, gx, gadj: T (fp32 or bf16 storage); bias, rinv, ws: fp32
+  const void* x; const void* adj; const void* w_rel; const void* w_root; const float* bias;
+  const void* gy; const void* y; const float* rinv_in;
+  void* y_out; float* rinv; void* gx; void* gadj; float* ws;
   int n; int C; int O; int adj_batched; int normalize; int ws_cols;
 };
 
+// read-only view of a T array that indexes like a float array (bf16 storage is widened on the load; every product and
+// sum below is fp32 either way, results are rounded once at the store)
+template <typename T>
+struct DsIn {
+  const T* p;
+  __device__ __forceinline__ float operator[](size_t i) const {
+    if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(p)[i];
+    else return bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+  }
+};
+template <typename T>
+__device__ __forceinline__ void ds_store(void* base, size_t i, float v) {
+  if constexpr (sizeof(T) == 4) static_cast<float*>(base)[i] = v;
+  else static_cast<uint16_t*>(base)[i] = f32_to_bf16(v);
+}
+
 // row sums of the adjacency: one wavefront per row, lanes across the columns (coalesced), shuffle reduction
-__device__ __forceinline__ void ds_degrees(const float* ab, int n, float* deg, float* raw) {
+template <typename AB>
+__device__ __forceinline__ void ds_degrees(const AB ab, int n, float* deg, float* raw) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   for (int r = wave; r < n; r += kDsWaves) {
     float s = 0.f;
@@ -73,6 +90,7 @@ inline size_t ds_bwd_lds_bytes(int n, int C, int O, bool adj_grad) {
   return f * 4;
 }
 
+template <typename T>
 __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p) {
   extern __shared__ __attribute__((aligned(16))) float ds_smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -85,8 +103,9 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
   float* deg = Xm_ + (size_t)L.np * SX;        // [NP]
 #define P(r, c) Pm_[(r) * SO + (c)]
 #define X(r, c) Xm_[(r) * SX + (c)]
-  const float* xb = p.x + (size_t)b * n * C;
-  const float* ab = p.adj + (p.adj_batched ? (size_t)b * n * n : 0);
+  const DsIn<T> xb{static_cast<const T*>(p.x) + (size_t)b * n * C};
+  const DsIn<T> ab{static_cast<const T*>(p.adj) + (p.adj_batched ? (size_t)b * n * n : 0)};
+  const DsIn<T> w_rel{static_cast<const T*>(p.w_rel)}, w_root{static_cast<const T*>(p.w_root)};
   const int NP = (n + 15) & ~15, OP = (O + 15) & ~15;
   const int Nt = NP / 16, Ot = OP / 16;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -102,7 +121,7 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
     const int i0 = (t / Ot) * 16, j0 = (t % Ot) * 16;
     const f32x4 acc = tile_gemm(C,
         [&](int i, int k) { return k < C ? X(i0 + i, k) : 0.f; },
-        [&](int k, int j) { return (j0 + j < O && k < C) ? p.w_rel[(size_t)(j0 + j) * C + k] : 0.f; });
+        [&](int k, int j) { return (j0 + j < O && k < C) ? w_rel[(size_t)(j0 + j) * C + k] : 0.f; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) P(i0 + lq * 4 + r, j0 + l15) = acc[r];
   }
@@ -117,7 +136,7 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
         [&](int k, int j) { return k < n ? P(k, j0 + j) : 0.f; });
     const f32x4 root = tile_gemm(C,
         [&](int i, int k) { return k < C ? X(i0 + i, k) : 0.f; },
-        [&](int k, int j) { return (j0 + j < O && k < C) ? p.w_root[(size_t)(j0 + j) * C + k] : 0.f; });
+        [&](int k, int j) { return (j0 + j < O && k < C) ? w_root[(size_t)(j0 + j) * C + k] : 0.f; });
     const float bj = (p.bias && j0 + l15 < O) ? p.bias[j0 + l15] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -141,13 +160,14 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
     const float ri = p.normalize ? 1.0f / fmaxf(sqrtf(ss), kDsNormEps) : 1.0f;
-    if (lane < O) p.y_out[((size_t)b * n + r) * O + lane] = v * ri;
+    if (lane < O) ds_store<T>(p.y_out, ((size_t)b * n + r) * O + lane, v * ri);
     if (lane == 0) p.rinv[(size_t)b * n + r] = ri;
   }
 }
 #undef P
 #undef X
 
+template <typename T>
 __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p) {
   extern __shared__ __attribute__((aligned(16))) float ds_smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -165,10 +185,11 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
 #define GP(r, c) GP_[(r) * SO + (c)]
 #define Pm(r, c) Pm_[(r) * SO + (c)]
 #define M(r, c) M_[(r) * SM + (c)]
-  const float* xb = p.x + (size_t)b * n * C;
-  const float* ab = p.adj + (p.adj_batched ? (size_t)b * n * n : 0);
-  const float* gyb = p.gy + (size_t)b * n * O;
-  const float* yb = p.y + (size_t)b * n * O;
+  const DsIn<T> xb{static_cast<const T*>(p.x) + (size_t)b * n * C};
+  const DsIn<T> ab{static_cast<const T*>(p.adj) + (p.adj_batched ? (size_t)b * n * n : 0)};
+  const DsIn<T> w_rel{static_cast<const T*>(p.w_rel)}, w_root{static_cast<const T*>(p.w_root)};
+  const DsIn<T> gyb{static_cast<const T*>(p.gy) + (size_t)b * n * O};
+  const DsIn<T> yb{static_cast<const T*>(p.y) + (size_t)b * n * O};
   const int NP = (n + 15) & ~15, OP = (O + 15) & ~15, CP = (C + 15) & ~15;
   const int Nt = NP / 16, Ot = OP / 16, Ct = CP / 16;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -197,19 +218,19 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
   }
   __syncthreads();
   // ---- gx = gP W_rel + g W_root  [n, C] ------------------------------------------------------------------
-  float* gxb = p.gx + (size_t)b * n * C;
+  const size_t gx_off = (size_t)b * n * C;
   for (int t = wave; t < Nt * Ct; t += kDsWaves) {
     const int i0 = (t / Ct) * 16, c0 = (t % Ct) * 16;
     f32x4 acc = tile_gemm(O,
         [&](int i, int k) { return k < O ? GP(i0 + i, k) : 0.f; },
-        [&](int k, int j) { return (k < O && c0 + j < C) ? p.w_rel[(size_t)k * C + c0 + j] : 0.f; });
+        [&](int k, int j) { return (k < O && c0 + j < C) ? w_rel[(size_t)k * C + c0 + j] : 0.f; });
     const f32x4 t2 = tile_gemm(O,
         [&](int i, int k) { return k < O ? G(i0 + i, k) : 0.f; },
-        [&](int k, int j) { return (k < O && c0 + j < C) ? p.w_root[(size_t)k * C + c0 + j] : 0.f; });
+        [&](int k, int j) { return (k < O && c0 + j < C) ? w_root[(size_t)k * C + c0 + j] : 0.f; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = i0 + lq * 4 + r, col = c0 + l15;
-      if (row < n && col < C) gxb[(size_t)row * C + col] = acc[r] + t2[r];
+      if (row < n && col < C) ds_store<T>(p.gx, gx_off + (size_t)row * C + col, acc[r] + t2[r]);
     }
   }
   // ---- weight / bias gradient partials: ws[b] = [gW_rel (O*C) | gW_root (O*C) | gb (O)] ---------------------
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
       const int i0 = (t / Ot) * 16, j0 = (t % Ot) * 16;
       const f32x4 acc = tile_gemm(C,
           [&](int i, int k) { return (i0 + i < n && k < C) ? xb[(size_t)(i0 + i) * C + k] : 0.f; },
-          [&](int k, int j) { return (j0 + j < O && k < C) ? p.w_rel[(size_t)(j0 + j) * C + k] : 0.f; });
+          [&](int k, int j) { return (j0 + j < O && k < C) ? w_rel[(size_t)(j0 + j) * C + k] : 0.f; });
 #pragma unroll
       for (int r = 0; r < 4; ++r) Pm(i0 + lq * 4 + r, j0 + l15) = acc[r];
     }
@@ -252,13 +273,13 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
       for (int r = 0; r < 4; ++r) M(i0 + lq * 4 + r, j0 + l15) = acc[r];
     }
     __syncthreads();
-    float* gab = p.gadj + (size_t)b * n * n;
+    const size_t ga_off = (size_t)b * n * n;
     for (int r = wave; r < n; r += kDsWaves) {
       float c = lane < n ? ab[(size_t)r * n + lane] * M(r, lane) : 0.f;      // n <= 48 < 64 lanes
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
       const float ci = raw[r] > 1.0f ? c / deg[r] : 0.f;                     // clamp(rowsum, 1) passes gradient above 1
-      if (lane < n) gab[(size_t)r * n + lane] = (M(r, lane) - ci) / deg[r];
+      if (lane < n) ds_store<T>(p.gadj, ga_off + (size_t)r * n + lane, (M(r, lane) - ci) / deg[r]);
     }
   }
 }
@@ -287,22 +308,24 @@ extern "C" int64_t mlgnn_dense_sage_bwd_workspace_floats(int64_t B, int64_t C, i
 extern "C" int mlgnn_dense_sage_fwd(const void* x, const void* adj, const void* w_rel, const void* w_root,
                                     const float* bias, void* y, float* rinv, int64_t B, int64_t n, int64_t C,
                                     int64_t O, int adj_batched, int normalize, int dtype, void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (B < 0 || !ds_dims_ok(n, C, O)) return MLGNN_E_SHAPE;
   if (B == 0) return 0;
   if (!x || !adj || !w_rel || !w_root || !y || !rinv) return MLGNN_E_NULL;
   DsArgs a = {};
-  a.x = (const float*)x; a.adj = (const float*)adj; a.w_rel = (const float*)w_rel; a.w_root = (const float*)w_root;
-  a.bias = bias; a.y_out = (float*)y; a.rinv = rinv;
+  a.x = x; a.adj = adj; a.w_rel = w_rel; a.w_root = w_root;
+  a.bias = bias; a.y_out = y; a.rinv = rinv;
   a.n = (int)n; a.C = (int)C; a.O = (int)O; a.adj_batched = adj_batched; a.normalize = normalize;
   const size_t lds = ds_fwd_lds_bytes((int)n, (int)C, (int)O);
   static size_t fwd_attr = 0;                   // (idempotent: a race only repeats the call)
   if (lds > fwd_attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_sage_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ds_fwd_lds_bytes(kDsMaxN, kDsMaxC, kDsMaxO));
-    fwd_attr = ds_fwd_lds_bytes(kDsMaxN, kDsMaxC, kDsMaxO);
+    const int most = (int)ds_fwd_lds_bytes(kDsMaxN, kDsMaxC, kDsMaxO);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_sage_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_sage_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    fwd_attr = (size_t)most;
   }
-  hipLaunchKernelGGL(dense_sage_fwd_kernel, dim3((unsigned)B), dim3(kDsBlock), lds, (hipStream_t)stream, a);
+  if (dtype == MLGNN_DTYPE_BF16) hipLaunchKernelGGL(dense_sage_fwd_kernel<bf16_t>, dim3((unsigned)B), dim3(kDsBlock), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(dense_sage_fwd_kernel<float>, dim3((unsigned)B), dim3(kDsBlock), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -311,7 +334,7 @@ extern "C" int mlgnn_dense_sage_bwd(const void* grad_y, const void* y, const flo
                                     void* grad_adj, float* grad_w, float* workspace, int64_t workspace_floats,
                                     int64_t B, int64_t n, int64_t C, int64_t O, int adj_batched, int normalize,
                                     int dtype, void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (B < 0 || !ds_dims_ok(n, C, O)) return MLGNN_E_SHAPE;
   if (grad_adj && n > kDsMaxNAdj) return MLGNN_E_SHAPE;
   if (!grad_w) return MLGNN_E_NULL;
@@ -321,19 +344,21 @@ extern "C" int mlgnn_dense_sage_bwd(const void* grad_y, const void* y, const flo
   if (!grad_y || !y || !rinv || !x || !adj || !w_rel || !w_root || !grad_x || !workspace) return MLGNN_E_NULL;
   if (workspace_floats < B * cols) return MLGNN_E_WORKSPACE;
   DsArgs a = {};
-  a.x = (const float*)x; a.adj = (const float*)adj; a.w_rel = (const float*)w_rel; a.w_root = (const float*)w_root;
-  a.gy = (const float*)grad_y; a.y = (const float*)y; a.rinv_in = rinv;
-  a.gx = (float*)grad_x; a.gadj = (float*)grad_adj; a.ws = workspace; a.ws_cols = cols;
+  a.x = x; a.adj = adj; a.w_rel = w_rel; a.w_root = w_root;
+  a.gy = grad_y; a.y = y; a.rinv_in = rinv;
+  a.gx = grad_x; a.gadj = grad_adj; a.ws = workspace; a.ws_cols = cols;
   a.n = (int)n; a.C = (int)C; a.O = (int)O; a.adj_batched = adj_batched; a.normalize = normalize;
   const size_t lds = ds_bwd_lds_bytes((int)n, (int)C, (int)O, grad_adj != nullptr);
   static size_t bwd_attr = 0;
   if (lds > bwd_attr) {
     const size_t most = ds_bwd_lds_bytes(kDsMaxN, kDsMaxC, kDsMaxO, false) > ds_bwd_lds_bytes(kDsMaxNAdj, kDsMaxC, kDsMaxO, true)
                             ? ds_bwd_lds_bytes(kDsMaxN, kDsMaxC, kDsMaxO, false) : ds_bwd_lds_bytes(kDsMaxNAdj, kDsMaxC, kDsMaxO, true);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_sage_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_sage_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_sage_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
     bwd_attr = most;
   }
-  hipLaunchKernelGGL(dense_sage_bwd_kernel, dim3((unsigned)B), dim3(kDsBlock), lds, s, a);
+  if (dtype == MLGNN_DTYPE_BF16) hipLaunchKernelGGL(dense_sage_bwd_kernel<bf16_t>, dim3((unsigned)B), dim3(kDsBlock), lds, s, a);
+  else hipLaunchKernelGGL(dense_sage_bwd_kernel<float>, dim3((unsigned)B), dim3(kDsBlock), lds, s, a);
   int err = (int)hipGetLastError();
   if (err) return err;
   launch_reduce_partials(workspace, grad_w, (int)B, cols, s);

@@ -18,15 +18,15 @@ namespace mlgnn {
 
 constexpr int kPUnroll = 4;
 
-struct ProjArgs {
-  const float* x; const float* w; const float* gout_t;
+struct ProjArgs {                  // x / gout_t / out are T (fp32 or bf16 storage); weights and their partials fp32
+  const void* x; const float* w; const void* gout_t;
   const int* ptr; const int* mem; const int* mem_row; const int* mem_seg;
-  float* out; float* gw_partial;
+  void* out; float* gw_partial;
   int rows; int C; int G; int lpr_log2;
 };
 
 // ---- forward: one wave per (batch, segment); out_t[seg, k, :] = sum_m x[row(m), :] * W[g(m), k]
-template <int VEC, int K>
+template <typename T, int VEC, int K>
 __global__ __launch_bounds__(kBlock) void segment_project_fwd_kernel(const ProjArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << a.lpr_log2;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void segment_project_fwd_kernel(const ProjA
             for (int k = 0; k < K; ++k) wk[u][k] = __shfl(my_w[k], src);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) xv[u][i] = 0.f;
-            if (idx < cnt && cact && row >= 0) load_vec<VEC>(xv[u], a.x + (size_t)row * a.C + c0);
+            if (idx < cnt && cact && row >= 0) load_t<T, VEC>(xv[u], static_cast<const T*>(a.x) + (size_t)row * a.C + c0);
           }
 #pragma unroll
           for (int u = 0; u < kPUnroll; ++u)
@@ -85,14 +85,14 @@ __global__ __launch_bounds__(kBlock) void segment_project_fwd_kernel(const ProjA
           for (int i = 0; i < VEC; ++i) acc[k][i] += __shfl_xor(acc[k][i], off);
       if (sub == 0 && cact) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) store_vec<VEC>(a.out + ((size_t)r * K + k) * a.C + c0, acc[k]);
+        for (int k = 0; k < K; ++k) store_t<T, VEC>(static_cast<T*>(a.out) + ((size_t)r * K + k) * a.C + c0, acc[k]);
       }
     }
   }
 }
 
 // ---- input gradient: one wave per node row; gx[row, :] = sum_{m -> row} sum_k gout_t[seg(m), k, :] * W[g(m), k]
-template <int VEC, int K>
+template <typename T, int VEC, int K>
 __global__ __launch_bounds__(kBlock) void segment_project_bwd_x_kernel(const ProjArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << a.lpr_log2;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void segment_project_bwd_x_kernel(const Pro
 #pragma unroll
             for (int k = 0; k < K; ++k) {
               float gv[VEC];
-              load_vec<VEC>(gv, a.gout_t + ((size_t)seg * K + k) * a.C + c0);
+              load_t<T, VEC>(gv, static_cast<const T*>(a.gout_t) + ((size_t)seg * K + k) * a.C + c0);
 #pragma unroll
               for (int i = 0; i < VEC; ++i) acc[i] = fmaf(gv[i], wk[k], acc[i]);
             }
@@ -142,14 +142,14 @@ __global__ __launch_bounds__(kBlock) void segment_project_bwd_x_kernel(const Pro
       for (int off = lpr; off < kWave; off <<= 1)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
-      if (sub == 0 && cact) store_vec<VEC>(a.out + (size_t)r * a.C + c0, acc);
+      if (sub == 0 && cact) store_t<T, VEC>(static_cast<T*>(a.out) + (size_t)r * a.C + c0, acc);
     }
   }
 }
 
 // ---- weight gradient: one wave per (batch, segment); gw_partial[f, k] = <x[row(f), :], gout_t[seg, k, :]>
 // (summed over the batch index by the caller).  Requires C <= 64*VEC (one channel chunk per wave).
-template <int VEC, int K>
+template <typename T, int VEC, int K>
 __global__ __launch_bounds__(kBlock) void segment_project_bwd_w_kernel(const ProjArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << a.lpr_log2;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void segment_project_bwd_w_kernel(const Pro
     for (int k = 0; k < K; ++k) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) gk[k][i] = 0.f;
-      if (cact && end > beg) load_vec<VEC>(gk[k], a.gout_t + ((size_t)r * K + k) * a.C + c0);
+      if (cact && end > beg) load_t<T, VEC>(gk[k], static_cast<const T*>(a.gout_t) + ((size_t)r * K + k) * a.C + c0);
     }
     for (int base = beg; base < end; base += kWave) {
       const int cnt = min(kWave, end - base);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void segment_project_bwd_w_kernel(const Pro
 #pragma unroll
         for (int i = 0; i < VEC; ++i) xv[i] = 0.f;
         const bool ok = idx < cnt;
-        if (ok && cact && row >= 0) load_vec<VEC>(xv, a.x + (size_t)row * a.C + c0);
+        if (ok && cact && row >= 0) load_t<T, VEC>(xv, static_cast<const T*>(a.x) + (size_t)row * a.C + c0);
         float dot[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -200,13 +200,24 @@ __global__ __launch_bounds__(kBlock) void segment_project_bwd_w_kernel(const Pro
   }
 }
 
-#define MLGNN_PROJ_LAUNCH(KERNEL, VEC, Kc, ...)                                              \
-  switch (Kc) {                                                                              \
-    case 1: hipLaunchKernelGGL((KERNEL<VEC, 1>), __VA_ARGS__); break;                        \
-    case 2: hipLaunchKernelGGL((KERNEL<VEC, 2>), __VA_ARGS__); break;                        \
-    case 3: hipLaunchKernelGGL((KERNEL<VEC, 3>), __VA_ARGS__); break;                        \
-    default: hipLaunchKernelGGL((KERNEL<VEC, 4>), __VA_ARGS__); break;                       \
+#define MLGNN_PROJ_LAUNCH(KERNEL, T, VEC, K, ...)                                            \
+  switch (K) {                                                                               \
+    case 1: hipLaunchKernelGGL((KERNEL<T, VEC, 1>), __VA_ARGS__); break;                     \
+    case 2: hipLaunchKernelGGL((KERNEL<T, VEC, 2>), __VA_ARGS__); break;                     \
+    case 3: hipLaunchKernelGGL((KERNEL<T, VEC, 3>), __VA_ARGS__); break;                     \
+    default: hipLaunchKernelGGL((KERNEL<T, VEC, 4>), __VA_ARGS__); break;                    \
   }
+// storage type x channels per lane: 16-byte accesses (4 x fp32 / 8 x bf16) when width and alignment allow, else scalar
+#define MLGNN_PROJ_DISPATCH(KERNEL, bf16, wide, K, ...)                                      \
+  do {                                                                                       \
+    if (bf16) {                                                                              \
+      if (wide) { MLGNN_PROJ_LAUNCH(KERNEL, bf16_t, 8, K, __VA_ARGS__) }                     \
+      else { MLGNN_PROJ_LAUNCH(KERNEL, bf16_t, 1, K, __VA_ARGS__) }                          \
+    } else {                                                                                 \
+      if (wide) { MLGNN_PROJ_LAUNCH(KERNEL, float, 4, K, __VA_ARGS__) }                      \
+      else { MLGNN_PROJ_LAUNCH(KERNEL, float, 1, K, __VA_ARGS__) }                           \
+    }                                                                                        \
+  } while (0)
 
 static bool p16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -218,22 +229,20 @@ extern "C" int mlgnn_segment_project_fwd(const void* x, const float* w, const in
                                          const int32_t* seg_mem, const int32_t* mem_row, void* out_t,
                                          int64_t n_segments, int64_t C, int64_t G, int64_t K, int dtype,
                                          void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (n_segments < 0 || C <= 0 || G <= 0 || K < 1 || K > 4 || n_segments > INT32_MAX) return MLGNN_E_SHAPE;
   if (n_segments == 0) return 0;
   if (!x || !w || !seg_ptr || !mem_row || !out_t) return MLGNN_E_NULL;
   ProjArgs a{};
-  a.x = (const float*)x; a.w = w; a.ptr = seg_ptr; a.mem = seg_mem; a.mem_row = mem_row;
-  a.out = (float*)out_t; a.rows = (int)n_segments; a.C = (int)C; a.G = (int)G;
+  a.x = x; a.w = w; a.ptr = seg_ptr; a.mem = seg_mem; a.mem_row = mem_row;
+  a.out = out_t; a.rows = (int)n_segments; a.C = (int)C; a.G = (int)G;
   const dim3 grid(grid_for_rows(n_segments)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
-  if (C % 4 == 0 && p16(x) && p16(out_t)) {
-    a.lpr_log2 = lanes_per_row_log2(C, 4);
-    MLGNN_PROJ_LAUNCH(segment_project_fwd_kernel, 4, (int)K, grid, block, 0, s, a)
-  } else {
-    a.lpr_log2 = lanes_per_row_log2(C, 1);
-    MLGNN_PROJ_LAUNCH(segment_project_fwd_kernel, 1, (int)K, grid, block, 0, s, a)
-  }
+  const bool bf16 = dtype == MLGNN_DTYPE_BF16;
+  const int vec = bf16 ? 8 : 4;
+  const bool wide = C % vec == 0 && p16(x) && p16(out_t);
+  a.lpr_log2 = lanes_per_row_log2(C, wide ? vec : 1);
+  MLGNN_PROJ_DISPATCH(segment_project_fwd_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -244,43 +253,35 @@ extern "C" int mlgnn_segment_project_bwd(const void* gout_t, const void* x, cons
                                          void* grad_x, float* gw_partial,
                                          int64_t n_segments, int64_t n_rows, int64_t C, int64_t G, int64_t K,
                                          int dtype, void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (n_segments < 0 || n_rows < 0 || C <= 0 || G <= 0 || K < 1 || K > 4 || n_rows > INT32_MAX ||
       n_segments > INT32_MAX) return MLGNN_E_SHAPE;
   if (!gout_t || !w) return MLGNN_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(kBlock);
-  const bool vec4 = (C % 4 == 0) && p16(gout_t) && (!x || p16(x)) && (!grad_x || p16(grad_x));
+  const bool bf16 = dtype == MLGNN_DTYPE_BF16;
+  const int vec = bf16 ? 8 : 4;
+  const bool wide = (C % vec == 0) && p16(gout_t) && (!x || p16(x)) && (!grad_x || p16(grad_x));
   if (grad_x && n_rows > 0) {
     if (!node_ptr || !mem_seg) return MLGNN_E_NULL;
     ProjArgs a{};
-    a.gout_t = (const float*)gout_t; a.w = w; a.ptr = node_ptr; a.mem = node_mem; a.mem_seg = mem_seg;
-    a.out = (float*)grad_x; a.rows = (int)n_rows; a.C = (int)C; a.G = (int)G;
+    a.gout_t = gout_t; a.w = w; a.ptr = node_ptr; a.mem = node_mem; a.mem_seg = mem_seg;
+    a.out = grad_x; a.rows = (int)n_rows; a.C = (int)C; a.G = (int)G;
     const dim3 grid(grid_for_rows(n_rows));
-    if (vec4) {
-      a.lpr_log2 = lanes_per_row_log2(C, 4);
-      MLGNN_PROJ_LAUNCH(segment_project_bwd_x_kernel, 4, (int)K, grid, block, 0, s, a)
-    } else {
-      a.lpr_log2 = lanes_per_row_log2(C, 1);
-      MLGNN_PROJ_LAUNCH(segment_project_bwd_x_kernel, 1, (int)K, grid, block, 0, s, a)
-    }
+    a.lpr_log2 = lanes_per_row_log2(C, wide ? vec : 1);
+    MLGNN_PROJ_DISPATCH(segment_project_bwd_x_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
     const int err = (int)hipGetLastError();
     if (err) return err;
   }
   if (gw_partial && n_segments > 0) {
     if (!x || !seg_ptr || !mem_row) return MLGNN_E_NULL;
-    if (C > (vec4 ? 256 : 64)) return MLGNN_E_SHAPE;      // one channel chunk per wave
+    if (C > (wide ? 64 * vec : 64)) return MLGNN_E_SHAPE;      // one channel chunk per wave
     ProjArgs a{};
-    a.gout_t = (const float*)gout_t; a.x = (const float*)x; a.ptr = seg_ptr; a.mem = seg_mem;
+    a.gout_t = gout_t; a.x = x; a.ptr = seg_ptr; a.mem = seg_mem;
     a.mem_row = mem_row; a.gw_partial = gw_partial; a.rows = (int)n_segments; a.C = (int)C; a.G = (int)G;
     const dim3 grid(grid_for_rows(n_segments));
-    if (vec4) {
-      a.lpr_log2 = lanes_per_row_log2(C, 4);
-      MLGNN_PROJ_LAUNCH(segment_project_bwd_w_kernel, 4, (int)K, grid, block, 0, s, a)
-    } else {
-      a.lpr_log2 = lanes_per_row_log2(C, 1);
-      MLGNN_PROJ_LAUNCH(segment_project_bwd_w_kernel, 1, (int)K, grid, block, 0, s, a)
-    }
+    a.lpr_log2 = lanes_per_row_log2(C, wide ? vec : 1);
+    MLGNN_PROJ_DISPATCH(segment_project_bwd_w_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
     const int err = (int)hipGetLastError();
     if (err) return err;
   }

@@ -466,7 +466,8 @@ def linear(x, weight, bias=None, residual=None):
 
 
 class _DenseSageFused(torch.autograd.Function):
-    """One fused fp32-MFMA launch per direction (``mlgnn_dense_sage_fwd`` / ``_bwd``), one workgroup per pooled graph."""
+    """One fused fp32-MFMA launch per direction (``mlgnn_dense_sage_fwd`` / ``_bwd``), one workgroup per pooled graph.
+    fp32 or bf16 storage (all of x, adj, the weights in one type; arithmetic fp32, one rounding at each store)."""
 
     @staticmethod
     def forward(ctx, x, adj, w_rel, w_root, bias, normalize):
@@ -476,9 +477,11 @@ class _DenseSageFused(torch.autograd.Function):
         batched = adj.dim() == 3 and adj.shape[0] == B and B > 1
         y = torch.empty((B, n, O), dtype=x.dtype, device=x.device)
         rinv = torch.empty((B, n), dtype=torch.float32, device=x.device)
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        bias32 = f32_cached(bias) if bias is not None else None           # the kernels add the bias in fp32
         rc = _lib.lib.mlgnn_dense_sage_fwd(x.data_ptr(), adj.data_ptr(), w_rel.data_ptr(), w_root.data_ptr(),
-                                           _lib.ptr(bias.contiguous() if bias is not None else None), y.data_ptr(),
-                                           rinv.data_ptr(), B, n, C, O, int(batched), int(normalize), 0,
+                                           _lib.ptr(bias32), y.data_ptr(),
+                                           rinv.data_ptr(), B, n, C, O, int(batched), int(normalize), _dt(x),
                                            torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_dense_sage_fwd")
         ctx.save_for_backward(x, adj, w_rel, w_root, y, rinv)
@@ -501,15 +504,17 @@ class _DenseSageFused(torch.autograd.Function):
         rc = _lib.lib.mlgnn_dense_sage_bwd(gy.data_ptr(), y.data_ptr(), rinv.data_ptr(), x.data_ptr(), adj.data_ptr(),
                                            w_rel.data_ptr(), w_root.data_ptr(), gx.data_ptr(), _lib.ptr(gadj),
                                            gw.data_ptr(), ws.data_ptr(), ws_n, B, n, C, O, int(batched),
-                                           int(normalize), 0, torch.cuda.current_stream().cuda_stream)
+                                           int(normalize), _dt(x), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_dense_sage_bwd")
         if need_adj and not batched:
-            gadj = gadj.sum(0, keepdim=True).reshape(adj.shape)          # shared adjacency
+            gadj = gadj.float().sum(0, keepdim=True).to(adj.dtype).reshape(adj.shape)          # shared adjacency
         elif need_adj:
             gadj = gadj.reshape(adj.shape)
+        if x.dtype != torch.float32:
+            gw = gw.to(x.dtype)                                           # (weight gradients: fp32 sums, one converting copy)
         g_rel = gw[:O * C].view(O, C)
         g_root = gw[O * C:2 * O * C].view(O, C)
-        g_b = gw[2 * O * C:] if has_bias else None
+        g_b = gw[2 * O * C:].to(ctx.bias_dtype) if has_bias else None
         return gx, gadj, g_rel, g_root, g_b, None
 
 
@@ -519,12 +524,11 @@ def dense_sage(x, adj, w_rel, w_root, b_root, normalize=True):
     x = x.unsqueeze(0) if x.dim() == 2 else x
     adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
     B, n, c = x.shape
-    if (x.is_cuda and x.dtype == torch.bfloat16 and adj.shape[0] in (1, B) and adj.shape[-1] == n and adj.shape[-2] == n
-            and _lib.lib.mlgnn_dense_sage_supported(n, c, w_rel.shape[0], int(adj.requires_grad))):
-        # bf16 model, small pooled graph: the fused fp32-MFMA kernel behind casts (tensors of a few hundred KB)
-        return dense_sage(x.float(), adj.float(), w_rel.float(), w_root.float(),
-                          None if b_root is None else b_root.float(), normalize).to(torch.bfloat16)
-    if (x.is_cuda and x.dtype == torch.float32 and adj.dtype == torch.float32 and adj.shape[0] in (1, B)
+    if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and adj.shape[0] in (1, B)
+            and (adj.dtype != x.dtype or w_rel.dtype != x.dtype or w_root.dtype != x.dtype)):
+        # (mixed storage types, e.g. an fp32 adjacency buffer in a bf16 model: one type for the kernel)
+        adj, w_rel, w_root = adj.to(x.dtype), w_rel.to(x.dtype), w_root.to(x.dtype)
+    if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and adj.dtype == x.dtype and adj.shape[0] in (1, B)
             and adj.shape[-1] == n and adj.shape[-2] == n
             and _lib.lib.mlgnn_dense_sage_supported(n, c, w_rel.shape[0], int(adj.requires_grad))):
         return _DenseSageFused.apply(x, adj, w_rel, w_root, b_root, bool(normalize))

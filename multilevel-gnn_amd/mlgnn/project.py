@@ -10,7 +10,7 @@ and weight gradient (``csrc/project.hip``).
 import torch
 
 from . import _lib
-from .ops import DTYPE_F32, _dev_f32, _stream
+from .ops import DTYPE_BF16, DTYPE_F32, _dev_f32, _stream
 
 
 class Membership:
@@ -69,17 +69,28 @@ def membership_tables(gene_pca_match, raw_indice, nodes_per_graph, n_segments, n
 class _SegmentProject(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, tables):
-        x, w = _dev_f32(x, "x"), _dev_f32(w, "weights")
+        # rows in the model's storage type (fp32 or bf16: the kernels accumulate in fp32 either way and round once at
+        # the store); the projection weights and their gradient partials stay fp32
+        if x.dtype == torch.bfloat16:
+            if not x.is_cuda:
+                raise RuntimeError("x must be a CUDA tensor (no CPU fallback)")
+            x = x.contiguous()
+        else:
+            x = _dev_f32(x, "x")
+        ctx.w_dtype = w.dtype
+        w = _dev_f32(w.float() if w.dtype != torch.float32 else w, "weights")
+        dt = DTYPE_BF16 if x.dtype == torch.bfloat16 else DTYPE_F32
         R, C = x.shape
         G, K = w.shape
         if G != tables.G or R != tables.R:
             raise ValueError("membership table does not match the inputs")
-        out_t = torch.empty((tables.B * tables.S, K, C), dtype=torch.float32, device=x.device)
+        out_t = torch.empty((tables.B * tables.S, K, C), dtype=x.dtype, device=x.device)
         rc = _lib.lib.mlgnn_segment_project_fwd(
             x.data_ptr(), w.data_ptr(), tables.seg_ptr.data_ptr(), _lib.ptr(tables.seg_mem),
-            tables.mem_row.data_ptr(), out_t.data_ptr(), tables.B * tables.S, C, G, K, DTYPE_F32, _stream())
+            tables.mem_row.data_ptr(), out_t.data_ptr(), tables.B * tables.S, C, G, K, dt, _stream())
         _lib.check(rc, "mlgnn_segment_project_fwd")
         ctx.tables = tables
+        ctx.dt = dt
         ctx.save_for_backward(x, w)
         return out_t
 
@@ -89,15 +100,15 @@ class _SegmentProject(torch.autograd.Function):
         t = ctx.tables
         R, C = x.shape
         G, K = w.shape
-        gout_t = _dev_f32(gout_t, "grad_out")
+        gout_t = gout_t.to(x.dtype).contiguous() if ctx.dt == DTYPE_BF16 else _dev_f32(gout_t, "grad_out")
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gwp = torch.empty((t.B * G, K), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
         rc = _lib.lib.mlgnn_segment_project_bwd(
             gout_t.data_ptr(), x.data_ptr(), w.data_ptr(), t.seg_ptr.data_ptr(), _lib.ptr(t.seg_mem),
             t.mem_row.data_ptr(), t.mem_seg.data_ptr(), t.node_ptr.data_ptr(), _lib.ptr(t.node_mem),
-            _lib.ptr(gx), _lib.ptr(gwp), t.B * t.S, R, C, G, K, DTYPE_F32, _stream())
+            _lib.ptr(gx), _lib.ptr(gwp), t.B * t.S, R, C, G, K, ctx.dt, _stream())
         _lib.check(rc, "mlgnn_segment_project_bwd")
-        gw = gwp.reshape(t.B, G, K).sum(0) if gwp is not None else None
+        gw = gwp.reshape(t.B, G, K).sum(0).to(ctx.w_dtype) if gwp is not None else None
         return gx, gw, None
 
 
@@ -109,11 +120,11 @@ def segment_project(x_nodes, gene_pca_match, raw_indice, weights, nodes_per_grap
     B = gene_pca_match.shape[0]
     tables = membership_tables(gene_pca_match, raw_indice, nodes_per_graph, n_segments, x_nodes.shape[0],
                                match_mask)
-    if x_nodes.dtype == torch.bfloat16:
-        # bf16 model: the gather-reduce kernels take fp32 rows (fp32 accumulation either way); the result goes back
-        # to the model's storage type
+    C_in = x_nodes.shape[1]
+    if x_nodes.dtype == torch.bfloat16 and C_in % 8 != 0 and C_in > 64:
+        # (a bf16 width the 16-byte path does not take and the scalar weight-gradient kernel does not cover: fp32 rows)
         out_t = _SegmentProject.apply(x_nodes.float(), weights.float(), tables).to(torch.bfloat16)
     else:
-        out_t = _SegmentProject.apply(x_nodes, weights, tables)      # [B*S, k, C]
+        out_t = _SegmentProject.apply(x_nodes, weights, tables)      # [B*S, k, C], in the storage type of x_nodes
     k, C = out_t.shape[1], out_t.shape[2]
     return out_t.reshape(B, n_segments, k, C).permute(0, 3, 1, 2)    # [B, C, S, k]

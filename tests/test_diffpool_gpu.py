@@ -111,3 +111,34 @@ def test_dense_sage_unsupported_shapes_take_the_library_path():
     ref_adj = adj2.detach().cpu().requires_grad_(True)
     P.dense_sage_conv(x2.cpu(), ref_adj, w1.cpu(), w2.cpu(), b.cpu()).sum().backward()
     assert_close(adj2.grad, ref_adj.grad, 1e-4)
+
+
+@pytest.mark.parametrize("B,n,C,O,batched,grad_adj", [(4, 146, 128, 32, False, False), (3, 37, 32, 10, True, True),
+                                                      (2, 160, 64, 64, False, False), (5, 10, 64, 64, True, True)])
+def test_dense_sage_bf16_storage_is_the_fp32_kernel_rounded_once(B, n, C, O, batched, grad_adj):
+    """bf16 storage of x / adj / weights (a bf16 model's pooled levels): the same kernel arithmetic in fp32 on the same
+    bf16-representable values, one rounding at each store -- the output equals the fp32 kernel's, rounded; gradients agree
+    to bf16 accuracy."""
+    from mlgnn.dense import dense_sage
+    gen = torch.Generator().manual_seed(B + n + C)
+    dev = "cuda:0"
+    x = torch.randn(B, n, C, generator=gen).bfloat16()
+    adj = torch.rand(*((B, n, n) if batched else (n, n)), generator=gen).bfloat16()
+    wr, wo = (torch.randn(O, C, generator=gen) * 0.2).bfloat16(), (torch.randn(O, C, generator=gen) * 0.2).bfloat16()
+    bias = (torch.randn(O, generator=gen) * 0.1).bfloat16()
+    cot = torch.randn(B, n, O, generator=gen).bfloat16()
+    res = []
+    for dt in (torch.float32, torch.bfloat16):
+        xd, ad = x.to(dev).to(dt).requires_grad_(True), adj.to(dev).to(dt).requires_grad_(grad_adj)
+        wrd, wod, bd = (t.to(dev).to(dt).requires_grad_(True) for t in (wr, wo, bias))
+        y = dense_sage(xd, ad, wrd, wod, bd, normalize=True)
+        assert y.dtype == dt
+        ins = [xd, wrd, wod, bd] + ([ad] if grad_adj else [])
+        res.append((y,) + torch.autograd.grad(y, ins, cot.to(dev).to(dt)))
+    for k, (r32, r16) in enumerate(zip(*res)):
+        assert r16.dtype == torch.bfloat16
+        if k == 0:                                             # y: rounded once from the fp32 result
+            assert torch.equal(r16, r32.bfloat16()), k
+        else:                                                  # gradients: the backward reads the SAVED y, which is the
+            # rounded one here (2^-9 relative per element) -- bf16-level agreement, not bitwise
+            assert float((r16.float() - r32).abs().max()) <= 2.0 ** -6 * float(r32.abs().max()), k

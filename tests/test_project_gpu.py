@@ -47,3 +47,38 @@ def test_membership_tables_are_cached_by_identity():
     assert membership_tables(match, seg, 10, 5, 20) is a
     match[0, 0] = -1                                  # in-place edit bumps the version -> rebuilt
     assert membership_tables(match, seg, 10, 5, 20) is not a
+
+
+@pytest.mark.parametrize("C,K", [(8, 2), (64, 3), (256, 2), (60, 1)])
+def test_bf16_storage_is_the_fp32_kernel_rounded_once(C, K):
+    """bf16 rows in, bf16 rows out (the storage type of a bf16 model, BASELINE configs[4]): the same fp32 accumulation as
+    the fp32 kernels on the same (bf16-representable) values, rounded ONCE at the store -- so the result is the fp32
+    kernel's result rounded to bf16, forward and input gradient; the weight gradient (fp32 partials) is the fp32
+    kernel's up to the order of its channel sum (8 channels per lane instead of 4).  C = 256 / 64 / 8 take the 16-byte
+    path, C = 60 the scalar one."""
+    from mlgnn.project import segment_project
+    gen = torch.Generator().manual_seed(C + K)
+    B, NN, G, S = 2, 40, 300, 57
+    dev = "cuda:0"
+    x = torch.randn(B * NN, C, generator=gen).bfloat16()
+    w = torch.randn(G, K, generator=gen) * 0.3
+    match = torch.randint(0, NN, (B, G), generator=gen)
+    match[:, ::7] = -1
+    seg = torch.sort(torch.randint(0, S, (B, G), generator=gen), dim=1)[0]
+    cot = torch.randn(B, C, S, K, generator=gen).bfloat16()
+    outs = []
+    for dt in (torch.float32, torch.bfloat16):
+        xd = x.to(dev).to(dt).requires_grad_(True)
+        wd = w.to(dev).requires_grad_(True)
+        out = segment_project(xd, match.to(dev), seg.to(dev), wd, NN, S, True)
+        assert out.dtype == dt
+        gx, gw = torch.autograd.grad(out, [xd, wd], cot.to(dev).to(dt))
+        outs.append((out, gx, gw))
+    (o32, gx32, gw32), (o16, gx16, gw16) = outs
+    # (a wider row splits the members of a segment / node over the lane groups differently with 8 channels per lane than
+    # with 4: the fp32 sums may differ in their last bit, which moves a bf16 rounding only at a tie)
+    for got, ref in ((o16, o32), (gx16, gx32)):
+        assert float((got.float() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
+        assert float((got != ref.bfloat16()).float().mean()) < 1e-3
+    assert gw16.dtype == torch.float32
+    assert float((gw16 - gw32).abs().max()) <= 2e-6 * float(gw32.abs().max())

@@ -108,6 +108,23 @@ __device__ __forceinline__ void store_t(T* __restrict__ p, const float (&r)[VEC]
   }
 }
 
+// Scalar access to fp32-or-bf16 storage for the small pooled-graph kernels (densesage.hip, diffpool.hip):
+// read-only view of a T array that indexes like a float array (bf16 storage is widened on the load; every product and
+// sum below is fp32 either way, results are rounded once at the store)
+template <typename T>
+struct StoredIn {
+  const T* p;
+  __device__ __forceinline__ float operator[](size_t i) const {
+    if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(p)[i];
+    else return bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+  }
+};
+template <typename T>
+__device__ __forceinline__ void stored_write(void* base, size_t i, float v) {
+  if constexpr (sizeof(T) == 4) static_cast<float*>(base)[i] = v;
+  else static_cast<uint16_t*>(base)[i] = f32_to_bf16(v);
+}
+
 // Streaming (written once, not read again by this kernel) 16-byte stores with the non-temporal hint, for kernels whose
 // speed hangs on the L2 hit rate of a gather running next to the stream (the CSR aggregations).  MLGNN_NT_STORES=0
 // compiles them as plain stores (same-box A/B through tools/build_variant.py).

@@ -35,22 +35,6 @@ struct DsArgs {                    // x, adj, weights, gy, y, y_out, gx, gadj: T
   int n; int C; int O; int adj_batched; int normalize; int ws_cols;
 };
 
-// read-only view of a T array that indexes like a float array (bf16 storage is widened on the load; every product and
-// sum below is fp32 either way, results are rounded once at the store)
-template <typename T>
-struct DsIn {
-  const T* p;
-  __device__ __forceinline__ float operator[](size_t i) const {
-    if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(p)[i];
-    else return bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
-  }
-};
-template <typename T>
-__device__ __forceinline__ void ds_store(void* base, size_t i, float v) {
-  if constexpr (sizeof(T) == 4) static_cast<float*>(base)[i] = v;
-  else static_cast<uint16_t*>(base)[i] = f32_to_bf16(v);
-}
-
 // row sums of the adjacency: one wavefront per row, lanes across the columns (coalesced), shuffle reduction
 template <typename AB>
 __device__ __forceinline__ void ds_degrees(const AB ab, int n, float* deg, float* raw) {
@@ -103,9 +87,9 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
   float* deg = Xm_ + (size_t)L.np * SX;        // [NP]
 #define P(r, c) Pm_[(r) * SO + (c)]
 #define X(r, c) Xm_[(r) * SX + (c)]
-  const DsIn<T> xb{static_cast<const T*>(p.x) + (size_t)b * n * C};
-  const DsIn<T> ab{static_cast<const T*>(p.adj) + (p.adj_batched ? (size_t)b * n * n : 0)};
-  const DsIn<T> w_rel{static_cast<const T*>(p.w_rel)}, w_root{static_cast<const T*>(p.w_root)};
+  const StoredIn<T> xb{static_cast<const T*>(p.x) + (size_t)b * n * C};
+  const StoredIn<T> ab{static_cast<const T*>(p.adj) + (p.adj_batched ? (size_t)b * n * n : 0)};
+  const StoredIn<T> w_rel{static_cast<const T*>(p.w_rel)}, w_root{static_cast<const T*>(p.w_root)};
   const int NP = (n + 15) & ~15, OP = (O + 15) & ~15;
   const int Nt = NP / 16, Ot = OP / 16;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -160,7 +144,7 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_fwd_kernel(const DsArgs p
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
     const float ri = p.normalize ? 1.0f / fmaxf(sqrtf(ss), kDsNormEps) : 1.0f;
-    if (lane < O) ds_store<T>(p.y_out, ((size_t)b * n + r) * O + lane, v * ri);
+    if (lane < O) stored_write<T>(p.y_out, ((size_t)b * n + r) * O + lane, v * ri);
     if (lane == 0) p.rinv[(size_t)b * n + r] = ri;
   }
 }
@@ -185,11 +169,11 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
 #define GP(r, c) GP_[(r) * SO + (c)]
 #define Pm(r, c) Pm_[(r) * SO + (c)]
 #define M(r, c) M_[(r) * SM + (c)]
-  const DsIn<T> xb{static_cast<const T*>(p.x) + (size_t)b * n * C};
-  const DsIn<T> ab{static_cast<const T*>(p.adj) + (p.adj_batched ? (size_t)b * n * n : 0)};
-  const DsIn<T> w_rel{static_cast<const T*>(p.w_rel)}, w_root{static_cast<const T*>(p.w_root)};
-  const DsIn<T> gyb{static_cast<const T*>(p.gy) + (size_t)b * n * O};
-  const DsIn<T> yb{static_cast<const T*>(p.y) + (size_t)b * n * O};
+  const StoredIn<T> xb{static_cast<const T*>(p.x) + (size_t)b * n * C};
+  const StoredIn<T> ab{static_cast<const T*>(p.adj) + (p.adj_batched ? (size_t)b * n * n : 0)};
+  const StoredIn<T> w_rel{static_cast<const T*>(p.w_rel)}, w_root{static_cast<const T*>(p.w_root)};
+  const StoredIn<T> gyb{static_cast<const T*>(p.gy) + (size_t)b * n * O};
+  const StoredIn<T> yb{static_cast<const T*>(p.y) + (size_t)b * n * O};
   const int NP = (n + 15) & ~15, OP = (O + 15) & ~15, CP = (C + 15) & ~15;
   const int Nt = NP / 16, Ot = OP / 16, Ct = CP / 16;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -230,7 +214,7 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = i0 + lq * 4 + r, col = c0 + l15;
-      if (row < n && col < C) ds_store<T>(p.gx, gx_off + (size_t)row * C + col, acc[r] + t2[r]);
+      if (row < n && col < C) stored_write<T>(p.gx, gx_off + (size_t)row * C + col, acc[r] + t2[r]);
     }
   }
   // ---- weight / bias gradient partials: ws[b] = [gW_rel (O*C) | gW_root (O*C) | gb (O)] ---------------------
@@ -279,7 +263,7 @@ __global__ __launch_bounds__(kDsBlock) void dense_sage_bwd_kernel(const DsArgs p
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
       const float ci = raw[r] > 1.0f ? c / deg[r] : 0.f;                     // clamp(rowsum, 1) passes gradient above 1
-      if (lane < n) ds_store<T>(p.gadj, ga_off + (size_t)r * n + lane, (M(r, lane) - ci) / deg[r]);
+      if (lane < n) stored_write<T>(p.gadj, ga_off + (size_t)r * n + lane, (M(r, lane) - ci) / deg[r]);
     }
   }
 }

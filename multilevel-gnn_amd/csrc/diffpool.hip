@@ -25,12 +25,13 @@ constexpr float kDpEps = 1e-15f;
 // 16 waves per pooled graph (see densesage.hip): independent latency-bound tiles spread over more waves
 constexpr int kDpBlock = 1024, kDpWaves = kDpBlock / kWave;
 
-struct DpArgs {
-  const float* z; const float* adj; const float* logits;
-  float* s_out; float* x_out; float* a_out; float* partial;   // partial[b] = {sum (A - S S^T)^2, sum entropy}
+struct DpArgs {                    // z, adj, logits, s_out, x_out, a_out: T (fp32 or bf16 storage); partial: fp32
+  const void* z; const void* adj; const void* logits;
+  void* s_out; void* x_out; void* a_out; float* partial;   // partial[b] = {sum (A - S S^T)^2, sum entropy}
   int N; int K; int C; int adj_batched;
 };
 
+template <typename ST>
 __global__ __launch_bounds__(kDpBlock) void diffpool_fwd_kernel(const DpArgs p) {
   __shared__ float S[kDpMaxN][kDpSK];
   __shared__ float T[kDpMaxN][kDpSK];
@@ -41,9 +42,9 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_fwd_kernel(const DpArgs p) 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid / kWave;
   const int N = p.N, K = p.K, C = p.C;
-  const float* zb = p.z + (size_t)b * N * C;
-  const float* lb = p.logits + (size_t)b * N * K;
-  const float* ab = p.adj + (p.adj_batched ? (size_t)b * N * N : 0);
+  const StoredIn<ST> zb{static_cast<const ST*>(p.z) + (size_t)b * N * C};
+  const StoredIn<ST> lb{static_cast<const ST*>(p.logits) + (size_t)b * N * K};
+  const StoredIn<ST> ab{static_cast<const ST*>(p.adj) + (p.adj_batched ? (size_t)b * N * N : 0)};
   const int NP = (N + 15) & ~15, KP = (K + 15) & ~15;
 
   // ---- softmax rows -> S (zero padded), entropy; Z -> LDS --------------------------------------
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_fwd_kernel(const DpArgs p) 
         const float s = S[r][k] * inv;
         S[r][k] = s;
         ent -= s * __logf(s + kDpEps);
-        p.s_out[((size_t)b * N + r) * K + k] = s;
+        stored_write<ST>(p.s_out, ((size_t)b * N + r) * K + k, s);
       }
       for (int k = K; k < KP; ++k) S[r][k] = 0.f;
     } else {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_fwd_kernel(const DpArgs p) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = i0 + lq * 4 + r, col = j0 + l15;
-      if (row < K && col < C) p.x_out[((size_t)b * K + row) * C + col] = acc[r];
+      if (row < K && col < C) stored_write<ST>(p.x_out, ((size_t)b * K + row) * C + col, acc[r]);
     }
   }
 
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_fwd_kernel(const DpArgs p) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = i0 + lq * 4 + r, col = j0 + l15;
-      if (row < K && col < K) p.a_out[((size_t)b * K + row) * K + col] = acc[r];
+      if (row < K && col < K) stored_write<ST>(p.a_out, ((size_t)b * K + row) * K + col, acc[r]);
     }
   }
 
@@ -148,12 +149,13 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_fwd_kernel(const DpArgs p) 
 // LDS: S, A S, A^T S, dS (4 x 31 KB) + S^T S (9 KB); Z, g, h and A are read from global memory
 // directly in MFMA operand layout.
 // ------------------------------------------------------------------------------------------------
-struct DpBwdArgs {
-  const float* z; const float* adj; const float* s; const float* gx; const float* ga; const float* coef;
-  float* gz; float* gs; float* gadj;
+struct DpBwdArgs {                 // everything T except coef (fp32)
+  const void* z; const void* adj; const void* s; const void* gx; const void* ga; const float* coef;
+  void* gz; void* gs; void* gadj;
   int N; int K; int C; int adj_batched;
 };
 
+template <typename ST>
 __global__ __launch_bounds__(kDpBlock) void diffpool_bwd_kernel(const DpBwdArgs p) {
   __shared__ float S[kDpMaxN][kDpSK];
   __shared__ float AS[kDpMaxN][kDpSK];
@@ -165,11 +167,11 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_bwd_kernel(const DpBwdArgs 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid / kWave;
   const int N = p.N, K = p.K, C = p.C;
-  const float* zb = p.z + (size_t)b * N * C;
-  const float* sb = p.s + (size_t)b * N * K;
-  const float* ab = p.adj + (p.adj_batched ? (size_t)b * N * N : 0);
-  const float* gxb = p.gx + (size_t)b * K * C;
-  const float* gab = p.ga + (size_t)b * K * K;
+  const StoredIn<ST> zb{static_cast<const ST*>(p.z) + (size_t)b * N * C};
+  const StoredIn<ST> sb{static_cast<const ST*>(p.s) + (size_t)b * N * K};
+  const StoredIn<ST> ab{static_cast<const ST*>(p.adj) + (p.adj_batched ? (size_t)b * N * N : 0)};
+  const StoredIn<ST> gxb{static_cast<const ST*>(p.gx) + (size_t)b * K * C};
+  const StoredIn<ST> gab{static_cast<const ST*>(p.ga) + (size_t)b * K * K};
   const float cl = p.coef[0], ce = p.coef[1];
   const int NP = (N + 15) & ~15, KP = (K + 15) & ~15;
   const int Nt = NP / 16, Kt = KP / 16, Ct = (C + 15) / 16;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_bwd_kernel(const DpBwdArgs 
   for (int r = tid; r < N; r += kDpBlock) {
     float dot = 0.f;
     for (int k = 0; k < K; ++k) dot = fmaf(GS[r][k], S[r][k], dot);
-    for (int k = 0; k < K; ++k) p.gs[((size_t)b * N + r) * K + k] = S[r][k] * (GS[r][k] - dot);
+    for (int k = 0; k < K; ++k) stored_write<ST>(p.gs, ((size_t)b * N + r) * K + k, S[r][k] * (GS[r][k] - dot));
   }
 
   // ---- dZ = S g  [N,C] ----------------------------------------------------------------------------
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_bwd_kernel(const DpBwdArgs 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = i0 + lq * 4 + r, col = j0 + l15;
-      if (row < N && col < C) p.gz[((size_t)b * N + row) * C + col] = acc[r];
+      if (row < N && col < C) stored_write<ST>(p.gz, ((size_t)b * N + row) * C + col, acc[r]);
     }
   }
 
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_bwd_kernel(const DpBwdArgs 
       for (int r = 0; r < 4; ++r) AS[i0 + lq * 4 + r][j0 + l15] = acc[r];
     }
     __syncthreads();
-    float* gb = p.gadj + (size_t)b * N * N;
+    const size_t gb_off = (size_t)b * N * N;
     for (int t = wave; t < Nt * Nt; t += kDpWaves) {
       const int i0 = (t / Nt) * 16, j0 = (t % Nt) * 16;
       const f32x4 pst = tile_gemm(K,
@@ -277,7 +279,8 @@ __global__ __launch_bounds__(kDpBlock) void diffpool_bwd_kernel(const DpBwdArgs 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = i0 + lq * 4 + r, col = j0 + l15;
-        if (row < N && col < N) gb[(size_t)row * N + col] = pst[r] + cl * (ab[(size_t)row * N + col] - sst[r]);
+        if (row < N && col < N)
+          stored_write<ST>(p.gadj, gb_off + (size_t)row * N + col, pst[r] + cl * (ab[(size_t)row * N + col] - sst[r]));
       }
     }
   }
@@ -294,15 +297,16 @@ extern "C" int mlgnn_diffpool_fwd_supported(int64_t N, int64_t K, int64_t C) {
 extern "C" int mlgnn_diffpool_fwd(const void* z, const void* adj, const void* s_logits, void* s_out,
                                   void* x_out, void* adj_out, float* partial, int64_t B, int64_t N,
                                   int64_t K, int64_t C, int adj_batched, int dtype, void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (B < 0 || B > INT32_MAX || !mlgnn_diffpool_fwd_supported(N, K, C)) return MLGNN_E_SHAPE;
   if (B == 0) return 0;
   if (!z || !adj || !s_logits || !s_out || !x_out || !adj_out || !partial) return MLGNN_E_NULL;
   DpArgs a;
-  a.z = (const float*)z; a.adj = (const float*)adj; a.logits = (const float*)s_logits;
-  a.s_out = (float*)s_out; a.x_out = (float*)x_out; a.a_out = (float*)adj_out; a.partial = partial;
+  a.z = z; a.adj = adj; a.logits = s_logits;
+  a.s_out = s_out; a.x_out = x_out; a.a_out = adj_out; a.partial = partial;
   a.N = (int)N; a.K = (int)K; a.C = (int)C; a.adj_batched = adj_batched;
-  hipLaunchKernelGGL(diffpool_fwd_kernel, dim3((unsigned)B), dim3(kDpBlock), 0, (hipStream_t)stream, a);
+  if (dtype == MLGNN_DTYPE_BF16) hipLaunchKernelGGL(diffpool_fwd_kernel<bf16_t>, dim3((unsigned)B), dim3(kDpBlock), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(diffpool_fwd_kernel<float>, dim3((unsigned)B), dim3(kDpBlock), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -310,15 +314,16 @@ extern "C" int mlgnn_diffpool_bwd(const void* z, const void* adj, const void* s_
                                   const void* grad_adj_out, const float* coef, void* grad_z, void* grad_s,
                                   void* grad_adj, int64_t B, int64_t N, int64_t K, int64_t C,
                                   int adj_batched, int dtype, void* stream) {
-  if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
+  if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (B < 0 || B > INT32_MAX || !mlgnn_diffpool_fwd_supported(N, K, C)) return MLGNN_E_SHAPE;
   if (B == 0) return 0;
   if (!z || !adj || !s_softmax || !grad_x || !grad_adj_out || !coef || !grad_z || !grad_s) return MLGNN_E_NULL;
   DpBwdArgs a;
-  a.z = (const float*)z; a.adj = (const float*)adj; a.s = (const float*)s_softmax;
-  a.gx = (const float*)grad_x; a.ga = (const float*)grad_adj_out; a.coef = coef;
-  a.gz = (float*)grad_z; a.gs = (float*)grad_s; a.gadj = (float*)grad_adj;
+  a.z = z; a.adj = adj; a.s = s_softmax;
+  a.gx = grad_x; a.ga = grad_adj_out; a.coef = coef;
+  a.gz = grad_z; a.gs = grad_s; a.gadj = grad_adj;
   a.N = (int)N; a.K = (int)K; a.C = (int)C; a.adj_batched = adj_batched;
-  hipLaunchKernelGGL(diffpool_bwd_kernel, dim3((unsigned)B), dim3(kDpBlock), 0, (hipStream_t)stream, a);
+  if (dtype == MLGNN_DTYPE_BF16) hipLaunchKernelGGL(diffpool_bwd_kernel<bf16_t>, dim3((unsigned)B), dim3(kDpBlock), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(diffpool_bwd_kernel<float>, dim3((unsigned)B), dim3(kDpBlock), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

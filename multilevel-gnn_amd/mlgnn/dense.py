@@ -541,7 +541,7 @@ def dense_sage(x, adj, w_rel, w_root, b_root, normalize=True):
 
 
 class _DiffPoolFused(torch.autograd.Function):
-    """Forward and backward are one fused fp32-MFMA launch each (``mlgnn_diffpool_fwd`` / ``_bwd``)."""
+    """Forward and backward are one fused fp32-MFMA launch each (``mlgnn_diffpool_fwd`` / ``_bwd``); fp32 or bf16 storage."""
 
     @staticmethod
     def forward(ctx, z, adj, s):
@@ -556,14 +556,14 @@ class _DiffPoolFused(torch.autograd.Function):
         partial = torch.empty((B, 2), dtype=torch.float32, device=z.device)
         rc = _lib.lib.mlgnn_diffpool_fwd(z.data_ptr(), adj_k.data_ptr(), s.data_ptr(), S.data_ptr(),
                                          x_out.data_ptr(), a_out.data_ptr(), partial.data_ptr(), B, N, K, C,
-                                         int(batched), 0, torch.cuda.current_stream().cuda_stream)
+                                         int(batched), _dt(z), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_diffpool_fwd")
         tot = partial.sum(0)
         norm = torch.sqrt(tot[0])
         link = norm / adj.numel()
         ent = tot[1] / (B * N)
         ctx.save_for_backward(z, adj, S, norm)
-        return x_out, a_out, link, ent
+        return x_out, a_out, link.to(z.dtype), ent.to(z.dtype)
 
     @staticmethod
     def backward(ctx, gx, ga, g_link, g_ent):
@@ -571,18 +571,18 @@ class _DiffPoolFused(torch.autograd.Function):
         B, N, C = z.shape
         K = S.shape[2]
         batched = adj.dim() == 3 and adj.shape[0] == B and B > 1
-        coef = torch.stack([g_link / (adj.numel() * norm), g_ent / (B * N)]).to(torch.float32).contiguous()
+        coef = torch.stack([g_link.float() / (adj.numel() * norm), g_ent.float() / (B * N)]).contiguous()
         gz = torch.empty_like(z)
         gs = torch.empty_like(S)
         need_adj = ctx.needs_input_grad[1]
         gadj = torch.empty((B, N, N), dtype=z.dtype, device=z.device) if need_adj else None
-        gx, ga = gx.contiguous(), ga.contiguous()
+        gx, ga = gx.to(z.dtype).contiguous(), ga.to(z.dtype).contiguous()
         rc = _lib.lib.mlgnn_diffpool_bwd(z.data_ptr(), adj.data_ptr(), S.data_ptr(), gx.data_ptr(), ga.data_ptr(),
                                          coef.data_ptr(), gz.data_ptr(), gs.data_ptr(), _lib.ptr(gadj), B, N, K, C,
-                                         int(batched), 0, torch.cuda.current_stream().cuda_stream)
+                                         int(batched), _dt(z), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_diffpool_bwd")
         if need_adj and not batched:
-            gadj = gadj.sum(0, keepdim=True).reshape(adj.shape)          # shared adjacency
+            gadj = gadj.float().sum(0, keepdim=True).to(adj.dtype).reshape(adj.shape)          # shared adjacency
         return gz, gadj, gs
 
 
@@ -778,13 +778,10 @@ def dense_diff_pool(z, adj, s, adj_symmetric=False):
     s = s.unsqueeze(0) if s.dim() == 2 else s
     B, N, C = z.shape
     K = s.shape[2]
-    if (z.is_cuda and z.dtype == torch.float32 and adj.shape[0] in (1, B)
+    if (z.is_cuda and z.dtype in (torch.float32, torch.bfloat16) and adj.shape[0] in (1, B)
             and _lib.lib.mlgnn_diffpool_fwd_supported(N, K, C)):
-        return _DiffPoolFused.apply(z, adj, s)
-    if (z.is_cuda and z.dtype == torch.bfloat16 and adj.shape[0] in (1, B)
-            and _lib.lib.mlgnn_diffpool_fwd_supported(N, K, C)):
-        # bf16 model, small pooled graph: the fused fp32-MFMA kernel behind casts
-        return tuple(t.to(torch.bfloat16) for t in _DiffPoolFused.apply(z.float(), adj.float(), s.float()))
+        # fp32 or bf16 storage (one type for z / adj / logits; fp32 arithmetic, one rounding at each store)
+        return _DiffPoolFused.apply(z, adj.to(z.dtype), s.to(z.dtype))
     if adj.shape[0] in (1, B) and diff_pool_large_supported(z, adj, s):
         return _diff_pool_large(z, adj, s, adj_symmetric)
     return _diff_pool_library(z, adj, s)

@@ -142,3 +142,31 @@ def test_dense_sage_bf16_storage_is_the_fp32_kernel_rounded_once(B, n, C, O, bat
         else:                                                  # gradients: the backward reads the SAVED y, which is the
             # rounded one here (2^-9 relative per element) -- bf16-level agreement, not bitwise
             assert float((r16.float() - r32).abs().max()) <= 2.0 ** -6 * float(r32.abs().max()), k
+
+
+@pytest.mark.parametrize("B,N,K,C,batched", [(4, 146, 37, 64, False), (3, 37, 10, 64, True)])
+def test_dense_diff_pool_bf16_storage_is_the_fp32_kernel_rounded_once(B, N, K, C, batched):
+    """bf16 storage of z / adj / logits in the fused small-graph kernel: outputs equal the fp32 kernel's on the same
+    bf16-representable values, rounded once; gradients (whose backward reads the SAVED, rounded softmax) agree to bf16
+    accuracy."""
+    from mlgnn.dense import dense_diff_pool
+    gen = torch.Generator().manual_seed(B + N)
+    dev = "cuda:0"
+    z = torch.randn(B, N, C, generator=gen).bfloat16()
+    s = (torch.randn(B, N, K, generator=gen) * 2).bfloat16()
+    adj = torch.rand(*((B, N, N) if batched else (N, N)), generator=gen).bfloat16()
+    c1, c2 = torch.randn(B, K, C, generator=gen).bfloat16(), torch.randn(B, K, K, generator=gen).bfloat16()
+    res = []
+    for dt in (torch.float32, torch.bfloat16):
+        zd, ad, sd = (t.to(dev).to(dt).requires_grad_(True) for t in (z, adj, s))
+        x, a, link, ent = dense_diff_pool(zd, ad, sd)
+        assert x.dtype == dt and a.dtype == dt
+        loss = (x.float() * c1.to(dev).float()).sum() + (a.float() * c2.to(dev).float()).sum() + 0.7 * link.float() + 0.3 * ent.float()
+        res.append((x, a, link, ent) + torch.autograd.grad(loss, [zd, ad, sd]))
+    r32, r16 = res
+    assert torch.equal(r16[0], r32[0].bfloat16()) and torch.equal(r16[1], r32[1].bfloat16())
+    assert abs(float(r16[2]) - float(r32[2])) <= 2.0 ** -8 * abs(float(r32[2]))
+    assert abs(float(r16[3]) - float(r32[3])) <= 2.0 ** -8 * abs(float(r32[3]))
+    for k in (4, 5, 6):
+        assert r16[k].dtype == torch.bfloat16
+        assert float((r16[k].float() - r32[k]).abs().max()) <= 2.0 ** -6 * float(r32[k].abs().max()), k

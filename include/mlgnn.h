@@ -150,6 +150,8 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
  *   grad_uv  [edge_rank+1,d]  EDGE_RANK1: d loss / d eu (edge_rank rows), then d loss / d ev
  *   learn_t  non-zero: SOFTMAX weights carry gradient (torch_message.py:51-52)
  *   workspace: mlgnn_csr_aggregate_bwd_workspace_floats(N,d,dtype,edge_rank,aggr,learn_t) floats
+ *   [N,d] tensors of 4 GiB and more (N * d * 4 >= 2^32) run on instantiations with 64-bit row addresses (d % 4 == 0 for
+ *            fp32, d % 8 == 0 for bf16 and 16-byte aligned operands; MLGNN_E_SHAPE otherwise); same results.
  *   grad_shifted [N,d], shift_flag [4 x int32]  optional (both or neither; SOFTMAX without learn_t): the rescaled
  *            cotangent grad_out * 2^(-aux) and its overflow flag, already written by the producer of grad_out
  *            (mlgnn_tallgemm_nt_shift); the streaming pre-pass that would compute them is skipped and the workspace

@@ -49,7 +49,7 @@ __device__ __forceinline__ void load_slots(int (&r)[VEC], const uint8_t* p) {
 // edge gathers ONE row (gt) instead of two (go, lse): half the gather traffic, and no per-edge scalar either.
 // SHIFT with max: the winning edge of (i, c) is looked up as a 1-byte slot inside row i (max_slot_kernel) instead of
 // the 4-byte by-destination position the forward wrote -- the second gathered row shrinks from 4 d to d bytes.
-template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool SHIFT, bool VIRT, bool LNB = false>
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool SHIFT, bool VIRT, bool LNB = false, bool WIDE = false>
 __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (*red)[kWave * VEC]) {
   static_assert(!LNB || (sizeof(T) == 4 && !VIRT && !LEARN_T), "LayerNorm-backward epilogue: fp32 rows of the main launch");
   constexpr int RK = rank_of<MODE>();
@@ -210,7 +210,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
         for (int k = 0; k < ESA; ++k) my_ew[k] = 0.f;
         if (lane < cnt) {
           const int dst = a.col_t[base + lane];
-          my_off = (uint32_t)dst * row_bytes;
+          my_off = row_key<WIDE>(dst, row_bytes);
           if (AGGR == A_MAX) my_pos = a.pos_t[base + lane] - (SHIFT ? a.rowptr[dst] : 0);
           if constexpr (ES > 0) {
             load_edge_scalars<ES>(my_ew, a.ew_t, (size_t)(base + lane));
@@ -235,7 +235,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
             const int idx = k + u * groups + sub;
             valid[u] = FULL || (idx < cnt);
             const int src = idx & (kWave - 1);
-            const uint32_t off = (uint32_t)__shfl((int)my_off, src) + c_bytes;
+            const auto off = row_offset<WIDE>((uint32_t)__shfl((int)my_off, src), row_bytes, c_bytes);
 #pragma unroll
             for (int q = 0; q < ESA; ++q) wa[u][q] = (ES > 0) ? __shfl(my_ew[q], src) : 0.f;
             inv[u] = (AGGR == A_SUM) ? __shfl(my_inv, src) : 1.f;
@@ -386,22 +386,22 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
 }
 
 // (LNB: four waves per SIMD asked for -- the parked row puts the softmax instantiation two registers past 128)
-template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool VIRT = false, bool LNB = false>
+template <typename T, int VEC, int MODE, int AGGR, bool LEARN_T, bool VIRT = false, bool LNB = false, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, LNB ? 4 : 1) void csr_aggregate_bwd_kernel(const BwdArgs a) {
   __shared__ float red[LNB ? 2 * kWavesPerBlock : kWavesPerBlock][kWave * VEC];     // LNB: + the d gamma / d beta slots
   if constexpr (AGGR == A_SOFTMAX && !LEARN_T) {
     // *a.spread != 0: softmax_shift_kernel met a node with |lse| > kMaxLse in some channel; the two-row path
     // stays as the fallback for such inputs (never seen in practice: lse = log2 sum_e 2^(t m_e))
     const bool shift_ok = a.gt != nullptr && *a.spread == 0;
-    if (shift_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT, LNB>(a, red);
-    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT, LNB>(a, red);
+    if (shift_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT, LNB, WIDE>(a, red);
+    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT, LNB, WIDE>(a, red);
   } else if constexpr (AGGR == A_MAX) {
     // *a.spread != 0: some node has more than 254 incoming edges, its slots do not fit a byte
     const bool slots_ok = a.slot8 != nullptr && *a.spread == 0;
-    if (slots_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT, LNB>(a, red);
-    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT, LNB>(a, red);
+    if (slots_ok) csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, true, VIRT, LNB, WIDE>(a, red);
+    else csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT, LNB, WIDE>(a, red);
   } else {
-    csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT, LNB>(a, red);
+    csr_aggregate_bwd_body<T, VEC, MODE, AGGR, LEARN_T, false, VIRT, LNB, WIDE>(a, red);
   }
 }
 
@@ -606,7 +606,6 @@ static int csr_aggregate_bwd_impl(const void* grad_out, const void* x, const voi
                                        const mlgnn_ln_fold_t* ln, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
-  if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;
   const int mode = pick_mode(msg, edge_mode, edge_rank);
   const int ag = pick_aggr(aggr);
   if (mode < 0 || ag < 0) return MLGNN_E_MODE;
@@ -662,12 +661,14 @@ static int csr_aggregate_bwd_impl(const void* grad_out, const void* x, const voi
   int launched_blocks = nblk;
   hipStream_t s = (hipStream_t)stream;
   a.lpr_log2 = lanes_per_row_log2(d, vec);
+  const bool wide = needs_wide_rows(N, d) || force_wide_rows();      // 64-bit row addresses (aggregate_common.h)
+  if (wide && vec == 1 && needs_wide_rows(N, d)) return MLGNN_E_SHAPE;
   a.ln_h = nullptr; a.ln_mean = a.ln_rstd = a.ln_gamma = a.ln_beta = a.ln_extra = nullptr;
   a.ln_rowmax = nullptr; a.ln_ws = nullptr; a.ln_relu = 0;
   if (ln) {
     // the epilogue holds whole fp32 rows in one lane group; long rows (whose gradient is finished by the combine
     // launch) and the d/dt path keep the separate LayerNorm backward
-    if (bf16 || vec != 4 || d != ((int64_t)4 << a.lpr_log2) || split || learn_t) return MLGNN_E_MODE;
+    if (bf16 || vec != 4 || d != ((int64_t)4 << a.lpr_log2) || split || learn_t || wide) return MLGNN_E_MODE;
     if (!ln->h || !ln->mean || !ln->rstd || !ln->gamma || !ln->beta || !ln->grad_gamma_beta || !ln->workspace) return MLGNN_E_NULL;
     if (ln->workspace_floats < (int64_t)nblk * 2 * d) return MLGNN_E_WORKSPACE;
     if (!aligned16(ln->h) || !aligned16(ln->gamma) || !aligned16(ln->beta) || (ln->grad_extra && !aligned16(ln->grad_extra)))
@@ -745,7 +746,18 @@ static int csr_aggregate_bwd_impl(const void* grad_out, const void* x, const voi
           hipLaunchKernelGGL(kernel, dim3(g), block, 0, s, args);
         };
         if constexpr (std::is_same<T, float>::value && VEC == 4 && !VIRT) {
-          if (ln) { go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false, VIRT, true>, IC<2>{}); return; }
+          if (ln) {
+            if (wide) return;                                  // (refused below: the fold keeps 32-bit rows)
+            go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false, VIRT, true>, IC<2>{});
+            return;
+          }
+        }
+        if constexpr (VEC > 1) {
+          if (wide) {
+            if (kCanLearn && lt) go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, kCanLearn, VIRT, false, true>, IC<3>{});
+            else go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false, VIRT, false, true>, IC<4>{});
+            return;
+          }
         }
         if (kCanLearn && lt) go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, kCanLearn, VIRT>, BC<true>{});
         else go(csr_aggregate_bwd_kernel<T, VEC, MODE, AGGR, false, VIRT>, BC<false>{});

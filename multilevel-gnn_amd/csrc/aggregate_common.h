@@ -1,5 +1,6 @@
 // Shared pieces of the CSR aggregation kernels (forward: aggregate_fwd.hip, backward: aggregate_bwd.hip).
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "mlgnn.h"
@@ -73,6 +74,31 @@ __device__ __forceinline__ void load_row(float (&r)[VEC], const T* base, uint32_
 template <int VEC>
 __device__ __forceinline__ void load_row(int (&r)[VEC], const int* base, uint32_t byte_off) {
   load_vec<VEC>(r, reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+// WIDE instantiations ([N,d] tensors of 4 GiB and more -- 288 GB of HBM hold graphs of tens of millions of nodes): the
+// lanes pass the ROW INDEX around and every gathered row pays a 64-bit multiply-add for its address; chosen on the host
+// only when N * d * 4 does not fit 32 bits.
+template <typename T, int VEC>
+__device__ __forceinline__ void load_row(float (&r)[VEC], const T* base, uint64_t byte_off) {
+  load_t<T, VEC>(r, reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+template <int VEC>
+__device__ __forceinline__ void load_row(int (&r)[VEC], const int* base, uint64_t byte_off) {
+  load_vec<VEC>(r, reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+// row key a lane keeps for its edge (what is shuffled to the lane groups) and the byte offset of the row chunk from it
+template <bool WIDE>
+__device__ __forceinline__ uint32_t row_key(int row, uint32_t row_bytes) { return WIDE ? (uint32_t)row : (uint32_t)row * row_bytes; }
+template <bool WIDE>
+__device__ __forceinline__ auto row_offset(uint32_t key, uint32_t row_bytes, uint32_t c_bytes) {
+  if constexpr (WIDE) return (uint64_t)key * row_bytes + c_bytes;
+  else return key + c_bytes;
+}
+// does an [N, d] tensor need the WIDE kernels?  (fp32 side arrays -- lse, argmax -- share the row index: 4 bytes / element)
+inline bool needs_wide_rows(int64_t N, int64_t d) { return N * d * 4 >= ((int64_t)1 << 32); }
+inline bool force_wide_rows() {                      // tests: the WIDE kernels on small inputs
+  static const int v = [] { const char* e = getenv("MLGNN_FORCE_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
 }
 
 // the ES scalars of edge slot e (row e of the [E, ES] table; rows are ES*4-byte aligned)

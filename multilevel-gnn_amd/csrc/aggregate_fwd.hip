@@ -18,7 +18,7 @@
 
 namespace mlgnn {
 
-template <typename T, int VEC, int MODE, int AGGR, bool SECOND, bool VIRT = false>
+template <typename T, int VEC, int MODE, int AGGR, bool SECOND, bool VIRT = false, bool WIDE = false>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs a) {
   const T* X = static_cast<const T*>(a.x);
   const T* EF = static_cast<const T*>(a.efull);
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
 #pragma unroll
         for (int k = 0; k < ESA; ++k) my_ew[k] = 0.f;
         if (lane < cnt) {
-          my_off = (uint32_t)a.col[base + lane] * row_bytes;
+          my_off = row_key<WIDE>(a.col[base + lane], row_bytes);
           if constexpr (ES > 0) {
             load_edge_scalars<ES>(my_ew, a.ew, (size_t)(base + lane));
           }
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
               const int idx = k + u * groups + sub;
               valid[u] = FULL || (idx < cnt);
               const int src = idx & (kWave - 1);
-              const uint32_t off = (uint32_t)__shfl((int)my_off, src) + c_bytes;
+              const auto off = row_offset<WIDE>((uint32_t)__shfl((int)my_off, src), row_bytes, c_bytes);
 #pragma unroll
               for (int q = 0; q < ESA; ++q) wa[u][q] = (ES > 0) ? __shfl(my_ew[q], src) : 0.f;
               const int e0 = (MODE == M_GEN_FULL) ? __shfl(my_eid, src) : 0;
@@ -370,7 +370,6 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
                                        float eps, int add_root, const mlgnn_hub_t* hub, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (N < 0 || d <= 0 || N > INT32_MAX || d > INT32_MAX) return MLGNN_E_SHAPE;
-  if (N * d * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;      // 32-bit row offsets: [N,d] tensors < 4 GiB
   if (hub && hub->cap > 0) {
     if (!hub->vrows || !hub->hubs || !hub->counts || !hub->tmp) return MLGNN_E_NULL;
     if (hub->capacity < 1 || hub->tmp_bytes < mlgnn_hub_scratch_bytes(hub->capacity, d)) return MLGNN_E_WORKSPACE;
@@ -412,6 +411,9 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
   const bool second = (aux2 != nullptr) && (ag == A_SOFTMAX || ag == A_POWER);
   a.lpr_log2 = lanes_per_row_log2(d, vec);
   a.rowmax = row_max;
+  // [N,d] of 4 GiB and more: 64-bit row addresses (16-byte path only: the scalar fallback is for odd widths of small inputs)
+  const bool wide = needs_wide_rows(N, d) || force_wide_rows();
+  if (wide && vec == 1 && needs_wide_rows(N, d)) return MLGNN_E_SHAPE;
   if (row_max && d != ((int64_t)vec << a.lpr_log2)) return MLGNN_E_SHAPE;    // row max: one chunk, no shadow lanes
   auto run = [&](const FwdArgs& args, const dim3 g, auto virt_c) {
     constexpr bool VIRT = decltype(virt_c)::value;
@@ -421,6 +423,13 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
       auto launch = [&](auto t_c, auto vec_c) {
         using T = typename decltype(t_c)::type;
         constexpr int VEC = decltype(vec_c)::value;
+        if constexpr (VEC > 1) {
+          if (wide) {
+            if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, kHasSecond, VIRT, true>), g, block, 0, s, args);
+            else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, false, VIRT, true>), g, block, 0, s, args);
+            return;
+          }
+        }
         if (kHasSecond && second) hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, kHasSecond, VIRT>), g, block, 0, s, args);
         else hipLaunchKernelGGL((csr_aggregate_fwd_kernel<T, VEC, MODE, AGGR, false, VIRT>), g, block, 0, s, args);
       };

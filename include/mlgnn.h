@@ -615,6 +615,33 @@ int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const void* s_logit
                              void* stream);
 
 /*
+ * The same call (models/diff_pooling.py:59-65, dense_diff_pool) on fp32 tensors at the large sizes: the product chain of
+ * mlgnn_diffpool_large_fwd / _bwd with every product as THREE bf16 terms on the matrix cores (x = x_hi + x_lo up to
+ * 2^-17 |x|; hi*hi + hi*lo + lo*hi, fp32 accumulation): fp32-level accuracy, within 1e-4 of fp64 (tests).  All
+ * tensors fp32: z [B,N,C], s_logits / s_out [B,N,K] (s_out = softmax), adj [B,N,N] (adj_batched) or ONE [N,N],
+ * x_out [B,K,C], adj_out [B,K,K], scal_out [2] = {link, entropy}, stats float[3] as above.  A batch runs as grouped
+ * launches with the reference's batch semantics for the scalars (see above).  Shapes: mlgnn_diffpool_large_supported.
+ * workspace: B consecutive blocks of mlgnn_diffpool_large_f32_workspace_bytes(N, K, C) bytes (256-byte aligned); the first
+ * mlgnn_diffpool_large_f32_saved_bytes(N, K, C) bytes of every block must reach the backward unchanged (`saved` = the
+ * same pointer: the backward finds block b at saved + b * workspace_bytes(N, K, C)).
+ * Backward: grad_x [B,K,C], grad_adj_out [B,K,K], grad_link / grad_ent (device scalars), outputs grad_z [B,N,C],
+ * grad_logits [B,N,K], grad_adj [B,N,N] or NULL (one block per graph also for a shared adjacency: the caller sums).
+ * workspace: B blocks of mlgnn_diffpool_large_f32_bwd_workspace_bytes(N, K, C, adj_symmetric) bytes.
+ */
+int64_t mlgnn_diffpool_large_f32_workspace_bytes(int64_t N, int64_t K, int64_t C);
+int64_t mlgnn_diffpool_large_f32_saved_bytes(int64_t N, int64_t K, int64_t C);
+int mlgnn_diffpool_large_f32_fwd(const float* z, const float* adj, const float* s_logits, float* s_out, float* x_out,
+                                 float* adj_out, float* scal_out, float* stats, void* workspace,
+                                 int64_t workspace_bytes, int64_t N, int64_t K, int64_t C, int64_t B, int adj_batched,
+                                 void* stream);
+int64_t mlgnn_diffpool_large_f32_bwd_workspace_bytes(int64_t N, int64_t K, int64_t C, int adj_symmetric);
+int mlgnn_diffpool_large_f32_bwd(const float* adj, const float* s_logits, const void* saved, const float* grad_x,
+                                 const float* grad_adj_out, const float* grad_link, const float* grad_ent,
+                                 const float* stats, float* grad_z, float* grad_logits, float* grad_adj,
+                                 int adj_symmetric, void* workspace, int64_t workspace_bytes, int64_t N, int64_t K,
+                                 int64_t C, int64_t B, int adj_batched, void* stream);
+
+/*
  * Optimizer step on one flat fp32 buffer: global-norm gradient clipping + Adam with L2 weight decay, two launches.
  * Replaces: train.py:63-66,112-114 -- clip_grad_norm_(parameters, max_norm=20, norm_type=2) (when --clip_grad) and
  * torch.optim.Adam(lr, betas, weight_decay).step(); torch's single-tensor formula, element by element:

@@ -422,6 +422,7 @@ struct SlabReduceArgs {
   void* ca; int64_t lda; int ca_f32;
   uint16_t* cb; int64_t ldb; float* sq_partial;
   void* cc; int64_t ldc; int cc_f32;
+  int cb_f32;                          // the middle column range is kept in fp32 (the three-term fp32 chain)
   int64_t s_ca, s_cc, ws_stride;       // grouped launch: element strides of ca / cc, bytes between per-graph workspaces
 };
 
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs p
   {
     const int64_t bz = blockIdx.y;
     p.slab += bz * (p.ws_stride / 4);
-    p.cb += bz * (p.ws_stride / 2);
+    p.cb = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(p.cb) + bz * p.ws_stride);
     p.sq_partial += bz * (p.ws_stride / 4);
     p.ca = p.ca_f32 ? (void*)(static_cast<float*>(p.ca) + bz * p.s_ca) : (void*)(static_cast<uint16_t*>(p.ca) + bz * p.s_ca);
     p.cc = p.cc_f32 ? (void*)(static_cast<float*>(p.cc) + bz * p.s_cc) : (void*)(static_cast<uint16_t*>(p.cc) + bz * p.s_cc);
@@ -457,7 +458,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs p
       }
     } else {
       sq += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
-      *reinterpret_cast<uint2*>(p.cb + (size_t)row * p.ldb + (col - p.n_a)) = make_uint2(dpl_pack2(s.x, s.y), dpl_pack2(s.z, s.w));
+      if (p.cb_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.cb) + (size_t)row * p.ldb + (col - p.n_a)) = s;
+      else *reinterpret_cast<uint2*>(p.cb + (size_t)row * p.ldb + (col - p.n_a)) = make_uint2(dpl_pack2(s.x, s.y), dpl_pack2(s.z, s.w));
     }
   }
   sq = wave_sum(sq);
@@ -869,5 +871,541 @@ extern "C" int mlgnn_diffpool_large_bwd(const void* z, const void* adj, const vo
     e.batch = batch; e.s_c = N * N; e.s_aux = s_adj;
     DPL_CHECK(gemm_nt_launch(e, st));
   }
+  return (int)hipGetLastError();
+}
+
+// =====================================================================================================================
+// fp32 inputs: the same product chain with every product as THREE bf16 terms on the matrix cores
+//     x y^T ~= x_hi y_hi^T + x_hi y_lo^T + x_lo y_hi^T,     x = x_hi + x_lo up to 2^-17 |x|  (the dropped lo x lo term is
+// 2^-18 relative), fp32 accumulation -- fp32-level accuracy (tests: 1e-4 of the fp64 oracle) at 3x the matrix work of
+// the bf16 chain, still far ahead of fp32 matrix instructions (1/16 of the bf16 rate).  One entry point each way
+// (mlgnn_diffpool_large_f32_fwd / _bwd), a batch as grouped launches; the three terms are three segments of ONE
+// gemm_nt launch (the contraction range concatenated).  Around the products: a softmax pass (fp32 S + entropy), a
+// multi-job "split" launch (fp32 matrix -> hi / lo bf16, row-major and / or transposed through LDS, optionally with the
+// partial sums of <src, other>), the split-K reduce and the scalar kernel of the bf16 chain.
+// Reference: the same call, models/diff_pooling.py:59-65 on fp32 tensors.
+namespace mlgnn {
+
+// S = softmax(logits) in fp32 (the expression the backward recomputes: __expf(v - max) / sum), entropy partials.
+// One wavefront per row, rows grid-strided; ent_partial[block] = sum over the block's rows of -sum_k S log(S + eps).
+__global__ __launch_bounds__(256) void dpl32_softmax_kernel(const float* __restrict__ logits, float* __restrict__ S,
+                                                            float* __restrict__ ent_partial, int N, int K, int64_t ws_floats) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  logits += (size_t)blockIdx.y * N * K;
+  S += (size_t)blockIdx.y * N * K;
+  ent_partial += (size_t)blockIdx.y * ws_floats;
+  float ent = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
+    const float* lr = logits + (size_t)row * K;
+    float mx = -3.0e38f;
+    for (int k = lane * 4; k < K; k += 256) {
+      float v[4];
+      load_vec<4>(v, lr + k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      float v[4];
+      load_vec<4>(v, lr + k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sum += __expf(v[i] - mx);
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int k = lane * 4; k < K; k += 256) {
+      float v[4], o[4];
+      load_vec<4>(v, lr + k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] = __expf(v[i] - mx) * inv;
+        ent -= o[i] * __logf(o[i] + kDplEps);
+      }
+      store_vec<4>(S + (size_t)row * K + k, o);
+    }
+  }
+  ent = wave_sum(ent);
+  if (lane == 0) wsum[wave] = ent;
+  __syncthreads();
+  if (threadIdx.x == 0) ent_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// One job of a split launch: src [R, Cc] fp32 (leading dimension ld; R, Cc multiples of 64) ->
+//   hi / lo   [R, Cc] bf16 (leading dimension ldo), when hi != NULL
+//   hit / lot [Cc, R] bf16 (leading dimension ldt), when hit != NULL  (64 x 64 tiles through LDS)
+//   partial[tile] = sum over the tile of src * dot (dot == src: the sum of squares), when dot != NULL
+// Batch: graph blockIdx.y < nb runs the job on pointers advanced by the s_* strides (elements of each pointer's type).
+struct SplitJob {
+  const float* src; int64_t ld; int R, Cc;
+  uint16_t *hi, *lo; int64_t ldo;
+  uint16_t *hit, *lot; int64_t ldt;
+  const float* dot; int64_t lddot; float* partial;
+  int64_t s_src, s_out, s_outt, s_dot, s_part;
+  int nb, tiles;
+};
+constexpr int kSplitMaxJobs = 4;
+struct SplitArgs { SplitJob job[kSplitMaxJobs]; int njobs; };
+
+__device__ __forceinline__ void split2(float v, uint16_t& h, uint16_t& l) {
+  h = f32_to_bf16(v);
+  l = f32_to_bf16(v - bf16_to_f32(h));
+}
+
+__global__ __launch_bounds__(256) void dpl32_split_kernel(const SplitArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t th[64][66];
+  __shared__ __attribute__((aligned(16))) uint16_t tl[64][66];
+  __shared__ float wsum[4];
+  int t = blockIdx.x, j = 0;
+#pragma unroll
+  for (int i = 0; i + 1 < kSplitMaxJobs; ++i)
+    if (j == i && i + 1 < a.njobs && t >= a.job[i].tiles) { t -= a.job[i].tiles; j = i + 1; }
+  SplitJob q;
+  // (a uniform select over the by-value argument: no dynamic indexing of the kernel argument segment)
+  q = a.job[0];
+  if (j == 1) q = a.job[1];
+  if (j == 2) q = a.job[2];
+  if (j == 3) q = a.job[3];
+  const int64_t bz = blockIdx.y;
+  if (bz >= q.nb) return;
+  const int tiles_c = q.Cc / 64, r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+  const float* src = q.src + bz * q.s_src;
+  const float* dot = q.dot ? q.dot + bz * q.s_dot : nullptr;
+  const int tid = threadIdx.x;
+  float part = 0.f;
+  // 64 rows x 256 B: 16 lanes per row, 16 bytes each; 256 threads = 16 rows per pass
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = pass * 16 + (tid >> 4), ch = tid & 15;
+    float v[4];
+    load_vec<4>(v, src + (size_t)(r0 + r) * q.ld + c0 + ch * 4);
+    if (dot) {
+      float d[4];
+      load_vec<4>(d, dot + (size_t)(r0 + r) * q.lddot + c0 + ch * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part += v[i] * d[i];
+    }
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2(v[i], h[i], l[i]);
+    if (q.hi) {
+      const size_t at = (size_t)(bz * q.s_out) + (size_t)(r0 + r) * q.ldo + c0 + ch * 4;
+      *reinterpret_cast<uint2*>(q.hi + at) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+      *reinterpret_cast<uint2*>(q.lo + at) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    }
+    if (q.hit) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        th[r][ch * 4 + i] = h[i];
+        tl[r][ch * 4 + i] = l[i];
+      }
+    }
+  }
+  if (q.hit) {
+    __syncthreads();
+    uint16_t* oh = q.hit + bz * q.s_outt;
+    uint16_t* ol = q.lot + bz * q.s_outt;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int c = pass * 32 + (tid >> 3), ch = tid & 7;                  // column of the tile = row of the transpose
+      uint32_t wh[4], wl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wh[i] = (uint32_t)th[ch * 8 + 2 * i][c] | ((uint32_t)th[ch * 8 + 2 * i + 1][c] << 16);
+        wl[i] = (uint32_t)tl[ch * 8 + 2 * i][c] | ((uint32_t)tl[ch * 8 + 2 * i + 1][c] << 16);
+      }
+      const size_t at = (size_t)(c0 + c) * q.ldt + r0 + ch * 8;
+      *reinterpret_cast<uint4*>(oh + at) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+      *reinterpret_cast<uint4*>(ol + at) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    }
+  }
+  if (dot) {
+    part = wave_sum(part);
+    if ((tid & 63) == 0) wsum[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) q.partial[bz * q.s_part + t] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  }
+}
+
+inline SplitJob split_job(const float* src, int64_t ld, int R, int Cc, int nb, int64_t s_src) {
+  SplitJob q{};
+  q.src = src; q.ld = ld; q.R = R; q.Cc = Cc; q.nb = nb; q.s_src = s_src;
+  q.tiles = (R / 64) * (Cc / 64);
+  return q;
+}
+
+inline int split_launch(const SplitArgs& a, int batch, hipStream_t st) {
+  int tiles = 0;
+  for (int i = 0; i < a.njobs; ++i) tiles += a.job[i].tiles;
+  hipLaunchKernelGGL(dpl32_split_kernel, dim3(tiles, batch), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+// backward operands from the cotangents: coef = {c, grad_ent / rows} (as in the bf16 chain),
+// b1 = ga - cI and b3 = 2c G as fp32 [K,K] (b2 = ga^T - cI is b1's transpose: the split launch writes it)
+struct Dpl32PrepArgs {
+  const float* g_link; const float* g_ent; const float* stats; float* coef; float inv_numel, inv_rows;
+  const float* ga; const float* G; float* b1; float* b3; int K;
+  int64_t fws_floats, bws_floats;
+};
+
+__global__ __launch_bounds__(256) void dpl32_prep_kernel(const Dpl32PrepArgs p) {
+  const float c = p.g_link[0] * p.inv_numel / p.stats[2];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    p.coef[0] = c;
+    p.coef[1] = p.g_ent[0] * p.inv_rows;
+  }
+  const int64_t bz = blockIdx.y;
+  const float* ga = p.ga + bz * (int64_t)p.K * p.K;
+  const float* G = p.G + bz * p.fws_floats;
+  float* b1 = p.b1 + bz * p.bws_floats;
+  float* b3 = p.b3 + bz * p.bws_floats;
+  const int per_row = p.K / 4;
+  const int64_t total = (int64_t)p.K * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / per_row), col = (int)(i % per_row) * 4;
+    float v[4], g[4], o1[4], o3[4];
+    load_vec<4>(v, ga + (size_t)row * p.K + col);
+    load_vec<4>(g, G + (size_t)row * p.K + col);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o1[k] = v[k] - (row == col + k ? c : 0.f);
+      o3[k] = 2.f * c * g[k];
+    }
+    store_vec<4>(b1 + (size_t)row * p.K + col, o1);
+    store_vec<4>(b3 + (size_t)row * p.K + col, o3);
+  }
+}
+
+struct Dpl32Layout {     // byte offsets into the per-graph forward workspace; [0, scratch) reaches the backward
+  size_t Sh, Sl, stack_h, stack_l, Th, Tl, Zh, Zl, Ah, Al, G, scratch, T, slab, part_a2, part_dot, part_g2, part_ent, total;
+  int splits, n_a2, n_dot, n_ent;
+};
+
+Dpl32Layout dpl32_layout(int64_t N, int64_t K, int64_t C) {
+  Dpl32Layout L;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += dpl_align(bytes); return at; };
+  L.Sh = take((size_t)N * K * 2); L.Sl = take((size_t)N * K * 2);
+  L.stack_h = take((size_t)(2 * K + C) * N * 2); L.stack_l = take((size_t)(2 * K + C) * N * 2);
+  L.Th = take((size_t)N * K * 2); L.Tl = take((size_t)N * K * 2);
+  L.Zh = take((size_t)N * C * 2); L.Zl = take((size_t)N * C * 2);
+  L.Ah = take((size_t)N * N * 2); L.Al = take((size_t)N * N * 2);
+  L.G = take((size_t)K * K * 4);
+  L.scratch = o;
+  L.T = take((size_t)N * K * 4);
+  const int tiles_agx = (int)((K / kGemmTile) * ((2 * K + C) / kGemmTile));
+  int sp = (384 + tiles_agx / 2) / tiles_agx;
+  const int ktiles = (int)(3 * N / kGemmBK);
+  if (sp > ktiles) sp = ktiles;
+  L.splits = sp < 1 ? 1 : sp;
+  L.slab = take((size_t)L.splits * K * (2 * K + C) * 4);
+  L.n_a2 = (int)((N / 64) * (N / 64));
+  L.n_dot = (int)((N / 64) * (K / 64));
+  L.n_ent = (int)((N + 3) / 4 < 1024 ? (N + 3) / 4 : 1024);
+  L.part_a2 = take((size_t)L.n_a2 * 4);
+  L.part_dot = take((size_t)L.n_dot * 4);
+  L.part_g2 = take(kDplPartials * 4);
+  L.part_ent = take((size_t)L.n_ent * 4);
+  L.total = o;
+  return L;
+}
+
+// three-term product: (a_hi, b_hi), (a_hi, b_lo), (a_lo, b_hi) as segments i0 .. i0 + 2 of a descriptor
+inline void seg3(GemmDesc& d, int i0, const uint16_t* ah, const uint16_t* al, const uint16_t* bh, const uint16_t* bl,
+                 int64_t lda, int64_t ldb, int K, int64_t sa, int64_t sb) {
+  d.seg[i0] = GemmSeg{ah, bh, lda, ldb, K, sa, sb};
+  d.seg[i0 + 1] = GemmSeg{ah, bl, lda, ldb, K, sa, sb};
+  d.seg[i0 + 2] = GemmSeg{al, bh, lda, ldb, K, sa, sb};
+}
+
+struct Dpl32Bwd {        // byte offsets into the per-graph backward workspace
+  size_t coef, b1f, b3f, b1h, b1l, b2h, b2l, b3h, b3l, gxh, gxl, gxth, gxtl, dS, Ath, Atl, T2, T2h, T2l, P, Ph, Pl, total;
+};
+
+Dpl32Bwd dpl32_bwd_layout(int64_t N, int64_t K, int64_t C, int sym) {
+  Dpl32Bwd W{};
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += dpl_align(bytes); return at; };
+  W.coef = take(16);
+  W.b1f = take((size_t)K * K * 4); W.b3f = take((size_t)K * K * 4);
+  W.b1h = take((size_t)K * K * 2); W.b1l = take((size_t)K * K * 2);
+  W.b2h = take((size_t)K * K * 2); W.b2l = take((size_t)K * K * 2);
+  W.b3h = take((size_t)K * K * 2); W.b3l = take((size_t)K * K * 2);
+  W.gxh = take((size_t)K * C * 2); W.gxl = take((size_t)K * C * 2);
+  W.gxth = take((size_t)K * C * 2); W.gxtl = take((size_t)K * C * 2);
+  W.dS = take((size_t)N * K * 4);
+  if (!sym) {
+    W.Ath = take((size_t)N * N * 2); W.Atl = take((size_t)N * N * 2);
+    W.T2 = take((size_t)N * K * 4);
+    W.T2h = take((size_t)N * K * 2); W.T2l = take((size_t)N * K * 2);
+  }
+  W.P = take((size_t)N * K * 4);
+  W.Ph = take((size_t)N * K * 2); W.Pl = take((size_t)N * K * 2);
+  W.total = o;
+  return W;
+}
+
+}  // namespace mlgnn
+
+extern "C" int64_t mlgnn_diffpool_large_f32_workspace_bytes(int64_t N, int64_t K, int64_t C) {
+  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+  return (int64_t)dpl32_layout(N, K, C).total;
+}
+
+extern "C" int64_t mlgnn_diffpool_large_f32_saved_bytes(int64_t N, int64_t K, int64_t C) {
+  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+  return (int64_t)dpl32_layout(N, K, C).scratch;
+}
+
+// Forward, SEVEN launches for the whole batch: softmax, split {S, Z, A}, T = A S, split {T} (+ <S, T>),
+// [A' | G | X'] = S^T [T | S | Z] split along K, its reduce, the scalars.  All tensors fp32; s_out [B,N,K] = softmax.
+extern "C" int mlgnn_diffpool_large_f32_fwd(const float* z, const float* adj, const float* s_logits, float* s_out,
+                                            float* x_out, float* adj_out, float* scal_out, float* stats, void* workspace,
+                                            int64_t workspace_bytes, int64_t N, int64_t K, int64_t C, int64_t B,
+                                            int adj_batched, void* stream) {
+  if (!dpl_supported(N, K, C) || B < 1 || B > 65535) return MLGNN_E_SHAPE;
+  if (!z || !adj || !s_logits || !s_out || !x_out || !adj_out || !scal_out || !stats || !workspace) return MLGNN_E_NULL;
+  const Dpl32Layout L = dpl32_layout(N, K, C);
+  if (workspace_bytes < (int64_t)L.total * B) return MLGNN_E_WORKSPACE;
+  if (((uintptr_t)z | (uintptr_t)adj | (uintptr_t)s_out | (uintptr_t)workspace | (uintptr_t)s_logits | (uintptr_t)x_out |
+       (uintptr_t)adj_out) & 15) return MLGNN_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  const int64_t WS = (int64_t)L.total, W2 = WS / 2, W4 = WS / 4;
+  const int batch = (int)B, adj_batch = adj_batched ? batch : 1;
+  const int n = (int)N, k = (int)K, c = (int)C;
+  uint16_t *Sh = (uint16_t*)(ws + L.Sh), *Sl = (uint16_t*)(ws + L.Sl);
+  uint16_t *stack_h = (uint16_t*)(ws + L.stack_h), *stack_l = (uint16_t*)(ws + L.stack_l);
+  uint16_t *Sth = stack_h + (size_t)K * N, *Stl = stack_l + (size_t)K * N;
+  uint16_t *Th = (uint16_t*)(ws + L.Th), *Tl = (uint16_t*)(ws + L.Tl);
+  uint16_t *Zh = (uint16_t*)(ws + L.Zh), *Zl = (uint16_t*)(ws + L.Zl);
+  uint16_t *Ah = (uint16_t*)(ws + L.Ah), *Al = (uint16_t*)(ws + L.Al);
+  float* G = (float*)(ws + L.G);
+  float* T = (float*)(ws + L.T);
+  float* slab = (float*)(ws + L.slab);
+  float *p_a2 = (float*)(ws + L.part_a2), *p_dot = (float*)(ws + L.part_dot), *p_g2 = (float*)(ws + L.part_g2),
+        *p_ent = (float*)(ws + L.part_ent);
+  // 1. S = softmax(logits), entropy partials
+  hipLaunchKernelGGL(dpl32_softmax_kernel, dim3(L.n_ent, batch), dim3(256), 0, st, s_logits, s_out, p_ent, n, k, W4);
+  // 2. hi / lo terms of S (and S^T), Z (and Z^T), A (with ||A||_F^2)
+  {
+    SplitArgs a{};
+    a.njobs = 3;
+    SplitJob& s = a.job[0];
+    s = split_job(s_out, K, n, k, batch, N * K);
+    s.hi = Sh; s.lo = Sl; s.ldo = K; s.s_out = W2;
+    s.hit = Sth; s.lot = Stl; s.ldt = N; s.s_outt = W2;
+    SplitJob& zj = a.job[1];
+    zj = split_job(z, C, n, c, batch, N * C);
+    zj.hi = Zh; zj.lo = Zl; zj.ldo = C; zj.s_out = W2;
+    zj.hit = stack_h + (size_t)2 * K * N; zj.lot = stack_l + (size_t)2 * K * N; zj.ldt = N; zj.s_outt = W2;
+    SplitJob& aj = a.job[2];
+    aj = split_job(adj, N, n, n, adj_batch, N * N);
+    aj.hi = Ah; aj.lo = Al; aj.ldo = N; aj.s_out = W2;
+    aj.dot = adj; aj.lddot = N; aj.s_dot = N * N; aj.partial = p_a2; aj.s_part = W4;
+    DPL_CHECK(split_launch(a, batch, st));
+  }
+  // 3. T = A S
+  {
+    GemmDesc d{};
+    d.nseg = 3;
+    seg3(d, 0, Ah, Al, Sth, Stl, N, N, n, adj_batched ? W2 : 0, W2);
+    d.M = n; d.N = k; d.splits = 1;
+    d.c = T; d.ldc = K; d.c_f32 = 1;
+    d.batch = batch; d.s_c = W4;
+    DPL_CHECK(gemm_nt_launch(d, st));
+  }
+  // 4. hi / lo terms of T and T^T, <S, T> partials
+  {
+    SplitArgs a{};
+    a.njobs = 1;
+    SplitJob& t = a.job[0];
+    t = split_job(T, K, n, k, batch, W4);
+    t.hi = Th; t.lo = Tl; t.ldo = K; t.s_out = W2;
+    t.hit = stack_h; t.lot = stack_l; t.ldt = N; t.s_outt = W2;
+    t.dot = s_out; t.lddot = K; t.s_dot = N * K; t.partial = p_dot; t.s_part = W4;
+    DPL_CHECK(split_launch(a, batch, st));
+  }
+  // 5. [A' | G | X'] = S^T [T | S | Z]: one three-term product over the stack, split along K, one reduce
+  {
+    GemmDesc d{};
+    d.nseg = 3;
+    seg3(d, 0, Sth, Stl, stack_h, stack_l, N, N, n, W2, W2);
+    d.M = k; d.N = 2 * k + c; d.splits = L.splits; d.slab = slab;
+    d.batch = batch; d.s_slab = W4;
+    DPL_CHECK(gemm_nt_launch(d, st));
+    SlabReduceArgs r{};
+    r.slab = slab; r.splits = L.splits; r.M = k; r.N = 2 * k + c; r.n_a = k; r.n_b = 2 * k;
+    r.ca = adj_out; r.lda = K; r.ca_f32 = 1;
+    r.cb = (uint16_t*)G; r.ldb = K; r.cb_f32 = 1; r.sq_partial = p_g2;
+    r.cc = x_out; r.ldc = C; r.cc_f32 = 1;
+    r.s_ca = K * K; r.s_cc = K * C; r.ws_stride = WS;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(kDplPartials, batch), dim3(256), 0, st, r);
+  }
+  // 6. scalars of the batch
+  DplFinalArgs f{p_a2, L.n_a2, p_dot, L.n_dot, p_g2, kDplPartials, p_ent, L.n_ent,
+                 stats, scal_out, 1, (float)(1.0 / ((double)adj_batch * (double)N * (double)N)),
+                 (float)(1.0 / ((double)B * (double)N)), batch, adj_batch, W4};
+  hipLaunchKernelGGL(dpl_final_kernel, dim3(1), dim3(256), 0, st, f);
+  return (int)hipGetLastError();
+}
+
+extern "C" int64_t mlgnn_diffpool_large_f32_bwd_workspace_bytes(int64_t N, int64_t K, int64_t C, int adj_symmetric) {
+  if (!dpl_supported(N, K, C)) return MLGNN_E_SHAPE;
+  return (int64_t)dpl32_bwd_layout(N, K, C, adj_symmetric).total;
+}
+
+// Backward: operand preparation, split {b1 (-> b2), b3, gx (, A^T)}, [T2 = A^T S, split {T2}], dS as three launches of
+// four segments (twelve terms), softmax backward, dZ, [P = S (dA' - cI), split {P}, dA = P S^T + c A].
+extern "C" int mlgnn_diffpool_large_f32_bwd(const float* adj, const float* s_logits, const void* saved,
+                                            const float* grad_x, const float* grad_adj_out, const float* grad_link,
+                                            const float* grad_ent, const float* stats, float* grad_z, float* grad_logits,
+                                            float* grad_adj, int adj_symmetric, void* workspace, int64_t workspace_bytes,
+                                            int64_t N, int64_t K, int64_t C, int64_t B, int adj_batched, void* stream) {
+  if (!dpl_supported(N, K, C) || B < 1 || B > 65535) return MLGNN_E_SHAPE;
+  if (!adj || !s_logits || !saved || !grad_x || !grad_adj_out || !grad_link || !grad_ent || !stats || !grad_z ||
+      !grad_logits || !workspace) return MLGNN_E_NULL;
+  const Dpl32Bwd Wl = dpl32_bwd_layout(N, K, C, adj_symmetric);
+  const int64_t W = (int64_t)Wl.total, Wh = W / 2, Wf = W / 4;
+  if (workspace_bytes < W * B) return MLGNN_E_WORKSPACE;
+  if (((uintptr_t)s_logits | (uintptr_t)grad_logits | (uintptr_t)workspace | (uintptr_t)adj | (uintptr_t)grad_x |
+       (uintptr_t)grad_adj_out | (uintptr_t)grad_z | (uintptr_t)saved | (uintptr_t)grad_adj) & 15) return MLGNN_E_ALIGN;
+  const Dpl32Layout L = dpl32_layout(N, K, C);
+  const int64_t WS = (int64_t)L.total, W2 = WS / 2, W4 = WS / 4;
+  const int batch = (int)B, adj_batch = adj_batched ? batch : 1;
+  const int64_t s_adj = adj_batched ? N * N : 0;
+  const int n = (int)N, k = (int)K, c = (int)C;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned char* sv = (const unsigned char*)saved;
+  const uint16_t *Sh = (const uint16_t*)(sv + L.Sh), *Sl = (const uint16_t*)(sv + L.Sl);
+  const uint16_t *Sth = (const uint16_t*)(sv + L.stack_h) + (size_t)K * N, *Stl = (const uint16_t*)(sv + L.stack_l) + (size_t)K * N;
+  const uint16_t *Th = (const uint16_t*)(sv + L.Th), *Tl = (const uint16_t*)(sv + L.Tl);
+  const uint16_t *Zh = (const uint16_t*)(sv + L.Zh), *Zl = (const uint16_t*)(sv + L.Zl);
+  const float* G = (const float*)(sv + L.G);
+  unsigned char* ws = (unsigned char*)workspace;
+  float* coef = (float*)(ws + Wl.coef);
+  float *b1f = (float*)(ws + Wl.b1f), *b3f = (float*)(ws + Wl.b3f);
+  uint16_t *b1h = (uint16_t*)(ws + Wl.b1h), *b1l = (uint16_t*)(ws + Wl.b1l), *b2h = (uint16_t*)(ws + Wl.b2h),
+           *b2l = (uint16_t*)(ws + Wl.b2l), *b3h = (uint16_t*)(ws + Wl.b3h), *b3l = (uint16_t*)(ws + Wl.b3l);
+  uint16_t *gxh = (uint16_t*)(ws + Wl.gxh), *gxl = (uint16_t*)(ws + Wl.gxl), *gxth = (uint16_t*)(ws + Wl.gxth),
+           *gxtl = (uint16_t*)(ws + Wl.gxtl);
+  float* dS = (float*)(ws + Wl.dS);
+  // 1. coef, b1 = ga - cI, b3 = 2c G (fp32)
+  {
+    Dpl32PrepArgs q{grad_link, grad_ent, stats, coef, (float)(1.0 / ((double)adj_batch * (double)N * (double)N)),
+                    (float)(1.0 / ((double)B * (double)N)), grad_adj_out, G, b1f, b3f, k, W4, Wf};
+    const int blocks = (int)(((int64_t)K * K / 4 + 255) / 256);
+    hipLaunchKernelGGL(dpl32_prep_kernel, dim3(blocks < 1024 ? blocks : 1024, batch), dim3(256), 0, st, q);
+  }
+  // 2. their hi / lo terms (b2 = b1^T), gx and gx^T, A^T when adj is not promised symmetric
+  {
+    SplitArgs a{};
+    a.njobs = adj_symmetric ? 3 : 4;
+    SplitJob& j1 = a.job[0];
+    j1 = split_job(b1f, K, k, k, batch, Wf);
+    j1.hi = b1h; j1.lo = b1l; j1.ldo = K; j1.s_out = Wh;
+    j1.hit = b2h; j1.lot = b2l; j1.ldt = K; j1.s_outt = Wh;
+    SplitJob& j3 = a.job[1];
+    j3 = split_job(b3f, K, k, k, batch, Wf);
+    j3.hi = b3h; j3.lo = b3l; j3.ldo = K; j3.s_out = Wh;
+    SplitJob& jx = a.job[2];
+    jx = split_job(grad_x, C, k, c, batch, K * C);
+    jx.hi = gxh; jx.lo = gxl; jx.ldo = C; jx.s_out = Wh;
+    jx.hit = gxth; jx.lot = gxtl; jx.ldt = K; jx.s_outt = Wh;
+    if (!adj_symmetric) {
+      SplitJob& ja = a.job[3];
+      ja = split_job(adj, N, n, n, adj_batch, N * N);
+      ja.hit = (uint16_t*)(ws + Wl.Ath); ja.lot = (uint16_t*)(ws + Wl.Atl); ja.ldt = N; ja.s_outt = Wh;
+    }
+    DPL_CHECK(split_launch(a, batch, st));
+  }
+  const uint16_t *T2h = Th, *T2l = Tl;
+  int64_t s_T2 = W2;
+  if (!adj_symmetric) {
+    uint16_t *Ath = (uint16_t*)(ws + Wl.Ath), *Atl = (uint16_t*)(ws + Wl.Atl);
+    float* T2 = (float*)(ws + Wl.T2);
+    GemmDesc d{};
+    d.nseg = 3;
+    seg3(d, 0, Ath, Atl, Sth, Stl, N, N, n, adj_batched ? Wh : 0, W2);
+    d.M = n; d.N = k; d.splits = 1;
+    d.c = T2; d.ldc = K; d.c_f32 = 1;
+    d.batch = batch; d.s_c = Wf;
+    DPL_CHECK(gemm_nt_launch(d, st));
+    SplitArgs a{};
+    a.njobs = 1;
+    SplitJob& t = a.job[0];
+    t = split_job(T2, K, n, k, batch, Wf);
+    t.hi = (uint16_t*)(ws + Wl.T2h); t.lo = (uint16_t*)(ws + Wl.T2l); t.ldo = K; t.s_out = Wh;
+    DPL_CHECK(split_launch(a, batch, st));
+    T2h = t.hi; T2l = t.lo; s_T2 = Wh;
+  }
+  // 3. dS = Z gx^T + T b1^T + T2 b2^T + S b3^T: twelve bf16 terms as three launches of four segments, the second and
+  //    third adding to the first's result (the epilogue's `+ 1 * aux` with aux = the output itself: every element is
+  //    read and written by the same lane)
+  {
+    GemmSeg all[12];
+    GemmDesc tmp{};
+    seg3(tmp, 0, Zh, Zl, gxh, gxl, C, C, c, W2, Wh);
+    for (int i = 0; i < 3; ++i) all[i] = tmp.seg[i];
+    seg3(tmp, 0, Th, Tl, b1h, b1l, K, K, k, W2, Wh);
+    for (int i = 0; i < 3; ++i) all[3 + i] = tmp.seg[i];
+    seg3(tmp, 0, T2h, T2l, b2h, b2l, K, K, k, s_T2, Wh);
+    for (int i = 0; i < 3; ++i) all[6 + i] = tmp.seg[i];
+    seg3(tmp, 0, Sh, Sl, b3h, b3l, K, K, k, W2, Wh);
+    for (int i = 0; i < 3; ++i) all[9 + i] = tmp.seg[i];
+    for (int part = 0; part < 3; ++part) {
+      GemmDesc d{};
+      d.nseg = 4;
+      for (int i = 0; i < 4; ++i) d.seg[i] = all[4 * part + i];
+      d.M = n; d.N = k; d.splits = 1;
+      d.c = dS; d.ldc = K; d.c_f32 = 1;
+      if (part > 0) { d.aux = dS; d.ldaux = K; d.aux_f32 = 1; d.alpha = 1.f; d.s_aux = Wf; }
+      d.batch = batch; d.s_c = Wf;
+      DPL_CHECK(gemm_nt_launch(d, st));
+    }
+  }
+  // 4. softmax backward with the entropy term
+  const int sm_blocks = (int)((N + 3) / 4 < 1024 ? (N + 3) / 4 : 1024);
+  hipLaunchKernelGGL(dpl_softmax_bwd_kernel<float>, dim3(sm_blocks, batch), dim3(256), 0, st, s_logits, dS, coef, grad_logits,
+                     n, k, Wf);
+  // 5. dZ = S gx
+  {
+    GemmDesc d{};
+    d.nseg = 3;
+    seg3(d, 0, Sh, Sl, gxth, gxtl, K, K, k, W2, Wh);
+    d.M = n; d.N = c; d.splits = 1;
+    d.c = grad_z; d.ldc = C; d.c_f32 = 1;
+    d.batch = batch; d.s_c = N * C;
+    DPL_CHECK(gemm_nt_launch(d, st));
+  }
+  // 6. dA = P S^T + c A,  P = S (dA' - cI)
+  if (grad_adj) {
+    float* P = (float*)(ws + Wl.P);
+    uint16_t *Ph = (uint16_t*)(ws + Wl.Ph), *Pl = (uint16_t*)(ws + Wl.Pl);
+    GemmDesc d{};
+    d.nseg = 3;
+    seg3(d, 0, Sh, Sl, b2h, b2l, K, K, k, W2, Wh);
+    d.M = n; d.N = k; d.splits = 1;
+    d.c = P; d.ldc = K; d.c_f32 = 1;
+    d.batch = batch; d.s_c = Wf;
+    DPL_CHECK(gemm_nt_launch(d, st));
+    SplitArgs a{};
+    a.njobs = 1;
+    SplitJob& t = a.job[0];
+    t = split_job(P, K, n, k, batch, Wf);
+    t.hi = Ph; t.lo = Pl; t.ldo = K; t.s_out = Wh;
+    DPL_CHECK(split_launch(a, batch, st));
+    GemmDesc e{};
+    e.nseg = 3;
+    seg3(e, 0, Ph, Pl, Sh, Sl, K, K, k, Wh, W2);
+    e.M = n; e.N = n; e.splits = 1;
+    e.c = grad_adj; e.ldc = N; e.c_f32 = 1;
+    e.aux = adj; e.ldaux = N; e.aux_f32 = 1; e.alpha = 0.f; e.alpha_dev = coef;
+    e.batch = batch; e.s_c = N * N; e.s_aux = s_adj;
+    DPL_CHECK(gemm_nt_launch(e, st));
+  }
+  (void)Sth; (void)Stl;
   return (int)hipGetLastError();
 }

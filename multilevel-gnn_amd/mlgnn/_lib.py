@@ -81,6 +81,12 @@ SIGNATURES = {
     "mlgnn_diffpool_large_bwd_workspace_bytes": (_I64, [_I64, _I64, _I64, _INT]),
     "mlgnn_diffpool_large_bwd": (_INT, [_P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _I64,
                                         _I64, _I64, _I64, _I64, _INT, _P]),
+    "mlgnn_diffpool_large_f32_workspace_bytes": (_I64, [_I64, _I64, _I64]),
+    "mlgnn_diffpool_large_f32_saved_bytes": (_I64, [_I64, _I64, _I64]),
+    "mlgnn_diffpool_large_f32_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _P]),
+    "mlgnn_diffpool_large_f32_bwd_workspace_bytes": (_I64, [_I64, _I64, _I64, _INT]),
+    "mlgnn_diffpool_large_f32_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _I64, _I64, _I64, _I64,
+                                            _I64, _INT, _P]),
     "mlgnn_adam_workspace_floats": (_I64, []),
     "mlgnn_adam_step": (_INT, [_P, _P, _P, _P, _I64, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
     "mlgnn_hub_capacity": (_I64, [_I64, _INT]),

@@ -652,77 +652,57 @@ def _dt(t):
     return 1 if t.dtype == torch.bfloat16 else 0
 
 
-def _split_bf16(x):
-    """fp32 ``x = hi + lo`` up to 2^-17 relative: two bf16 terms (``lo`` carries the next 8 significant bits)."""
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.float()).to(torch.bfloat16)
-    return hi, lo
-
-
-def _matmul_nt_3term(a, b, out=None, accumulate=False, splits=1):
-    """``a [M,K] @ b [N,K]^T`` for fp32 operands at fp32-level accuracy on the bf16 matrix cores: both operands are
-    split into two bf16 terms and the three leading partial products run as ONE multi-term launch of
-    ``mlgnn_gemm_bf16_nt`` (fp32 accumulation; the dropped ``lo x lo`` term is 2^-18 relative).  ``a`` / ``b`` may be
-    ``(hi, lo)`` pairs already.  ``accumulate``: add to ``out`` (the kernel's ``C + 1 * aux`` epilogue)."""
-    from .gemm import gemm_bf16_nt
-    ah, al = a if isinstance(a, tuple) else _split_bf16(a)
-    bh, bl = b if isinstance(b, tuple) else _split_bf16(b)
-    segs = [(ah, bh), (ah, bl), (al, bh)]
-    if splits > 1:
-        return gemm_bf16_nt(segs, splits=splits)["slab"].sum(0)
-    r = gemm_bf16_nt(segs, out_dtype=torch.float32, aux=out if accumulate else None, alpha=1.0 if accumulate else 0.0)["c"]
-    return r
-
-
 class _DiffPoolLargeFP32(torch.autograd.Function):
-    """fp32 inputs at sizes past the fused small-graph kernel (multiples of 128): the same product chain as
-    :class:`_DiffPoolLarge`, every product as three bf16 terms on the matrix cores (fp32-level accuracy, 1e-5 of the
-    absolute-value bound), the streaming pieces (softmax, splits, transposes) on ATen.  Orchestrated from Python: three
-    times the matrix work of the bf16 chain and a few dozen small launches -- still ahead of the library's fp32 GEMMs."""
+    """fp32 inputs at sizes past the fused small-graph kernel (multiples of 128): the product chain of
+    :class:`_DiffPoolLarge` with every product as three bf16 terms on the matrix cores (fp32-level accuracy: within 1e-4
+    of fp64), one C entry point each way (``mlgnn_diffpool_large_f32_fwd`` / ``_bwd``, csrc/diffpool_large.hip); a batch
+    ``z [B,N,C]``, ``s [B,N,K]``, ``adj [B,N,N]`` or ``[1,N,N]`` (shared) runs as grouped launches."""
 
     @staticmethod
     def forward(ctx, z, adj, s, adj_symmetric):
-        N, C = z.shape
-        K = s.shape[1]
-        S = torch.softmax(s, dim=-1)
-        ent = (-S * torch.log(S + DIFFPOOL_EPS)).sum(dim=-1).mean()
-        Sp, Stp, Ap = _split_bf16(S), _split_bf16(S.t().contiguous()), _split_bf16(adj)
-        T = _matmul_nt_3term(Ap, Stp)                                        # A S  [N,K]
-        Ttp = _split_bf16(T.t().contiguous())
-        tiles = (K // 128) * (K // 128)
-        sp = max(1, min(256 // tiles, 3 * N // 64))
-        a_out = _matmul_nt_3term(Stp, Ttp, splits=sp)                        # S^T (A S)  [K,K]
-        G = _matmul_nt_3term(Stp, Stp, splits=sp)                            # S^T S
-        x_out = _matmul_nt_3term(Stp, _split_bf16(z.t().contiguous()), splits=max(1, min(256 // ((K // 128) * (C // 128)), 3 * N // 64)))
-        sq = (adj * adj).sum() - 2.0 * (S * T).sum() + (G * G).sum()         # ||A - S S^T||_F^2 (csrc/diffpool_large.hip)
-        norm = torch.sqrt(sq.clamp(min=0.0))
-        ctx.save_for_backward(z, adj, S, T, G, norm)
-        ctx.sym = bool(adj_symmetric)
-        return x_out, a_out, norm / adj.numel(), ent
+        B, N, C = z.shape
+        K = s.shape[2]
+        dev = z.device
+        z, adj, s = z.contiguous(), adj.contiguous(), s.contiguous()
+        adj_batched = int(adj.shape[0] == B and B > 1)
+        S = torch.empty((B, N, K), dtype=torch.float32, device=dev)
+        x_out = torch.empty((B, K, C), dtype=torch.float32, device=dev)
+        a_out = torch.empty((B, K, K), dtype=torch.float32, device=dev)
+        stats = torch.empty(3, dtype=torch.float32, device=dev)
+        scal = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = torch.empty(B * int(_lib.lib.mlgnn_diffpool_large_f32_workspace_bytes(N, K, C)), dtype=torch.uint8, device=dev)
+        rc = _lib.lib.mlgnn_diffpool_large_f32_fwd(z.data_ptr(), adj.data_ptr(), s.data_ptr(), S.data_ptr(), x_out.data_ptr(),
+                                                   a_out.data_ptr(), scal.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), N, K, C, B, adj_batched,
+                                                   torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_diffpool_large_f32_fwd")
+        ctx.save_for_backward(adj, s, ws, stats)
+        ctx.cfg = (bool(adj_symmetric), adj_batched, (B, N, K, C))
+        ctx.adj_shape = adj.shape
+        return x_out, a_out, scal[0], scal[1]
 
     @staticmethod
     def backward(ctx, gx, ga, g_link, g_ent):
-        z, adj, S, T, G, norm = ctx.saved_tensors
-        N, C = z.shape
-        K = S.shape[1]
-        c = g_link / (adj.numel() * norm)
-        eye = torch.eye(K, device=z.device, dtype=torch.float32)
-        Sp = _split_bf16(S)
-        T2 = T if ctx.sym else _matmul_nt_3term(_split_bf16(adj.t().contiguous()), _split_bf16(S.t().contiguous()))
-        ga = ga.float()
-        dS = _matmul_nt_3term(z, gx.float().contiguous())                                     # Z dX'^T
-        dS = _matmul_nt_3term(T, (ga - c * eye).contiguous(), out=dS, accumulate=True)        # T (dA' - cI)^T
-        dS = _matmul_nt_3term(T2, (ga.t() - c * eye).contiguous(), out=dS, accumulate=True)   # T2 (dA'^T - cI)^T
-        dS = _matmul_nt_3term(Sp, (2.0 * c * G).contiguous(), out=dS, accumulate=True)        # S (2cG)
-        dS = dS - (g_ent / N) * (torch.log(S + DIFFPOOL_EPS) + S / (S + DIFFPOOL_EPS))
-        gs = S * (dS - (dS * S).sum(dim=-1, keepdim=True))
-        tiles = (N // 128) * (C // 128)
-        gz = _matmul_nt_3term(Sp, gx.float().t().contiguous(), splits=max(1, min(256 // tiles, 3 * K // 64)))
-        gadj = None
-        if ctx.needs_input_grad[1]:
-            # dA = S (dA' - cI) S^T + c A   (through A' = S^T A S and through the link term)
-            P = _matmul_nt_3term(Sp, (ga.t() - c * eye).contiguous())
-            gadj = _matmul_nt_3term(P, Sp) + c * adj
+        adj, s, ws, stats = ctx.saved_tensors
+        sym, adj_batched, (B, N, K, C) = ctx.cfg
+        dev = s.device
+        gx, ga = gx.float().contiguous(), ga.float().contiguous()
+        g_link, g_ent = g_link.float().contiguous(), g_ent.float().contiguous()
+        gz = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        gs = torch.empty((B, N, K), dtype=torch.float32, device=dev)
+        # the adjacency of a second pooling level is the first level's S^T A S (diff_pooling.py:116-127)
+        gadj = torch.empty((B, N, N), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        wb = torch.empty(B * int(_lib.lib.mlgnn_diffpool_large_f32_bwd_workspace_bytes(N, K, C, int(sym))), dtype=torch.uint8,
+                         device=dev)
+        rc = _lib.lib.mlgnn_diffpool_large_f32_bwd(adj.data_ptr(), s.data_ptr(), ws.data_ptr(), gx.data_ptr(), ga.data_ptr(),
+                                                   g_link.data_ptr(), g_ent.data_ptr(), stats.data_ptr(), gz.data_ptr(),
+                                                   gs.data_ptr(), _lib.ptr(gadj), int(sym), wb.data_ptr(), wb.numel(),
+                                                   N, K, C, B, adj_batched, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_diffpool_large_f32_bwd")
+        if gadj is not None:
+            if not adj_batched and B > 1:
+                gadj = gadj.sum(0, keepdim=True)                 # shared adjacency: the sum over the graphs that read it
+            gadj = gadj.reshape(ctx.adj_shape)
         return gz, gadj, gs, None
 
 
@@ -733,28 +713,10 @@ def diff_pool_large_supported(z, adj, s):
 
 
 def _diff_pool_large(z, adj, s, adj_symmetric=False):
-    """bf16: the whole batch through the grouped launches of the C entry points.  fp32: a batch loop around the one-graph
-    three-term chain; losses are combined as the reference does (one Frobenius norm over the whole batch, entropy
-    averaged over all nodes)."""
-    B = z.shape[0]
-    if z.dtype == torch.bfloat16:
-        return _DiffPoolLarge.apply(z, adj, s, adj_symmetric)        # the whole batch as grouped launches
-    fn = _DiffPoolLargeFP32
-    if B == 1:
-        # views, not selects: the backward of `z[0]` would allocate and fill a full-size zero tensor per operand
-        N, C = z.shape[1], z.shape[2]
-        x, a, link, ent = fn.apply(z.reshape(N, C), adj.reshape(N, N), s.reshape(N, -1), adj_symmetric)
-        return x.unsqueeze(0), a.unsqueeze(0), link, ent
-    xs, as_, l2, es = [], [], [], []
-    for b in range(B):
-        a_b = adj[b if adj.shape[0] == B and B > 1 else 0]
-        x, a, link, ent = fn.apply(z[b], a_b.contiguous(), s[b], adj_symmetric)
-        xs.append(x)
-        as_.append(a)
-        l2.append((link.float() * a_b.numel()) ** 2)
-        es.append(ent.float())
-    link = torch.sqrt(torch.stack(l2).sum()) / adj.numel()
-    return torch.stack(xs), torch.stack(as_), link.to(z.dtype), torch.stack(es).mean().to(z.dtype)
+    """The whole batch through the grouped launches of the C entry points: bf16 storage on the bf16 chain, fp32 on its
+    three-term form.  Losses as the reference combines them (one Frobenius norm over the batch, entropy over all nodes)."""
+    fn = _DiffPoolLarge if z.dtype == torch.bfloat16 else _DiffPoolLargeFP32
+    return fn.apply(z, adj, s, adj_symmetric)
 
 
 def _diff_pool_library(z, adj, s):

@@ -317,3 +317,72 @@ def test_two_level_chain_gradients_through_both_levels():
     for got, ref, name in ((zc.grad, zd.grad, "grad z"), (sc1.grad, sd1.grad, "grad logits 1"), (sc2.grad, sd2.grad, "grad logits 2")):
         err = float((got.double() - ref).abs().max())
         assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (name, err)
+
+
+@pytest.mark.parametrize("shared_adj", [False, True])
+def test_fp32_batch_is_grouped_launches_with_the_references_batch_semantics(shared_adj):
+    """fp32, B = 3 through ``mlgnn_diffpool_large_f32_fwd`` / ``_bwd`` (grid.y = graph): per-graph outputs bitwise those of
+    single calls, the batch's scalars and every gradient (z, logits, adjacency -- summed over the batch when shared)
+    within 1e-4 of the fp64 oracle on the batched call."""
+    from mlgnn.dense import dense_diff_pool
+    N, K, C, B = 256, 128, 128, 3
+    g = torch.Generator().manual_seed(51)
+    dev = "cuda:0"
+    z = torch.randn(B, N, C, generator=g)
+    a = torch.rand(1 if shared_adj else B, N, N, generator=g) + torch.eye(N)
+    s = torch.randn(B, N, K, generator=g) * 2.0
+    zd, ad, sd = (t.double().to(dev).requires_grad_(True) for t in (z, a, s))
+    rx, ra, rl, re = OP.dense_diff_pool(zd, ad, sd)
+    wx, wa = torch.randn(B, K, C, generator=g).double().to(dev), (torch.randn(B, K, K, generator=g) / K).double().to(dev)
+    ((rx * wx).sum() + (ra * wa).sum() + rl * 3e4 + re * 2.0).backward()
+    zc, ac, sc = (t.to(dev).requires_grad_(True) for t in (z, a, s))
+    x, ao, link, ent = dense_diff_pool(zc, ac, sc)
+    assert x.shape == (B, K, C) and ao.shape == (B, K, K) and x.dtype == torch.float32
+    for b in range(B):
+        xb, ab_, _, _ = dense_diff_pool(z[b:b + 1].to(dev), a[0 if shared_adj else b][None].to(dev), s[b:b + 1].to(dev))
+        assert torch.equal(x[b], xb[0]) and torch.equal(ao[b], ab_[0])
+    assert abs(float(link) - float(rl)) <= 1e-4 * float(rl)
+    assert abs(float(ent) - float(re)) <= 1e-4 * abs(float(re))
+    assert float((x.double() - rx.detach()).abs().max()) <= 1e-4 * max(1.0, float(rx.abs().max()))
+    assert float((ao.double() - ra.detach()).abs().max()) <= 1e-4 * max(1.0, float(ra.abs().max()))
+    ((x * wx.float()).sum() + (ao * wa.float()).sum() + link * 3e4 + ent * 2.0).backward()
+    assert ac.grad.shape == a.shape
+    for got, ref, name in ((ac.grad, ad.grad, "grad adj"), (zc.grad, zd.grad, "grad z"), (sc.grad, sd.grad, "grad logits")):
+        err = float((got.double() - ref).abs().max())
+        assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (name, err)
+
+
+def test_fp32_symmetric_shortcut_and_argument_errors():
+    """A symmetric adjacency with ``adj_symmetric=True`` (T2 = T: no A^T product) gives the gradients of the general
+    path to rounding; the C entry point refuses bad shapes / workspaces / pointers with its error codes."""
+    from mlgnn import _lib
+    from mlgnn.dense import dense_diff_pool
+    N, K, C = 256, 128, 128
+    g = torch.Generator().manual_seed(61)
+    z, s = torch.randn(N, C, generator=g).cuda(), (torch.randn(N, K, generator=g) * 2.0).cuda()
+    a = torch.rand(N, N, generator=g)
+    a = ((a + a.t()) * 0.5).cuda()
+    grads = []
+    for sym in (False, True):
+        zc, sc = z.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        x, ao, link, ent = dense_diff_pool(zc, a, sc, adj_symmetric=sym)
+        (x.sum() + (ao ** 2).sum() + 1e4 * link + ent).backward()
+        grads.append((zc.grad, sc.grad))
+    for u, v in zip(*grads):
+        assert float((u - v).abs().max()) <= 1e-5 * max(1.0, float(u.abs().max()))
+    L = _lib.lib
+    assert L.mlgnn_diffpool_large_f32_workspace_bytes(100, 128, 128) == -2
+    need = int(L.mlgnn_diffpool_large_f32_workspace_bytes(N, K, C))
+    assert 0 < int(L.mlgnn_diffpool_large_f32_saved_bytes(N, K, C)) < need
+    S, xo, aout = torch.empty(N, K).cuda(), torch.empty(K, C).cuda(), torch.empty(K, K).cuda()
+    scal, stats = torch.empty(2).cuda(), torch.empty(3).cuda()
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    args = [z.data_ptr(), a.data_ptr(), s.data_ptr(), S.data_ptr(), xo.data_ptr(), aout.data_ptr(), scal.data_ptr(),
+            stats.data_ptr(), ws.data_ptr()]
+    assert L.mlgnn_diffpool_large_f32_fwd(*args, need - 1, N, K, C, 1, 0, st) == -5
+    assert L.mlgnn_diffpool_large_f32_fwd(*args, need, N, K + 1, C, 1, 0, st) == -2
+    assert L.mlgnn_diffpool_large_f32_fwd(*args[:3], None, *args[4:], need, N, K, C, 1, 0, st) == -1
+    assert L.mlgnn_diffpool_large_f32_fwd(*args, need, N, K, C, 1, 0, st) == 0
+    torch.cuda.synchronize()
+    assert float((S.sum(-1) - 1.0).abs().max()) <= 1e-5

@@ -128,7 +128,7 @@ def main():
                                  "approx_TFLOPs_fwd_bwd": 3 * flop_fwd / dtp / 1e12,
                                  "dense_peak_TFLOPs": peak,
                                  "path": "csrc/diffpool_large.hip + gemm_nt.hip (bf16 MFMA)" if a.dtype == "bf16"
-                                 else ("gemm_nt.hip, every product as three bf16 terms (mlgnn.dense._DiffPoolLargeFP32)"
+                                 else ("gemm_nt.hip, every product as three bf16 terms (mlgnn_diffpool_large_f32_fwd / _bwd)"
                                        if large_fp32 else "library GEMMs (fp32)"),
                                  "note": "FLOP counted in the reference's formulation (incl. S S^T); see tools/bench_diffpool.py"}
     print(json.dumps(res, indent=1))

@@ -147,6 +147,11 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
  *   accumulate_efull  non-zero: grad_efull += instead of = (the same [E0,d] embedding feeds several layers --
  *                   deepergcn.py:232-281 passes one edge_emb to every GENConv -- and their edge gradients are
  *                   summed in place instead of by separate [E0,d] additions)
+ *                   2 (MAX over fp32 rows with a TABLE read through eid): grad_efull is the fixed-point accumulator of
+ *                   the TABLE's gradient prepared by mlgnn_table_grad_begin and geid_t names every edge's table row
+ *                   (= eid_t): with max only the winning edge of (i, c) has a gradient, 1 / degree of the [E,d]
+ *                   per-edge gradient is non-zero, and it is added to the table directly with integer atomics (sums
+ *                   independent of arrival order: bitwise reproducible) -- no [E,d] gradient is written or re-read
  *   grad_uv  [edge_rank+1,d]  EDGE_RANK1: d loss / d eu (edge_rank rows), then d loss / d ev
  *   learn_t  non-zero: SOFTMAX weights carry gradient (torch_message.py:51-52)
  *   workspace: mlgnn_csr_aggregate_bwd_workspace_floats(N,d,dtype,edge_rank,aggr,learn_t) floats
@@ -540,6 +545,22 @@ int mlgnn_tallgemm_lnbwd(const float* grad_out, const float* w, int w_transposed
  */
 int mlgnn_embedding_bwd(const float* grad_e, const int32_t* perm, const int32_t* rowptr, float* grad_table,
                         int64_t T, int64_t d, int dtype, void* stream);
+
+/*
+ * Table gradient through a fixed-point accumulator -- the max aggregator's way to the gradient of a table edge term
+ * (deepergcn.py:103-104,189-190: nn.Embedding(pathway_edge_num, hidden) read by every GENConv layer; the reference's
+ * DEFAULT flags gcn_aggr=max, global_edge=onehot):
+ *   accumulator: mlgnn_table_grad_bytes(T, d) bytes, 16-byte aligned, ZEROED once by the caller;
+ *   mlgnn_table_grad_begin(grad_out [rows,d] fp32 -- the cotangent mlgnn_csr_aggregate_bwd is about to receive)
+ *     records max |grad_out| (and a non-finite flag) on the device: the power-of-two scale of the sums;
+ *   mlgnn_csr_aggregate_bwd(..., grad_efull = accumulator, geid_t = table row per edge, accumulate_efull = 2);
+ *   mlgnn_table_grad_finish: grad_table [T,d] = (accumulate ? grad_table : 0) + sums / scale, accumulator cleared for
+ *     the next layer.  Resolution 2^-(61 - log2(rows)) of max |grad_out|; a non-finite cotangent gives an all-NaN table
+ *     gradient (the per-edge path would confine it to the rows it touches).
+ */
+int64_t mlgnn_table_grad_bytes(int64_t T, int64_t d);
+int mlgnn_table_grad_begin(const float* grad_out, int64_t rows, int64_t d, void* accumulator, void* stream);
+int mlgnn_table_grad_finish(void* accumulator, float* grad_table, int64_t T, int64_t d, int accumulate, void* stream);
 
 /*
  * Large bf16 GEMM with fp32 accumulation on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16), both operands with the

@@ -73,6 +73,13 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
   const Scalars sc = read_scalars(a.t_dev, a.p_dev, a.t, a.p);
   const float t_eps = sc.t_log2e * a.eps;
   const uint32_t row_bytes = (uint32_t)a.d * (uint32_t)sizeof(T);
+  // max with a TABLE edge term (ge_accumulate == 2): only the winning edge of (i, c) has a gradient -- 1 / degree of the
+  // [E, d] per-edge gradient is non-zero -- so it is added straight to the table's fixed-point accumulator (integer
+  // atomics: order-independent) instead of being written per edge and reduced later (csrc/embedding.hip)
+  constexpr bool kCanFix = MODE == M_GEN_FULL && AGGR == A_MAX && sizeof(T) == 4;
+  const bool fix = kCanFix && a.ge_accumulate == 2;
+  const float fix_scale = fix ? fix_scale_of(static_cast<const uint32_t*>(a.ge)) : 0.f;
+  unsigned long long* fix_tab = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(a.ge) + kFixHeaderBytes);
 
   for (int cbase = 0; cbase < a.d; cbase += lpr * VEC) {
     const bool cact = cbase + cl * VEC < a.d;          // inactive lanes shadow the last chunk (see forward)
@@ -293,6 +300,17 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
               if constexpr (RK > 0) {               // (d loss / d v = sum of all dz: taken from gx once per row, below)
 #pragma unroll
                 for (int q = 0; q < RK; ++q) gu[i][q] = fmaf(wa[u][q], dz[i], gu[i][q]);
+              }
+            }
+            if constexpr (kCanFix) {
+              if (fix) {
+                if (valid[u] && cact) {
+                  unsigned long long* tp = fix_tab + (size_t)g0[u] * a.d + c0;
+#pragma unroll
+                  for (int i = 0; i < VEC; ++i)
+                    if (dz[i] != 0.f) atomicAdd(tp + i, (unsigned long long)__float2ll_rn(dz[i] * fix_scale));
+                }
+                continue;
               }
             }
             if (MODE == M_GEN_FULL && valid[u] && cact) {
@@ -564,12 +582,72 @@ __global__ __launch_bounds__(kRedWQuads * kRedWSlices) void reduce_partials_wide
   }
 }
 
+// Narrow tables with many rows (LayerNorm / edge-term parameter gradients: 512 .. 2048 partial rows of 256 .. 1024
+// columns): the 32-columns-per-workgroup kernel above runs on cols / 32 = 8 .. 32 workgroups, i.e. on a tenth of the
+// chip (19 us for an 8 MB table at BASELINE configs[4]).  Here a workgroup owns CQ column quads (16-byte loads) and
+// 1024 / CQ row slices; CQ is picked so that the launch has >= 128 workgroups.  Fixed summation order: a thread's rows
+// in order, then the slices in two levels (32 groups in order, the groups in order).
+template <int CQ>
+__global__ __launch_bounds__(1024) void reduce_partials_quads_kernel(const float4* __restrict__ ws, float4* __restrict__ out,
+                                                                    int nblk, int quads) {
+  constexpr int kSlices = 1024 / CQ;
+  __shared__ float4 part[kSlices][CQ];
+  __shared__ float4 part2[32][CQ];
+  const int ql = threadIdx.x % CQ, slice = threadIdx.x / CQ;
+  const int q = blockIdx.x * CQ + ql;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < quads) {
+#pragma unroll 4
+    for (int b = slice; b < nblk; b += kSlices) {
+      const float4 v = ws[(size_t)b * quads + q];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[slice][ql] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 * CQ) {
+    constexpr int kPer = kSlices / 32;
+    const int g = threadIdx.x / CQ;
+    float4 t = part[g * kPer][ql];
+#pragma unroll
+    for (int k = 1; k < kPer; ++k) {
+      const float4 v = part[g * kPer + k][ql];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    part2[g][ql] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < CQ && q < quads) {
+    float4 t = part2[0][ql];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) {
+      const float4 v = part2[k][ql];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    out[q] = t;
+  }
+}
+
 void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream) {
-  if (cols >= 4096 && cols % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+  const bool vec_ok = cols % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (cols >= 4096 && vec_ok) {
     const int quads = cols / 4;
     hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((quads + kRedWQuads - 1) / kRedWQuads),
                        dim3(kRedWQuads * kRedWSlices), 0, stream, reinterpret_cast<const float4*>(ws),
                        reinterpret_cast<float4*>(out), nblk, quads);
+    return;
+  }
+  static const bool quads_on = [] { const char* e = getenv("MLGNN_RED_QUADS"); return !(e && e[0] == '0'); }();   // A/B switch
+  if (quads_on && vec_ok && cols >= 64 && nblk >= 256) {
+    const int quads = cols / 4;
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    if (quads >= 128 * 8)
+      hipLaunchKernelGGL(reduce_partials_quads_kernel<8>, dim3((quads + 7) / 8), dim3(1024), 0, stream, w4, o4, nblk, quads);
+    else if (quads >= 128 * 4)
+      hipLaunchKernelGGL(reduce_partials_quads_kernel<4>, dim3((quads + 3) / 4), dim3(1024), 0, stream, w4, o4, nblk, quads);
+    else
+      hipLaunchKernelGGL(reduce_partials_quads_kernel<2>, dim3((quads + 1) / 2), dim3(1024), 0, stream, w4, o4, nblk, quads);
     return;
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + kRedCols - 1) / kRedCols), dim3(kRedCols * kRedSlices),
@@ -645,6 +723,9 @@ static int csr_aggregate_bwd_impl(const void* grad_out, const void* x, const voi
   a.N = (int)N; a.d = (int)d; a.mean = (aggr == MLGNN_AGGR_MEAN); a.learn_t = learn_t;
   a.t = t; a.p = p; a.eps = eps; a.t_dev = t_dev; a.p_dev = p_dev; a.add_root = add_root;
   a.ge_accumulate = accumulate_efull;
+  // 2: grad_efull is the fixed-point accumulator of a TABLE gradient (mlgnn_table_grad_begin), geid_t names every
+  // edge's table row -- the max aggregator over fp32 rows only
+  if (accumulate_efull == 2 && (ag != A_MAX || mode != M_GEN_FULL || bf16 || !grad_efull || !geid_t)) return MLGNN_E_MODE;
   a.cap = split ? hub->cap : kNoCap; a.vrows = nullptr; a.vcount = nullptr;
   if (add_root && learn_t) return MLGNN_E_MODE;       // `out` must be the bare aggregate for d/dt
 

@@ -253,6 +253,21 @@ inline int lanes_per_row_log2(int64_t d, int vec) {
 }
 
 // ws[nblk][cols] -> out[cols] in a fixed summation order (defined in aggregate_bwd.hip)
+// Fixed-point accumulator of a table gradient (csrc/embedding.hip, the max-aggregation backward with a table edge
+// term): a 256-byte header {bits of max |cotangent|, non-finite flag, headroom bits} followed by int64 [T, d].
+// Integer atomic adds commute, so the sums are independent of the order the edges arrive in (bitwise reproducible).
+// The scale is the power of two that maps |v| <= max onto |v * scale| < 2^bits.
+constexpr int kFixHeaderBytes = 256;
+__device__ __forceinline__ int fix_scale_exponent(const uint32_t* hdr) {
+  int e = (int)((hdr[0] >> 23) & 0xffu);                     // biased exponent of the maximum: |v| < 2^(e - 126)
+  e = e < 1 ? 1 : e;
+  const int se = (int)hdr[2] - e + 253;                     // biased exponent of 2^(bits - (e - 126))
+  return se < 1 ? 1 : (se > 253 ? 253 : se);
+}
+__device__ __forceinline__ float fix_scale_of(const uint32_t* hdr) {
+  return __builtin_bit_cast(float, (uint32_t)fix_scale_exponent(hdr) << 23);
+}
+
 void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream);
 
 }  // namespace mlgnn

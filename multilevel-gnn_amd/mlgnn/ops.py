@@ -307,12 +307,23 @@ def edge_type_embedding(table, idx):
     return torch.nn.functional.embedding(idx, table)
 
 
+# max + TableEdge: the table gradient summed inside the backward kernel (fixed-point atomics) instead of through an [E, d]
+# per-edge gradient.  Saves that buffer (5.2 GB for a BASELINE configs[1] batch) but measured 3 % SLOWER per step with
+# the reference's default DeeperGCN flags (22.6 vs 21.9 ms, same box): 82 M sparse 8-byte atomics per layer execute at
+# the memory side, one 64-byte request each.  Off by default.
+TABLE_DIRECT = os.environ.get("MLGNN_TABLE_DIRECT", "0") == "1"
+
+
 class _GradSink:
     """Accumulation buffer shared by the aggregation layers that consume one dense edge embedding."""
 
     def __init__(self):
         self.buf = None
         self.graph = None          # TableEdge: the graph whose by-source edge order the rows of buf follow
+        # TableEdge under the max aggregator: the table's gradient is summed directly (fixed-point accumulator,
+        # csrc/embedding.hip) -- `total` collects the layers of one backward
+        self.fix = None
+        self.total = None
 
 
 class _EdgeFanout(torch.autograd.Function):
@@ -350,6 +361,7 @@ class _TableFanout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         per_edge, ctx.sink.buf = ctx.sink.buf, None
+        direct, ctx.sink.total = ctx.sink.total, None
         total = None
         if per_edge is not None:
             order, rowptr = ctx.owner.sorted_by_type(ctx.sink.graph)
@@ -358,6 +370,8 @@ class _TableFanout(torch.autograd.Function):
             rc = _lib.lib.mlgnn_embedding_bwd(per_edge.data_ptr(), order.data_ptr(), rowptr.data_ptr(),
                                               total.data_ptr(), T, d, DTYPE_F32, _stream())
             _lib.check(rc, "mlgnn_embedding_bwd")
+        if direct is not None:
+            total = direct if total is None else total + direct
         if g is not None:
             total = g if total is None else total + g
         return total, None
@@ -535,7 +549,18 @@ class _GenAggregate(torch.autograd.Function):
                 if sink.graph is not None and sink.graph is not g:
                     raise RuntimeError("a TableEdge is tied to one graph (one batch)")
                 sink.graph = g
-        if edge_mode == EDGE_FULL and (te is None or sink is not None):
+        # max over a table edge term: only the winning edge of (i, c) has a gradient -- it goes straight to the table's
+        # fixed-point accumulator inside the kernel (no [E, d] gradient written, re-read and reduced)
+        fix_table = (TABLE_DIRECT and te is not None and sink is not None and aggr_id == AGGR_MAX and edge_mode == EDGE_FULL
+                     and x.dtype == torch.float32 and d % 4 == 0 and ctx.post_ln is None)
+        if fix_table:
+            T = te.table_rows
+            if sink.fix is None or sink.fix.numel() != int(_lib.lib.mlgnn_table_grad_bytes(T, d)):
+                sink.fix = torch.zeros(int(_lib.lib.mlgnn_table_grad_bytes(T, d)), dtype=torch.uint8, device=x.device)
+            _lib.check(_lib.lib.mlgnn_table_grad_begin(go_k.data_ptr(), N, d, sink.fix.data_ptr(), _stream()),
+                       "mlgnn_table_grad_begin")
+            ge, ge_accumulate, geid_t = sink.fix, 2, eid_t
+        elif edge_mode == EDGE_FULL and (te is None or sink is not None):
             if sink is not None and sink.buf is not None:
                 ge, ge_accumulate = sink.buf, 1              # add this layer's share to the layers that ran before
             else:
@@ -598,6 +623,12 @@ class _GenAggregate(torch.autograd.Function):
                 _lib.ptr(shifted[0]) if shifted else None, _lib.ptr(shifted[1]) if shifted else None, _stream())
             _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         del hub_keep
+        if fix_table:
+            first = sink.total is None
+            if first:
+                sink.total = torch.empty((te.table_rows, d), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib.mlgnn_table_grad_finish(sink.fix.data_ptr(), sink.total.data_ptr(), te.table_rows, d,
+                                                        0 if first else 1, _stream()), "mlgnn_table_grad_finish")
         SHIFT_STATS["given" if shifted else "computed"] += int(aggr_id == AGGR_SOFTMAX and not learn_t)
         if sink is not None or te is not None:
             ge = None                                        # reported once, by the fan-out node of the shared term

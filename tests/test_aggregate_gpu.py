@@ -404,3 +404,43 @@ def test_table_edge_matches_the_materialised_embedding(aggr, layers, encode):
         out = gen_aggregate(xd, graph, TableEdge(td.detach(), idx.to(dev)), aggr=aggr, t=1.0, p=2.0)
     first = G.gen_aggregate(torch.relu(x0[ei[0]] + table0[idx]) + 1e-7, ei[1], N, aggr, t=1.0, p=2.0)
     assert_close(out, first, TOL, "table edge, inference")
+
+
+@pytest.mark.parametrize("layers", [1, 3])
+def test_max_table_gradient_summed_in_the_kernel(layers, monkeypatch):
+    """max + ``TableEdge`` (the reference's default flags: gcn_aggr=max, global_edge=onehot): the table gradient is added
+    to a fixed-point accumulator inside the backward kernel (``accumulate_efull = 2``, mlgnn_table_grad_begin / _finish)
+    instead of being written per edge and reduced.  Against the per-edge path on the same inputs (both sum the same
+    values: equal up to fp32 summation order + 2^-40 of max |cotangent|), bitwise repeatable, untouched rows stay zero,
+    a non-finite cotangent poisons the table gradient."""
+    from mlgnn import CSRGraph, TableEdge, gen_aggregate, ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(90 + layers)
+    N, E, d, T = 3000, 50000, 128, 200
+    ei = _graph(gen, N, E, hub=True).to(dev)
+    x0 = torch.randn(N, d, generator=gen).to(dev)
+    table0 = (torch.randn(T, d, generator=gen) * 0.5).to(dev)
+    idx = torch.randint(0, T - 3, (E,), generator=gen).to(dev)
+    cot = torch.randn(N, d, generator=gen).to(dev)
+    graph = CSRGraph(ei, N)
+
+    def run(direct, cotangent):
+        monkeypatch.setattr(ops, "TABLE_DIRECT", direct)
+        xd, td = x0.clone().requires_grad_(True), table0.clone().requires_grad_(True)
+        te = TableEdge(td, idx)
+        h = xd
+        for _ in range(layers):
+            h = gen_aggregate(h, graph, te, aggr="max") * 0.5
+        return torch.autograd.grad((h * cotangent).sum(), [xd, td])
+
+    gx0, gt0 = run(False, cot)
+    gx1, gt1 = run(True, cot)
+    gx2, gt2 = run(True, cot)
+    assert torch.equal(gx0, gx1) and torch.equal(gt1, gt2) and torch.equal(gx1, gx2)
+    scale = float(gt0.abs().max())
+    assert float((gt1 - gt0).abs().max()) <= 2e-6 * scale, float((gt1 - gt0).abs().max()) / scale
+    assert not bool(gt1[T - 3:].any())
+    bad = cot.clone()
+    bad[5, 7] = float("nan")
+    _, gtn = run(True, bad)
+    assert bool(torch.isnan(gtn).all())

@@ -132,3 +132,29 @@ def test_argument_errors_of_the_one_pass_linear_backward():
     assert lib.mlgnn_tallgemm_bf16_shift_supported(1000, 40, 64) == 0 and lib.mlgnn_tallgemm_bf16_shift_supported(0, 512, 256) == 0
     sh = lambda N, R, J, ws=1 << 20: lib.mlgnn_tallgemm_bf16_shift(None, None, None, None, None, None, None, ws, N, R, J, None)
     assert sh(0, 512, 256) == 0 and sh(1000, 512, 256) == -1 and sh(1000, 40, 64) == -2
+
+
+def test_argument_errors_of_the_fp32_large_diffpool_and_table_gradient():
+    """mlgnn_diffpool_large_f32_* and mlgnn_table_grad_*: sizes, NULL operands and workspaces are checked before
+    anything is launched (no GPU needed)."""
+    from mlgnn import _lib
+    lib = _lib.lib
+    N, K, C = 256, 128, 128
+    need = lib.mlgnn_diffpool_large_f32_workspace_bytes(N, K, C)
+    saved = lib.mlgnn_diffpool_large_f32_saved_bytes(N, K, C)
+    assert 0 < saved < need and need % 256 == 0
+    assert lib.mlgnn_diffpool_large_f32_workspace_bytes(N, K + 64, C) == -2
+    assert lib.mlgnn_diffpool_large_f32_bwd_workspace_bytes(N, K, C, 1) < lib.mlgnn_diffpool_large_f32_bwd_workspace_bytes(N, K, C, 0)
+    fwd = lambda n=N, b=1, ws=need: lib.mlgnn_diffpool_large_f32_fwd(None, None, None, None, None, None, None, None, None,
+                                                                      ws, n, K, C, b, 0, None)
+    assert fwd() == -1 and fwd(n=100) == -2 and fwd(b=0) == -2 and fwd(b=70000) == -2
+    bwd = lambda n=N: lib.mlgnn_diffpool_large_f32_bwd(None, None, None, None, None, None, None, None, None, None, None, 0,
+                                                       None, 1 << 40, n, K, C, 1, 0, None)
+    assert bwd() == -1 and bwd(n=130) == -2
+    # fixed-point table gradient (max aggregator with a table edge term)
+    assert lib.mlgnn_table_grad_bytes(20000, 128) == 256 + 20000 * 128 * 8
+    assert lib.mlgnn_table_grad_bytes(10, 130) == -2 and lib.mlgnn_table_grad_bytes(0, 128) == -2
+    assert lib.mlgnn_table_grad_begin(None, 100, 128, None, None) == -1
+    assert lib.mlgnn_table_grad_begin(None, 0, 128, None, None) == -2 and lib.mlgnn_table_grad_begin(None, 10, 6, None, None) == -2
+    assert lib.mlgnn_table_grad_finish(None, None, 10, 128, 0, None) == -1
+    assert lib.mlgnn_table_grad_finish(None, None, 10, 127, 0, None) == -2

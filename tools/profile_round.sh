@@ -6,7 +6,7 @@
 #    once the kernel sources change), <tag>_bench.json (the bench line of the un-profiled run)
 # 2. configs[4] stress run (bf16): stats -> profiles/<tag>_stress_bf16_kernel_stats.md, <tag>_stress_configs4_bf16.json
 # 3. configs[4] DiffPool (4096 nodes / 1024 clusters): bench + stats + MFMA counters
-#    -> profiles/<tag>_diffpool_configs4.json (+ _fp32.json), <tag>_diffpool_kernel_stats.md, <tag>_diffpool_mfma_pmc.json
+#    -> profiles/<tag>_diffpool_configs4.json (+ _fp32.json), <tag>_diffpool_kernel_stats.md (+ _fp32_), <tag>_diffpool_mfma_pmc.json
 # 4. hub-row benchmark -> profiles/<tag>_skew.json
 # 5. topology build on its own -> profiles/<tag>_csr_build.json, <tag>_csr_kernel_stats.md
 # The program always follows `rocprofv3 ... --` directly (no wrapper process).  Outputs: gpurun_out/prof_*_<tag>/.
@@ -29,6 +29,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stres
 echo "stress pass done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dp_stats_$TAG -- $DP > $R/gpurun_out/prof_dp_stats_$TAG.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_dp_pmc_$TAG -- $DP > $R/gpurun_out/prof_dp_pmc_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dp32_stats_$TAG -- $DP --dtype fp32 > $R/gpurun_out/prof_dp32_stats_$TAG.log 2>&1
 echo "diffpool passes done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_csr_$TAG -- python3 $R/tools/bench_csr.py > $R/gpurun_out/prof_csr_$TAG.log 2>&1
 echo "csr pass done"
@@ -57,6 +58,8 @@ python3 tools/summarize_prof.py --stats "gpurun_out/prof_stress_$TAG/**/*kernel_
   --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/stress.py --steps 3 --dtype bf16   (configs[4]: N=200000 E=3000000 d=256, 28 layers, bf16 storage; 4 steps incl. 1 warm-up)"
 python3 tools/summarize_prof.py --stats "gpurun_out/prof_dp_stats_$TAG/**/*kernel_stats.csv" --tag ${TAG}_diffpool --commit "$MLGNN_COMMIT" \
   --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/bench_diffpool.py --skip-library --iters 10   (configs[4] DiffPool: 4096 nodes, 1024 clusters, 256 channels, bf16)"
+python3 tools/summarize_prof.py --stats "gpurun_out/prof_dp32_stats_$TAG/**/*kernel_stats.csv" --tag ${TAG}_diffpool_fp32 --commit "$MLGNN_COMMIT" \
+  --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/bench_diffpool.py --skip-library --iters 10 --dtype fp32   (configs[4] DiffPool on fp32 tensors: three-term bf16 products, mlgnn_diffpool_large_f32_fwd / _bwd)"
 python3 tools/bench_csr.py > gpurun_out/csr_$TAG.log 2>&1
 if grep -q '^{' gpurun_out/csr_$TAG.log; then grep '^{' gpurun_out/csr_$TAG.log | tail -1 > profiles/${TAG}_csr_build.json; fi
 python3 tools/summarize_prof.py --stats "gpurun_out/prof_csr_$TAG/**/*kernel_stats.csv" --tag ${TAG}_csr --commit "$MLGNN_COMMIT" \

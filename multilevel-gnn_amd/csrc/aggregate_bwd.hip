@@ -316,6 +316,12 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
             if (MODE == M_GEN_FULL && valid[u] && cact) {
               T* gep = GE + (size_t)g0[u] * a.d + c0;
               if (a.ge_accumulate) {                 // this layer's share on top of the layers that ran before it
+                if constexpr (AGGR == A_MAX) {       // max: only a row's winners carry gradient -- most pieces add nothing
+                  bool any = false;
+#pragma unroll
+                  for (int i = 0; i < VEC; ++i) any |= dz[i] != 0.f;
+                  if (!any) continue;
+                }
                 float prev[VEC];
                 load_t<T, VEC>(prev, gep);
 #pragma unroll

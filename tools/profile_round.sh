@@ -26,6 +26,7 @@ echo "fetch pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write_$TAG -- $BENCH > $R/gpurun_out/prof_write_$TAG.log 2>&1
 echo "write pass done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stress_$TAG -- $STRESS > $R/gpurun_out/prof_stress_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stress32_$TAG -- python3 $R/tools/stress.py --steps 3 --dtype fp32 > $R/gpurun_out/prof_stress32_$TAG.log 2>&1 || echo "fp32 stress pass failed"
 echo "stress pass done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dp_stats_$TAG -- $DP > $R/gpurun_out/prof_dp_stats_$TAG.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_dp_pmc_$TAG -- $DP > $R/gpurun_out/prof_dp_pmc_$TAG.log 2>&1
@@ -56,6 +57,16 @@ python3 tools/summarize_prof.py --stats "gpurun_out/prof_stats_$TAG/**/*kernel_s
   --pmc-fetch "gpurun_out/prof_fetch_$TAG/**/*counter_collection.csv" --pmc-write "gpurun_out/prof_write_$TAG/**/*counter_collection.csv"
 python3 tools/summarize_prof.py --stats "gpurun_out/prof_stress_$TAG/**/*kernel_stats.csv" --tag ${TAG}_stress_bf16 --commit "$MLGNN_COMMIT" \
   --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/stress.py --steps 3 --dtype bf16   (configs[4]: N=200000 E=3000000 d=256, 28 layers, bf16 storage; 4 steps incl. 1 warm-up)"
+python3 tools/summarize_prof.py --stats "gpurun_out/prof_stress32_$TAG/**/*kernel_stats.csv" --tag ${TAG}_stress_fp32 --commit "$MLGNN_COMMIT" \
+  --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/stress.py --steps 3 --dtype fp32   (configs[4] shape in fp32 -- NOT the dtype the config names: hidden width 512 is past the fp32 tall kernels, those products run on the library)"
+python3 tools/stress.py --steps 3 --dtype fp32 > gpurun_out/stress32_$TAG.log 2>&1
+python3 - <<PY
+txt = open("gpurun_out/stress32_$TAG.log").read()
+if "{" in txt:
+    open("profiles/${TAG}_stress_configs4_fp32.json", "w").write(txt[txt.index("{"):])
+else:
+    print("WARNING: no JSON line in gpurun_out/stress32_$TAG.log")
+PY
 python3 tools/summarize_prof.py --stats "gpurun_out/prof_dp_stats_$TAG/**/*kernel_stats.csv" --tag ${TAG}_diffpool --commit "$MLGNN_COMMIT" \
   --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/bench_diffpool.py --skip-library --iters 10   (configs[4] DiffPool: 4096 nodes, 1024 clusters, 256 channels, bf16)"
 python3 tools/summarize_prof.py --stats "gpurun_out/prof_dp32_stats_$TAG/**/*kernel_stats.csv" --tag ${TAG}_diffpool_fp32 --commit "$MLGNN_COMMIT" \

@@ -385,10 +385,15 @@ class TableEdge:
     kernels produce is reduced to the table once for all layers that share it.  ``through_linear`` composes with a
     per-layer ``Linear(H, d)`` edge encoder (torch_vertex.py:68,77) as a ``[T, H] x [H, d]`` product."""
 
-    def __init__(self, table, idx):
+    def __init__(self, table, idx, source=None):
+        """``source``: the tensor ``idx`` was derived from (the batch's ``edge_attr``).  The index arrays derived from
+        ``idx`` for a graph (rows in by-destination / by-source order, the sort by table row) are then kept ON THE GRAPH
+        and reused while the same ``source`` (same elements, same version) comes back with the same graph -- a training
+        loop over one graph (BASELINE configs[4]) or a reused batch pays the gathers and the sort once, not per step."""
         if table.dim() != 2 or idx.dim() != 1 or idx.dtype != torch.long:
             raise ValueError("TableEdge takes table [T, d] and idx [E] (long)")
         self.idx = idx
+        self.source = source
         self.table_rows = table.shape[0]
         self.sink = None
         if table.requires_grad and torch.is_grad_enabled() and table.is_cuda and table.dtype == torch.float32:
@@ -399,7 +404,20 @@ class TableEdge:
         self._sorted = None
 
     def through_linear(self, W, b):
-        return TableEdge(torch.nn.functional.linear(self.table, W, b), self.idx)
+        return TableEdge(torch.nn.functional.linear(self.table, W, b), self.idx, self.source)
+
+    def _graph_cache(self, graph):
+        """The dict on ``graph`` that holds what this term derived from (``source``, graph): valid while ``source`` is the
+        same view at the same version (the entry holds the tensor, so its storage cannot be recycled under it)."""
+        from .graph import _same_view
+        src = self.source
+        if src is None:
+            return None
+        ent = getattr(graph, "_table_edge_cache", None)
+        if (ent is None or ent[1] != src._version or ent[2] != self.table_rows or not _same_view(ent[0], src)):
+            ent = (src, src._version, self.table_rows, {})
+            graph._table_edge_cache = ent
+        return ent[3]
 
     def dense(self):
         return self.table.index_select(0, self.idx)
@@ -410,20 +428,32 @@ class TableEdge:
         that it is written (and, from the second layer on, re-read) as a stream instead of as scattered rows."""
         key = id(graph)
         if key not in self._by_graph:
+            shared = self._graph_cache(graph)
+            if shared is not None and "rows" in shared:
+                self._by_graph[key] = shared["rows"]
+                return self._by_graph[key]
             i32 = self.idx.to(torch.int32)
             self._by_graph[key] = (i32[graph.eid.long()].contiguous(), i32[graph.eid_t.long()].contiguous(),
                                    torch.arange(self.idx.numel(), dtype=torch.int32, device=self.idx.device))
+            if shared is not None:
+                shared["rows"] = self._by_graph[key]
         return self._by_graph[key]
 
     def sorted_by_type(self, graph):
         """By-source edge positions sorted (stably) by table row, and the row pointer over them (int32)."""
         key = id(graph)
         if self._sorted is None or self._sorted[0] != key:
+            shared = self._graph_cache(graph)
+            if shared is not None and "sorted" in shared:
+                self._sorted = (key,) + shared["sorted"]
+                return self._sorted[1], self._sorted[2]
             by_src = self.rows_for(graph)[1].long()
             order = torch.sort(by_src, stable=True)[1].to(torch.int32)
             rowptr = torch.zeros(self.table_rows + 1, dtype=torch.int64, device=self.idx.device)
             torch.cumsum(torch.bincount(by_src, minlength=self.table_rows), 0, out=rowptr[1:])
             self._sorted = (key, order, rowptr.to(torch.int32))
+            if shared is not None:
+                shared["sorted"] = (self._sorted[1], self._sorted[2])
         return self._sorted[1], self._sorted[2]
 
 

@@ -124,7 +124,7 @@ class DeeperGCN(torch.nn.Module):
             if (idx.dim() == 2 and idx.shape[1] == 1 and enc.padding_idx is None and enc.max_norm is None
                     and enc.weight.is_cuda and enc.weight.dtype == torch.float32):
                 # [E, 1, H] flattened = table[idx]: kept as (table, row per edge); the kernels read the table rows
-                return TableEdge(enc.weight, idx[:, 0])
+                return TableEdge(enc.weight, idx[:, 0], source=edge_attr)
             emb = enc(idx).flatten(1)
         elif edge_attr.dim() == 2 and 1 <= edge_attr.shape[1] <= LowRankEdge.MAX_RANK:
             return LowRankEdge(edge_attr, self.edge_encoder.weight, self.edge_encoder.bias)
@@ -184,7 +184,9 @@ class DeeperGCN(torch.nn.Module):
             raise NotImplementedError("pca_only is outside the accelerated path")
         graph = getattr(input_batch, "csr", None)
         if graph is None:
-            graph = CSRGraph(input_batch.edge_index, x.shape[0])
+            # the SAME edge_index tensor again (a training loop over one graph, a reused batch): the CSR built the first
+            # time (identity + version match, no device work); a fresh tensor builds as before
+            graph = CSRGraph.from_cache(input_batch.edge_index, x.shape[0])
         batch = input_batch.batch
         age = input_batch.age
 

@@ -444,3 +444,38 @@ def test_max_table_gradient_summed_in_the_kernel(layers, monkeypatch):
     bad[5, 7] = float("nan")
     _, gtn = run(True, bad)
     assert bool(torch.isnan(gtn).all())
+
+
+def test_table_edge_index_arrays_are_kept_on_the_graph_for_a_repeated_source():
+    """``TableEdge(table, idx, source=edge_attr)``: the per-graph index arrays (rows in both edge orders, the sort by table
+    row) are derived once per (graph, source tensor at one version) -- a loop over one graph does not redo the gathers and
+    the sort every step -- and re-derived when the source changes in place."""
+    from mlgnn import CSRGraph, TableEdge, gen_aggregate
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(77)
+    N, E, d, T = 500, 8000, 64, 40
+    ei = _graph(gen, N, E, hub=False).to(dev)
+    graph = CSRGraph(ei, N)
+    attr = torch.randint(0, T, (E, 1), generator=gen).float().to(dev)
+    table = torch.randn(T, d, generator=gen).to(dev).requires_grad_(True)
+    x = torch.randn(N, d, generator=gen).to(dev)
+
+    def step():
+        te = TableEdge(table, attr.to(torch.long)[:, 0], source=attr)
+        out = gen_aggregate(gen_aggregate(x, graph, te, aggr="softmax"), graph, te, aggr="softmax")
+        g, = torch.autograd.grad(out.sum(), table)
+        return te, out, g
+
+    te1, o1, g1 = step()
+    rows1, sorted1 = te1.rows_for(graph), te1.sorted_by_type(graph)
+    te2, o2, g2 = step()
+    assert te2.rows_for(graph) is rows1 and te2.sorted_by_type(graph)[0] is sorted1[0]
+    assert torch.equal(o1, o2) and torch.equal(g1, g2)
+    ref = TableEdge(table, attr.to(torch.long)[:, 0])                     # no source: derives its own arrays
+    assert all(torch.equal(a, b) for a, b in zip(ref.rows_for(graph), rows1))
+    attr[:10] = (attr[:10] + 1) % T                                       # in place: the version moves
+    te3, o3, g3 = step()
+    assert te3.rows_for(graph) is not rows1
+    want = TableEdge(table, attr.to(torch.long)[:, 0])
+    assert all(torch.equal(a, b) for a, b in zip(want.rows_for(graph), te3.rows_for(graph)))
+    assert not torch.equal(o3, o1)

@@ -663,6 +663,25 @@ int mlgnn_diffpool_large_f32_bwd(const float* adj, const float* s_logits, const 
                                  int64_t C, int64_t B, int adj_batched, void* stream);
 
 /*
+ * fp32 nn.Linear on tall inputs past the widths of mlgnn_tallgemm_nt / mlgnn_linear_wgrad (hidden width 512 at d = 256:
+ * the fp32 weight image does not fit LDS) -- torch_nn.py:54-75 at BASELINE configs[4]'s sizes in fp32.  Every product
+ * as three bf16 terms on the matrix cores (see mlgnn_diffpool_large_f32_fwd), fp32 accumulation; the library's fp32
+ * GEMMs for these shapes run at ~40 TFLOP/s.  R, J multiples of 128 (mlgnn_linear_f32x3_supported).
+ *   fwd:  y [Npad, J] = x [N,R] w[J,R]^T + bias [J] (or NULL); Npad = mlgnn_linear_f32x3_padded_rows(N): the first N
+ *         rows are the result (the rest is scratch)
+ *   bwd:  grad_x [Npad, R] (or NULL) = grad_out [N,J] w;  grad_w [J,R] = grad_out^T x  (one product over the row index,
+ *         split along it, fixed-order reduce); the bias gradient (column sums of grad_out) is the caller's
+ */
+int mlgnn_linear_f32x3_supported(int64_t N, int64_t R, int64_t J);
+int64_t mlgnn_linear_f32x3_padded_rows(int64_t N);
+int64_t mlgnn_linear_f32x3_fwd_workspace_bytes(int64_t N, int64_t R, int64_t J);
+int mlgnn_linear_f32x3_fwd(const float* x, const float* w, const float* bias, float* y, void* workspace,
+                           int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream);
+int64_t mlgnn_linear_f32x3_bwd_workspace_bytes(int64_t N, int64_t R, int64_t J);
+int mlgnn_linear_f32x3_bwd(const float* grad_out, const float* x, const float* w, float* grad_x, float* grad_w,
+                           void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream);
+
+/*
  * Optimizer step on one flat fp32 buffer: global-norm gradient clipping + Adam with L2 weight decay, two launches.
  * Replaces: train.py:63-66,112-114 -- clip_grad_norm_(parameters, max_norm=20, norm_type=2) (when --clip_grad) and
  * torch.optim.Adam(lr, betas, weight_decay).step(); torch's single-tensor formula, element by element:

@@ -944,6 +944,7 @@ struct SplitJob {
   const float* dot; int64_t lddot; float* partial;
   int64_t s_src, s_out, s_outt, s_dot, s_part;
   int nb, tiles;
+  int rows_valid;            // rows >= rows_valid of src do not exist: they split to zeros (a tall operand padded to R rows)
 };
 constexpr int kSplitMaxJobs = 4;
 struct SplitArgs { SplitJob job[kSplitMaxJobs]; int njobs; };
@@ -978,8 +979,8 @@ __global__ __launch_bounds__(256) void dpl32_split_kernel(const SplitArgs a) {
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int r = pass * 16 + (tid >> 4), ch = tid & 15;
-    float v[4];
-    load_vec<4>(v, src + (size_t)(r0 + r) * q.ld + c0 + ch * 4);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + r < q.rows_valid) load_vec<4>(v, src + (size_t)(r0 + r) * q.ld + c0 + ch * 4);
     if (dot) {
       float d[4];
       load_vec<4>(d, dot + (size_t)(r0 + r) * q.lddot + c0 + ch * 4);
@@ -1032,6 +1033,7 @@ inline SplitJob split_job(const float* src, int64_t ld, int R, int Cc, int nb, i
   SplitJob q{};
   q.src = src; q.ld = ld; q.R = R; q.Cc = Cc; q.nb = nb; q.s_src = s_src;
   q.tiles = (R / 64) * (Cc / 64);
+  q.rows_valid = R;
   return q;
 }
 
@@ -1407,5 +1409,145 @@ extern "C" int mlgnn_diffpool_large_f32_bwd(const float* adj, const float* s_log
     DPL_CHECK(gemm_nt_launch(e, st));
   }
   (void)Sth; (void)Stl;
+  return (int)hipGetLastError();
+}
+
+
+// =====================================================================================================================
+// fp32 nn.Linear on tall inputs whose widths are past the fp32 tall kernels (csrc/tallgemm.hip: weight image <= 128 KB,
+// i.e. hidden width 512 at BASELINE configs[4]'s d = 256): the same three-term bf16 products as above -- the library's
+// fp32 GEMMs for these shapes (200 000 x 256 x 512) run at ~40 TFLOP/s, 1.35 ms each.
+//     forward   y  = x W^T + b          x [N,R], W [J,R]:  split {x, W}, one three-segment product (bias through aux, ld 0)
+//     backward  dx = go W               split {go (+ go^T), x^T, W^T}, one product
+//               dW = go^T x             one product over the row index, split along it, one reduce
+// Reference: torch_nn.py:54-75 (the Linears of MLP).  R, J multiples of 128; the rows are padded to a multiple of 128
+// inside the workspace (zero rows), y / dx are [Npad, .] buffers whose first N rows are the result.
+namespace mlgnn {
+
+inline int64_t lin3_pad(int64_t N) { return (N + 127) / 128 * 128; }
+inline bool lin3_ok(int64_t N, int64_t R, int64_t J) {
+  return N > 0 && N <= (int64_t)1 << 26 && R >= 128 && J >= 128 && R % 128 == 0 && J % 128 == 0 && R <= 8192 && J <= 8192;
+}
+inline int lin3_splits(int64_t Np, int64_t R, int64_t J) {
+  const int tiles = (int)((J / kGemmTile) * (R / kGemmTile));
+  int sp = 512 / tiles;
+  const int64_t ktiles = 3 * Np / kGemmBK;
+  if (sp > ktiles / 8) sp = (int)(ktiles / 8);
+  return sp < 1 ? 1 : sp;
+}
+
+}  // namespace mlgnn
+
+extern "C" int mlgnn_linear_f32x3_supported(int64_t N, int64_t R, int64_t J) { return lin3_ok(N, R, J) ? 1 : 0; }
+
+extern "C" int64_t mlgnn_linear_f32x3_padded_rows(int64_t N) { return N > 0 ? lin3_pad(N) : 0; }
+
+extern "C" int64_t mlgnn_linear_f32x3_fwd_workspace_bytes(int64_t N, int64_t R, int64_t J) {
+  if (!lin3_ok(N, R, J)) return MLGNN_E_SHAPE;
+  const int64_t Np = lin3_pad(N);
+  return (int64_t)(2 * dpl_align((size_t)Np * R * 2) + 2 * dpl_align((size_t)J * R * 2));
+}
+
+extern "C" int mlgnn_linear_f32x3_fwd(const float* x, const float* w, const float* bias, float* y, void* workspace,
+                                      int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream) {
+  if (!lin3_ok(N, R, J)) return MLGNN_E_SHAPE;
+  if (!x || !w || !y || !workspace) return MLGNN_E_NULL;
+  if (workspace_bytes < mlgnn_linear_f32x3_fwd_workspace_bytes(N, R, J)) return MLGNN_E_WORKSPACE;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) return MLGNN_E_ALIGN;
+  const int64_t Np = lin3_pad(N);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { unsigned char* p = ws + o; o += dpl_align(bytes); return (uint16_t*)p; };
+  uint16_t *xh = take((size_t)Np * R * 2), *xl = take((size_t)Np * R * 2);
+  uint16_t *wh = take((size_t)J * R * 2), *wl = take((size_t)J * R * 2);
+  SplitArgs a{};
+  a.njobs = 2;
+  a.job[0] = split_job(x, R, (int)Np, (int)R, 1, 0);
+  a.job[0].rows_valid = (int)N; a.job[0].hi = xh; a.job[0].lo = xl; a.job[0].ldo = R;
+  a.job[1] = split_job(w, R, (int)J, (int)R, 1, 0);
+  a.job[1].hi = wh; a.job[1].lo = wl; a.job[1].ldo = R;
+  DPL_CHECK(split_launch(a, 1, st));
+  GemmDesc d{};
+  d.nseg = 3;
+  seg3(d, 0, xh, xl, wh, wl, R, R, (int)R, 0, 0);
+  d.M = (int)Np; d.N = (int)J; d.splits = 1;
+  d.c = y; d.ldc = J; d.c_f32 = 1;
+  if (bias) { d.aux = bias; d.ldaux = 0; d.aux_f32 = 1; d.alpha = 1.f; }      // leading dimension 0: one row for all
+  d.batch = 1;
+  return gemm_nt_launch(d, st);
+}
+
+extern "C" int64_t mlgnn_linear_f32x3_bwd_workspace_bytes(int64_t N, int64_t R, int64_t J) {
+  if (!lin3_ok(N, R, J)) return MLGNN_E_SHAPE;
+  const int64_t Np = lin3_pad(N);
+  size_t o = 0;
+  o += 4 * dpl_align((size_t)Np * J * 2);             // go hi / lo, go^T hi / lo
+  o += 2 * dpl_align((size_t)Np * R * 2);             // x^T hi / lo
+  o += 2 * dpl_align((size_t)J * R * 2);              // W^T hi / lo
+  o += dpl_align((size_t)lin3_splits(Np, R, J) * J * R * 4);
+  o += dpl_align(kDplPartials * 4);
+  return (int64_t)o;
+}
+
+// grad_x [Npad, R] (first N rows = the gradient; NULL: not wanted), grad_w [J, R]; the bias gradient (column sums of
+// grad_out) is the caller's.
+extern "C" int mlgnn_linear_f32x3_bwd(const float* grad_out, const float* x, const float* w, float* grad_x, float* grad_w,
+                                      void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J,
+                                      void* stream) {
+  if (!lin3_ok(N, R, J)) return MLGNN_E_SHAPE;
+  if (!grad_out || !x || !w || !grad_w || !workspace) return MLGNN_E_NULL;
+  if (workspace_bytes < mlgnn_linear_f32x3_bwd_workspace_bytes(N, R, J)) return MLGNN_E_WORKSPACE;
+  if (((uintptr_t)grad_out | (uintptr_t)x | (uintptr_t)w | (uintptr_t)grad_x | (uintptr_t)grad_w | (uintptr_t)workspace) & 15)
+    return MLGNN_E_ALIGN;
+  const int64_t Np = lin3_pad(N);
+  const int splits = lin3_splits(Np, R, J);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { unsigned char* p = ws + o; o += dpl_align(bytes); return p; };
+  uint16_t *gh = (uint16_t*)take((size_t)Np * J * 2), *gl = (uint16_t*)take((size_t)Np * J * 2);
+  uint16_t *gth = (uint16_t*)take((size_t)Np * J * 2), *gtl = (uint16_t*)take((size_t)Np * J * 2);
+  uint16_t *xth = (uint16_t*)take((size_t)Np * R * 2), *xtl = (uint16_t*)take((size_t)Np * R * 2);
+  uint16_t *wth = (uint16_t*)take((size_t)J * R * 2), *wtl = (uint16_t*)take((size_t)J * R * 2);
+  float* slab = (float*)take((size_t)splits * J * R * 4);
+  float* scratch = (float*)take(kDplPartials * 4);
+  {
+    SplitArgs a{};
+    a.njobs = 3;
+    SplitJob& g = a.job[0];
+    g = split_job(grad_out, J, (int)Np, (int)J, 1, 0);
+    g.rows_valid = (int)N; g.hi = gh; g.lo = gl; g.ldo = J; g.hit = gth; g.lot = gtl; g.ldt = Np;
+    SplitJob& xj = a.job[1];
+    xj = split_job(x, R, (int)Np, (int)R, 1, 0);
+    xj.rows_valid = (int)N; xj.hit = xth; xj.lot = xtl; xj.ldt = Np;
+    SplitJob& wj = a.job[2];
+    wj = split_job(w, R, (int)J, (int)R, 1, 0);
+    wj.hit = wth; wj.lot = wtl; wj.ldt = J;
+    DPL_CHECK(split_launch(a, 1, st));
+  }
+  if (grad_x) {                                        // dx = go W:  go [Np, J] x (W^T [R, J])^T
+    GemmDesc d{};
+    d.nseg = 3;
+    seg3(d, 0, gh, gl, wth, wtl, J, J, (int)J, 0, 0);
+    d.M = (int)Np; d.N = (int)R; d.splits = 1;
+    d.c = grad_x; d.ldc = R; d.c_f32 = 1;
+    d.batch = 1;
+    DPL_CHECK(gemm_nt_launch(d, st));
+  }
+  {                                                    // dW = go^T x:  go^T [J, Np] x (x^T [R, Np])^T, split along the rows
+    GemmDesc d{};
+    d.nseg = 3;
+    seg3(d, 0, gth, gtl, xth, xtl, Np, Np, (int)Np, 0, 0);
+    d.M = (int)J; d.N = (int)R; d.splits = splits; d.slab = slab;
+    d.batch = 1;
+    DPL_CHECK(gemm_nt_launch(d, st));
+    SlabReduceArgs r{};
+    r.slab = slab; r.splits = splits; r.M = (int)J; r.N = (int)R; r.n_a = (int)R; r.n_b = (int)R;
+    r.ca = grad_w; r.lda = R; r.ca_f32 = 1;
+    r.cb = (uint16_t*)scratch; r.ldb = R; r.sq_partial = scratch;
+    r.cc = grad_w; r.ldc = R; r.cc_f32 = 1;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(kDplPartials, 1), dim3(256), 0, st, r);
+  }
   return (int)hipGetLastError();
 }

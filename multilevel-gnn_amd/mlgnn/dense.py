@@ -448,6 +448,47 @@ def fused_mlp2_post_supported(x, w1, w2, post_weight):
             and bool(_lib.lib.mlgnn_tallgemm_lnin_postln_supported(x.shape[0], w1.shape[0], w2.shape[0])))
 
 
+class _WideLinearF32(torch.autograd.Function):
+    """``y = x W^T + b`` for a tall fp32 ``x`` whose widths are past the fp32 tall kernels (hidden width 512): forward,
+    ``dX`` and ``dW`` as three-term bf16 products on the matrix cores (``mlgnn_linear_f32x3_fwd`` / ``_bwd``,
+    csrc/diffpool_large.hip) instead of the library's fp32 GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, R = x.shape
+        J = weight.shape[0]
+        x, weight = x.contiguous(), weight.contiguous()
+        Np = int(_lib.lib.mlgnn_linear_f32x3_padded_rows(N))
+        y = torch.empty((Np, J), dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(_lib.lib.mlgnn_linear_f32x3_fwd_workspace_bytes(N, R, J)), dtype=torch.uint8, device=x.device)
+        b = bias.contiguous() if bias is not None else None
+        rc = _lib.lib.mlgnn_linear_f32x3_fwd(x.data_ptr(), weight.data_ptr(), _lib.ptr(b), y.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), N, R, J, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_linear_f32x3_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y[:N]
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight = ctx.saved_tensors
+        N, R = x.shape
+        J = weight.shape[0]
+        go = go.contiguous()
+        Np = int(_lib.lib.mlgnn_linear_f32x3_padded_rows(N))
+        gx = torch.empty((Np, R), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
+        gw = torch.empty((J, R), dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(_lib.lib.mlgnn_linear_f32x3_bwd_workspace_bytes(N, R, J)), dtype=torch.uint8, device=x.device)
+        rc = _lib.lib.mlgnn_linear_f32x3_bwd(go.data_ptr(), x.data_ptr(), weight.data_ptr(), _lib.ptr(gx), gw.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), N, R, J, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_linear_f32x3_bwd")
+        gb = go.sum(0) if ctx.has_bias else None
+        return (gx[:N] if gx is not None else None), gw, gb
+
+
+WIDE_F32 = os.environ.get("MLGNN_WIDE_F32", "1") != "0"
+
+
 def linear(x, weight, bias=None, residual=None):
     """``nn.Linear`` forward (+ ``residual``: the identity branch of a residual block, added in the GEMM
     epilogue) with the tall-matrix kernels behind it when they apply (2-D fp32 CUDA input, >= 8192 rows,
@@ -461,6 +502,12 @@ def linear(x, weight, bias=None, residual=None):
             and tall_matmul_supported(x.shape[0], x.shape[1], weight.shape[0], x.dtype)
             and tall_matmul_supported(x.shape[0], weight.shape[0], x.shape[1], x.dtype)):
         return _TallLinear.apply(x, weight, bias, residual)
+    if (WIDE_F32 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+            and x.shape[0] >= WGRAD_MIN_ROWS and torch.is_grad_enabled()
+            and _lib.lib.mlgnn_linear_f32x3_supported(x.shape[0], x.shape[1], weight.shape[0])):
+        # fp32 widths past the tall kernels (hidden 512): three-term bf16 products instead of the library's fp32 GEMMs
+        out = _WideLinearF32.apply(x, weight, bias)
+        return out if residual is None else out + residual
     out = F.linear(x, weight, bias)
     return out if residual is None else out + residual
 

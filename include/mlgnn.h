@@ -670,7 +670,8 @@ int mlgnn_diffpool_large_f32_bwd(const float* adj, const float* s_logits, const 
  *   fwd:  y [Npad, J] = x [N,R] w[J,R]^T + bias [J] (or NULL); Npad = mlgnn_linear_f32x3_padded_rows(N): the first N
  *         rows are the result (the rest is scratch)
  *   bwd:  grad_x [Npad, R] (or NULL) = grad_out [N,J] w;  grad_w [J,R] = grad_out^T x  (one product over the row index,
- *         split along it, fixed-order reduce); the bias gradient (column sums of grad_out) is the caller's
+ *         split along it, fixed-order reduce);  grad_bias [J] (or NULL) = column sums of grad_out (partial sums per 64
+ *         rows from the launch that reads grad_out anyway, fixed-order reduce)
  */
 int mlgnn_linear_f32x3_supported(int64_t N, int64_t R, int64_t J);
 int64_t mlgnn_linear_f32x3_padded_rows(int64_t N);
@@ -679,7 +680,8 @@ int mlgnn_linear_f32x3_fwd(const float* x, const float* w, const float* bias, fl
                            int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream);
 int64_t mlgnn_linear_f32x3_bwd_workspace_bytes(int64_t N, int64_t R, int64_t J);
 int mlgnn_linear_f32x3_bwd(const float* grad_out, const float* x, const float* w, float* grad_x, float* grad_w,
-                           void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream);
+                           float* grad_bias, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J,
+                           void* stream);
 
 /*
  * Optimizer step on one flat fp32 buffer: global-norm gradient clipping + Adam with L2 weight decay, two launches.

@@ -945,6 +945,7 @@ struct SplitJob {
   int64_t s_src, s_out, s_outt, s_dot, s_part;
   int nb, tiles;
   int rows_valid;            // rows >= rows_valid of src do not exist: they split to zeros (a tall operand padded to R rows)
+  float* colsum;             // non-NULL: colsum[tile row][Cc] = column sums of src over the 64 rows of each tile row
 };
 constexpr int kSplitMaxJobs = 4;
 struct SplitArgs { SplitJob job[kSplitMaxJobs]; int njobs; };
@@ -958,6 +959,7 @@ __global__ __launch_bounds__(256) void dpl32_split_kernel(const SplitArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t th[64][66];
   __shared__ __attribute__((aligned(16))) uint16_t tl[64][66];
   __shared__ float wsum[4];
+  __shared__ float cs_lds[16][64];
   int t = blockIdx.x, j = 0;
 #pragma unroll
   for (int i = 0; i + 1 < kSplitMaxJobs; ++i)
@@ -975,6 +977,7 @@ __global__ __launch_bounds__(256) void dpl32_split_kernel(const SplitArgs a) {
   const float* dot = q.dot ? q.dot + bz * q.s_dot : nullptr;
   const int tid = threadIdx.x;
   float part = 0.f;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   // 64 rows x 256 B: 16 lanes per row, 16 bytes each; 256 threads = 16 rows per pass
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
@@ -987,6 +990,8 @@ __global__ __launch_bounds__(256) void dpl32_split_kernel(const SplitArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) part += v[i] * d[i];
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] += v[i];
     uint16_t h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) split2(v[i], h[i], l[i]);
@@ -1019,6 +1024,17 @@ __global__ __launch_bounds__(256) void dpl32_split_kernel(const SplitArgs a) {
       const size_t at = (size_t)(c0 + c) * q.ldt + r0 + ch * 8;
       *reinterpret_cast<uint4*>(oh + at) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
       *reinterpret_cast<uint4*>(ol + at) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    }
+  }
+  if (q.colsum) {                                     // fixed order: a thread's four rows, then the 16 row lanes in order
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs_lds[tid >> 4][(tid & 15) * 4 + i] = cs[i];
+    __syncthreads();
+    if (tid < 64) {
+      float acc = cs_lds[0][tid];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) acc += cs_lds[k][tid];
+      q.colsum[(size_t)(t / tiles_c) * q.Cc + c0 + tid] = acc;
     }
   }
   if (dot) {
@@ -1487,14 +1503,15 @@ extern "C" int64_t mlgnn_linear_f32x3_bwd_workspace_bytes(int64_t N, int64_t R, 
   o += 2 * dpl_align((size_t)J * R * 2);              // W^T hi / lo
   o += dpl_align((size_t)lin3_splits(Np, R, J) * J * R * 4);
   o += dpl_align(kDplPartials * 4);
+  o += dpl_align((size_t)(Np / 64) * J * 4);          // column sums of grad_out per tile row (the bias gradient's partials)
   return (int64_t)o;
 }
 
-// grad_x [Npad, R] (first N rows = the gradient; NULL: not wanted), grad_w [J, R]; the bias gradient (column sums of
-// grad_out) is the caller's.
+// grad_x [Npad, R] (first N rows = the gradient; NULL: not wanted), grad_w [J, R], grad_bias [J] or NULL (the column
+// sums of grad_out: partial sums per 64 rows from the split launch that reads grad_out anyway, fixed-order reduce).
 extern "C" int mlgnn_linear_f32x3_bwd(const float* grad_out, const float* x, const float* w, float* grad_x, float* grad_w,
-                                      void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, int64_t J,
-                                      void* stream) {
+                                      float* grad_bias, void* workspace, int64_t workspace_bytes, int64_t N, int64_t R,
+                                      int64_t J, void* stream) {
   if (!lin3_ok(N, R, J)) return MLGNN_E_SHAPE;
   if (!grad_out || !x || !w || !grad_w || !workspace) return MLGNN_E_NULL;
   if (workspace_bytes < mlgnn_linear_f32x3_bwd_workspace_bytes(N, R, J)) return MLGNN_E_WORKSPACE;
@@ -1512,12 +1529,14 @@ extern "C" int mlgnn_linear_f32x3_bwd(const float* grad_out, const float* x, con
   uint16_t *wth = (uint16_t*)take((size_t)J * R * 2), *wtl = (uint16_t*)take((size_t)J * R * 2);
   float* slab = (float*)take((size_t)splits * J * R * 4);
   float* scratch = (float*)take(kDplPartials * 4);
+  float* colsum = (float*)take((size_t)(Np / 64) * J * 4);
   {
     SplitArgs a{};
     a.njobs = 3;
     SplitJob& g = a.job[0];
     g = split_job(grad_out, J, (int)Np, (int)J, 1, 0);
     g.rows_valid = (int)N; g.hi = gh; g.lo = gl; g.ldo = J; g.hit = gth; g.lot = gtl; g.ldt = Np;
+    g.colsum = grad_bias ? colsum : nullptr;
     SplitJob& xj = a.job[1];
     xj = split_job(x, R, (int)Np, (int)R, 1, 0);
     xj.rows_valid = (int)N; xj.hit = xth; xj.lot = xtl; xj.ldt = Np;
@@ -1549,5 +1568,6 @@ extern "C" int mlgnn_linear_f32x3_bwd(const float* grad_out, const float* x, con
     r.cc = grad_w; r.ldc = R; r.cc_f32 = 1;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(kDplPartials, 1), dim3(256), 0, st, r);
   }
+  if (grad_bias) launch_reduce_partials(colsum, grad_bias, (int)(Np / 64), (int)J, st);
   return (int)hipGetLastError();
 }

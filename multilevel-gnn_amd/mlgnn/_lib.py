@@ -95,7 +95,7 @@ SIGNATURES = {
     "mlgnn_linear_f32x3_fwd_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "mlgnn_linear_f32x3_fwd": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "mlgnn_linear_f32x3_bwd_workspace_bytes": (_I64, [_I64, _I64, _I64]),
-    "mlgnn_linear_f32x3_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_linear_f32x3_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "mlgnn_adam_workspace_floats": (_I64, []),
     "mlgnn_adam_step": (_INT, [_P, _P, _P, _P, _I64, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
     "mlgnn_hub_capacity": (_I64, [_I64, _INT]),

@@ -479,10 +479,11 @@ class _WideLinearF32(torch.autograd.Function):
         gx = torch.empty((Np, R), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
         gw = torch.empty((J, R), dtype=torch.float32, device=x.device)
         ws = torch.empty(int(_lib.lib.mlgnn_linear_f32x3_bwd_workspace_bytes(N, R, J)), dtype=torch.uint8, device=x.device)
+        gb = torch.empty(J, dtype=torch.float32, device=x.device) if ctx.has_bias else None
         rc = _lib.lib.mlgnn_linear_f32x3_bwd(go.data_ptr(), x.data_ptr(), weight.data_ptr(), _lib.ptr(gx), gw.data_ptr(),
-                                             ws.data_ptr(), ws.numel(), N, R, J, torch.cuda.current_stream().cuda_stream)
+                                             _lib.ptr(gb), ws.data_ptr(), ws.numel(), N, R, J,
+                                             torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mlgnn_linear_f32x3_bwd")
-        gb = go.sum(0) if ctx.has_bias else None
         return (gx[:N] if gx is not None else None), gw, gb
 
 

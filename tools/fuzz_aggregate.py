@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Development tool: randomised sweep of the aggregation kernels against the CPU oracle (tests/test_aggregate_gpu.py's
 case runner) over odd sizes -- widths with and without the vector path, tiny and hub-heavy graphs, every aggregator
-and edge term.  `python tools/fuzz_aggregate.py [cases] [seed]`; prints the first failing configuration."""
+and edge term.  `python tools/fuzz_aggregate.py [cases] [seed] [first case]`; prints the first failing configuration.
+Known: seed 11, case 171 (5 nodes / 9000 edges, softmax with a learnable t) fails on d loss / dt by 1.3e-4 -- the fp32
+ORACLE is 1.0e-4 off the fp64 value there, the kernels 2.7e-5 (tools/fuzz_case_fp64.py); cases 0-170 and 172-499 pass."""
 import os
 import random
 import sys
@@ -16,6 +18,7 @@ def main():
     import test_aggregate_gpu as T
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    start = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # skip the first `start` cases of the sequence
     aggrs = ["add", "mean", "max", "softmax", "softmax_sg", "power"]
     kinds = ["none", "rank1", "rank2", "rank3", "rank7", "rank8", "full"]
     for i in range(n_cases):
@@ -28,6 +31,8 @@ def main():
         t = rng.choice([1.0, 0.5, 2.0, -1.0])
         cfg = dict(N=N, E=E, d=d, aggr=aggr, edge_kind=kind, t=t, p=rng.choice([1.0, 2.0, 3.0]), learn=learn, hub=hub,
                    seed=i)
+        if i < start:                             # (the configuration is still drawn: the sequence stays the same)
+            continue
         try:
             T._run_case(**cfg)
         except Exception as exc:              # noqa: BLE001 -- report the configuration, then fail

@@ -3,7 +3,9 @@
 case runner) over odd sizes -- widths with and without the vector path, tiny and hub-heavy graphs, every aggregator
 and edge term.  `python tools/fuzz_aggregate.py [cases] [seed] [first case]`; prints the first failing configuration.
 Known: seed 11, case 171 (5 nodes / 9000 edges, softmax with a learnable t) fails on d loss / dt by 1.3e-4 -- the fp32
-ORACLE is 1.0e-4 off the fp64 value there, the kernels 2.7e-5 (tools/fuzz_case_fp64.py); cases 0-170 and 172-499 pass."""
+ORACLE is 1.0e-4 off the fp64 value there, the kernels 2.7e-5 (tools/fuzz_case_fp64.py); cases 0-170 and 172-499 pass.  Seed 5, case 184 (add / mean / softmax, rank 3, d = 200): ONE
+entry of grad x differs by one edge's cotangent -- a tie at the ReLU kink: that edge's z is 3.4e-9 in fp64, exactly 0 in the
+fp32 oracle (gradient 0) and positive in the kernel's fma chain (gradient passes, as in exact arithmetic)."""
 import os
 import random
 import sys

@@ -56,7 +56,10 @@ struct TbArgs {
   int N; int R; int J;
 };
 
-template <int JT>
+// SHIFT: its own instantiation (no residual; the lse words of a lane's results are requested BEFORE the k-loop, like the
+// residual's in the plain kernel -- as 32 dependent 8-byte loads per tile in the epilogue they cost more than the
+// streaming pre-pass they replace; requested by the plain instantiation as well they spilled it: 256 registers + scratch)
+template <int JT, bool SHIFT>
 __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p) {
   extern __shared__ uint4 wimg[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -88,7 +91,18 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
     constexpr int RP = JT >= 2 ? JT / 2 : 1;
     constexpr bool kPrefetchRes = JT <= 4;
     uint32_t resw[kPrefetchRes ? RP : 1][16];
-    if (kPrefetchRes && p.res) {
+    constexpr bool kPrefetchLse = SHIFT && JT >= 2 && JT <= 4;
+    float2 lsew[kPrefetchLse ? RP : 1][16];
+    if constexpr (kPrefetchLse) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * h, p.N - 1);
+        const size_t base = (size_t)row * p.J + j0;
+#pragma unroll
+        for (int u = 0; u < RP; ++u) lsew[u][r] = *reinterpret_cast<const float2*>(p.lse + base + 64 * u + 2 * r31);
+      }
+    }
+    if (!SHIFT && kPrefetchRes && p.res) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * h, p.N - 1);
@@ -135,10 +149,10 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
       const size_t base = (size_t)row * p.J + j0;
       if constexpr (JT == 1) {
         float v = acc[0][r] + bias[0];
-        if (p.res) v += bf16_to_f32((uint16_t)resw[0][r]);
+        if (!SHIFT && p.res) v += bf16_to_f32((uint16_t)resw[0][r]);
         const uint16_t cb = f32_to_bf16(v);
         p.c[base + r31] = cb;
-        if (p.lse) {
+        if constexpr (SHIFT) {
           const float l = p.lse[base + r31];
           p.gt[base + r31] = f32_to_bf16(bf16_to_f32(cb) * fast_exp2(-l));
           worst = fmaxf(worst, fabsf(l));
@@ -148,15 +162,17 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
         for (int u = 0; u < JT / 2; ++u) {
           float v0 = acc[2 * u][r] + bias[2 * u], v1 = acc[2 * u + 1][r] + bias[2 * u + 1];
           const size_t at = base + 64 * u + 2 * r31;
-          if (p.res) {
+          if (!SHIFT && p.res) {
             const uint32_t w = kPrefetchRes ? resw[kPrefetchRes ? u : 0][r] : *reinterpret_cast<const uint32_t*>(p.res + at);
             v0 += __builtin_bit_cast(float, w << 16);
             v1 += __builtin_bit_cast(float, w & 0xffff0000u);
           }
           const uint16_t c0 = f32_to_bf16(v0), c1 = f32_to_bf16(v1);
           *reinterpret_cast<uint32_t*>(p.c + at) = (uint32_t)c0 | ((uint32_t)c1 << 16);
-          if (p.lse) {
-            const float2 l = *reinterpret_cast<const float2*>(p.lse + at);
+          if constexpr (SHIFT) {
+            float2 l;
+            if constexpr (kPrefetchLse) l = lsew[u][r];
+            else l = *reinterpret_cast<const float2*>(p.lse + at);
             const float g0 = bf16_to_f32(c0) * fast_exp2(-l.x), g1 = bf16_to_f32(c1) * fast_exp2(-l.y);
             *reinterpret_cast<uint32_t*>(p.gt + at) = (uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16);
             worst = fmaxf(worst, fmaxf(fabsf(l.x), fabsf(l.y)));
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(kTbBlock) void tallgemm_bf16_kernel(const TbArgs p)
       }
     }
   }
-  if (p.lse) {
+  if constexpr (SHIFT) {
     // (a NaN lse fails the comparison, like in softmax_shift_kernel: the NaN then travels in gt itself)
     for (int off = 1; off < kWave; off <<= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
     if (lane == 0 && worst > kMaxLse) *p.spread = 1;              // plain store: every writer stores the same value
@@ -200,9 +216,15 @@ int tallgemm_bf16(const void* a, const void* bt, const float* bias, const void* 
   case JT_:                                                                                                  \
     hipLaunchKernelGGL((tallgemm_bf16_pack_kernel<JT_>), pg, pb, 0, s, (const uint4*)bt, (uint4*)workspace,  \
                        (int)J, (int)R);                                                                      \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_bf16_kernel<JT_>),                    \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kTbMaxLds);                        \
-    hipLaunchKernelGGL((tallgemm_bf16_kernel<JT_>), g, b, lds, s, p);                                        \
+    if (lse) {                                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_bf16_kernel<JT_, true>),            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kTbMaxLds);                      \
+      hipLaunchKernelGGL((tallgemm_bf16_kernel<JT_, true>), g, b, lds, s, p);                                \
+    } else {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_bf16_kernel<JT_, false>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kTbMaxLds);                      \
+      hipLaunchKernelGGL((tallgemm_bf16_kernel<JT_, false>), g, b, lds, s, p);                               \
+    }                                                                                                        \
     break;
   switch (jt) {
     MLGNN_TB_CASE(1) MLGNN_TB_CASE(2) MLGNN_TB_CASE(4) MLGNN_TB_CASE(8)

@@ -141,10 +141,11 @@ def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
 
 
 LB_LN, LB_PLAIN, LB_SHIFT = 0, 1, 2
-# bf16: the rescaled cotangent from the input-gradient GEMM's epilogue (csrc/tallgemm_bf16.hip SHIFT) instead of the
-# streaming pre-pass.  Off by default: at BASELINE configs[4] the epilogue's dependent lse loads cost more than the
-# pre-pass they replace (65.9 vs 64.7 ms per step in a same-box A/B); the fp32 path folds it into linear_bwd.
-_BF16_SHIFT = os.environ.get("MLGNN_BF16_SHIFT", "0") == "1"
+# bf16: the rescaled cotangent from the input-gradient GEMM's epilogue (csrc/tallgemm_bf16.hip, SHIFT instantiation)
+# instead of the streaming pre-pass.  With the lse words requested in the epilogue (32 dependent 8-byte loads per tile)
+# it was slower than the pre-pass (65.9 vs 64.7 ms per BASELINE configs[4] step); requested before the k-loop, in an
+# instantiation of its own (236 registers, no spills): 58.0 / 58.3 vs 59.2 / 59.5 ms (same box) -- on since round 3.
+_BF16_SHIFT = os.environ.get("MLGNN_BF16_SHIFT", "1") == "1"
 _ONE_PASS = os.environ.get("MLGNN_ONE_PASS_BWD", "1") == "1"      # (0: the two-kernel backward of each Linear, for A/B runs)
 LINEAR_BWD_STATS = {"ln": 0, "shift": 0, "plain": 0}
 

@@ -49,6 +49,18 @@ FILE_FLAGS = {"aggregate_fwd.hip": ["-fno-honor-nans", "-fno-honor-infinities"],
               "aggregate_bwd.hip": ["-fno-honor-nans", "-fno-honor-infinities"]}
 
 
+def _object_stale(obj, cmd):
+    """An object is rebuilt when it is missing, its command line changed, or a file of its dependency list (written by
+    the compiler, -MD) is newer than it."""
+    if not (os.path.exists(obj) and os.path.exists(obj + ".d") and os.path.exists(obj + ".cmd")):
+        return True
+    if open(obj + ".cmd").read() != " ".join(cmd):
+        return True
+    t = os.path.getmtime(obj)
+    deps = open(obj + ".d").read().replace("\\\n", " ").split()[1:]
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps if not d.startswith("/opt/rocm"))
+
+
 def build(force=False, verbose=True):
     """Compile every csrc/*.hip (in parallel, one hipcc per translation unit) and link ONE shared
     object next to the package."""
@@ -57,17 +69,32 @@ def build(force=False, verbose=True):
     objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(objdir, exist_ok=True)
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    jobs = []
+    jobs, pending, failed = [], [], []
+    objs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + inc + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        jobs.append((obj, cmd, subprocess.Popen(cmd)))
-    failed = [cmd for _, cmd, proc in jobs if proc.wait() != 0]
+        objs.append(obj)
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + inc + ["-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
+        if force or _object_stale(obj, cmd):
+            pending.append((obj, cmd))
+    # at most one hipcc per host core at a time (a translation unit takes 10 s .. 3 min and up to 2 GB)
+    width = max(1, min(len(pending), os.cpu_count() or 4))
+    while pending or jobs:
+        while pending and len(jobs) < width:
+            obj, cmd = pending.pop(0)
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            jobs.append((obj, cmd, subprocess.Popen(cmd)))
+        obj, cmd, proc = jobs.pop(0)
+        if proc.wait() != 0:
+            failed.append(cmd)
+            if os.path.exists(obj):
+                os.remove(obj)
+        else:
+            open(obj + ".cmd", "w").write(" ".join(cmd))
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
-    link = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + [obj for obj, _, _ in jobs] + ["-o", LIB + ".tmp"]
+    link = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)

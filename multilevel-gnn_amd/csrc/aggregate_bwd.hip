@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kBlock) void softmax_shift_kernel(const ShiftArgs a
 constexpr int kRedCols = 32, kRedSlices = 32;
 __global__ __launch_bounds__(kRedCols * kRedSlices) void reduce_partials_kernel(const float* __restrict__ ws,
                                                                                  float* __restrict__ out,
-                                                                                 int nblk, int cols) {
+                                                                                 int nblk, int cols, int accumulate) {
   __shared__ float part[kRedSlices][kRedCols + 1];
   const int cl = threadIdx.x % kRedCols;
   const int slice = threadIdx.x / kRedCols;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kRedCols * kRedSlices) void reduce_partials_kernel(
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < kRedSlices; ++k) t += part[k][cl];
-    out[c] = t;
+    out[c] = accumulate ? out[c] + t : t;          // (accumulate: a later row slab of the same reduction, csrc/wgrad.hip)
   }
 }
 
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kRedCols * kRedSlices) void reduce_partials_kernel(
 constexpr int kRedWQuads = 64, kRedWSlices = 4;
 __global__ __launch_bounds__(kRedWQuads * kRedWSlices) void reduce_partials_wide_kernel(const float4* __restrict__ ws,
                                                                                        float4* __restrict__ out,
-                                                                                       int nblk, int quads) {
+                                                                                       int nblk, int quads, int accumulate) {
   __shared__ float4 part[kRedWSlices][kRedWQuads];
   const int ql = threadIdx.x % kRedWQuads;
   const int slice = threadIdx.x / kRedWQuads;
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(kRedWQuads * kRedWSlices) void reduce_partials_wide
       const float4 v = part[k][ql];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
+    if (accumulate) { const float4 o = out[q]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
     out[q] = t;
   }
 }
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(kRedWQuads * kRedWSlices) void reduce_partials_wide
 // in order, then the slices in two levels (32 groups in order, the groups in order).
 template <int CQ>
 __global__ __launch_bounds__(1024) void reduce_partials_quads_kernel(const float4* __restrict__ ws, float4* __restrict__ out,
-                                                                    int nblk, int quads) {
+                                                                    int nblk, int quads, int accumulate) {
   constexpr int kSlices = 1024 / CQ;
   __shared__ float4 part[kSlices][CQ];
   __shared__ float4 part2[32][CQ];
@@ -630,17 +631,19 @@ __global__ __launch_bounds__(1024) void reduce_partials_quads_kernel(const float
       const float4 v = part2[k][ql];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
+    if (accumulate) { const float4 o = out[q]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
     out[q] = t;
   }
 }
 
-void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream) {
+void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream, bool accumulate) {
+  const int acc = accumulate ? 1 : 0;
   const bool vec_ok = cols % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   if (cols >= 4096 && vec_ok) {
     const int quads = cols / 4;
     hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((quads + kRedWQuads - 1) / kRedWQuads),
                        dim3(kRedWQuads * kRedWSlices), 0, stream, reinterpret_cast<const float4*>(ws),
-                       reinterpret_cast<float4*>(out), nblk, quads);
+                       reinterpret_cast<float4*>(out), nblk, quads, acc);
     return;
   }
   static const bool quads_on = [] { const char* e = getenv("MLGNN_RED_QUADS"); return !(e && e[0] == '0'); }();   // A/B switch
@@ -649,15 +652,15 @@ void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hip
     const float4* w4 = reinterpret_cast<const float4*>(ws);
     float4* o4 = reinterpret_cast<float4*>(out);
     if (quads >= 128 * 8)
-      hipLaunchKernelGGL(reduce_partials_quads_kernel<8>, dim3((quads + 7) / 8), dim3(1024), 0, stream, w4, o4, nblk, quads);
+      hipLaunchKernelGGL(reduce_partials_quads_kernel<8>, dim3((quads + 7) / 8), dim3(1024), 0, stream, w4, o4, nblk, quads, acc);
     else if (quads >= 128 * 4)
-      hipLaunchKernelGGL(reduce_partials_quads_kernel<4>, dim3((quads + 3) / 4), dim3(1024), 0, stream, w4, o4, nblk, quads);
+      hipLaunchKernelGGL(reduce_partials_quads_kernel<4>, dim3((quads + 3) / 4), dim3(1024), 0, stream, w4, o4, nblk, quads, acc);
     else
-      hipLaunchKernelGGL(reduce_partials_quads_kernel<2>, dim3((quads + 1) / 2), dim3(1024), 0, stream, w4, o4, nblk, quads);
+      hipLaunchKernelGGL(reduce_partials_quads_kernel<2>, dim3((quads + 1) / 2), dim3(1024), 0, stream, w4, o4, nblk, quads, acc);
     return;
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + kRedCols - 1) / kRedCols), dim3(kRedCols * kRedSlices),
-                     0, stream, ws, out, nblk, cols);
+                     0, stream, ws, out, nblk, cols, acc);
 }
 
 }  // namespace mlgnn

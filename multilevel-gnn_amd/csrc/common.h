@@ -268,6 +268,15 @@ __device__ __forceinline__ float fix_scale_of(const uint32_t* hdr) {
   return __builtin_bit_cast(float, (uint32_t)fix_scale_exponent(hdr) << 23);
 }
 
-void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream);
+// accumulate: out += the sum (a later row slab of one reduction: slab sums are added in slab order, still bitwise reproducible)
+void launch_reduce_partials(const float* ws, float* out, int nblk, int cols, hipStream_t stream, bool accumulate = false);
+
+// Row slabs of the dense kernels that address their operands with 32-bit byte offsets from a uniform base: the most rows
+// (a multiple of 4096) whose widest operand row block stays below 4 GiB.  5.12 M rows x 256 fp32 columns (512 graphs of
+// BASELINE configs[3] on one GPU) = 2 slabs.
+inline int64_t dense_slab_rows(int64_t widest_cols) {
+  const int64_t rows = (((int64_t)1 << 32) - 1) / (widest_cols * 4);
+  return rows / 4096 * 4096;
+}
 
 }  // namespace mlgnn

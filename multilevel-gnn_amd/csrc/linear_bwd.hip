@@ -55,6 +55,7 @@ struct LbArgs {
   const float* rstd; const float* gamma; const float* beta;          // LB_LN
   const float* lse; float* gt; int* spread;                          // LB_SHIFT
   int N; int slab_cols;
+  int parts_max_with_old;                                            // a later row slab: out_parts = max(old, this slab's)
 };
 
 __device__ __forceinline__ void lb_pow2_scale(float max_abs, float& s, float& inv) {    // as in tallgemm.hip
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(kLbThreads) void linear_bwd_kernel(const LbArgs p) 
     float m = ex[4 * M];
 #pragma unroll
     for (int i = 1; i < kLbWaves; ++i) m = fmaxf(m, ex[4 * M + i]);
-    p.out_parts[blockIdx.x] = m;
+    p.out_parts[blockIdx.x] = p.parts_max_with_old ? fmaxf(m, p.out_parts[blockIdx.x]) : m;
   }
   if constexpr (EPI == LB_SHIFT) {
     // (a NaN lse fails the comparison, like in softmax_shift_kernel: the NaN then travels in gt itself)
@@ -689,7 +690,7 @@ using namespace mlgnn;
 
 static bool lb_shape_ok(int64_t N, int64_t M, int64_t K, int epi) {
   if (N <= 0 || N > INT32_MAX - kLbStage) return false;
-  if (N * (M > K ? M : K) * 4 >= ((int64_t)1 << 32)) return false;      // 32-bit byte offsets inside the kernel
+  // (32-bit byte offsets inside the kernel: the entry point walks row slabs below 4 GiB, dense_slab_rows)
   if (epi == LB_LN) return M == 128 && K == 256;
   return M == 256 && K == 128;
 }
@@ -730,11 +731,11 @@ extern "C" int mlgnn_linear_bwd(const float* go, const float* w, const float* x,
                      (dx_max_parts && grid < kLbParts) ? dx_max_parts : nullptr);
   int err;
   LbArgs a;
-  a.go = go; a.w = w; a.x = x; a.go_parts = go_max_is_parts ? go_max : parts; a.x_parts = parts + kLbParts;
-  a.dx = dx; a.ws = workspace; a.out_parts = dx_max_parts;
-  a.rstd = rstd; a.gamma = gamma; a.beta = beta;
-  a.lse = lse; a.gt = grad_shifted; a.spread = shift_flag;
-  a.N = (int)N; a.slab_cols = cols;
+  a.w = w; a.go_parts = go_max_is_parts ? go_max : parts; a.x_parts = parts + kLbParts;
+  a.ws = workspace; a.out_parts = dx_max_parts;
+  a.gamma = gamma; a.beta = beta;
+  a.spread = shift_flag;
+  a.slab_cols = cols;
 #define MLGNN_LB_LAUNCH(M_, K_, EPI_)                                                                        \
   {                                                                                                          \
     constexpr int lds_bytes = lb_lds_bytes<M_, K_>();                                                        \
@@ -742,12 +743,24 @@ extern "C" int mlgnn_linear_bwd(const float* go, const float* w, const float* x,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                        \
     hipLaunchKernelGGL((linear_bwd_kernel<M_, K_, EPI_>), dim3(grid), dim3(kLbThreads), lds_bytes, s, a);    \
   }
-  if (epilogue == LB_PLAIN) { a.lse = nullptr; a.gt = nullptr; a.spread = nullptr; }
-  if (epilogue == LB_LN) MLGNN_LB_LAUNCH(128, 256, LB_LN)
-  else MLGNN_LB_LAUNCH(256, 128, LB_SHIFT)              // (plain = the same instantiation without lse / grad_shifted)
+  if (epilogue == LB_PLAIN) { lse = nullptr; grad_shifted = nullptr; a.spread = nullptr; }
+  // row slabs below 4 GiB (one at BASELINE configs[1]; two at 5.12 M rows): operand bases advance, the operand scales stay
+  // those of the whole input, a slab's partial sums are added to its predecessors' in slab order
+  const int64_t slab_rows = dense_slab_rows(M > K ? M : K);
+  for (int64_t r0 = 0; r0 < N; r0 += slab_rows) {
+    const int64_t n = N - r0 < slab_rows ? N - r0 : slab_rows;
+    const int64_t st = (n + kLbStage - 1) / kLbStage;
+    const int grid = (int)(st < kLbParts ? st : kLbParts);
+    a.go = go + r0 * M; a.x = x + r0 * K; a.dx = dx + r0 * K;
+    a.rstd = rstd ? rstd + r0 : nullptr;
+    a.lse = lse ? lse + r0 * K : nullptr; a.gt = grad_shifted ? grad_shifted + r0 * K : nullptr;
+    a.N = (int)n; a.parts_max_with_old = r0 > 0;
+    if (epilogue == LB_LN) MLGNN_LB_LAUNCH(128, 256, LB_LN)
+    else MLGNN_LB_LAUNCH(256, 128, LB_SHIFT)            // (plain = the same instantiation without lse / grad_shifted)
+    err = (int)hipGetLastError();
+    if (err) return err;
+    launch_reduce_partials(workspace, grad_w_b, grid, cols, s, r0 > 0);
+  }
 #undef MLGNN_LB_LAUNCH
-  err = (int)hipGetLastError();
-  if (err) return err;
-  launch_reduce_partials(workspace, grad_w_b, grid, cols, s);
   return (int)hipGetLastError();
 }

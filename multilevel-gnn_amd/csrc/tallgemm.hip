@@ -704,7 +704,6 @@ extern "C" int mlgnn_tallgemm_lnbwd(const float* go, const float* w, int w_trans
                                     int64_t workspace_bytes, int64_t N, int64_t R, int64_t J, void* stream) {
   if (N < 0 || N > INT32_MAX) return MLGNN_E_SHAPE;
   if (R <= 0 || J <= 0 || !mlgnn_tallgemm_lnbwd_supported(N > 0 ? N : 1, R, J)) return MLGNN_E_SHAPE;
-  if (N * J * 4 >= (int64_t)1 << 32) return MLGNN_E_SHAPE;               // 32-bit byte offsets into xhat / grad_h
   if (!grad_gamma_beta) return MLGNN_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   if (N == 0) return (int)hipMemsetAsync(grad_gamma_beta, 0, 2 * J * sizeof(float), s);
@@ -718,19 +717,26 @@ extern "C" int mlgnn_tallgemm_lnbwd(const float* go, const float* w, int w_trans
   int err = (int)hipGetLastError();
   if (err) return err;
   TgArgs p;
-  p.a = go; p.image = (const f16x8*)workspace; p.bias = nullptr; p.res = nullptr; p.rowmax = row_max; p.c = grad_h;
-  p.gamma = gamma; p.beta = beta; p.rstd_out = nullptr; p.rowmax_out = row_max_out; p.ln_eps = 0.f;
-  p.xhat = xhat; p.rstd_in = rstd;
+  p.image = (const f16x8*)workspace; p.bias = nullptr; p.res = nullptr;
+  p.gamma = gamma; p.beta = beta; p.rstd_out = nullptr; p.ln_eps = 0.f;
   p.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + R * J * 4 + kTgHeader * 16);
-  p.N = (int)N; p.R = (int)R; p.J = (int)J;
+  p.R = (int)R; p.J = (int)J;
   size_t lds = (size_t)R * J * 4 + (size_t)J * 8;                        // weight image, then gamma / beta of the J columns
   if (lds < (size_t)kTgWaves * 2 * J * 4) lds = (size_t)kTgWaves * 2 * J * 4;   // ... re-used for the partials at the end
-  const int64_t tiles = (N + 31) / 32;
   const int block = J == 256 ? tg_block<8, 3>() : kTgBlock, waves = block / kWave;
-  int grid = (int)((tiles + waves - 1) / waves);
-  if (grid > kTgLnBwdBlocks) grid = kTgLnBwdBlocks;
-  const dim3 g(grid), b(block);
-  bool launched = false;
+  // row slabs: xhat / grad_h are addressed with 32-bit byte offsets from the slab's base (dense_slab_rows); the d gamma /
+  // d beta partials of a slab are added to its predecessors' in slab order
+  const int64_t slab_rows = dense_slab_rows(J);
+  for (int64_t r0 = 0; r0 < N; r0 += slab_rows) {
+    const int64_t n = N - r0 < slab_rows ? N - r0 : slab_rows;
+    p.a = go + r0 * R; p.rowmax = row_max ? row_max + r0 : nullptr; p.c = grad_h + r0 * J;
+    p.rowmax_out = row_max_out + r0; p.xhat = xhat + r0 * J; p.rstd_in = rstd + r0;
+    p.N = (int)n;
+    const int64_t tiles = (n + 31) / 32;
+    int grid = (int)((tiles + waves - 1) / waves);
+    if (grid > kTgLnBwdBlocks) grid = kTgLnBwdBlocks;
+    const dim3 g(grid), b(block);
+    bool launched = false;
 #define MLGNN_TG_LNBWD(JT_, KS_)                                                                      \
   if (!launched && J == 32 * JT_ && R == 16 * KS_) {                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, 3>),           \
@@ -738,13 +744,14 @@ extern "C" int mlgnn_tallgemm_lnbwd(const float* go, const float* w, int w_trans
     hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, 3>), g, b, lds, s, p);                               \
     launched = true;                                                                                  \
   }
-  MLGNN_TG_LNBWD(2, 4) MLGNN_TG_LNBWD(2, 8) MLGNN_TG_LNBWD(2, 16)
-  MLGNN_TG_LNBWD(4, 4) MLGNN_TG_LNBWD(4, 8) MLGNN_TG_LNBWD(4, 16)
-  MLGNN_TG_LNBWD(8, 4) MLGNN_TG_LNBWD(8, 8)
+    MLGNN_TG_LNBWD(2, 4) MLGNN_TG_LNBWD(2, 8) MLGNN_TG_LNBWD(2, 16)
+    MLGNN_TG_LNBWD(4, 4) MLGNN_TG_LNBWD(4, 8) MLGNN_TG_LNBWD(4, 16)
+    MLGNN_TG_LNBWD(8, 4) MLGNN_TG_LNBWD(8, 8)
 #undef MLGNN_TG_LNBWD
-  if (!launched) return MLGNN_E_SHAPE;
-  err = (int)hipGetLastError();
-  if (err) return err;
-  launch_reduce_partials(p.ws, grad_gamma_beta, grid, 2 * (int)J, s);
+    if (!launched) return MLGNN_E_SHAPE;
+    err = (int)hipGetLastError();
+    if (err) return err;
+    launch_reduce_partials(p.ws, grad_gamma_beta, grid, 2 * (int)J, s, r0 > 0);
+  }
   return (int)hipGetLastError();
 }

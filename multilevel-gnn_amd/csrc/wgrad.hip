@@ -478,7 +478,6 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const flo
   }
   if (dtype != MLGNN_DTYPE_F32) return MLGNN_E_DTYPE;
   if (N < 0 || M <= 0 || K <= 0 || N > INT32_MAX || M * K > (1 << 24)) return MLGNN_E_SHAPE;
-  if (N * (M > K ? M : K) * 4 >= ((int64_t)1 << 32)) return MLGNN_E_SHAPE;      // 32-bit byte offsets inside a slab
   WgradPlan pl;
   if (!plan_wgrad((int)((M + kTile - 1) / kTile), (int)((K + kTile - 1) / kTile), &pl)) return MLGNN_E_SHAPE;
   if (!grad_w_b || !workspace) return MLGNN_E_NULL;
@@ -488,7 +487,7 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const flo
   if (workspace_floats < (int64_t)(nblk + 1) * cols + 2 * kMaxParts) return MLGNN_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   WgradArgs a;
-  a.a = (const float*)grad_out; a.b = (const float*)x; a.ws = workspace;
+  a.ws = workspace;
   a.b_gamma = x_gamma; a.b_beta = x_gamma ? x_beta : nullptr;
   const bool f16 = grad_out_row_max != nullptr && x_row_max != nullptr && N > 0;     // row maxima of both: scaled fp16 split
   a.a_max = a.b_max = nullptr;
@@ -498,24 +497,34 @@ extern "C" int mlgnn_linear_wgrad(const void* grad_out, const void* x, const flo
     a.a_max = part; a.b_max = part + kMaxParts;
   }
   if (x_gamma && !x_beta) return MLGNN_E_NULL;
-  a.N = (int)N; a.M = (int)M; a.K = (int)K; a.out_cols = cols;
-  // unpadded operands: whole stages go through the unmasked kernel, the last N % 32 rows through the masked one
+  a.M = (int)M; a.K = (int)K; a.out_cols = cols;
   const bool padded = (M % kTile != 0) || (K % kTile != 0);
-  const int main_rows = padded ? 0 : (int)(N / kSlabAlign * kSlabAlign);
-  int slots = 0;
-  if (main_rows > 0) {
-    a.row0 = 0; a.rows = main_rows; a.slot0 = 0;
-    if (!(f16 ? launch_wgrad<false, true>(pl, a, nblk, s) : launch_wgrad<false, false>(pl, a, nblk, s))) return MLGNN_E_SHAPE;
-    slots = nblk;
-  }
-  if (main_rows < N || N == 0) {
-    a.row0 = main_rows; a.rows = (int)N - main_rows; a.slot0 = slots;
-    const int nb = padded ? nblk : 1;
-    if (!(f16 ? launch_wgrad<true, true>(pl, a, nb, s) : launch_wgrad<true, false>(pl, a, nb, s))) return MLGNN_E_SHAPE;
-    slots += nb;
-  }
-  int err = (int)hipGetLastError();
-  if (err) return err;
-  launch_reduce_partials(workspace, grad_w_b, slots, cols, s);
+  // row slabs below 4 GiB per operand (dense_slab_rows; one slab up to 4.19 M rows x 256 columns): the operand bases
+  // advance, the operand scales stay those of the whole input, slab sums are added in slab order
+  const int64_t slab_rows = dense_slab_rows(M > K ? M : K);
+  int64_t r0 = 0;
+  do {
+    const int64_t n = N - r0 < slab_rows ? N - r0 : slab_rows;
+    a.a = (const float*)grad_out + r0 * M; a.b = (const float*)x + r0 * K; a.N = (int)n;
+    // unpadded operands: whole stages go through the unmasked kernel, the last n % 32 rows through the masked one
+    const int main_rows = padded ? 0 : (int)(n / kSlabAlign * kSlabAlign);
+    const int nb_main = wgrad_blocks(n, pl);
+    int slots = 0;
+    if (main_rows > 0) {
+      a.row0 = 0; a.rows = main_rows; a.slot0 = 0;
+      if (!(f16 ? launch_wgrad<false, true>(pl, a, nb_main, s) : launch_wgrad<false, false>(pl, a, nb_main, s))) return MLGNN_E_SHAPE;
+      slots = nb_main;
+    }
+    if (main_rows < n || n == 0) {
+      a.row0 = main_rows; a.rows = (int)n - main_rows; a.slot0 = slots;
+      const int nb = padded ? nb_main : 1;
+      if (!(f16 ? launch_wgrad<true, true>(pl, a, nb, s) : launch_wgrad<true, false>(pl, a, nb, s))) return MLGNN_E_SHAPE;
+      slots += nb;
+    }
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    launch_reduce_partials(workspace, grad_w_b, slots, cols, s, r0 > 0);
+    r0 += n;
+  } while (r0 < N);
   return (int)hipGetLastError();
 }

@@ -189,7 +189,7 @@ def linear_backward(go, w, x, go_max, x_max, epilogue, rstd=None, gamma=None, be
 
 
 def tall_matmul_ln_backward_supported(N, R, J):
-    return bool(_lib.lib.mlgnn_tallgemm_lnbwd_supported(N, R, J)) and N * J * 4 < (1 << 32)
+    return bool(_lib.lib.mlgnn_tallgemm_lnbwd_supported(N, R, J))
 
 
 def tall_matmul_supported(N, R, J, dtype=torch.float32):

@@ -119,7 +119,7 @@ def test_argument_errors_of_the_one_pass_linear_backward():
     assert lib.mlgnn_linear_bwd_supported(640000, 256, 128, LN) == 0            # the LayerNorm epilogue: 128 -> 256 only
     assert lib.mlgnn_linear_bwd_supported(640000, 128, 128, PLAIN) == 0 and lib.mlgnn_linear_bwd_supported(0, 128, 256, LN) == 0
     assert lib.mlgnn_linear_bwd_supported(640000, 128, 256, 7) == 0
-    assert lib.mlgnn_linear_bwd_supported(5000000, 128, 256, LN) == 0           # 32-bit byte offsets: N K 4 < 4 GiB
+    assert lib.mlgnn_linear_bwd_supported(5000000, 128, 256, LN) == 1           # row slabs inside the entry point (>= 4 GiB operands)
     assert lib.mlgnn_linear_bwd_workspace_floats(1000, 128, 256, LN) == 256 * (128 * 256 + 128 + 512) + 768
     assert lib.mlgnn_linear_bwd_workspace_floats(1000, 256, 128, SHIFT) == 256 * (256 * 128 + 256) + 768
     assert lib.mlgnn_linear_bwd_workspace_floats(1000, 100, 256, LN) == -2
@@ -158,3 +158,39 @@ def test_argument_errors_of_the_fp32_large_diffpool_and_table_gradient():
     assert lib.mlgnn_table_grad_begin(None, 0, 128, None, None) == -2 and lib.mlgnn_table_grad_begin(None, 10, 6, None, None) == -2
     assert lib.mlgnn_table_grad_finish(None, None, 10, 128, 0, None) == -1
     assert lib.mlgnn_table_grad_finish(None, None, 10, 127, 0, None) == -2
+
+
+def test_supported_and_entry_points_agree_past_4_gib():
+    """The dense backward entry points at row counts around and past the 4 GiB operand mark (4.19 M rows x 256 fp32
+    columns; 5.12 M rows = 512 graphs of BASELINE configs[3] on one GPU): what ``*_supported`` / ``*_workspace_floats``
+    promise is what the entry point accepts -- with NULL operands an accepted shape reports MLGNN_E_NULL (-1), a refused
+    one MLGNN_E_SHAPE (-2); nothing is launched (no GPU needed)."""
+    from mlgnn import _lib
+    lib = _lib.lib
+    LN, PLAIN, SHIFT = 0, 1, 2
+    for N in (4_000_000, 4_194_304, 4_200_000, 5_120_000):
+        for (M, K, epi) in ((128, 256, LN), (256, 128, SHIFT), (256, 128, PLAIN)):
+            ok = lib.mlgnn_linear_bwd_supported(N, M, K, epi)
+            ws = lib.mlgnn_linear_bwd_workspace_floats(N, M, K, epi)
+            rc = lib.mlgnn_linear_bwd(None, None, None, None, 0, None, epi, None, None, None, None, None, None, None, None,
+                                      None, None, 1 << 40, N, M, K, None)
+            assert ok == 1 and ws > 0 and rc == -1, (N, M, K, epi, ok, ws, rc)
+        for (M, K) in ((128, 256), (256, 128), (128, 128), (64, 128)):
+            ws = lib.mlgnn_linear_wgrad_workspace_floats(N, M, K, 0)
+            rc = lib.mlgnn_linear_wgrad(None, None, None, None, None, None, None, None, 1 << 40, N, M, K, 0, None)
+            assert ws > 0 and rc == -1, (N, M, K, ws, rc)
+        for (R, J) in ((128, 256), (256, 128), (128, 128)):
+            ok = lib.mlgnn_tallgemm_lnbwd_supported(N, R, J)
+            # (NULL grad_gamma_beta is the first pointer the entry point looks at, after every shape check)
+            rc = lib.mlgnn_tallgemm_lnbwd(None, None, 1, None, None, None, None, None, None, None, None, None, 1 << 40,
+                                          N, R, J, None)
+            assert ok == 1 and rc == -1, (N, R, J, ok, rc)
+            assert lib.mlgnn_tallgemm_supported(N, R, J, 0) == 1
+            assert lib.mlgnn_tallgemm_nt_shift_supported(N, J, R) == lib.mlgnn_tallgemm_lnin_postln_supported(N, J, R)
+    # refused shapes are refused by both
+    assert lib.mlgnn_linear_bwd_supported(5_120_000, 256, 128, LN) == 0
+    assert lib.mlgnn_linear_bwd(None, None, None, None, 0, None, LN, None, None, None, None, None, None, None, None, None,
+                                None, 1 << 40, 5_120_000, 256, 128, None) == -2
+    assert lib.mlgnn_tallgemm_lnbwd_supported(5_120_000, 512, 128) == 0
+    assert lib.mlgnn_tallgemm_lnbwd(None, None, 1, None, None, None, None, None, None, None, None, None, 1 << 40,
+                                    5_120_000, 512, 128, None) == -2

@@ -1,0 +1,183 @@
+"""The dense backward kernels past the 4 GiB operand mark (BASELINE configs[3] at global batch 512 on ONE GPU is 5.12 M
+node rows x hidden 256 fp32 = 5.2 GB per activation; reference step: train.py:38-69 runs any batch size).  The entry
+points walk row slabs below 4 GiB (csrc/common.h dense_slab_rows = 4 190 208 rows at 256 columns): here two slabs, the
+second one short and ragged, against fp64 computed in row chunks on the device."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+N_BIG = 4_190_208 + 70_001            # one full slab + a ragged tail that is not a multiple of the 32-row stage
+CHUNK = 1 << 18
+
+
+def _chunks(n):
+    for lo in range(0, n, CHUNK):
+        yield slice(lo, min(n, lo + CHUNK))
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return torch.randn(*shape, device=DEV, generator=g) * scale
+
+
+def _rel(a, b):
+    return float((a.double() - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+def test_one_pass_backward_ln_epilogue_two_slabs():
+    from mlgnn import dense as D
+    M, K = 128, 256
+    N = N_BIG
+    go, xhat, w = _rand((N, M), 1), _rand((N, K), 2), _rand((M, K), 3, 0.1)
+    rstd = torch.rand(N, device=DEV) + 0.5
+    gamma, beta = torch.rand(K, device=DEV) + 0.5, _rand((K,), 4, 0.3)
+    go_max = go.abs().amax(1)
+    act_max = torch.empty(N, device=DEV)
+    for c in _chunks(N):
+        act_max[c] = torch.relu(torch.addcmul(beta, xhat[c], gamma)).amax(1)
+    assert D.linear_backward_supported(N, M, K, D.LB_LN)
+    out = D.linear_backward(go, w, xhat, go_max, act_max, D.LB_LN, rstd=rstd, gamma=gamma, beta=beta)
+    torch.cuda.synchronize()
+    gw = torch.zeros(M, K, dtype=torch.float64, device=DEV)
+    gb = torch.zeros(M, dtype=torch.float64, device=DEV)
+    gg = torch.zeros(K, dtype=torch.float64, device=DEV)
+    gbe = torch.zeros(K, dtype=torch.float64, device=DEV)
+    worst, dx_max = 0.0, 0.0
+    for c in _chunks(N):
+        go64, x64 = go[c].double(), xhat[c].double()
+        act = torch.relu((gamma.double() * x64 + beta.double()).float()).double()
+        gy = (go64 @ w.double()) * (act > 0)
+        g_ = gy * gamma.double()
+        dh = rstd[c].double()[:, None] * (g_ - g_.mean(1, keepdim=True) - x64 * (g_ * x64).mean(1, keepdim=True))
+        worst = max(worst, float((out["dx"][c].double() - dh).abs().max()))
+        dx_max = max(dx_max, float(dh.abs().max()))
+        gw += go64.t() @ act
+        gb += go64.sum(0)
+        gg += (gy * x64).sum(0)
+        gbe += gy.sum(0)
+    assert worst <= 2e-5 * dx_max, (worst, dx_max)
+    assert _rel(out["gw"], gw) <= 1e-5 and _rel(out["gb"], gb) <= 1e-5
+    assert _rel(out["ggamma"], gg) <= 2e-5 and _rel(out["gbeta"], gbe) <= 2e-5
+    # the chained partial maxima cover BOTH slabs
+    assert abs(float(out["parts"].max()) - float(out["dx"].abs().max())) <= 1e-6 * dx_max
+    # the tail slab on its own through the single-slab path (the same code the small tests pin): same dx rows
+    lo = 4_190_208
+    n_tail = N - lo
+    tail = D.linear_backward(go[lo:].contiguous(), w, xhat[lo:].contiguous(), torch.full((n_tail,), float(go_max.max()), device=DEV),
+                             torch.full((n_tail,), float(act_max.max()), device=DEV), D.LB_LN,
+                             rstd=rstd[lo:].contiguous(), gamma=gamma, beta=beta)
+    assert torch.equal(tail["dx"], out["dx"][lo:])          # (same global scales: bitwise)
+
+
+@pytest.mark.parametrize("shift", [False, True])
+def test_one_pass_backward_plain_and_shift_two_slabs(shift):
+    from mlgnn import dense as D
+    M, K = 256, 128
+    N = N_BIG
+    go, x, w = _rand((N, M), 5), _rand((N, K), 6), _rand((M, K), 7, 0.1)
+    lse = _rand((N, K), 8, 5.0) if shift else None
+    out = D.linear_backward(go, w, x, go.abs().amax(1), x.abs().amax(1), D.LB_SHIFT if shift else D.LB_PLAIN, lse=lse)
+    torch.cuda.synchronize()
+    gw = torch.zeros(M, K, dtype=torch.float64, device=DEV)
+    gb = torch.zeros(M, dtype=torch.float64, device=DEV)
+    worst, worst_t, dmax, tmax = 0.0, 0.0, 0.0, 0.0
+    for c in _chunks(N):
+        go64 = go[c].double()
+        dx = go64 @ w.double()
+        worst = max(worst, float((out["dx"][c].double() - dx).abs().max()))
+        dmax = max(dmax, float(dx.abs().max()))
+        if shift:
+            gt = dx * torch.exp2(-lse[c].double())
+            live = lse[c].abs() < 60
+            worst_t = max(worst_t, float(((out["gt"][c].double() - gt) * live).abs().max() / (gt * live).abs().max()))
+        gw += go64.t() @ x[c].double()
+        gb += go64.sum(0)
+    assert worst <= 2e-5 * dmax
+    assert worst_t <= 2e-5
+    assert _rel(out["gw"], gw) <= 1e-5 and _rel(out["gb"], gb) <= 1e-5
+    if shift:
+        assert int(out["flag"][0]) == 0
+
+
+def test_weight_gradient_and_ln_backward_gemm_two_slabs():
+    from mlgnn import dense as D
+    N = N_BIG
+    M, K = 128, 256
+    go, xhat, w = _rand((N, M), 9), _rand((N, K), 10), _rand((M, K), 11, 0.1)
+    rstd = torch.rand(N, device=DEV) + 0.5
+    gamma, beta = torch.rand(K, device=DEV) + 0.5, _rand((K,), 12, 0.3)
+    # weight gradient with the affine + ReLU prologue, exact three-term split (no maxima given)
+    gw, gb = D._wgrad(go, xhat, gamma, beta)
+    # ... and the scaled fp16 split
+    act_max = torch.empty(N, device=DEV)
+    for c in _chunks(N):
+        act_max[c] = torch.relu(torch.addcmul(beta, xhat[c], gamma)).amax(1)
+    gw2, gb2 = D._wgrad(go, xhat, gamma, beta, go_max=go.abs().amax(1), x_max=act_max)
+    assert D.tall_matmul_ln_backward_supported(N, M, K)
+    gh, ggam, gbet, rmax = D.tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, go.abs().amax(1))
+    torch.cuda.synchronize()
+    ref_w = torch.zeros(M, K, dtype=torch.float64, device=DEV)
+    ref_b = torch.zeros(M, dtype=torch.float64, device=DEV)
+    ref_g = torch.zeros(K, dtype=torch.float64, device=DEV)
+    ref_be = torch.zeros(K, dtype=torch.float64, device=DEV)
+    worst, hmax = 0.0, 0.0
+    for c in _chunks(N):
+        go64, x64 = go[c].double(), xhat[c].double()
+        act = torch.relu((gamma.double() * x64 + beta.double()).float()).double()
+        ref_w += go64.t() @ act
+        ref_b += go64.sum(0)
+        gy = (go64 @ w.double()) * (act > 0)
+        g_ = gy * gamma.double()
+        dh = rstd[c].double()[:, None] * (g_ - g_.mean(1, keepdim=True) - x64 * (g_ * x64).mean(1, keepdim=True))
+        worst = max(worst, float((gh[c].double() - dh).abs().max()))
+        hmax = max(hmax, float(dh.abs().max()))
+        ref_g += (gy * x64).sum(0)
+        ref_be += gy.sum(0)
+        assert float((rmax[c].double() - gh[c].double().abs().amax(1)).abs().max()) <= 1e-6 * hmax
+    assert _rel(gw, ref_w) <= 1e-5 and _rel(gb, ref_b) <= 1e-5
+    assert _rel(gw2, ref_w) <= 1e-5 and _rel(gb2, ref_b) <= 1e-5
+    assert worst <= 2e-5 * hmax
+    assert _rel(ggam, ref_g) <= 2e-5 and _rel(gbet, ref_be) <= 2e-5
+
+
+def test_fused_mlp_forward_backward_past_4_gib():
+    """``Linear(128,256) -> LayerNorm -> ReLU -> Linear(256,128) + residual`` (the GENConv MLP, torch_nn.py:54-75) over
+    4.26 M rows: every tensor of the hidden width is past 4 GiB.  Forward and every gradient against fp64 in chunks."""
+    from mlgnn import dense as D
+    N, Kin, H = N_BIG, 128, 256
+    x = _rand((N, Kin), 20).requires_grad_(True)
+    res = _rand((N, Kin), 21)
+    w1 = _rand((H, Kin), 22, 0.1).requires_grad_(True)
+    b1 = _rand((H,), 23, 0.1).requires_grad_(True)
+    gamma = (torch.rand(H, device=DEV) + 0.5).requires_grad_(True)
+    beta = _rand((H,), 24, 0.3).requires_grad_(True)
+    w2 = _rand((Kin, H), 25, 0.1).requires_grad_(True)
+    b2 = _rand((Kin,), 26, 0.1).requires_grad_(True)
+    assert D.fused_mlp2_supported(x, w1, w2)
+    before = dict(D.LINEAR_BWD_STATS)
+    out = D.fused_mlp2(x, w1, b1, gamma, beta, 1e-5, w2, b2, residual=res)
+    go = _rand((N, Kin), 27)
+    out.backward(go)
+    torch.cuda.synchronize()
+    assert D.LINEAR_BWD_STATS["ln"] == before["ln"] + 1          # the one-pass kernels ran (no fallback at this size)
+    assert D.LINEAR_BWD_STATS["plain"] + D.LINEAR_BWD_STATS["shift"] == before["plain"] + before["shift"] + 1
+    params = [w1, b1, gamma, beta, w2, b2]
+    ref = [torch.zeros_like(p, dtype=torch.float64) for p in params]
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    worst_o = worst_x = omax = xmax = 0.0
+    for c in _chunks(N):
+        xc = x.detach()[c].double().requires_grad_(True)
+        h = torch.nn.functional.layer_norm(xc @ p64[0].t() + p64[1], (H,), p64[2], p64[3], 1e-5)
+        o = torch.relu(h) @ p64[4].t() + p64[5] + res[c].double()
+        grads = torch.autograd.grad(o, [xc] + p64, go[c].double())
+        worst_o = max(worst_o, float((out.detach()[c].double() - o.detach()).abs().max()))
+        omax = max(omax, float(o.detach().abs().max()))
+        worst_x = max(worst_x, float((x.grad[c].double() - grads[0]).abs().max()))
+        xmax = max(xmax, float(grads[0].abs().max()))
+        for r, g_ in zip(ref, grads[1:]):
+            r += g_
+    assert worst_o <= 1e-4 * omax and worst_x <= 1e-4 * xmax, (worst_o, omax, worst_x, xmax)
+    for p, r, name in zip(params, ref, ("w1", "b1", "gamma", "beta", "w2", "b2")):
+        assert _rel(p.grad, r) <= 1e-4, name

@@ -13,6 +13,13 @@ WGRAD_MIN_ROWS = 8192          # below this the library's TN GEMM is not the bot
 ROW_MAX_STATS = {"given": 0, "computed": 0}      # tall GEMMs whose operand came with / without its row maxima
 
 
+def _aligned(t):
+    """Contiguous and on a 16-byte boundary (the kernels read operands with 16-byte loads): a view at an odd offset of
+    somebody's flat buffer is copied once (mlgnn.optim.FlatAdam aligns its slots, so its views never are)."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None, bt_transposed=False):
     """``a [N,R] @ bt[J,R]^T (+ bias) (+ residual [N,J])`` through the scaled split-precision fp16-MFMA kernel
     (``csrc/tallgemm.hip``).  The caller checks :func:`tall_matmul_supported` first.  ``row_max`` [N]: ``max |a[i]|``
@@ -24,7 +31,7 @@ def tall_matmul_nt(a, bt, bias=None, residual=None, row_max=None, ln=None, bt_tr
     if bt_transposed and a.dtype != torch.float32:           # (the bf16 kernel packs a [J, R] operand)
         bt, bt_transposed = bt.t(), False
     J = bt.shape[1] if bt_transposed else bt.shape[0]        # bt_transposed: bt is [R, J], read with swapped indices
-    a, bt = a.contiguous(), bt.contiguous()
+    a, bt = _aligned(a), _aligned(bt)
     dt = _DTYPE_IDS[a.dtype]
     out = torch.empty((N, J), dtype=a.dtype, device=a.device)
     nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(R, J, dt))
@@ -58,7 +65,7 @@ def tall_matmul_lnin_postln(xhat, w, bias, residual, row_max, gamma, beta, post)
     ``y = relu?(LayerNorm(out))`` (csrc/tallgemm.hip POST)."""
     N, R = xhat.shape
     J = w.shape[0]
-    xhat, w = xhat.contiguous(), w.contiguous()
+    xhat, w = _aligned(xhat), _aligned(w)
     f32 = dict(dtype=torch.float32, device=xhat.device)
     out, y = torch.empty((N, J), **f32), torch.empty((N, J), **f32)
     mean, rstd = torch.empty(N, **f32), torch.empty(N, **f32)
@@ -86,7 +93,7 @@ def tall_matmul_nt_shift(a, w, row_max, lse, rowptr):
     ``-> (gx, gx * 2^(-lse), flag)``."""
     N, R = a.shape
     J = w.shape[1]
-    a, w = a.contiguous(), w.contiguous()
+    a, w = _aligned(a), _aligned(w)
     gx = torch.empty((N, J), dtype=torch.float32, device=a.device)
     gt = torch.empty_like(gx)
     flag = torch.empty(4, dtype=torch.int32, device=a.device)
@@ -125,7 +132,7 @@ def tall_matmul_ln_backward(go, w, xhat, rstd, gamma, beta, row_max=None):
     hidden activation stored normalised (``xhat``, ``rstd``).  The caller checks :func:`tall_matmul_ln_backward_supported`."""
     N, R = go.shape
     J = w.shape[1]
-    go, w, xhat = go.contiguous(), w.contiguous(), xhat.contiguous()
+    go, w, xhat = _aligned(go), _aligned(w), _aligned(xhat)
     gh = torch.empty((N, J), dtype=torch.float32, device=go.device)
     ggb = torch.empty((2, J), dtype=torch.float32, device=go.device)
     rmax = torch.empty(N, dtype=torch.float32, device=go.device)
@@ -164,7 +171,7 @@ def linear_backward(go, w, x, go_max, x_max, epilogue, rstd=None, gamma=None, be
     ``|x'|``.  -> ``dict(dx, gw [M,K], gb [M], parts [256], [ggamma, gbeta], [gt, flag])``."""
     N, M = go.shape
     K = x.shape[1]
-    go, w, x = go.contiguous(), w.contiguous(), x.contiguous()
+    go, w, x = _aligned(go), _aligned(w), _aligned(x)
     f32 = dict(dtype=torch.float32, device=go.device)
     dx = torch.empty((N, K), **f32)
     cols = M * K + M + (2 * K if epilogue == LB_LN else 0)

@@ -11,13 +11,23 @@ import torch
 import torch.distributed as dist
 
 
+SLOT_ALIGN = 4            # elements: 16 bytes of fp32
+
+
 class FlatGradBucket:
     def __init__(self, module, process_group=None):
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
-        total = sum(p.numel() for p in self.params)
+        # every parameter's slot starts on a 16-byte boundary (SLOT_ALIGN elements): the kernels read weights with
+        # 16-byte loads straight out of the flat parameter buffer that mirrors this layout (mlgnn.optim.FlatAdam);
+        # learnable_pca_params [25015, 2] alone would misalign everything behind it.  The gaps stay zero.
+        self.offsets = [0]
+        for p in self.params:
+            self.offsets.append(self.offsets[-1] + (p.numel() + SLOT_ALIGN - 1) // SLOT_ALIGN * SLOT_ALIGN)
+        total = self.offsets[-1]
+        self._gap_zeros = torch.zeros(SLOT_ALIGN, dtype=dt, device=dev)
         # gradients, then one "reached" flag per parameter: the flags travel with the gradients in the ONE all-reduce,
         # so every rank learns the union of what any rank's backward reached (a parameter reached on rank 0 only is
         # stepped, with the averaged gradient, on every rank -- or the replicas would drift apart silently)
@@ -26,15 +36,12 @@ class FlatGradBucket:
         self.live = self.flat_all[total:]
         self.live.fill_(1)
         self.group = process_group
-        off = 0
         self.views = []
         self.reached = [True] * len(self.params)       # which parameters the last collected LOCAL backward reached
         self._live_local = (tuple(self.reached), self.live.clone())
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
             self.views.append(p.grad)
-            off += n
 
     # Two ways to fill the bucket.  (a) zero() before backward: autograd accumulates into the views in place -- one
     # small add kernel per parameter.  (b) release() before backward, collect() after it: autograd hands over fresh
@@ -48,29 +55,31 @@ class FlatGradBucket:
         # runs of consecutive parameters with a fresh gradient tensor are concatenated straight into their slice of
         # the flat buffer: ONE launch per run (`torch.cat(..., out=)`, public API) -- one launch in all when every
         # parameter was reached, as in every shipped model
-        run, run_start, off = [], 0, 0
+        # (the alignment gap behind a parameter is written with zeros by the same launch)
+        run, run_start = [], 0
 
         def flush(end):
             if run:
-                torch.cat([g.reshape(-1) for g in run], out=self.flat[run_start:end])
+                torch.cat(run, out=self.flat[run_start:end])
                 del run[:]
 
         for i, (p, v) in enumerate(zip(self.params, self.views)):
-            n = p.numel()
+            off, nxt = self.offsets[i], self.offsets[i + 1]
             self.reached[i] = p.grad is not None
             fresh = p.grad is not None and p.grad.data_ptr() != v.data_ptr()
             if fresh and p.grad.dtype == self.flat.dtype:
                 if not run:
                     run_start = off
-                run.append(p.grad)
+                run.append(p.grad.reshape(-1))
+                if nxt - off > p.numel():
+                    run.append(self._gap_zeros[:nxt - off - p.numel()])
             else:
                 flush(off)
                 if p.grad is None:
                     v.zero_()                      # parameter not reached by this backward: zero in the flat buffer
                 elif fresh:
                     v.copy_(p.grad)                # (a gradient of another dtype: converting copy)
-            off += n
-        flush(off)
+        flush(self.offsets[-1])
         for p, v in zip(self.params, self.views):
             p.grad = v
         key = tuple(self.reached)
@@ -103,11 +112,9 @@ class FlatGradBucket:
 
     def check_views(self):
         """True while every ``p.grad`` still aliases the bucket."""
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
                 return False
-            off += p.numel()
         return True
 
 

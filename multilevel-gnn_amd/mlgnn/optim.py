@@ -35,14 +35,15 @@ class FlatAdam:
         dev = params[0].device
         if not all(p.dtype == torch.float32 and p.device == dev for p in params):
             raise TypeError("FlatAdam wants fp32 parameters on one device")
-        self.sizes = [p.numel() for p in params]
-        self.flat_p = torch.empty(sum(self.sizes), dtype=torch.float32, device=dev)
-        off = 0
-        for p, n in zip(params, self.sizes):
-            view = self.flat_p[off:off + n].view_as(p)
+        # the bucket's slot layout (every parameter on a 16-byte boundary, zero gaps): parameters, gradients and
+        # moments line up element for element
+        offs = self.bucket.offsets
+        self.sizes = [b - a for a, b in zip(offs[:-1], offs[1:])]
+        self.flat_p = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
+        for p, off in zip(params, offs):
+            view = self.flat_p[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
-            off += n
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.param_groups = [dict(lr=lr, initial_lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
@@ -50,9 +51,6 @@ class FlatAdam:
         self.step_count = 0
         self._ws = torch.zeros(int(_lib.lib.mlgnn_adam_workspace_floats()), dtype=torch.float32, device=dev) \
             if dev.type == "cuda" else None
-        offs = [0]
-        for n in self.sizes:
-            offs.append(offs[-1] + n)
         self._offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
 
     @property

@@ -11,8 +11,48 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 
+_STDERR_TEE = {}
+
+
+def _start_stderr_tee():
+    """Passive abort catcher: everything written to file descriptor 2 of this process -- HIP / MIOpen / rocBLAS runtime
+    messages included -- also lands in gpurun_out/stderr_<pid>.log, and faulthandler dumps the Python stacks there on a
+    fatal signal.  The copy is made by a separate ``tee`` process at the other end of a pipe, so the last words of a
+    process that aborts are still drained and written after it has died.  pytest.ini sets ``--capture=sys``: pytest then
+    captures ``sys.stderr`` only and leaves descriptor 2 alone (with its default fd capture it would point descriptor 2
+    at a temporary file of its own for the length of every test and take the runtime's message down with the process)."""
+    import faulthandler
+    import subprocess
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    path = os.path.join(out_dir, "stderr_%d.log" % os.getpid())
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        log = open(path, "ab", buffering=0)
+        keep = os.dup(2)                                # the terminal / the harness' pipe
+        tee = subprocess.Popen(["tee", "-a", path], stdin=subprocess.PIPE, stdout=keep, stderr=subprocess.DEVNULL,
+                               close_fds=True, start_new_session=True)
+    except OSError:
+        return
+    faulthandler.enable(file=log, all_threads=True)
+    os.dup2(tee.stdin.fileno(), 2)
+    tee.stdin.close()                                   # descriptor 2 is now the pipe's only write end in this process
+    _STDERR_TEE.update(keep=keep, log=log, tee=tee)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("MLGNN_STDERR_TEE", "1") == "1" and not _STDERR_TEE and not hasattr(config, "workerinput"):
+        _start_stderr_tee()
+
+
+def pytest_unconfigure(config):
+    if _STDERR_TEE:
+        try:
+            os.dup2(_STDERR_TEE["keep"], 2)            # closes the pipe's last write end: tee drains and exits
+            _STDERR_TEE["tee"].wait(timeout=5.0)
+        except Exception:                              # noqa: BLE001
+            pass
+        _STDERR_TEE.clear()
 
 
 def pytest_collection_modifyitems(config, items):

@@ -53,7 +53,10 @@ def _worker(rank, world, port, q):
             bucket.collect()
         assert bucket.check_views()
         bucket.all_reduce_mean()
-    q.put((rank, bucket.flat.clone(), torch.cat([p.detach().reshape(-1) for p in model.parameters()])))
+    # (the bucket's slots are 16-byte aligned: the parameters' gradients are its views, gaps between them stay zero)
+    for p_, a, b in zip(bucket.params, bucket.offsets[:-1], bucket.offsets[1:]):
+        assert a % 4 == 0 and (b - a == p_.numel() or float(bucket.flat[a + p_.numel():b].abs().max()) == 0.0)
+    q.put((rank, torch.cat([v.reshape(-1) for v in bucket.views]), torch.cat([p.detach().reshape(-1) for p in model.parameters()])))
     try:                                                # teardown only: the results are already with the parent
         dist.barrier()
         dist.destroy_process_group()
@@ -127,7 +130,9 @@ def test_reached_flags_are_agreed_across_ranks():
         assert any0 == any1 == want_local[0]                       # the union, on both ranks
         assert torch.equal(live0, live1) and torch.equal(flat0, flat1)
         assert live0.tolist() == [1.0, 1.0, 0.5, 0.5, 0.0, 0.0]
-        assert torch.allclose(flat0[14:28], g_extra0 / 2, atol=1e-7)
+        # slots start on 16-byte boundaries: base.weight [0,12), base.bias [12,14) + gap, extra.weight [16,28), extra.bias [28,30)
+        assert torch.allclose(torch.cat([flat0[16:28], flat0[28:30]]), g_extra0 / 2, atol=1e-7)
+        assert float(flat0[14:16].abs().max()) == 0.0 and float(flat0[30:32].abs().max()) == 0.0
 
 
 def _run_world(world, target=None):

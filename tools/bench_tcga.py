@@ -1,6 +1,16 @@
 #!/usr/bin/env python3
-"""Development tool: MultilevelGNN training step at config/gbm.yaml shape (B=32, 15 405 nodes per graph,
-2 x GraphConv('sage') 64->64->32, G=25 015 memberships) on synthetic TCGA-shaped data."""
+"""Training step of the model the reference ships configs for -- ``model: multilevel_gnn``, ``gnn_name: sage``
+(config/kirc.yaml, config/gbm.yaml; models/multilevel_gnn.py:132-292 + gcn_lib/sparse/torch_vertex.py:269-304) -- at the
+real TCGA shape on synthetic data (the dataset does not ship): 5135 genes x 3 omics = 15 405 nodes per sample, one shared
+topology of 60 000 weighted edges, 25 015 pathway memberships in 438 segments.
+
+  kirc: batch 64, node embedding 32 -> 64 -> 32, pca_dim 3, pool dims 1, head 512     (config/kirc.yaml)
+  gbm : batch 32, node embedding 64 -> 64 -> 32, pca_dim 2, pool dims 4/2, head 256, age input   (config/gbm.yaml)
+
+Step = forward + BCE + feature loss + backward + clip_grad_norm_(20) + Adam through ``mlgnn.optim.FlatAdam``
+(train.py:38-69,112-114).  Prints one JSON line; ``--json`` also writes it to a file."""
+import argparse
+import json
 import os
 import sys
 import time
@@ -14,21 +24,35 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _util import make_args  # noqa: E402
 from models import get_model  # noqa: E402
 
-GBM = dict(model="multilevel_gnn", num_layers=2, hidden_channels=64, final_channels=32, final_head=4,
-           node_embedding=True, node_embedding_dim=64, gnn_name="sage", head_dim=256, use_age=True,
-           weighted_edge=True, value_att_mask=True, pca_match_mask=True, mutual_info_mask=True,
-           learnable_pca=True, pca_indep_loss=True, pca_dim=2, pathway_pool_dim=4, pca_pool_dim=2,
-           feature_drop=True, dropout=0.25)
+KIRC = dict(model="multilevel_gnn", num_layers=2, hidden_channels=64, final_channels=32, final_head=4,
+            node_embedding=True, node_embedding_dim=32, gnn_name="sage", head_dim=512, use_age=False,
+            weighted_edge=True, value_att_mask=True, pca_match_mask=True, mutual_info_mask=True,
+            learnable_pca=True, pca_indep_loss=True, pca_dim=3, pathway_pool_dim=1, pca_pool_dim=1,
+            feature_drop=True, dropout=0.25, num_layer_head=2)
+GBM = dict(KIRC, node_embedding_dim=64, head_dim=256, use_age=True, pca_dim=2, pathway_pool_dim=4, pca_pool_dim=2)
+SHAPES = {"kirc": (KIRC, 64), "gbm": (GBM, 32)}
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", choices=sorted(SHAPES), default="kirc")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of FlatAdam")
+    ap.add_argument("--json")
+    a = ap.parse_args()
+    from mlgnn.optim import FlatAdam
+    cfg, B = SHAPES[a.shape]
+    B = a.batch or B
     dev = torch.device("cuda:0")
-    B, NN, G, S, E = 32, 5135 * 3, 25015, 438, 60000
+    NN, G, S, E = 5135 * 3, 25015, 438, 60000
     gen = torch.Generator().manual_seed(0)
-    args = make_args(**GBM)
+    torch.manual_seed(0)
+    args = make_args(**cfg)
     model = get_model("multilevel_gnn")(args)
     mask = (torch.rand(G, generator=gen) > 0.3).float()
-    model.set_pca_params(torch.randn(int(mask.sum()), 2, generator=gen) * 0.1, mask)
+    model.set_pca_params(torch.randn(int(mask.sum()), args.pca_dim, generator=gen) * 0.1, mask)
     model.set_info_mask(mask[:, None].clone())
     seg = torch.sort(torch.randint(0, S, (G,), generator=gen))[0]
     model.set_pathway_indexs(seg.to(dev))
@@ -36,30 +60,54 @@ def main():
     src, dst = torch.randint(0, NN, (E,), generator=gen), torch.randint(0, NN, (E,), generator=gen)
     ei = torch.cat([torch.stack([src, dst]) + b * NN for b in range(B)], dim=1).to(dev)
     match = torch.randint(0, NN, (G,), generator=gen)
-    batch = SimpleNamespace(x=torch.rand(B * NN, 1, device=dev), edge_index=ei,
-                            edge_attr=(torch.rand(E, 1, generator=gen) * 2 - 1).repeat(B, 1).to(dev),
+    match[torch.rand(G, generator=gen) < 0.02] = -1
+    w = torch.rand(E, 1, generator=gen) * 2 - 1
+    w[:2000] = torch.where(torch.rand(2000, 1, generator=gen) < 0.5, -1.0, 1.0)        # cross-omics edges (multiloader.py:664-671)
+    batch = SimpleNamespace(x=torch.rand(B * NN, 1, device=dev), edge_index=ei, edge_attr=w.repeat(B, 1).to(dev),
                             gene_pca_match=match[None].repeat(B, 1).to(dev), raw_indice=seg[None].repeat(B, 1).to(dev),
                             age=torch.rand(B, device=dev))
     y = torch.nn.functional.one_hot(torch.randint(0, 2, (B,), device=dev), 2).float()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    if a.torch_adam:
+        opt = torch.optim.Adam(model.parameters(), lr=5e-5)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        pred, feat = model(batch)
-        loss = torch.nn.functional.binary_cross_entropy(pred, y) + model.get_feature_loss(feat)
-        loss.backward()
-        opt.step()
+        def step():
+            opt.zero_grad(set_to_none=True)
+            pred, feat = model(batch)
+            loss = torch.nn.functional.binary_cross_entropy(pred, y) + model.get_feature_loss(feat)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 20)
+            opt.step()
+            return loss
+    else:
+        opt = FlatAdam(model, lr=5e-5, clip_grad_norm=20)
+        bucket = opt.bucket
 
-    for _ in range(3):
+        def step():
+            bucket.release()
+            pred, feat = model(batch)
+            loss = torch.nn.functional.binary_cross_entropy(pred, y) + model.get_feature_loss(feat)
+            loss.backward()
+            bucket.collect()
+            opt.step()
+            return loss
+
+    for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 20
-    for _ in range(n):
-        step()
+    for _ in range(a.steps):
+        loss = step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
-    print("MultilevelGNN gbm shape: %.2f ms/step, %.0f graphs/s (B=%d)" % (dt * 1e3, B / dt, B))
+    dt = (time.perf_counter() - t0) / a.steps
+    out = {"workload": "MultilevelGNN (gnn_name=sage) at config/%s.yaml shape: B=%d x 15405 nodes, 60000 shared edges, "
+                       "G=25015 memberships, embedding %d -> 64 -> 32, pca_dim=%d, head_dim=%d; synthetic data; step = fwd + "
+                       "loss + bwd + clip(20) + Adam (%s)" % (a.shape, B, args.node_embedding_dim, args.pca_dim,
+                                                               args.head_dim, "torch.optim" if a.torch_adam else "FlatAdam"),
+           "shape": a.shape, "batch": B, "steps": a.steps, "ms_per_step": dt * 1e3, "graphs_per_s": B / dt,
+           "final_loss": float(loss.detach()), "params": sum(p.numel() for p in model.parameters())}
+    print(json.dumps(out), flush=True)
+    if a.json:
+        json.dump(out, open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -59,6 +59,11 @@ def main():
         if a.cmd:
             f.write("Command: `%s`\n\n" % a.cmd)
         f.write("Total kernel time: %.2f ms over %d distinct kernels.\n\n" % (total / 1e6, len(rows)))
+        own = sum(float(r["TotalDurationNs"]) for r in rows if "mlgnn::" in r["Name"])
+        own_calls = sum(int(r["Calls"]) for r in rows if "mlgnn::" in r["Name"])
+        calls = sum(int(r["Calls"]) for r in rows)
+        f.write("Hand-written (`mlgnn::`) kernels: %.1f %% of kernel time, %d of %d launches.\n\n"
+                % (100.0 * own / max(total, 1.0), own_calls, calls))
         f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
         for r in rows[:a.top]:
             f.write("| `%s` | %s | %.2f | %.1f | %.1f | %.1f | %.1f |\n" % (

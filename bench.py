@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the also_aggr (max / mean) and no-overlap legs after the timed run")
     ap.add_argument("--extra-steps", type=int, default=5)
+    ap.add_argument("--loss", choices=["full", "bce"], default="full",
+                    help="bce: without the DiffPool link / entropy terms (the link loss is one Frobenius norm over the "
+                         "batch, so only the BCE step of N ranks equals the single-process step on the global batch)")
+    ap.add_argument("--dump-params", help="rank 0 saves its parameters (one flat fp32 tensor) here after the timed run")
     return ap.parse_args()
 
 
@@ -234,7 +238,7 @@ def main():
                 if not last:
                     build_topology(i + 1)
             bucket.release()
-            loss = W.training_loss(model, batch)
+            loss = W.training_loss(model, batch, aux=(args.loss == "full"))
             loss.backward()
             bucket.collect()
             if ar_events is not None:
@@ -267,9 +271,11 @@ def main():
     elapsed, summ, ar_events, final_loss, bucket, model = run(args.aggr, args.steps, args.warmup, not args.no_overlap,
                                                                not args.no_kernel_timer)
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
+    if rank == 0 and args.dump_params:
+        torch.save(torch.cat([p.detach().reshape(-1).float() for p in model.parameters()]).cpu(), args.dump_params)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

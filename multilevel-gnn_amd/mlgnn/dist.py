@@ -14,6 +14,18 @@ import torch.distributed as dist
 SLOT_ALIGN = 4            # elements: 16 bytes of fp32
 
 
+def _collective(fn, tensor, group, **kw):
+    """``fn(tensor, group=group, **kw)`` in place.  RCCL takes the device buffer as it is; the ``gloo`` rehearsal backend
+    (several ranks sharing the single GPU of a test box: bench.py's MLGNN_BENCH_BACKEND=gloo, tests/test_bench_gpu.py)
+    gets a host copy, so that path does not depend on gloo having been built with device support."""
+    if tensor.is_cuda and dist.get_backend(group) == "gloo":
+        host = tensor.cpu()
+        fn(host, group=group, **kw)
+        tensor.copy_(host)
+    else:
+        fn(tensor, group=group, **kw)
+
+
 class FlatGradBucket:
     def __init__(self, module, process_group=None):
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -103,7 +115,7 @@ class FlatGradBucket:
         world = dist.get_world_size(self.group)
         if world == 1:
             return
-        dist.all_reduce(self.flat_all, op=dist.ReduceOp.SUM, group=self.group)
+        _collective(dist.all_reduce, self.flat_all, self.group, op=dist.ReduceOp.SUM)
         self.flat_all.div_(world)                  # flags: (ranks that reached the parameter) / world, > 0 = live
 
     def reached_anywhere(self):
@@ -124,7 +136,7 @@ def broadcast_parameters(module, src=0, process_group=None):
         return
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b.dtype.is_floating_point]
     flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.broadcast(flat, src=src, group=process_group)
+    _collective(dist.broadcast, flat, process_group, src=src)
     off = 0
     for t in tensors:
         t.copy_(flat[off:off + t.numel()].view_as(t))

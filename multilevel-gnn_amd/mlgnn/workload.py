@@ -138,7 +138,10 @@ class ThreeLevelGNN(nn.Module):
         return F.softmax(self.head(z.reshape(B, -1)), dim=-1), link, ent
 
 
-def training_loss(model, batch):
-    """BCE on the class probabilities (train.py:118,60) + the DiffPool auxiliary losses."""
+def training_loss(model, batch, aux=True):
+    """BCE on the class probabilities (train.py:118,60) + the DiffPool auxiliary losses.  ``aux=False``: BCE only -- the
+    link loss is ONE Frobenius norm over the batch (``dense_diff_pool``), not a mean over graphs, so only the BCE part of
+    a data-parallel step equals the single-process step on the global batch (tests/test_bench_gpu.py)."""
     pred, link, ent = model(batch)
-    return F.binary_cross_entropy(pred, batch.y.reshape(-1, 2)) + link + ent
+    bce = F.binary_cross_entropy(pred, batch.y.reshape(-1, 2))
+    return bce + link + ent if aux else bce

@@ -81,3 +81,48 @@ def test_bench_two_gpus_as_the_driver_launches_it(line_n1):
     assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["collective_backend"] == "nccl"
     assert out["config"]["global_batch"] == 8 and out["config"]["allreduce_ms"] > 0
     assert abs(out["value"] - 8 * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(line_n1, tmp_path):
+    """BASELINE configs[3]'s launch rehearsed on a ONE-GPU box: ``python -m torch.distributed.run --nproc-per-node 2
+    bench.py --gpus 2`` exactly as the driver starts it, both ranks on the single device, the collective over ``gloo``
+    (MLGNN_BENCH_BACKEND=gloo: RCCL wants one device per rank).  Everything but the transport is the measured code path:
+    rank sharding by graph id, the flat bucket, ONE all-reduce per step, the reached flags, max-over-ranks timing, rank
+    0's single JSON line.  Then the data-parallel step itself: the same global batch of 8 graphs through two ranks of 4
+    and through one process of 8 gives the same parameters after three optimizer steps (BCE loss: the DiffPool link loss
+    is one Frobenius norm over the batch and does not decompose over ranks; reference step: train.py:38-69)."""
+    env = dict(os.environ, MLGNN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    small = [a for a in SMALL]
+    small[small.index("--graphs-per-gpu") + 1] = "4"
+    out = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                 "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + small, env)
+    single_only = {"cpu_baseline", "also_aggr", "no_overlap_ms_per_step", "roofline.stream_copy_GBps",
+                   "roofline.frac_of_stream_copy"}
+    want = {k for k in _keys(line_n1) if not any(k == s or k.startswith(s + ".") for s in single_only)}
+    assert _keys(out) == want
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["collective_backend"] == "gloo"
+    assert out["config"]["global_batch"] == 8 and out["config"]["allreduce_ms"] > 0 and out["scaling"] == "weak"
+    assert abs(out["value"] - 8 * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]
+    # strong scaling at a fixed global batch: 2 ranks x 4 graphs == 1 process x 8 graphs
+    common = ["--global-batch", "8", "--steps", "2", "--warmup", "1", "--nodes", "3000", "--edges", "24000", "--members",
+              "6000", "--loss", "bce", "--no-extras", "--no-cpu-baseline"]
+    two, one = str(tmp_path / "two.pt"), str(tmp_path / "one.pt")
+    o2 = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--dump-params", two] + common,
+               env)
+    o1 = _line([sys.executable, "bench.py", "--gpus", "1", "--dump-params", one] + common)
+    assert o2["scaling"] == o1["scaling"] == "strong"
+    assert o2["config"]["graphs_per_gpu"] == 4 and o1["config"]["graphs_per_gpu"] == 8
+    assert o2["config"]["global_batch"] == o1["config"]["global_batch"] == 8
+    p2, p1 = torch.load(two, weights_only=True), torch.load(one, weights_only=True)
+    assert p1.shape == p2.shape and bool(torch.isfinite(p1).all())
+    assert float((p2 - p1).abs().max()) <= 1e-5, float((p2 - p1).abs().max())
+    assert abs(o2["config"]["final_loss"] - o1["config"]["final_loss"]) <= 0.7        # (rank 0's shard vs the whole batch)

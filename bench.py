@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--loss", choices=["full", "bce"], default="full",
                     help="bce: without the DiffPool link / entropy terms (the link loss is one Frobenius norm over the "
                          "batch, so only the BCE step of N ranks equals the single-process step on the global batch)")
-    ap.add_argument("--dump-params", help="rank 0 saves its parameters (one flat fp32 tensor) here after the timed run")
+    ap.add_argument("--dump-params", help="rank 0 saves {'params', 'grads'} (flat fp32 tensors: its parameters after the "
+                                          "timed run, the all-reduced gradient of the last step) here")
     return ap.parse_args()
 
 
@@ -275,7 +276,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
     if rank == 0 and args.dump_params:
-        torch.save(torch.cat([p.detach().reshape(-1).float() for p in model.parameters()]).cpu(), args.dump_params)
+        torch.save({"params": torch.cat([p.detach().reshape(-1).float() for p in bucket.params]).cpu(),
+                    "grads": torch.cat([v.reshape(-1).float() for v in bucket.views]).cpu()}, args.dump_params)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

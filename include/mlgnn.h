@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 14
+#define MLGNN_ABI_VERSION 15
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -526,7 +526,8 @@ int mlgnn_linear_bwd(const float* grad_out, const float* w, const float* x, cons
  *     grad_gamma_beta [2,J] = (sum_rows gy xhat, sum_rows gy),  row_max_out [N] = max_c |grad_h|
  * Replaces: the autograd of Linear <- ReLU <- LayerNorm inside MLP (models/gcn_lib/sparse/torch_nn.py:54-75) for a
  * hidden activation stored normalised (xhat, rstd: mlgnn_tallgemm_nt ln_mode 1) -- the product dA never reaches memory.
- * R, J in {64, 128, 256} with R * J * 4 <= 128 KiB, N * J * 4 < 4 GiB; row_max [N] or NULL: max |grad_out[i]|.
+ * R, J in {64, 128, 256} with R * J * 4 <= 128 KiB; any N <= INT32_MAX (operands past 4 GiB are walked in row slabs
+ * inside the call, as in mlgnn_linear_bwd / mlgnn_linear_wgrad); row_max [N] or NULL: max |grad_out[i]|.
  * workspace: mlgnn_tallgemm_lnbwd_workspace_bytes(R, J) bytes.  Deterministic (fixed-order partial sums).
  */
 int mlgnn_tallgemm_lnbwd_supported(int64_t N, int64_t R, int64_t J);
@@ -706,6 +707,45 @@ int mlgnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
                     const int64_t* param_offsets, const float* live, int64_t n_params, float max_norm, float beta1,
                     float beta2, float eps, float weight_decay, float step_size, float bias2_sqrt,
                     float* workspace, void* stream);
+
+/*
+ * SAGE update of one graph layer in ONE product (fp32):
+ *     c [N,J] = leaky_relu([a | a2] * Bt^T + bias, act_slope) * row_scale[row]
+ * a [N,R1], a2 [N,R2]: two column blocks of the left operand in tensors of their own (the node features and their
+ * weighted neighbourhood mean) -- the concatenation [x || aggr] of the reference never exists; bt [J, R1+R2] row major.
+ * Replaces: SAGEConv.update `self.nn(torch.cat((x, aggr_out), dim=1))` with nn = MLP([in+out, out], act) =
+ * Linear -> LeakyReLU(0.2) (models/gcn_lib/sparse/torch_vertex.py:288-291,297-304; torch_nn.py:9-24,54-75), with
+ * `lin_r` (:282-286) folded into bt by the caller (mean and lin_r commute), and the value mask of
+ * MultilevelGNN.forward (models/multilevel_gnn.py:205-207: `x * mask_x`) as row_scale [N] (NULL: none).
+ * act_slope: 1 = identity, 0 = ReLU, 0.2 = the reference's LeakyReLU.  row_max_out [N] (NULL: skipped): max |c[i]|;
+ * a_row_max_out [N] (NULL: skipped): max over both blocks of |A[i]| -- the operand scales of the backward's products.
+ * R1, R2 multiples of 16 with R1 + R2 in {64, 128, 256}; J in {32, 64, 128}; workspace:
+ * mlgnn_tallgemm_workspace_bytes(R1 + R2, J, f32); 16-byte aligned a, a2, bt, workspace.
+ */
+int mlgnn_tallgemm_dual_supported(int64_t N, int64_t R1, int64_t R2, int64_t J);
+int mlgnn_tallgemm_dual(const float* a, const float* a2, const float* bt, const float* bias, float act_slope,
+                        const float* row_scale, float* c, float* row_max_out, float* a_row_max_out, void* workspace,
+                        int64_t workspace_bytes, int64_t N, int64_t R1, int64_t R2, int64_t J, void* stream);
+
+/*
+ * Backward of that epilogue (csrc/sage.hip):  grad_z = grad_out * row_scale[row] * (z > 0 ? 1 : slope), the sign of z
+ * taken from the stored result y = leaky_relu(z) * row_scale (slope > 0);  grad_z_row_max [N] (NULL: skipped) =
+ * max |grad_z[i]|.  Replaces: autograd of LeakyReLU and of the mask product (torch_nn.py:9-24, multilevel_gnn.py:205-207).
+ * J / 4 a power of two <= 64; 16-byte aligned tensors.
+ */
+int mlgnn_leaky_relu_bwd(const float* grad_out, const float* y, const float* row_scale, float slope, float* grad_z,
+                         float* grad_z_row_max, int64_t N, int64_t J, void* stream);
+
+/*
+ * Node embedding of MultilevelGNN (models/multilevel_gnn.py:151: `x.reshape(-1, nodes, 1) * self.node_embedding`):
+ *     h [batch * nodes, C] = x[b, n] * embedding[n, :]        (+ h_row_max [batch * nodes] or NULL)
+ *     grad_embedding [nodes, C] = sum_b x[b, n] * grad_h[b, n, :]     (samples in order: bitwise reproducible)
+ * C / 4 a power of two <= 64.
+ */
+int mlgnn_node_embed_fwd(const float* x, const float* embedding, float* h, float* h_row_max, int64_t batch,
+                         int64_t nodes, int64_t C, void* stream);
+int mlgnn_node_embed_bwd(const float* x, const float* grad_h, float* grad_embedding, int64_t batch, int64_t nodes,
+                         int64_t C, void* stream);
 
 /*
  * Debug facility (csrc/canary.hip; never on the product path, the entry points above never allocate): a guard-band

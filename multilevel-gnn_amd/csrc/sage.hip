@@ -1,0 +1,178 @@
+// Streaming pieces of the SAGE update  out = leaky_relu([x | agg] W^T + b) * mask  (reference:
+// models/gcn_lib/sparse/torch_vertex.py:288-291 `update`, torch_nn.py:9-24 `act_layer('leakyrelu', 0.2)`,
+// multilevel_gnn.py:205-207 value_att_mask) that are not a GEMM epilogue:
+//
+//   leaky_relu_bwd:   dz = dy * mask[row] * (z > 0 ? 1 : slope)   with the sign of z recovered from the stored result
+//                     y = leaky_relu(z) * mask (slope > 0: sign(y) = sign(z) sign(mask)); also max |dz| per row, the
+//                     operand scale of the two input-gradient GEMMs and the weight gradient that consume dz
+//   node_embed_fwd:   h[b, n, :] = x[b, n] * E[n, :]   (multilevel_gnn.py:151: the per-gene embedding scaled by the
+//                     sample's value) + max |h| per row
+//   node_embed_bwd:   dE[n, :] = sum_b x[b, n] * dh[b, n, :]   (one thread group per gene row, samples in order:
+//                     bitwise reproducible, no atomics)
+//
+// All three are HBM-bound streams: 16-byte accesses, one pass, nothing kept.
+#include "common.h"
+#include "mlgnn.h"
+
+namespace mlgnn {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+// read-once stream: non-temporal 16-byte load
+__device__ __forceinline__ float4 stream_load4(const float4* p) {
+  const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// LPR = lanes per row (J / 4): a power of two <= 64, so a row's lanes sit in one wave and its maximum is an xor butterfly
+template <int LPR>
+__global__ __launch_bounds__(256) void leaky_relu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                             const float* __restrict__ row_scale, float slope,
+                                                             float4* __restrict__ dz, float* __restrict__ row_max,
+                                                             int64_t n_units) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // (n_units is a multiple of LPR and blockDim of 64: whole rows per wave, all lanes of a row in or out together)
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += stride) {
+    const int64_t row = u / LPR;
+    const float4 g = stream_load4(dy + u);
+    const float4 v = y[u];
+    const float sc = row_scale ? row_scale[row] : 1.f;
+    const bool flip = sc < 0.f;
+    float4 o;
+    // z > 0  <=>  y and the mask have the same (non-zero) sign; a zero mask kills the gradient itself
+    o.x = g.x * sc * ((flip ? v.x < 0.f : v.x > 0.f) ? 1.f : slope);
+    o.y = g.y * sc * ((flip ? v.y < 0.f : v.y > 0.f) ? 1.f : slope);
+    o.z = g.z * sc * ((flip ? v.z < 0.f : v.z > 0.f) ? 1.f : slope);
+    o.w = g.w * sc * ((flip ? v.w < 0.f : v.w > 0.f) ? 1.f : slope);
+    dz[u] = o;
+    if (row_max) {
+      float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+#pragma unroll
+      for (int off = 1; off < LPR; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+      if ((u & (LPR - 1)) == 0) row_max[row] = m;
+    }
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void node_embed_fwd_kernel(const float* __restrict__ x, const float4* __restrict__ emb,
+                                                             float4* __restrict__ h, float* __restrict__ row_max,
+                                                             int64_t n_units, int nodes) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += stride) {
+    const int64_t row = u / LPR;
+    const int n = (int)(row % nodes);
+    const float s = x[row];
+    const float4 e = emb[(int64_t)n * LPR + (u & (LPR - 1))];
+    const float4 o = make_float4(e.x * s, e.y * s, e.z * s, e.w * s);
+    h[u] = o;
+    if (row_max) {
+      float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+#pragma unroll
+      for (int off = 1; off < LPR; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+      if ((u & (LPR - 1)) == 0) row_max[row] = m;
+    }
+  }
+}
+
+// one thread per (gene, column quad): its B cotangent rows are `nodes` rows apart -- independent 16-byte loads, 8 in
+// flight per thread
+template <int LPR>
+__global__ __launch_bounds__(256) void node_embed_bwd_kernel(const float* __restrict__ x, const float4* __restrict__ dh,
+                                                             float4* __restrict__ demb, int nodes, int batch) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= (int64_t)nodes * LPR) return;
+  const int n = (int)(u / LPR);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t step = (int64_t)nodes * LPR;
+  int b = 0;
+  for (; b + 8 <= batch; b += 8) {
+    float4 g[8];
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      g[i] = stream_load4(dh + u + (int64_t)(b + i) * step);
+      s[i] = x[(int64_t)(b + i) * nodes + n];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc.x = fmaf(g[i].x, s[i], acc.x); acc.y = fmaf(g[i].y, s[i], acc.y);
+      acc.z = fmaf(g[i].z, s[i], acc.z); acc.w = fmaf(g[i].w, s[i], acc.w);
+    }
+  }
+  for (; b < batch; ++b) {
+    const float4 g = dh[u + (int64_t)b * step];
+    const float s = x[(int64_t)b * nodes + n];
+    acc.x = fmaf(g.x, s, acc.x); acc.y = fmaf(g.y, s, acc.y); acc.z = fmaf(g.z, s, acc.z); acc.w = fmaf(g.w, s, acc.w);
+  }
+  demb[u] = acc;
+}
+
+static bool width_ok(int64_t J) {
+  const int64_t l = J / 4;
+  return J >= 4 && J % 4 == 0 && l <= 64 && (l & (l - 1)) == 0;
+}
+
+static int stream_grid(int64_t n_units) {
+  int64_t b = (n_units + 255) / 256;
+  const int64_t cap = 256 * 16;                       // 16 workgroups of 4 waves per CU: enough loads in flight, few tails
+  return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
+}  // namespace mlgnn
+
+using namespace mlgnn;
+
+#define MLGNN_LPR_SWITCH(LPR_, BODY)                  \
+  switch (LPR_) {                                     \
+    case 1: { constexpr int L = 1; BODY } break;      \
+    case 2: { constexpr int L = 2; BODY } break;      \
+    case 4: { constexpr int L = 4; BODY } break;      \
+    case 8: { constexpr int L = 8; BODY } break;      \
+    case 16: { constexpr int L = 16; BODY } break;    \
+    case 32: { constexpr int L = 32; BODY } break;    \
+    default: { constexpr int L = 64; BODY } break;    \
+  }
+
+extern "C" int mlgnn_leaky_relu_bwd(const float* grad_out, const float* y, const float* row_scale, float slope,
+                                    float* grad_z, float* grad_z_row_max, int64_t N, int64_t J, void* stream) {
+  if (N < 0 || N > INT32_MAX || !width_ok(J)) return MLGNN_E_SHAPE;
+  if (N == 0) return 0;
+  if (!grad_out || !y || !grad_z) return MLGNN_E_NULL;
+  if (((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(grad_z)) & 15) != 0)
+    return MLGNN_E_ALIGN;
+  const int64_t units = N * (J / 4);
+  hipStream_t s = (hipStream_t)stream;
+  MLGNN_LPR_SWITCH((int)(J / 4), hipLaunchKernelGGL((leaky_relu_bwd_kernel<L>), dim3(stream_grid(units)), dim3(256), 0, s,
+                   reinterpret_cast<const float4*>(grad_out), reinterpret_cast<const float4*>(y), row_scale, slope,
+                   reinterpret_cast<float4*>(grad_z), grad_z_row_max, units);)
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_node_embed_fwd(const float* x, const float* embedding, float* h, float* h_row_max, int64_t batch,
+                                    int64_t nodes, int64_t C, void* stream) {
+  if (batch < 0 || nodes <= 0 || nodes > INT32_MAX || batch * nodes > INT32_MAX || !width_ok(C)) return MLGNN_E_SHAPE;
+  if (batch == 0) return 0;
+  if (!x || !embedding || !h) return MLGNN_E_NULL;
+  if (((reinterpret_cast<uintptr_t>(embedding) | reinterpret_cast<uintptr_t>(h)) & 15) != 0) return MLGNN_E_ALIGN;
+  const int64_t units = batch * nodes * (C / 4);
+  hipStream_t s = (hipStream_t)stream;
+  MLGNN_LPR_SWITCH((int)(C / 4), hipLaunchKernelGGL((node_embed_fwd_kernel<L>), dim3(stream_grid(units)), dim3(256), 0, s, x,
+                   reinterpret_cast<const float4*>(embedding), reinterpret_cast<float4*>(h), h_row_max, units, (int)nodes);)
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_node_embed_bwd(const float* x, const float* grad_h, float* grad_embedding, int64_t batch,
+                                    int64_t nodes, int64_t C, void* stream) {
+  if (batch < 0 || batch > INT32_MAX || nodes <= 0 || nodes > INT32_MAX || batch * nodes > INT32_MAX || !width_ok(C))
+    return MLGNN_E_SHAPE;
+  if (!grad_embedding) return MLGNN_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (batch == 0) return (int)hipMemsetAsync(grad_embedding, 0, (size_t)(nodes * C) * sizeof(float), s);
+  if (!x || !grad_h) return MLGNN_E_NULL;
+  if (((reinterpret_cast<uintptr_t>(grad_h) | reinterpret_cast<uintptr_t>(grad_embedding)) & 15) != 0) return MLGNN_E_ALIGN;
+  const int64_t units = nodes * (C / 4);
+  MLGNN_LPR_SWITCH((int)(C / 4), hipLaunchKernelGGL((node_embed_bwd_kernel<L>), dim3((unsigned)((units + 255) / 256)), dim3(256),
+                   0, s, x, reinterpret_cast<const float4*>(grad_h), reinterpret_cast<float4*>(grad_embedding), (int)nodes,
+                   (int)batch);)
+  return (int)hipGetLastError();
+}

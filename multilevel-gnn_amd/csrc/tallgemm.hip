@@ -95,6 +95,10 @@ struct TgArgs {
   const float* pgamma; const float* pbeta; float* y; float* mean_out; float peps; int prelu;
   // SHIFT: res holds lse [N,J] of the softmax aggregation whose backward consumes c; y receives c * 2^(-lse)
   const int* rowptr; int* spread;
+  // DUAL (SAGE update, torch_vertex.py:288-291): A = [a | a2] column blocks of two tensors (k-steps [0, ks1) from a,
+  // row stride 16 ks1; the rest from a2), c = leaky_relu(A Bt^T + bias, act_slope) * row_scale[row]; max |c| per row to
+  // rowmax_out, max |A row| to amax_out
+  const float* a2; int ks1; float act_slope; const float* row_scale; float* amax_out;
   int N; int R; int J;
 };
 
@@ -150,9 +154,10 @@ template <int JT, int LN> constexpr int tg_block() { return (LN == 3 && JT == 8)
 //     y[i][c] = c[i][c] * 2^(-lse[i][c])      (rows without incoming edges: 0),
 // with lse arriving through the residual slot, and raises *spread when some |lse| > kMaxLse -- the streaming pre-pass
 // of csrc/aggregate_bwd.hip (softmax_shift_kernel: read c and lse, write y) becomes one load and one store here.
-template <int JT, int KS, int LN, bool POST = false, bool SHIFT = false>       // 32-column tiles = J / 32, 16-deep k-steps = R / 16
+template <int JT, int KS, int LN, bool POST = false, bool SHIFT = false, bool DUAL = false>   // 32-column tiles = J / 32, 16-deep k-steps = R / 16
 __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const TgArgs p) {
   static_assert(!POST || (LN == 2 && JT <= 4), "POST epilogue: second GEMM of the MLP, whole rows of <= 128 columns");
+  static_assert(!DUAL || (LN == 0 && !POST && !SHIFT && JT <= 4), "DUAL: plain product with the activation epilogue");
   static_assert(!SHIFT || (LN == 0 && JT <= 4 && !POST), "SHIFT epilogue: plain product, lse tile in the residual registers");
   float worst_lse = 0.f;
   constexpr int kTgBlock = tg_block<JT, LN>(), kTgWaves = kTgBlock / kWave;      // (shadow the defaults above)
@@ -241,7 +246,10 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
   for (int tile = blockIdx.x * kTgWaves + wave; tile < n_tiles; tile += t_stride) {
     const int row0 = tile * 32;
     const int arow = min(row0 + r31, p.N - 1);                 // rows past N re-read the last row, never stored
-    const float* ap = p.a + (size_t)arow * R + 8 * h;
+    const float* ap = p.a + (size_t)arow * (DUAL ? 16 * p.ks1 : R) + 8 * h;
+    // DUAL: k-step s of the row comes from a (s < ks1) or from a2; ap2 is biased so that ap2 + 16 s is its address
+    const float* ap2 = DUAL ? p.a2 + (size_t)arow * (R - 16 * p.ks1) + 8 * h - 16 * p.ks1 : nullptr;
+    auto kstep = [&](int s_) { return (DUAL && s_ >= p.ks1 ? ap2 : ap) + 16 * s_; };
 
     float m = 0.f;
     if (p.rowmax) {                                             // the producer of A already knows max |row|
@@ -249,14 +257,17 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
     } else {
 #pragma unroll 2
       for (int s = 0; s < KS; ++s) {
-        const float4 q0 = *reinterpret_cast<const float4*>(ap + 16 * s);
-        const float4 q1 = *reinterpret_cast<const float4*>(ap + 16 * s + 4);
+        const float4 q0 = *reinterpret_cast<const float4*>(kstep(s));
+        const float4 q1 = *reinterpret_cast<const float4*>(kstep(s) + 4);
         float e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
         activate(e, s);
 #pragma unroll
         for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(e[j]));
       }
       m = fmaxf(m, __shfl_xor(m, 32));                          // the other half of the row
+    }
+    if constexpr (DUAL) {
+      if (p.amax_out && h == 0 && row0 + r31 < p.N) p.amax_out[arow] = m;
     }
     float sa, inv_a;
     pow2_scale(m, sa, inv_a);
@@ -293,8 +304,8 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
     if constexpr (!XT) {
 #pragma unroll
       for (int i = 0; i < PF; ++i) {
-        n0[i] = *reinterpret_cast<const float4*>(ap + 16 * i);
-        n1[i] = *reinterpret_cast<const float4*>(ap + 16 * i + 4);
+        n0[i] = *reinterpret_cast<const float4*>(kstep(i));
+        n1[i] = *reinterpret_cast<const float4*>(kstep(i) + 4);
       }
     }
 #pragma unroll 1
@@ -304,8 +315,8 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
         const int s = s0 + i;
         float e[8] = {n0[i].x, n0[i].y, n0[i].z, n0[i].w, n1[i].x, n1[i].y, n1[i].z, n1[i].w};
         if (s + PF < KS) {
-          n0[i] = *reinterpret_cast<const float4*>(ap + 16 * (s + PF));
-          n1[i] = *reinterpret_cast<const float4*>(ap + 16 * (s + PF) + 4);
+          n0[i] = *reinterpret_cast<const float4*>(kstep(s + PF));
+          n1[i] = *reinterpret_cast<const float4*>(kstep(s + PF) + 4);
         }
         activate(e, s);
         f16x8 ahi, alo;
@@ -459,6 +470,24 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
             if (live) worst_lse = fmaxf(worst_lse, fabsf(l));
           }
         }
+      } else if constexpr (DUAL) {
+        // SAGE update: activation, the per-row mask (value_att_mask, multilevel_gnn.py:205-207), max |row| for the
+        // consumers' operand scales
+        const float sc = p.row_scale ? p.row_scale[min(row, p.N - 1)] : 1.f;
+        float v[JT], om = 0.f;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+          const float z = fmaf(acc[t][r], us, bias[t]);
+          // (slope 0 = ReLU: relu(-inf) = 0 and relu(NaN) = NaN as in torch, not -inf * 0)
+          v[t] = (z > 0.f ? z : (p.act_slope == 0.f ? (z < 0.f ? 0.f : z) : z * p.act_slope)) * sc;
+          om = fmaxf(om, fabsf(v[t]));
+        }
+        om = half_max(om);
+        if (row < p.N) {
+#pragma unroll
+          for (int t = 0; t < JT; ++t) p.c[(size_t)row * p.J + 32 * t + r31] = v[t];
+          if (r31 == 0 && p.rowmax_out) p.rowmax_out[row] = om;
+        }
       } else if (row < p.N) {
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
@@ -594,6 +623,7 @@ static int tallgemm_nt_any(const void* a, const void* bt, int bt_transposed, con
     p.peps = post->eps; p.prelu = post->relu;
   }
   p.rowptr = nullptr; p.spread = nullptr;
+  p.a2 = nullptr; p.ks1 = 0; p.act_slope = 1.f; p.row_scale = nullptr; p.amax_out = nullptr;
   if (shift) { p.res = shift->lse; p.y = shift->gt; p.rowptr = shift->rowptr; p.spread = shift->flag; }
   p.N = (int)N; p.R = (int)R; p.J = (int)J;
   const size_t lds = (size_t)R * J * 4 + (ln_mode == 2 ? (size_t)R * 8 : 0) + (ln_mode == 1 ? (size_t)J * 12 : 0);
@@ -683,6 +713,60 @@ extern "C" int mlgnn_tallgemm_lnin_postln(const float* xhat, const float* bt, co
                          workspace_bytes, N, R, J, MLGNN_DTYPE_F32, &post, nullptr, stream);
 }
 
+// ---- SAGE update: leaky_relu([a | a2] Bt^T + bias) * row_scale (DUAL above) ---------------------------------------------
+extern "C" int mlgnn_tallgemm_dual_supported(int64_t N, int64_t R1, int64_t R2, int64_t J) {
+  const int64_t R = R1 + R2;
+  const bool ok = R1 >= 16 && R2 >= 16 && R1 % 16 == 0 && R2 % 16 == 0 && (R == 64 || R == 128 || R == 256) &&
+                  (J == 32 || J == 64 || J == 128) && R * J * 4 <= kTgMaxLds;
+  return (N > 0 && N <= INT32_MAX && ok) ? 1 : 0;
+}
+
+extern "C" int mlgnn_tallgemm_dual(const float* a, const float* a2, const float* bt, const float* bias, float act_slope,
+                                   const float* row_scale, float* c, float* row_max_out, float* a_row_max_out,
+                                   void* workspace, int64_t workspace_bytes, int64_t N, int64_t R1, int64_t R2, int64_t J,
+                                   void* stream) {
+  if (N == 0) return 0;
+  if (!mlgnn_tallgemm_dual_supported(N, R1, R2, J)) return MLGNN_E_SHAPE;
+  const int64_t R = R1 + R2;
+  if (!a || !a2 || !bt || !c || !workspace) return MLGNN_E_NULL;
+  if (workspace_bytes < R * J * 4 + kTgHeader * 16) return MLGNN_E_WORKSPACE;
+  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(a2) | reinterpret_cast<uintptr_t>(bt) |
+        reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
+    return MLGNN_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int n_frag_lanes = (int)(R / 16) * (int)(J / 32) * 64;
+  hipLaunchKernelGGL(tallgemm_split_weight_kernel, dim3((n_frag_lanes + 255) / 256), dim3(256), 0, s, bt,
+                     (f16x8*)workspace, (int)J, (int)R, 0);
+  int err = (int)hipGetLastError();
+  if (err) return err;
+  TgArgs p;
+  p.a = a; p.image = (const f16x8*)workspace; p.bias = bias; p.res = nullptr; p.rowmax = nullptr; p.c = c;
+  p.gamma = nullptr; p.beta = nullptr; p.rstd_out = nullptr; p.rowmax_out = row_max_out; p.ln_eps = 0.f;
+  p.xhat = nullptr; p.rstd_in = nullptr; p.ws = nullptr;
+  p.pgamma = nullptr; p.pbeta = nullptr; p.y = nullptr; p.mean_out = nullptr; p.peps = 0.f; p.prelu = 0;
+  p.rowptr = nullptr; p.spread = nullptr;
+  p.a2 = a2; p.ks1 = (int)(R1 / 16); p.act_slope = act_slope; p.row_scale = row_scale; p.amax_out = a_row_max_out;
+  p.N = (int)N; p.R = (int)R; p.J = (int)J;
+  const size_t lds = (size_t)R * J * 4;
+  const int64_t tiles = (N + 31) / 32;
+  int grid = (int)((tiles + kTgWaves - 1) / kTgWaves);
+  if (grid > 256) grid = 256;
+  bool launched = false;
+#define MLGNN_TG_DUAL(JT_, KS_)                                                                                  \
+  if (!launched && J == 32 * JT_ && R == 16 * KS_) {                                                             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tallgemm_kernel<JT_, KS_, 0, false, false, true>),  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kTgMaxLds + 4096);                     \
+    hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, 0, false, false, true>), dim3(grid), dim3(kTgBlock), lds, s, p); \
+    launched = true;                                                                                             \
+  }
+  MLGNN_TG_DUAL(1, 4) MLGNN_TG_DUAL(1, 8) MLGNN_TG_DUAL(1, 16)
+  MLGNN_TG_DUAL(2, 4) MLGNN_TG_DUAL(2, 8) MLGNN_TG_DUAL(2, 16)
+  MLGNN_TG_DUAL(4, 4) MLGNN_TG_DUAL(4, 8) MLGNN_TG_DUAL(4, 16)
+#undef MLGNN_TG_DUAL
+  if (!launched) return MLGNN_E_SHAPE;
+  return (int)hipGetLastError();
+}
+
 // ---- dA = go W through ReLU + LayerNorm backward in the epilogue (LN = 3 above) --------------------------------------
 namespace mlgnn {
 constexpr int kTgLnBwdBlocks = 256;        // persistent workgroups = rows of the d gamma / d beta partial table
@@ -720,6 +804,9 @@ extern "C" int mlgnn_tallgemm_lnbwd(const float* go, const float* w, int w_trans
   p.image = (const f16x8*)workspace; p.bias = nullptr; p.res = nullptr;
   p.gamma = gamma; p.beta = beta; p.rstd_out = nullptr; p.ln_eps = 0.f;
   p.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + R * J * 4 + kTgHeader * 16);
+  p.a2 = nullptr; p.ks1 = 0; p.act_slope = 1.f; p.row_scale = nullptr; p.amax_out = nullptr;
+  p.pgamma = nullptr; p.pbeta = nullptr; p.y = nullptr; p.mean_out = nullptr; p.peps = 0.f; p.prelu = 0;
+  p.rowptr = nullptr; p.spread = nullptr;
   p.R = (int)R; p.J = (int)J;
   size_t lds = (size_t)R * J * 4 + (size_t)J * 8;                        // weight image, then gamma / beta of the J columns
   if (lds < (size_t)kTgWaves * 2 * J * 4) lds = (size_t)kTgWaves * 2 * J * 4;   // ... re-used for the partials at the end

@@ -73,6 +73,11 @@ SIGNATURES = {
     "mlgnn_tallgemm_lnbwd_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_tallgemm_lnbwd_workspace_bytes": (_I64, [_I64, _I64]),
     "mlgnn_tallgemm_lnbwd": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_tallgemm_dual_supported": (_INT, [_I64, _I64, _I64, _I64]),
+    "mlgnn_tallgemm_dual": (_INT, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_leaky_relu_bwd": (_INT, [_P, _P, _P, _F, _P, _P, _I64, _I64, _P]),
+    "mlgnn_node_embed_fwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "mlgnn_node_embed_bwd": (_INT, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "mlgnn_gemm_bf16_nt_workgroups": (_INT, [_I64, _I64, _INT]),
     "mlgnn_gemm_bf16_nt": (_INT, [_c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64),
                                   _INT, _I64, _I64, _INT, _P, _P, _I64, _INT, _P, _I64, _P, _I64, _INT, _F,

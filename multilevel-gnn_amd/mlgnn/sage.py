@@ -1,0 +1,172 @@
+"""One GraphSAGE layer of the shipped configs (``gnn_name: sage``, config/kirc.yaml / gbm.yaml) as a single autograd
+node over the hand-written kernels.
+
+Reference (models/gcn_lib/sparse/torch_vertex.py:269-304, torch_nn.py:54-75): per edge ``(x_j w_ij [- x_i]) W_r^T``,
+mean over the incoming edges incl. the added self loop, ``nn(cat(x, aggr))`` with ``nn = Linear(in + out, out) ->
+LeakyReLU(0.2)``; MultilevelGNN then multiplies the last layer's rows by the input value (multilevel_gnn.py:205-207).
+
+Here, by linearity, with ``W_nn = [W_x | W_a]`` split at column ``in``::
+
+    agg = weighted mean_j(x_j)                       csr_aggregate_fwd (mean and W_r commute: N rows instead of E + N)
+    W_c = W_a W_r   (relative: W_x <- W_x - W_c)     [out, in] -- lin_r folded into the update's weight
+    y   = leaky_relu([x | agg] [W_x | W_c]^T + b) * mask          ONE product, mlgnn_tallgemm_dual: neither
+                                                                   aggr_out [N,out] nor cat(x, aggr_out) exists
+
+backward: ``dz`` = LeakyReLU / mask backward (mlgnn_leaky_relu_bwd, with max |row|), ``d agg = dz W_c`` (tall GEMM),
+the aggregation's transpose, ``dx = dz W_x + (that)`` (tall GEMM, the sum in its epilogue), ``dW = dz^T [x | agg]``
+(two split-row weight-gradient products), and the chain rule of the fold on [out, in]-sized matrices."""
+import torch
+
+from . import _lib
+from .dense import WGRAD_MIN_ROWS, _aligned, _wgrad, tall_matmul_nt, tall_matmul_supported
+from .ops import AGGR_MEAN, EDGE_NONE, MSG_IDENTITY, MSG_WEIGHTED, _DTYPE_IDS, _stream, tag_row_max
+
+STATS = {"fused": 0, "fallback": 0}
+
+
+def sage_layer_supported(x, w_nn, w_r, has_conv_bias):
+    """fp32 CUDA rows tall enough for the tall kernels, ``in`` a multiple of 16 with ``2 in`` in {64, 128, 256},
+    ``out`` in {32, 64, 128}, the reference's bias-free ``lin_r`` / SAGEConv (RSAGEConv passes ``bias=False``)."""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and not has_conv_bias
+            and x.shape[0] >= WGRAD_MIN_ROWS and torch.is_grad_enabled()):
+        return False
+    n, cin = x.shape
+    cout = w_nn.shape[0]
+    if w_nn.shape[1] != cin + cout or tuple(w_r.shape) != (cout, cin) or w_nn.dtype != torch.float32:
+        return False
+    return (bool(_lib.lib.mlgnn_tallgemm_dual_supported(n, cin, cin, cout))
+            and tall_matmul_supported(n, cout, cin) and _lib.lib.mlgnn_linear_wgrad_workspace_floats(n, cout, cin, 0) > 0)
+
+
+class _SageLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_nn, b_nn, w_r, row_scale, graph, ew_pair, slope, relative):
+        x = _aligned(x)
+        N, cin = x.shape
+        cout = w_nn.shape[0]
+        dev = x.device
+        # neighbourhood mean (weighted; count = number of edges incl. the self loop)
+        agg = torch.empty_like(x)
+        msg = MSG_WEIGHTED if ew_pair is not None else MSG_IDENTITY
+        ew = ew_pair[0] if ew_pair is not None else None
+        hub, hub_keep = graph.hub_arg("dst", cin)
+        rc = _lib.lib.mlgnn_csr_aggregate_fwd(
+            x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), None, None, None, None,
+            agg.data_ptr(), None, None, None, None, N, cin, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, 0, AGGR_MEAN, 1.0, 1.0,
+            None, None, 0.0, 0, hub, _stream())
+        _lib.check(rc, "mlgnn_csr_aggregate_fwd")
+        # lin_r folded into the update's weight
+        w_x, w_a = w_nn[:, :cin], w_nn[:, cin:]
+        w_c = w_a @ w_r                                            # [out, in]
+        w_cat = torch.cat([w_x - w_c if relative else w_x, w_c], dim=1).contiguous()
+        y = torch.empty((N, cout), dtype=torch.float32, device=dev)
+        y_max = torch.empty(N, dtype=torch.float32, device=dev)
+        a_max = torch.empty(N, dtype=torch.float32, device=dev)
+        nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(2 * cin, cout, 0))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        bias = b_nn.contiguous() if b_nn is not None else None
+        rs = row_scale.reshape(-1).contiguous() if row_scale is not None else None
+        rc = _lib.lib.mlgnn_tallgemm_dual(x.data_ptr(), agg.data_ptr(), w_cat.data_ptr(), _lib.ptr(bias), float(slope),
+                                          _lib.ptr(rs), y.data_ptr(), y_max.data_ptr(), a_max.data_ptr(), ws.data_ptr(),
+                                          nbytes, N, cin, cin, cout, _stream())
+        _lib.check(rc, "mlgnn_tallgemm_dual")
+        ctx.save_for_backward(x, agg, y, w_nn, w_r, w_cat, rs, a_max)
+        ctx.graph, ctx.ew_pair = graph, ew_pair
+        ctx.cfg = (float(slope), bool(relative), b_nn is not None, msg)
+        ctx.mark_non_differentiable(y_max)
+        return y, y_max
+
+    @staticmethod
+    def backward(ctx, gy, _g_max):
+        x, agg, y, w_nn, w_r, w_cat, rs, a_max = ctx.saved_tensors
+        slope, relative, has_bias, msg = ctx.cfg
+        g = ctx.graph
+        N, cin = x.shape
+        cout = y.shape[1]
+        gy = _aligned(gy)
+        dz = torch.empty_like(y)
+        dz_max = torch.empty(N, dtype=torch.float32, device=x.device)
+        rc = _lib.lib.mlgnn_leaky_relu_bwd(gy.data_ptr(), y.data_ptr(), _lib.ptr(rs), slope, dz.data_ptr(), dz_max.data_ptr(),
+                                           N, cout, _stream())
+        _lib.check(rc, "mlgnn_leaky_relu_bwd")
+        w_x1, w_c = w_cat[:, :cin], w_cat[:, cin:]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # d agg = dz W_c, through the transposed aggregation, then dx = dz W_x' + that (the sum in the GEMM's epilogue)
+            dagg = tall_matmul_nt(dz, w_c.contiguous(), row_max=dz_max, bt_transposed=True)
+            gagg = torch.empty_like(dagg)
+            ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
+            hub, hub_keep = g.hub_arg("src", cin)
+            rc = _lib.lib.mlgnn_csr_aggregate_bwd(
+                dagg.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
+                g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, None, gagg.data_ptr(), None, None, None, 0,
+                N, cin, _DTYPE_IDS[dagg.dtype], msg, EDGE_NONE, 0, AGGR_MEAN, 0, 1.0, 1.0, None, None, 0.0, 0, 0, hub,
+                None, None, _stream())
+            _lib.check(rc, "mlgnn_csr_aggregate_bwd")
+            gx = tall_matmul_nt(dz, w_x1.contiguous(), residual=gagg, row_max=dz_max, bt_transposed=True)
+        # dW of the folded weight: dz^T x and dz^T agg (split-row kernels; a_max bounds both operands' rows)
+        gw_x1, gb = _wgrad(dz, x, go_max=dz_max, x_max=a_max)
+        gw_c, _ = _wgrad(dz, agg, go_max=dz_max, x_max=a_max)
+        if relative:
+            gw_c = gw_c - gw_x1                                    # W_x' = W_x - W_c
+        # chain rule of the fold W_c = W_a W_r
+        w_a = w_nn[:, cin:]
+        g_nn = torch.cat([gw_x1, gw_c @ w_r.t()], dim=1)
+        g_r = w_a.t() @ gw_c
+        return gx, g_nn, (gb if has_bias else None), g_r, None, None, None, None, None
+
+
+def sage_layer(x, graph, edge_weight, w_nn, b_nn, w_r, slope=0.2, relative=False, row_scale=None):
+    """``leaky_relu(cat(x, mean_j(x_j w_ij [- x_i]) W_r^T) W_nn^T + b_nn, slope) [* row_scale]`` -- see the module
+    docstring; the caller checks :func:`sage_layer_supported`.  ``edge_weight``: [E] in COO order of ``graph`` or None.
+    The result carries its row maxima for the next layer's kernels."""
+    ew_pair = graph.edge_scalar(edge_weight) if edge_weight is not None else None
+    y, y_max = _SageLayer.apply(x, w_nn, b_nn, w_r, row_scale, graph, ew_pair, float(slope), bool(relative))
+    tag_row_max(y, y_max)
+    STATS["fused"] += 1
+    return y
+
+
+class _NodeEmbed(torch.autograd.Function):
+    """``h[b, n, :] = x[b, n] * E[n, :]`` (multilevel_gnn.py:151) with the row maxima of ``h``; gradient to ``E`` only
+    (the input values are data)."""
+
+    @staticmethod
+    def forward(ctx, x, emb):
+        nodes, C = emb.shape
+        x = x.reshape(-1).contiguous()
+        batch = x.numel() // nodes
+        emb = _aligned(emb)
+        h = torch.empty((batch * nodes, C), dtype=torch.float32, device=x.device)
+        h_max = torch.empty(batch * nodes, dtype=torch.float32, device=x.device)
+        rc = _lib.lib.mlgnn_node_embed_fwd(x.data_ptr(), emb.data_ptr(), h.data_ptr(), h_max.data_ptr(), batch, nodes, C,
+                                           _stream())
+        _lib.check(rc, "mlgnn_node_embed_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (batch, nodes, C)
+        ctx.mark_non_differentiable(h_max)
+        return h, h_max
+
+    @staticmethod
+    def backward(ctx, gh, _g):
+        (x,) = ctx.saved_tensors
+        batch, nodes, C = ctx.cfg
+        gh = _aligned(gh)
+        ge = torch.empty((nodes, C), dtype=torch.float32, device=gh.device)
+        rc = _lib.lib.mlgnn_node_embed_bwd(x.data_ptr(), gh.data_ptr(), ge.data_ptr(), batch, nodes, C, _stream())
+        _lib.check(rc, "mlgnn_node_embed_bwd")
+        return None, ge
+
+
+def node_embed_supported(x, emb):
+    C = emb.shape[-1]
+    lanes = C // 4
+    return (x.is_cuda and x.dtype == torch.float32 and emb.dtype == torch.float32 and emb.dim() == 2 and not x.requires_grad
+            and C % 4 == 0 and 0 < lanes <= 64 and lanes & (lanes - 1) == 0 and x.numel() % emb.shape[0] == 0
+            and x.numel() < 2 ** 31)
+
+
+def node_embed(x, emb):
+    """-> ``[x.numel(), C]`` rows ``x[b, n] * emb[n]``, tagged with their row maxima."""
+    h, h_max = _NodeEmbed.apply(x, emb)
+    return tag_row_max(h, h_max)

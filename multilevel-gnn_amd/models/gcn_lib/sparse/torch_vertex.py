@@ -6,6 +6,7 @@ Only the conv types reachable from the shipped configs are provided (``gen``, ``
 the PyG-wrapper types (edge/mr/gat/gcn/gin) raise ``NotImplementedError``.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -17,6 +18,8 @@ from mlgnn.graph import sage_graph
 from mlgnn.norm import msg_norm_add
 from .torch_message import GenMessagePassing, MsgNorm
 from .torch_nn import MLP
+
+_SAGE_FUSED = os.environ.get("MLGNN_SAGE_FUSED", "1") == "1"      # (0: the separate aggregate / lin_r / cat / Linear / act ops, for A/B runs)
 
 
 class GENConv(GenMessagePassing):
@@ -114,11 +117,38 @@ class SAGEConv(nn.Module):
         else:
             self.bias = None
 
-    def forward(self, x, edge_index, size=None, edge_attr=None):
+    def _fused_update(self):
+        """``(slope,)`` when ``self.nn`` is the shipped ``Linear -> LeakyReLU / ReLU`` (or a bare Linear) and nothing else
+        of this conv stands in the way of the one-product form (mlgnn.sage); None otherwise."""
+        mods = list(self.nn) if isinstance(self.nn, nn.Sequential) else None
+        if mods is None or self.normalize or self.bias is not None or not mods or type(mods[0]) is not nn.Linear:
+            return None
+        if len(mods) == 1:
+            return (1.0,)
+        if len(mods) == 2 and isinstance(mods[1], nn.LeakyReLU) and mods[1].negative_slope > 0:
+            return (float(mods[1].negative_slope),)
+        if len(mods) == 2 and type(mods[1]) is nn.ReLU:
+            return (0.0,)
+        return None
+
+    def forward(self, x, edge_index, size=None, edge_attr=None, row_scale=None):
+        """``row_scale`` [N] or None: the caller's next step is ``out * row_scale[:, None]`` (MultilevelGNN's value mask,
+        multilevel_gnn.py:205-207) -- applied here, in the update's epilogue when the fused layer runs."""
         if size is not None:
             raise NotImplementedError("bipartite propagation is outside the accelerated path")
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         graph, weight = sage_graph(edge_index, edge_attr, x.shape[0])
+        fused = self._fused_update() if _SAGE_FUSED else None
+        if fused is not None and (row_scale is None or not row_scale.requires_grad):
+            from mlgnn.sage import sage_layer, sage_layer_supported
+            lin = self.nn[0]
+            if sage_layer_supported(x, lin.weight, self.lin_r.weight, False):
+                return sage_layer(x, graph, weight, lin.weight, lin.bias, self.lin_r.weight, fused[0], self.relative,
+                                  row_scale)
+        out = self._forward_unfused(x, graph, weight)
+        return out if row_scale is None else out * row_scale.reshape(-1, 1)
+
+    def _forward_unfused(self, x, graph, weight):
         agg = weighted_mean_aggregate(x, graph, weight, mean=True)
         if self.relative:
             agg = agg - x                    # every node has its self loop: mean_j(x_i) = x_i
@@ -154,5 +184,5 @@ class GraphConv(nn.Module):
         else:
             raise NotImplementedError('conv {} is not implemented'.format(conv))
 
-    def forward(self, x, edge_index, edge_attr=None):
-        return self.gconv(x, edge_index, edge_attr=edge_attr)
+    def forward(self, x, edge_index, edge_attr=None, row_scale=None):
+        return self.gconv(x, edge_index, edge_attr=edge_attr, row_scale=row_scale)

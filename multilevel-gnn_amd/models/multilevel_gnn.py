@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from mlgnn.project import segment_project
+from mlgnn.sage import node_embed, node_embed_supported
 from .gcn_lib.sparse.torch_vertex import GraphConv
 
 
@@ -160,7 +161,10 @@ class MultilevelGNN(nn.Module):
             if self.input_drop is not None:
                 x = self.input_drop(x)
             if args.node_embedding:
-                x = (x.reshape(-1, nodes_per_graph, 1) * self.node_embedding).reshape(-1, self.node_embedding.shape[-1])
+                if self.input_drop is None and node_embed_supported(x, self.node_embedding):
+                    x = node_embed(x, self.node_embedding)           # one pass, with the rows' maxima for the first layer
+                else:
+                    x = (x.reshape(-1, nodes_per_graph, 1) * self.node_embedding).reshape(-1, self.node_embedding.shape[-1])
             if self.input_emb_drop is not None:
                 x = self.input_emb_drop(x)
 
@@ -174,12 +178,17 @@ class MultilevelGNN(nn.Module):
 
             feats = []
             last = len(self.gnn_model) - 1
+            # the value mask behind the last layer (:205-207) rides that layer's epilogue
+            mask_in_layer = (args.value_att_mask and args.merge_mode == 'mult' and not args.dense_gnn and not args.resgnn
+                             and last >= 0 and not mask_x.requires_grad)
             for i, layer in enumerate(self.gnn_model):
                 if args.dense_gnn:
                     x = layer(x, edge_index, edge_attr)
                     feats.append(x)
                 elif args.resgnn:
                     x = layer(x, edge_index, edge_attr) + x
+                elif mask_in_layer and i == last:
+                    x = layer(x, edge_index, edge_attr, row_scale=mask_x.reshape(-1))
                 else:
                     x = layer(x, edge_index, edge_attr)
                 if i != last and args.repeat_mask and (i + 1) % args.repeat_cyclic == 0:
@@ -188,7 +197,7 @@ class MultilevelGNN(nn.Module):
                     x = x * mask_x.reshape(-1, 1)
             if args.dense_gnn:
                 x = torch.cat(feats, dim=-1)
-            if args.value_att_mask:
+            if args.value_att_mask and not mask_in_layer:
                 if args.merge_mode == 'mult':
                     x = x * mask_x.reshape(-1, 1)
                 elif args.merge_mode in ('add', 'cat'):

@@ -111,8 +111,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(line_n1, tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["collective_backend"] == "gloo"
     assert out["config"]["global_batch"] == 8 and out["config"]["allreduce_ms"] > 0 and out["scaling"] == "weak"
     assert abs(out["value"] - 8 * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]
-    # strong scaling at a fixed global batch: 2 ranks x 4 graphs == 1 process x 8 graphs
-    common = ["--global-batch", "8", "--steps", "2", "--warmup", "1", "--nodes", "3000", "--edges", "24000", "--members",
+    # strong scaling at a fixed global batch: 2 ranks x 4 graphs == 1 process x 8 graphs, one optimizer step
+    common = ["--global-batch", "8", "--steps", "1", "--warmup", "0", "--nodes", "3000", "--edges", "24000", "--members",
               "6000", "--loss", "bce", "--no-extras", "--no-cpu-baseline"]
     two, one = str(tmp_path / "two.pt"), str(tmp_path / "one.pt")
     o2 = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -122,7 +122,16 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(line_n1, tmp_path):
     assert o2["scaling"] == o1["scaling"] == "strong"
     assert o2["config"]["graphs_per_gpu"] == 4 and o1["config"]["graphs_per_gpu"] == 8
     assert o2["config"]["global_batch"] == o1["config"]["global_batch"] == 8
-    p2, p1 = torch.load(two, weights_only=True), torch.load(one, weights_only=True)
-    assert p1.shape == p2.shape and bool(torch.isfinite(p1).all())
-    assert float((p2 - p1).abs().max()) <= 1e-5, float((p2 - p1).abs().max())
-    assert abs(o2["config"]["final_loss"] - o1["config"]["final_loss"]) <= 0.7        # (rank 0's shard vs the whole batch)
+    d2, d1 = torch.load(two, weights_only=True), torch.load(one, weights_only=True)
+    g2, g1, p2, p1 = d2["grads"], d1["grads"], d2["params"], d1["params"]
+    assert g1.shape == g2.shape and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    # the averaged gradient of the two ranks IS the gradient of the global batch (mean of equal shard means)
+    gmax = float(g1.abs().max())
+    assert float((g2 - g1).abs().max()) <= 1e-5 * gmax, (float((g2 - g1).abs().max()), gmax)
+    # ... and so are the stepped parameters, wherever Adam's first step lr g / (|g| + 1e-8) is well conditioned (an entry
+    # whose gradient is at the level of the fp32 summation noise moves by an arbitrary fraction of lr under any
+    # implementation -- torch's DDP included)
+    solid = g1.abs() >= 1e-3 * gmax
+    assert int(solid.sum()) > 1000
+    assert float(((p2 - p1).abs() * solid).max()) <= 1e-5
+    assert float((p2 - p1).abs().max()) <= 2.1e-3                       # nobody moved further than 2 lr apart

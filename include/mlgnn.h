@@ -709,6 +709,16 @@ int mlgnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
                     float* workspace, void* stream);
 
 /*
+ * The edge list SAGEConv propagates over (models/gcn_lib/sparse/torch_vertex.py:272-273: remove_self_loops, then
+ * add_self_loops with weight 1.0), one pass, no compaction:  out_edge_index [2, E + N] int64 = the E input edges with
+ * every existing self loop (i, i) re-pointed to the SPARE node N, followed by (i, i) for i < N;  out_weight [E + N]
+ * (NULL: skipped) = edge_attr[e * attr_stride] (NULL: 1) then N ones.  Build the CSR over N + 1 nodes
+ * (mlgnn_coo_to_csr) and aggregate over the first N rows: row N is never a destination and never gathered from.
+ */
+int mlgnn_sage_rewrite(const int64_t* edge_index, const float* edge_attr, int64_t attr_stride, int64_t E, int64_t N,
+                       int64_t* out_edge_index, float* out_weight, void* stream);
+
+/*
  * SAGE update of one graph layer in ONE product (fp32):
  *     c [N,J] = leaky_relu([a | a2] * Bt^T + bias, act_slope) * row_scale[row]
  * a [N,R1], a2 [N,R2]: two column blocks of the left operand in tensors of their own (the node features and their
@@ -719,7 +729,9 @@ int mlgnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
  * MultilevelGNN.forward (models/multilevel_gnn.py:205-207: `x * mask_x`) as row_scale [N] (NULL: none).
  * act_slope: 1 = identity, 0 = ReLU, 0.2 = the reference's LeakyReLU.  row_max_out [N] (NULL: skipped): max |c[i]|;
  * a_row_max_out [N] (NULL: skipped): max over both blocks of |A[i]| -- the operand scales of the backward's products.
- * R1, R2 multiples of 16 with R1 + R2 in {64, 128, 256}; J in {32, 64, 128}; workspace:
+ * R1, R2 multiples of 16 with R1 + R2 in {32, 64, 128, 256} (R2 = 0, a2 = NULL: one operand -- a Linear with the
+ * activation epilogue, e.g. the 1x1 convolutions + ReLU of the pathway head, models/multilevel_gnn.py:98-104);
+ * J in {32, 64, 128}; workspace:
  * mlgnn_tallgemm_workspace_bytes(R1 + R2, J, f32); 16-byte aligned a, a2, bt, workspace.
  */
 int mlgnn_tallgemm_dual_supported(int64_t N, int64_t R1, int64_t R2, int64_t J);

@@ -427,6 +427,43 @@ extern "C" int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
   return (int)hipGetLastError();
 }
 
+// SAGEConv's edge list (reference: models/gcn_lib/sparse/torch_vertex.py:272-273 `remove_self_loops` then
+// `add_self_loops(..., fill_value=1.0)`) in ONE pass and without a compaction: an existing self loop (i, i) is parked on
+// the spare node N -- a row nobody aggregates and nobody gathers from -- instead of being squeezed out of the list, and
+// the N loops (i, i) with weight 1 follow the E original edges.  The CSR is then built over N + 1 nodes and used with N.
+__global__ __launch_bounds__(256) void sage_rewrite_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                                          const float* __restrict__ attr, int64_t attr_stride,
+                                                          int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst,
+                                                          float* __restrict__ out_w, int64_t E, int64_t N) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E + N; i += stride) {
+    if (i < E) {
+      const int64_t a = src[i], b = dst[i];
+      const bool loop = a == b;
+      out_src[i] = loop ? N : a;
+      out_dst[i] = loop ? N : b;
+      if (out_w) out_w[i] = attr ? attr[i * attr_stride] : 1.f;
+    } else {
+      out_src[i] = i - E;
+      out_dst[i] = i - E;
+      if (out_w) out_w[i] = 1.f;
+    }
+  }
+}
+
+extern "C" int mlgnn_sage_rewrite(const int64_t* edge_index, const float* edge_attr, int64_t attr_stride, int64_t E,
+                                  int64_t N, int64_t* out_edge_index, float* out_weight, void* stream) {
+  if (N < 0 || E < 0 || N > INT32_MAX - 2 || E + N > INT32_MAX || (edge_attr && attr_stride < 1)) return MLGNN_E_SHAPE;
+  if (E + N == 0) return 0;
+  if ((E > 0 && !edge_index) || !out_edge_index) return MLGNN_E_NULL;
+  const int64_t n = E + N;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sage_rewrite_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, edge_index,
+                     edge_index + E, edge_attr, attr_stride, out_edge_index, out_edge_index + n, out_weight, E, N);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mlgnn_edge_table_to_csr(const float* attr, int64_t row_stride, int64_t r, int64_t width,
                                        const int32_t* eid, const int32_t* eid_t, float* by_dst, float* by_src,
                                        int64_t E, void* stream) {

@@ -716,7 +716,8 @@ extern "C" int mlgnn_tallgemm_lnin_postln(const float* xhat, const float* bt, co
 // ---- SAGE update: leaky_relu([a | a2] Bt^T + bias) * row_scale (DUAL above) ---------------------------------------------
 extern "C" int mlgnn_tallgemm_dual_supported(int64_t N, int64_t R1, int64_t R2, int64_t J) {
   const int64_t R = R1 + R2;
-  const bool ok = R1 >= 16 && R2 >= 16 && R1 % 16 == 0 && R2 % 16 == 0 && (R == 64 || R == 128 || R == 256) &&
+  // (R2 = 0: one operand, the activation epilogue only)
+  const bool ok = R1 >= 16 && R2 >= 0 && R1 % 16 == 0 && R2 % 16 == 0 && (R == 32 || R == 64 || R == 128 || R == 256) &&
                   (J == 32 || J == 64 || J == 128) && R * J * 4 <= kTgMaxLds;
   return (N > 0 && N <= INT32_MAX && ok) ? 1 : 0;
 }
@@ -728,7 +729,8 @@ extern "C" int mlgnn_tallgemm_dual(const float* a, const float* a2, const float*
   if (N == 0) return 0;
   if (!mlgnn_tallgemm_dual_supported(N, R1, R2, J)) return MLGNN_E_SHAPE;
   const int64_t R = R1 + R2;
-  if (!a || !a2 || !bt || !c || !workspace) return MLGNN_E_NULL;
+  if (!a || (!a2 && R2 > 0) || !bt || !c || !workspace) return MLGNN_E_NULL;
+  if (R2 == 0) a2 = a;                                    // (never dereferenced: every k-step comes from a)
   if (workspace_bytes < R * J * 4 + kTgHeader * 16) return MLGNN_E_WORKSPACE;
   if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(a2) | reinterpret_cast<uintptr_t>(bt) |
         reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
@@ -759,9 +761,9 @@ extern "C" int mlgnn_tallgemm_dual(const float* a, const float* a2, const float*
     hipLaunchKernelGGL((tallgemm_kernel<JT_, KS_, 0, false, false, true>), dim3(grid), dim3(kTgBlock), lds, s, p); \
     launched = true;                                                                                             \
   }
-  MLGNN_TG_DUAL(1, 4) MLGNN_TG_DUAL(1, 8) MLGNN_TG_DUAL(1, 16)
-  MLGNN_TG_DUAL(2, 4) MLGNN_TG_DUAL(2, 8) MLGNN_TG_DUAL(2, 16)
-  MLGNN_TG_DUAL(4, 4) MLGNN_TG_DUAL(4, 8) MLGNN_TG_DUAL(4, 16)
+  MLGNN_TG_DUAL(1, 2) MLGNN_TG_DUAL(1, 4) MLGNN_TG_DUAL(1, 8) MLGNN_TG_DUAL(1, 16)
+  MLGNN_TG_DUAL(2, 2) MLGNN_TG_DUAL(2, 4) MLGNN_TG_DUAL(2, 8) MLGNN_TG_DUAL(2, 16)
+  MLGNN_TG_DUAL(4, 2) MLGNN_TG_DUAL(4, 4) MLGNN_TG_DUAL(4, 8) MLGNN_TG_DUAL(4, 16)
 #undef MLGNN_TG_DUAL
   if (!launched) return MLGNN_E_SHAPE;
   return (int)hipGetLastError();

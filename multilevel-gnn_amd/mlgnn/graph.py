@@ -192,7 +192,8 @@ class CSRGraph:
     def in_degree(self):
         """float [N]: number of incoming edges (PyG ``degree(index, N)``)."""
         if self._deg is None:
-            self._deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
+            n = self.num_nodes               # (a SAGE graph carries one spare row behind it)
+            self._deg = (self.rowptr[1:n + 1] - self.rowptr[:n]).to(torch.float32)
         return self._deg
 
     def edge_scalar(self, a):
@@ -275,6 +276,30 @@ def as_graph(edge_index, num_nodes):
 _SAGE_CACHE = []          # [(edge_index, edge_attr, N, ei_version, ea_version, graph, weight)]
 
 
+def _sage_graph_device(edge_index, edge_attr, num_nodes):
+    """One kernel writes the rewritten edge list (``mlgnn_sage_rewrite``: self loops parked on a spare node ``N``, the
+    ``N`` unit-weight loops appended) instead of the mask / nonzero / two index / two cat launches of the torch form;
+    the CSR is built over ``N + 1`` nodes and presented as an ``N``-node graph."""
+    from . import _lib
+    E, N = int(edge_index.shape[1]), int(num_nodes)
+    ei = edge_index.to(torch.int64).contiguous()
+    attr, stride = None, 1
+    if edge_attr is not None:
+        ea = edge_attr.reshape(edge_attr.shape[0], -1)
+        if ea.shape[1] != 1:
+            raise ValueError("SAGE edge weights must be scalar per edge")
+        attr = ea if ea.dtype == torch.float32 else ea.to(torch.float32)
+        stride = attr.stride(0) if E > 0 else 1
+    out = torch.empty((2, E + N), dtype=torch.int64, device=ei.device)
+    weight = torch.empty(E + N, dtype=torch.float32, device=ei.device) if attr is not None else None
+    rc = _lib.lib.mlgnn_sage_rewrite(ei.data_ptr(), _lib.ptr(attr), stride, E, N, out.data_ptr(), _lib.ptr(weight),
+                                     torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mlgnn_sage_rewrite")
+    graph = CSRGraph(out, N + 1)
+    graph.num_nodes = N                      # rowptr / rowptr_t carry one more (unused) row: the parked self loops
+    return graph, weight
+
+
 def sage_graph(edge_index, edge_attr, num_nodes):
     """Topology + weights SAGEConv propagates over (torch_vertex.py:272-273): existing self loops
     dropped, one self loop of weight 1.0 appended per node.  The layers of one forward pass hand in
@@ -287,15 +312,18 @@ def sage_graph(edge_index, edge_attr, num_nodes):
         if ent[0] is edge_index and ent[1] is edge_attr and ent[2] == num_nodes and \
                 ent[3] == edge_index._version and ent[4] == ea_v:
             return ent[5], ent[6]
-    keep = edge_index[0] != edge_index[1]
-    loops = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device)
-    ei = torch.cat([edge_index[:, keep], loops.unsqueeze(0).expand(2, -1)], dim=1)
-    weight = None
-    if edge_attr is not None:
-        ea = edge_attr.reshape(edge_attr.shape[0], -1)
-        if ea.shape[1] != 1:
-            raise ValueError("SAGE edge weights must be scalar per edge")
-        weight = torch.cat([ea[keep, 0].to(torch.float32), torch.ones(num_nodes, device=ea.device)])
-    graph = CSRGraph(ei, num_nodes)
+    if edge_index.is_cuda:
+        graph, weight = _sage_graph_device(edge_index, edge_attr, num_nodes)
+    else:
+        keep = edge_index[0] != edge_index[1]
+        loops = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device)
+        ei = torch.cat([edge_index[:, keep], loops.unsqueeze(0).expand(2, -1)], dim=1)
+        weight = None
+        if edge_attr is not None:
+            ea = edge_attr.reshape(edge_attr.shape[0], -1)
+            if ea.shape[1] != 1:
+                raise ValueError("SAGE edge weights must be scalar per edge")
+            weight = torch.cat([ea[keep, 0].to(torch.float32), torch.ones(num_nodes, device=ea.device)])
+        graph = CSRGraph(ei, num_nodes)
     _SAGE_CACHE[:] = [(edge_index, edge_attr, num_nodes, edge_index._version, ea_v, graph, weight)]
     return graph, weight

@@ -120,7 +120,8 @@ def sage_layer(x, graph, edge_weight, w_nn, b_nn, w_r, slope=0.2, relative=False
     """``leaky_relu(cat(x, mean_j(x_j w_ij [- x_i]) W_r^T) W_nn^T + b_nn, slope) [* row_scale]`` -- see the module
     docstring; the caller checks :func:`sage_layer_supported`.  ``edge_weight``: [E] in COO order of ``graph`` or None.
     The result carries its row maxima for the next layer's kernels."""
-    ew_pair = graph.edge_scalar(edge_weight) if edge_weight is not None else None
+    # (by-destination / by-source copies of the weights: one launch, mlgnn_edge_table_to_csr)
+    ew_pair = graph.edge_table(edge_weight, 1) if edge_weight is not None else None
     y, y_max = _SageLayer.apply(x, w_nn, b_nn, w_r, row_scale, graph, ew_pair, float(slope), bool(relative))
     tag_row_max(y, y_max)
     STATS["fused"] += 1
@@ -170,3 +171,60 @@ def node_embed(x, emb):
     """-> ``[x.numel(), C]`` rows ``x[b, n] * emb[n]``, tagged with their row maxima."""
     h, h_max = _NodeEmbed.apply(x, emb)
     return tag_row_max(h, h_max)
+
+
+class _LinearAct(torch.autograd.Function):
+    """``leaky_relu(x W^T + b, slope)`` (slope 0: ReLU) for tall fp32 rows: the activation in the GEMM's epilogue
+    (mlgnn_tallgemm_dual with one operand), its backward as ONE stream that also yields the row maxima the input- and
+    weight-gradient products scale their operands with.  The 1x1 convolutions + ReLU of MultilevelGNN's pathway head
+    (multilevel_gnn.py:98-104) over the [B * 146 * 3k] positions."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        x, w = _aligned(x), _aligned(w)
+        N, R = x.shape
+        J = w.shape[0]
+        y = torch.empty((N, J), dtype=torch.float32, device=x.device)
+        y_max = torch.empty(N, dtype=torch.float32, device=x.device)
+        a_max = torch.empty(N, dtype=torch.float32, device=x.device)
+        nbytes = int(_lib.lib.mlgnn_tallgemm_workspace_bytes(R, J, 0))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        bias = b.contiguous() if b is not None else None
+        rc = _lib.lib.mlgnn_tallgemm_dual(x.data_ptr(), None, w.data_ptr(), _lib.ptr(bias), float(slope), None, y.data_ptr(),
+                                          y_max.data_ptr(), a_max.data_ptr(), ws.data_ptr(), nbytes, N, R, 0, J, _stream())
+        _lib.check(rc, "mlgnn_tallgemm_dual")
+        ctx.save_for_backward(x, w, y, a_max)
+        ctx.cfg = (float(slope), b is not None)
+        ctx.mark_non_differentiable(y_max)
+        return y, y_max
+
+    @staticmethod
+    def backward(ctx, gy, _g):
+        x, w, y, a_max = ctx.saved_tensors
+        slope, has_bias = ctx.cfg
+        N, J = y.shape
+        gy = _aligned(gy)
+        dz = torch.empty_like(y)
+        dz_max = torch.empty(N, dtype=torch.float32, device=y.device)
+        rc = _lib.lib.mlgnn_leaky_relu_bwd(gy.data_ptr(), y.data_ptr(), None, slope, dz.data_ptr(), dz_max.data_ptr(), N, J,
+                                           _stream())
+        _lib.check(rc, "mlgnn_leaky_relu_bwd")
+        gx = tall_matmul_nt(dz, w, row_max=dz_max, bt_transposed=True) if ctx.needs_input_grad[0] else None
+        gw, gb = _wgrad(dz, x, go_max=dz_max, x_max=a_max)
+        return gx, gw, (gb if has_bias else None), None
+
+
+def linear_act_supported(x, w):
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+            and x.shape[0] >= WGRAD_MIN_ROWS and torch.is_grad_enabled() and w.dtype == torch.float32 and w.dim() == 2):
+        return False
+    n, r = x.shape
+    j = w.shape[0]
+    return (bool(_lib.lib.mlgnn_tallgemm_dual_supported(n, r, 0, j)) and tall_matmul_supported(n, j, r)
+            and _lib.lib.mlgnn_linear_wgrad_workspace_floats(n, j, r, 0) > 0)
+
+
+def linear_act(x, w, b, slope):
+    """-> ``leaky_relu(x @ w.T + b, slope)`` tagged with its row maxima; the caller checks :func:`linear_act_supported`."""
+    y, y_max = _LinearAct.apply(x, w, b, float(slope))
+    return tag_row_max(y, y_max)

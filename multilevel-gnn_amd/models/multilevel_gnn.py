@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from mlgnn.project import segment_project
-from mlgnn.sage import node_embed, node_embed_supported
+from mlgnn.sage import linear_act, linear_act_supported, node_embed, node_embed_supported
 from .gcn_lib.sparse.torch_vertex import GraphConv
 
 
@@ -29,12 +29,22 @@ class HeadConv2d(nn.Conv2d):
     # test runs of round 2 aborted)
     FORCE_LIBRARY = os.environ.get("MLGNN_HEAD_CONV2D", "0") == "1"
 
-    def forward(self, x):
+    def forward(self, x, relu=False):
+        """``relu``: the caller's next module is ``nn.ReLU`` -- applied here (the GEMM's epilogue when the tall kernels
+        take the rows)."""
         if (not self.FORCE_LIBRARY and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.dilation == (1, 1)
                 and self.groups == 1 and self.padding_mode == "zeros" and x.dim() == 4):
-            y = torch.nn.functional.linear(x.permute(0, 2, 3, 1), self.weight[:, :, 0, 0], self.bias)
+            xr = x.permute(0, 2, 3, 1)                    # the projection's output is channel-last in memory: a view
+            w2 = self.weight[:, :, 0, 0]
+            rows = xr.reshape(-1, xr.shape[-1]) if xr.is_contiguous() else None
+            if rows is not None and linear_act_supported(rows, w2):
+                y = linear_act(rows, w2, self.bias, 0.0 if relu else 1.0).view(*xr.shape[:-1], w2.shape[0])
+            else:
+                y = torch.nn.functional.linear(xr, w2, self.bias)
+                y = torch.relu(y) if relu else y
             return y.permute(0, 3, 1, 2)
-        return super().forward(x)
+        y = super().forward(x)
+        return torch.relu(y) if relu else y
 
 N_PATHWAYS = 146          # hard-coded in the reference's forward (:239) and head sizing (:121)
 N_OMICS = 3
@@ -57,6 +67,7 @@ class MultilevelGNN(nn.Module):
         self.pathway_pool_dim = args.pathway_pool_dim
         self.pca_pool_dim = args.pca_pool_dim
         self.pathway_indexs = None
+        self._n_seg, self._n_seg_of = 0, None
         self.reorder_idxs = None
         self.mutual_info_mask = args.mutual_info_mask
         self.mutual_info_threshold = args.mutual_info_threshold
@@ -134,12 +145,17 @@ class MultilevelGNN(nn.Module):
 
     def _apply_head(self, x, age):
         """:262-291"""
-        for layer in self.conv_model:
-            x = layer(x)
+        mods = list(self.conv_model)
+        i = 0
+        while i < len(mods):
+            fuse = isinstance(mods[i], HeadConv2d) and i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+            x = mods[i](x, relu=True) if fuse else mods[i](x)
+            i += 2 if fuse else 1
         if len(self.used_omics) != N_OMICS:
             cols = [c for o in self.used_omics for c in range(int(o) * self.pca_dim, (int(o) + 1) * self.pca_dim)]
             x = x[:, :, :, cols]
-        x = self.pooling(x)
+        if (self.pathway_pool_dim, self.pca_pool_dim) != (1, 1):     # (a 1 x 1 window is the identity: kirc.yaml)
+            x = self.pooling(x)
         x = self.drop1(x)
         x = torch.flatten(x, start_dim=1)
         if self.args.use_age:
@@ -251,19 +267,18 @@ class MultilevelGNN(nn.Module):
         if self.pca_indep_loss:
             w = (self.learnable_pca_params * self.info_mask).detach()
             seg = self.pathway_indexs.to(w.device)
-            n_seg = int(seg.max()) + 1
-
-            def seg_sum(v):
-                return torch.zeros(n_seg, dtype=w.dtype, device=w.device).index_add_(0, seg, v)
-
-            indep, count = 0, 0
-            for i in range(self.pca_dim - 1):
-                for j in range(i + 1, self.pca_dim):
-                    count += 1
-                    dot = seg_sum(w[:, i] * w[:, j])
-                    length = torch.sqrt(seg_sum(w[:, i] ** 2) * seg_sum(w[:, j] ** 2))
-                indep = indep + torch.mean(torch.abs(dot / (length + 1e-7)))
-            loss = loss + indep / count
+            if self._n_seg_of is not self.pathway_indexs:               # (one host read per pathway table, not per step)
+                self._n_seg, self._n_seg_of = int(seg.max()) + 1, self.pathway_indexs
+            n_seg, k = self._n_seg, self.pca_dim
+            # the reference adds to `indep` once per outer index i, after its inner loop (:345): only the pair (i, k-1)
+            # of every i enters the sum, while `count` counts all pairs.  All the per-pathway sums in ONE index_add.
+            count = k * (k - 1) // 2
+            if count > 0:
+                cols = torch.cat([w * w, w[:, :k - 1] * w[:, k - 1:k]], dim=1)          # [G, k + (k-1)]
+                sums = torch.zeros(n_seg, cols.shape[1], dtype=w.dtype, device=w.device).index_add_(0, seg, cols)
+                length = torch.sqrt(sums[:, :k - 1] * sums[:, k - 1:k])
+                indep = torch.abs(sums[:, k:] / (length + 1e-7)).mean(0).sum()
+                loss = loss + indep / count
         return loss
 
     def generate_mutual_mask(self, x, y, mutual_classif=True, fold=0, tf_token=None):

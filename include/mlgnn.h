@@ -760,6 +760,12 @@ int mlgnn_node_embed_bwd(const float* x, const float* grad_h, float* grad_embedd
                          int64_t C, void* stream);
 
 /*
+ * Measurement aid (bench.py: the box's streaming ceiling next to the 8 TB/s spec peak): dst = src, 16 bytes per lane,
+ * non-temporal loads and stores.  bytes a multiple of 16, 16-byte aligned pointers.
+ */
+int mlgnn_stream_copy(const void* src, void* dst, int64_t bytes, void* stream);
+
+/*
  * Debug facility (csrc/canary.hip; never on the product path, the entry points above never allocate): a guard-band
  * device allocator in the shape torch.cuda.memory.CUDAPluggableAllocator binds -- every block sits between two 4 KiB
  * bands of a byte pattern, the rear one starting at the first byte past the requested size -- and a checker.

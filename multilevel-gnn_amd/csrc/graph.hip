@@ -427,6 +427,7 @@ extern "C" int mlgnn_coo_to_csr(const int64_t* edge_index, int64_t E, int64_t N,
   return (int)hipGetLastError();
 }
 
+namespace mlgnn {
 // SAGEConv's edge list (reference: models/gcn_lib/sparse/torch_vertex.py:272-273 `remove_self_loops` then
 // `add_self_loops(..., fill_value=1.0)`) in ONE pass and without a compaction: an existing self loop (i, i) is parked on
 // the spare node N -- a row nobody aggregates and nobody gathers from -- instead of being squeezed out of the list, and
@@ -450,6 +451,7 @@ __global__ __launch_bounds__(256) void sage_rewrite_kernel(const int64_t* __rest
     }
   }
 }
+}  // namespace mlgnn
 
 extern "C" int mlgnn_sage_rewrite(const int64_t* edge_index, const float* edge_attr, int64_t attr_stride, int64_t E,
                                   int64_t N, int64_t* out_edge_index, float* out_weight, void* stream) {

@@ -107,6 +107,24 @@ __global__ __launch_bounds__(256) void node_embed_bwd_kernel(const float* __rest
   demb[u] = acc;
 }
 
+// Streaming ceiling of the box (bench.py `roofline.stream_copy_GBps`): 16 bytes per lane, non-temporal both ways, eight
+// independent loads in flight per thread -- the shape MI355X_MICROARCH.md quotes its float4-copy figure for.
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 7 * stride < n; i += 8 * stride) {
+    float4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = stream_load4(src + i + q * stride);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f4 t = {v[q].x, v[q].y, v[q].z, v[q].w};
+      __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst + i + q * stride));
+    }
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+
 static bool width_ok(int64_t J) {
   const int64_t l = J / 4;
   return J >= 4 && J % 4 == 0 && l <= 64 && (l & (l - 1)) == 0;
@@ -174,5 +192,15 @@ extern "C" int mlgnn_node_embed_bwd(const float* x, const float* grad_h, float* 
   MLGNN_LPR_SWITCH((int)(C / 4), hipLaunchKernelGGL((node_embed_bwd_kernel<L>), dim3((unsigned)((units + 255) / 256)), dim3(256),
                    0, s, x, reinterpret_cast<const float4*>(grad_h), reinterpret_cast<float4*>(grad_embedding), (int)nodes,
                    (int)batch);)
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_stream_copy(const void* src, void* dst, int64_t bytes, void* stream) {
+  if (bytes < 0 || bytes % 16 != 0) return MLGNN_E_SHAPE;
+  if (bytes == 0) return 0;
+  if (!src || !dst) return MLGNN_E_NULL;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) return MLGNN_E_ALIGN;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), bytes / 16);
   return (int)hipGetLastError();
 }

@@ -79,6 +79,7 @@ SIGNATURES = {
     "mlgnn_leaky_relu_bwd": (_INT, [_P, _P, _P, _F, _P, _P, _I64, _I64, _P]),
     "mlgnn_node_embed_fwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "mlgnn_node_embed_bwd": (_INT, [_P, _P, _P, _I64, _I64, _I64, _P]),
+    "mlgnn_stream_copy": (_INT, [_P, _P, _I64, _P]),
     "mlgnn_gemm_bf16_nt_workgroups": (_INT, [_I64, _I64, _INT]),
     "mlgnn_gemm_bf16_nt": (_INT, [_c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64),
                                   _INT, _I64, _I64, _INT, _P, _P, _I64, _INT, _P, _I64, _P, _I64, _INT, _F,

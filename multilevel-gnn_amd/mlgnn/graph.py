@@ -39,13 +39,24 @@ class CSRGraph:
         self._scalar_cache = None
         self._table_cache = None
         self._hub = {}
+        self._built = None
+        if edge_index.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._built = (ev, torch.cuda.current_stream(dev))
 
     # ---- topology cache --------------------------------------------------------------------------------------------
     # The reference's loader hands the SAME gene-gene topology to every sample of a fold
     # (dataloader/multiloader.py:687-691): a training loop that passes the same edge_index tensor again (or, with
     # ``content=True``, an equal one) gets the CSR it built the first time.
+    # Contract: a hit is decided by tensor identity / view + the tensor's VERSION counter.  An edge_index buffer refilled
+    # behind autograd's back (``.data``, DLPack, an external kernel) keeps its version: call ``CSRGraph.clear_cache()``
+    # after such a refill, or hand the model a prebuilt graph (``batch.csr``).  Entries pin their batch's index tensors
+    # and CSR arrays (~0.5 GB at BASELINE configs[1]), so the cache is small: MLGNN_CSR_CACHE entries (default 2, 0 = off;
+    # a loader that collates a fresh edge_index per step never hits and should set 0 or attach ``batch.csr``).
+    # A hit from another stream than the one that built the graph waits on the build's event.
     _CACHE = []                    # [(edge_index, version, num_nodes, content key or None, graph)], most recent first
-    CACHE_SIZE = 8
+    CACHE_SIZE = int(os.environ.get("MLGNN_CSR_CACHE", "2"))
     CACHE_STATS = {"hit": 0, "miss": 0}
 
     @classmethod
@@ -56,11 +67,13 @@ class CSRGraph:
         index list and one 16-byte read back: a host synchronisation per lookup, still far cheaper than a build); for
         loaders that collate a fresh but identical ``edge_index`` per batch."""
         N = int(num_nodes)
+        if cls.CACHE_SIZE <= 0:
+            return cls(edge_index, N)
         for k, ent in enumerate(cls._CACHE):
             if ent[2] == N and ent[1] == edge_index._version and _same_view(ent[0], edge_index):
                 cls.CACHE_STATS["hit"] += 1
                 cls._CACHE.insert(0, cls._CACHE.pop(k))
-                return ent[4]
+                return ent[4]._ordered_after_build()
         key = None
         if content:
             key = _content_key(edge_index)
@@ -68,7 +81,7 @@ class CSRGraph:
                 if ent[2] == N and ent[3] == key and ent[0].shape == edge_index.shape:
                     cls.CACHE_STATS["hit"] += 1
                     cls._CACHE.insert(0, cls._CACHE.pop(k))
-                    return ent[4]
+                    return ent[4]._ordered_after_build()
         cls.CACHE_STATS["miss"] += 1
         graph = cls(edge_index, N)
         # (the entry holds the tensor: its storage cannot be recycled under the cache)
@@ -79,6 +92,14 @@ class CSRGraph:
     @classmethod
     def clear_cache(cls):
         del cls._CACHE[:]
+
+    def _ordered_after_build(self):
+        """A cached graph handed to a stream other than the one its build was enqueued on: that stream waits for the
+        build (an event recorded behind it) before any kernel of the caller can read the arrays."""
+        ev = getattr(self, "_built", None)
+        if ev is not None and torch.cuda.current_stream(self.device) != ev[1]:
+            torch.cuda.current_stream(self.device).wait_event(ev[0])
+        return self
 
     def hub_tables(self, direction):
         """Chunk tables of the long rows of one direction (``"dst"``: by-destination CSR, forward; ``"src"``:

@@ -196,18 +196,48 @@ def tag_post_ln(y, h, tag):
     return y
 
 
+_PARAM_EPOCH = [0]          # bumped after every step of ANY torch.optim.Optimizer (global post-step hook below)
+
+
+def _after_optimizer_step(optimizer, args, kwargs):
+    _PARAM_EPOCH[0] += 1
+    for group in optimizer.param_groups:
+        for p in group["params"]:
+            p._mlgnn_stepped = True
+
+
+try:                                                        # (public since torch 2.0)
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(_after_optimizer_step)
+except ImportError:                                         # pragma: no cover
+    pass
+
+
+def invalidate_param_cache():
+    """Call after editing parameters behind autograd's back outside an optimizer step (``p.data.copy_``, an EMA swap that
+    keeps the storage): drops every cached fp32 copy at its next use."""
+    _PARAM_EPOCH[0] += 1
+
+
 def f32_cached(t):
     """``t`` as a contiguous fp32 tensor for a kernel argument (LayerNorm gamma / beta, a bias: the kernels read their
-    [d]-sized parameters in fp32).  The copy of a non-fp32 parameter is kept on the tensor until its version changes, so
-    a bf16 model casts each parameter once per optimizer step instead of once per use (forward and backward: ~20 tiny
-    launches per layer at BASELINE configs[4]).  Only for use inside autograd Functions (the copy is detached)."""
+    [d]-sized parameters in fp32).  A non-fp32 tensor is cast per call -- always correct -- unless it is a parameter some
+    ``torch.optim.Optimizer`` has stepped: its copy is then kept until the next optimizer step of the process (a global
+    post-step hook counts them: updates through ``p.data.copy_`` inside an optimizer, as the reference's utils/optim.py
+    does, are seen although they do not bump the version counter), a version bump, or a change of storage address /
+    device, so a bf16 model casts each parameter once per step instead of once per use (~20 tiny launches per layer at
+    BASELINE configs[4]).  Edits through ``.data`` between optimizer steps: :func:`invalidate_param_cache`.
+    Only for use inside autograd Functions (the copy is detached)."""
     if t.dtype == torch.float32:
         return t.contiguous()
+    if not getattr(t, "_mlgnn_stepped", False):
+        return t.detach().float().contiguous()
+    key = (_PARAM_EPOCH[0], t._version, t.data_ptr(), t.device)
     tag = getattr(t, "_mlgnn_f32", None)
-    if tag is not None and tag[0] == t._version:
+    if tag is not None and tag[0] == key:
         return tag[1]
     c = t.detach().float().contiguous()
-    t._mlgnn_f32 = (t._version, c)
+    t._mlgnn_f32 = (key, c)
     return c
 
 

@@ -18,7 +18,7 @@ SMALL = ["--steps", "2", "--warmup", "1", "--graphs-per-gpu", "4", "--nodes", "3
 CONTRACT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "kernels"}
 ROOFLINE = {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "frac_hbm_counter", "frac_compulsory",
-            "avg_launch_ms", "algorithmic_bytes_per_launch"}
+            "avg_launch_ms", "algorithmic_bytes_per_launch", "frac_basis", "frac_algorithmic", "achieved_algorithmic"}
 
 
 def _line(cmd, env=None):
@@ -53,14 +53,17 @@ def test_bench_line_n1_schema(line_n1):
     assert out["unit"] == "graphs/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
     assert abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]
     assert out["config"]["world_size"] == 1 and out["config"]["allreduce_ms"] is None
-    assert out["roofline"]["kernel"].startswith("csr_aggregate_") and 0 < out["roofline"]["frac"]
+    assert out["roofline"]["kernel"].startswith("csr_aggregate_") and 0 < out["roofline"]["frac"] <= 1.0
+    assert out["roofline"]["frac_basis"] in ("hbm_counter", "compulsory") and "arith" in out
+    assert 0 < out["roofline"]["frac_of_stream_copy"] <= 1.5 and out["roofline"]["stream_copy_GBps"] > 1000
+    assert all(0 < k["frac"] <= 1.0 for k in out["roofline"].get("also", []))
     assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])
     # all three aggregators in the line, headline = softmax; and the in-line-build figure
     assert [a["aggr"] for a in out["also_aggr"]] == ["max", "mean"]
     for a in out["also_aggr"]:
         names = [k["kernel"] for k in a["kernels"]]
         assert names == ["csr_aggregate_bwd/%s/rank1" % a["aggr"], "csr_aggregate_fwd/%s/rank1" % a["aggr"]]
-        assert a["ms_per_step"] > 0 and all(k["frac"] > 0 and k["frac_compulsory"] > 0 for k in a["kernels"])
+        assert a["ms_per_step"] > 0 and all(0 < k["frac"] <= 1.0 and k["frac_compulsory"] > 0 for k in a["kernels"])
     assert out["no_overlap_ms_per_step"] > 0
 
 

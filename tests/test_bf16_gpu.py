@@ -328,3 +328,54 @@ def test_bf16_input_gradient_with_shifted_cotangent(N, M, K):
     lse[N // 2, 3] = -61.0
     _, _, flag = D.tall_matmul_bf16_shift(go, w, lse)
     assert int(flag[0]) == 1
+
+
+def test_bf16_parameter_copies_are_never_stale():
+    """The fp32 copies the kernels read of a bf16 model's [d]-sized parameters (mlgnn.ops.f32_cached): an edit through
+    ``.data`` does not bump the version counter, so (a) a parameter no optimizer has stepped is cast per call, and (b) one
+    an optimizer steps is re-cast after every optimizer step -- also when that optimizer writes through
+    ``p.data.copy_`` as the reference's utils/optim.py (RAdam, AdamW) does -- and after a storage change."""
+    from mlgnn.norm import layer_norm_act
+    from mlgnn import ops
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(9000, 256, device=DEV, generator=g).to(torch.bfloat16)
+    ln = torch.nn.LayerNorm(256).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        y0 = layer_norm_act(x, ln.weight, ln.bias, ln.eps, True).float()
+        ln.weight.data.copy_(torch.full_like(ln.weight, 3.0))          # (a) never stepped: version unchanged, still seen
+        y1 = layer_norm_act(x, ln.weight, ln.bias, ln.eps, True).float()
+    assert not torch.equal(y0, y1)
+
+    class DataCopySGD(torch.optim.Optimizer):                          # updates like utils/optim.py: p.data.copy_(...)
+        def __init__(self, params):
+            super().__init__(params, dict(lr=0.5))
+
+        def step(self):
+            for grp in self.param_groups:
+                for p in grp["params"]:
+                    if p.grad is not None:
+                        p.data.copy_((p.data.float() - grp["lr"] * p.grad.float()).to(p.dtype))
+
+    opt = DataCopySGD(ln.parameters())
+    outs = []
+    for _ in range(3):
+        opt.zero_grad()
+        y = layer_norm_act(x, ln.weight, ln.bias, ln.eps, True)
+        y.float().square().mean().backward()
+        v = ln.weight._version
+        opt.step()
+        assert ln.weight._version == v                                 # the update did not bump the version ...
+        outs.append(y.detach().float())
+    assert getattr(ln.weight, "_mlgnn_stepped", False)
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])   # ... and was seen all the same
+    with torch.no_grad():
+        ref = torch.relu(torch.nn.functional.layer_norm(x.float(), (256,), ln.weight.float(), ln.bias.float(), ln.eps))
+        got = layer_norm_act(x, ln.weight, ln.bias, ln.eps, True).float()
+        assert float((got - ref).abs().max()) <= 0.05 * float(ref.abs().max())
+        # (b') between optimizer steps the copy is kept: same object twice
+        assert ops.f32_cached(ln.weight) is ops.f32_cached(ln.weight)
+        ln.weight.data = ln.weight.data.clone()                        # a storage change is seen
+        c1 = ops.f32_cached(ln.weight)
+        ln.weight.data.mul_(2.0)
+        ops.invalidate_param_cache()                                   # the documented way for a manual in-place edit
+        assert not torch.equal(c1, ops.f32_cached(ln.weight))

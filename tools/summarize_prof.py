@@ -91,10 +91,24 @@ def main():
             if nf[k] > most.get(short, -1) or (nf[k] == most.get(short) and hbm > traffic.get(short, 0.0)):
                 most[short] = nf[k]
                 traffic[short] = hbm
+        # per aggregator ("csr_aggregate_fwd/max", ...: bench.py's also_aggr legs): template arguments <T, VEC, MODE, AGGR,
+        # ...> with AGGR 0 = sum / mean (the bench only runs mean), 2 = max, 3 = softmax; the main launch plus the
+        # long-row (VIRT) launch of the same call
+        import re
+        names = {0: "mean", 2: "max", 3: "softmax"}
+        per_aggr = {}
+        for k, d in detail.items():
+            m = re.search(r"mlgnn::(csr_aggregate_(?:fwd|bwd))_kernel<\w+, \d+, \d+, (\d+),", k)
+            if m and int(m.group(2)) in names:
+                key = "%s/%s" % (m.group(1), names[int(m.group(2))])
+                per_aggr[key] = per_aggr.get(key, 0.0) + d["hbm_bytes_per_launch"]
+        traffic.update(per_aggr)
         # one mlgnn_csr_aggregate_bwd call = the softmax shift pre-pass + the main kernel: bench.py times the call,
         # so its traffic entry is the sum of the two launches
         if "softmax_shift" in traffic and "csr_aggregate_bwd" in traffic:
             traffic["csr_aggregate_bwd"] += traffic["softmax_shift"]
+            if "csr_aggregate_bwd/softmax" in traffic:
+                traffic["csr_aggregate_bwd/softmax"] += traffic["softmax_shift"]
         # provenance travels with the numbers: bench.py refuses them when the kernel sources have changed since
         import build_native
         blob = {"_source": {"tag": a.tag, "commit": a.commit or os.environ.get("MLGNN_COMMIT", "unknown"),

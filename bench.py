@@ -136,18 +136,30 @@ def stream_copy_ceiling(dev, mib=1024, reps=10):
     dst = torch.empty_like(src)
     st = torch.cuda.current_stream().cuda_stream
 
-    def copy():
-        _lib.check(_lib.lib.mlgnn_stream_copy(src.data_ptr(), dst.data_ptr(), src.numel(), st), "mlgnn_stream_copy")
-
+    best = {}
+    for name, nt in (("plain", 0), ("non_temporal", 1)):
+        def copy():
+            _lib.check(_lib.lib.mlgnn_stream_copy(src.data_ptr(), dst.data_ptr(), src.numel(), nt, st), "mlgnn_stream_copy")
+        for _ in range(2):
+            copy()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            copy()
+        b.record()
+        b.synchronize()
+        best[name] = 2.0 * src.numel() * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+    # ... and the runtime's own device-to-device copy, for reference
     for _ in range(2):
-        copy()
+        dst.copy_(src)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        copy()
+        dst.copy_(src)
     b.record()
     b.synchronize()
-    return 2.0 * src.numel() * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+    best["tensor_copy_"] = 2.0 * src.numel() * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+    return max(best.values()), best
 
 
 def main():
@@ -371,8 +383,9 @@ def main():
             if other:
                 out["roofline"]["also"] = [view(kernels, n) for n in sorted(other)]
             if world == 1:
-                ceil = stream_copy_ceiling(dev)
+                ceil, variants = stream_copy_ceiling(dev)
                 out["roofline"]["stream_copy_GBps"] = ceil
+                out["roofline"]["stream_copy_variants_GBps"] = variants
                 out["roofline"]["frac_of_stream_copy"] = v["achieved"] / ceil
             out["kernels"] = kernels
         if world == 1 and not args.no_extras:

@@ -244,11 +244,16 @@ int mlgnn_power_bwd_prologue(const void* grad_out, const float* mu, const int32_
  *   mem_seg [M]   (batch, segment) id of the member
  *   node_ptr [n_rows+1], node_mem [.]     present members grouped by x row
  *   x [n_rows, C], w [G, K] (K <= 4), out_t / gout_t [n_segments, K, C] (channel-contiguous)
+ * n_groups = 0: that layout ([B, S, K, C]; segs_per_sample unused).  n_groups = NG > 0 with S = segs_per_sample a multiple
+ * of NG and n_segments a multiple of S: the "pooled" layout [B, NG * K, S / NG, C] -- segment s = p * NG + o of a sample
+ * goes to row ((b * NG + o) * K + k) * (S / NG) + p: the [B * NG * K, 146, C] batch of pathway graphs the DiffPool
+ * levels consume (models/vae.py:238-243 `x.permute(0, 3, 2, 1).reshape(-1, 146, C)` on the [B, C, 146, NG * K] view),
+ * written directly instead of through a transposing copy of the result and of its gradient.
  */
 int mlgnn_segment_project_fwd(const void* x, const float* w, const int32_t* seg_ptr,
                               const int32_t* seg_mem, const int32_t* mem_row, void* out_t,
-                              int64_t n_segments, int64_t C, int64_t G, int64_t K, int dtype,
-                              void* stream);
+                              int64_t n_segments, int64_t C, int64_t G, int64_t K, int64_t segs_per_sample,
+                              int64_t n_groups, int dtype, void* stream);
 
 /*
  * Backward of the above.  grad_x [n_rows, C] (NULL to skip) and gw_partial [M, K] (NULL to skip):
@@ -261,7 +266,7 @@ int mlgnn_segment_project_bwd(const void* gout_t, const void* x, const float* w,
                               const int32_t* node_ptr, const int32_t* node_mem,
                               void* grad_x, float* gw_partial,
                               int64_t n_segments, int64_t n_rows, int64_t C, int64_t G, int64_t K,
-                              int dtype, void* stream);
+                              int64_t segs_per_sample, int64_t n_groups, int dtype, void* stream);
 
 /*
  * Fused LayerNorm (+ ReLU) over [rows, d]: fp32 (d <= 256 with d % 4 == 0, or d <= 512 with d % 8 == 0) or bf16 storage with fp32 statistics and
@@ -760,10 +765,24 @@ int mlgnn_node_embed_bwd(const float* x, const float* grad_h, float* grad_embedd
                          int64_t C, void* stream);
 
 /*
- * Measurement aid (bench.py: the box's streaming ceiling next to the 8 TB/s spec peak): dst = src, 16 bytes per lane,
- * non-temporal loads and stores.  bytes a multiple of 16, 16-byte aligned pointers.
+ * Linear with 1..8 input columns over tall rows (fp32): out [N,J] = x [N,R] w[J,R]^T + bias, and its weight / bias
+ * gradient grad_w_b = [grad_out^T x  (J x R) | column sums of grad_out (J)] (fixed-order partial sums: deterministic).
+ * Replaces: DeeperGCN.node_features_encoder = Linear(3 [+ emb], hidden) forward and weight gradient
+ * (models/deepergcn.py:199-210), which a GEMM library runs as K = 3 products; here both are single streams over the
+ * [N, J] tensor.  J in {32, 64, 128, 256}; workspace: mlgnn_narrow_linear_bwd_workspace_floats(R, J) floats.
  */
-int mlgnn_stream_copy(const void* src, void* dst, int64_t bytes, void* stream);
+int mlgnn_narrow_linear_supported(int64_t N, int64_t R, int64_t J);
+int64_t mlgnn_narrow_linear_bwd_workspace_floats(int64_t R, int64_t J);
+int mlgnn_narrow_linear_fwd(const float* x, const float* w, const float* bias, float* out, int64_t N, int64_t R, int64_t J,
+                            void* stream);
+int mlgnn_narrow_linear_bwd(const float* grad_out, const float* x, float* grad_w_b, float* workspace,
+                            int64_t workspace_floats, int64_t N, int64_t R, int64_t J, void* stream);
+
+/*
+ * Measurement aid (bench.py: the box's streaming ceiling next to the 8 TB/s spec peak): dst = src, 16 bytes per lane,
+ * non_temporal != 0: non-temporal loads and stores.  bytes a multiple of 16, 16-byte aligned pointers.
+ */
+int mlgnn_stream_copy(const void* src, void* dst, int64_t bytes, int non_temporal, void* stream);
 
 /*
  * Debug facility (csrc/canary.hip; never on the product path, the entry points above never allocate): a guard-band

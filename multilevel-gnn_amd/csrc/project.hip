@@ -23,7 +23,20 @@ struct ProjArgs {                  // x / gout_t / out are T (fp32 or bf16 stora
   const int* ptr; const int* mem; const int* mem_row; const int* mem_seg;
   void* out; float* gw_partial;
   int rows; int C; int G; int lpr_log2;
+  // row of out_t / gout_t that (segment row r = b * S + s, k) lives in.  n_groups = 0: r * K + k  ([B, S, K, C]).
+  // n_groups = NG > 0 ("pooled" layout [B, NG * K, S / NG, C], s = p * NG + o): the rows of one (group o, column k) of a
+  // sample are its S / NG pathways in order -- the [B', 146, C] batch the DiffPool levels consume (vae.py:238-243,
+  // mlgnn/workload.py), written directly instead of through a transposing copy of the result (and of its gradient)
+  int S; int n_groups;
 };
+
+template <int K>
+__device__ __forceinline__ size_t proj_out_row(const ProjArgs& a, int r, int k) {
+  if (a.n_groups <= 0) return (size_t)r * K + k;
+  const int b = r / a.S, s = r - b * a.S;
+  const int p = s / a.n_groups, o = s - p * a.n_groups;
+  return ((size_t)(b * a.n_groups + o) * K + k) * (a.S / a.n_groups) + p;
+}
 
 // ---- forward: one wave per (batch, segment); out_t[seg, k, :] = sum_m x[row(m), :] * W[g(m), k]
 template <typename T, int VEC, int K>
@@ -85,13 +98,20 @@ __global__ __launch_bounds__(kBlock) void segment_project_fwd_kernel(const ProjA
           for (int i = 0; i < VEC; ++i) acc[k][i] += __shfl_xor(acc[k][i], off);
       if (sub == 0 && cact) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) store_t<T, VEC>(static_cast<T*>(a.out) + ((size_t)r * K + k) * a.C + c0, acc[k]);
+        for (int k = 0; k < K; ++k) store_t<T, VEC>(static_cast<T*>(a.out) + proj_out_row<K>(a, r, k) * a.C + c0, acc[k]);
       }
     }
   }
 }
 
-// ---- input gradient: one wave per node row; gx[row, :] = sum_{m -> row} sum_k gout_t[seg(m), k, :] * W[g(m), k]
+// ---- input gradient: gx[row, :] = sum_{m -> row} sum_k gout_t[seg(m), k, :] * W[g(m), k]
+// A node has 2.5 memberships on average (G = 25 000 over 10 000 genes), so the work per row is one short chain of
+// dependent loads (row pointer -> member -> segment / weights -> K cotangent rows) and one 512-byte store: a wave that
+// walks ONE row at a time (rounds 1-3: 184 us for a 328 MB write) waits out four memory latencies per row.  Here every
+// lane group owns a row of its own and a wave keeps kXRows of them per group in flight -- the pointer loads of all of
+// them, then the j-th member of all of them, then their K * kXRows gathers -- and walks units of kXRows * groups
+// consecutive rows (XCD-aware like the other row walks), so the stores of a unit are one contiguous block.
+constexpr int kXRows = 4;
 template <typename T, int VEC, int K>
 __global__ __launch_bounds__(kBlock) void segment_project_bwd_x_kernel(const ProjArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -99,50 +119,67 @@ __global__ __launch_bounds__(kBlock) void segment_project_bwd_x_kernel(const Pro
   const int groups = kWave >> a.lpr_log2;
   const int sub = lane >> a.lpr_log2;
   const int cl = lane & (lpr - 1);
-  const RowWalk walk = make_row_walk(a.rows);
+  const int rows_per_unit = kXRows * groups;
+  const RowWalk walk = make_row_walk((a.rows + rows_per_unit - 1) / rows_per_unit);
   for (int cbase = 0; cbase < a.C; cbase += lpr * VEC) {
     const int c0 = cbase + cl * VEC;
     const bool cact = c0 < a.C;
-    for (int r = walk.first; r < walk.r_end; r += walk.stride) {
-      const int beg = a.ptr[r], end = a.ptr[r + 1];
-      float acc[VEC];
+    for (int unit = walk.first; unit < walk.r_end; unit += walk.stride) {
+      int row[kXRows], beg[kXRows], cnt[kXRows];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-      for (int base = beg; base < end; base += kWave) {
-        const int cnt = min(kWave, end - base);
-        int my_seg = 0;
-        float my_w[K];
+      for (int u = 0; u < kXRows; ++u) {
+        row[u] = unit * rows_per_unit + u * groups + sub;
+        const bool valid = row[u] < a.rows;
+        beg[u] = valid ? a.ptr[row[u]] : 0;
+        cnt[u] = valid ? a.ptr[row[u] + 1] - beg[u] : 0;
+      }
+      float acc[kXRows][VEC];
 #pragma unroll
-        for (int k = 0; k < K; ++k) my_w[k] = 0.f;
-        if (lane < cnt) {
-          const int f = a.mem[base + lane];
-          my_seg = a.mem_seg[f];
-          const int g = f % a.G;
+      for (int u = 0; u < kXRows; ++u)
 #pragma unroll
-          for (int k = 0; k < K; ++k) my_w[k] = a.w[(size_t)g * K + k];
-        }
-        for (int kk = 0; kk < cnt; kk += groups) {
-          const int idx = kk + sub;
-          const int src = idx & (kWave - 1);
-          const int seg = __shfl(my_seg, src);
-          float wk[K];
+        for (int i = 0; i < VEC; ++i) acc[u][i] = 0.f;
+      for (int j = 0;; ++j) {
+        bool more = false;
 #pragma unroll
-          for (int k = 0; k < K; ++k) wk[k] = __shfl(my_w[k], src);
-          if (idx < cnt && cact) {
+        for (int u = 0; u < kXRows; ++u) more |= j < cnt[u];
+        if (!__any(more)) break;                                  // (wave-uniform: every row of the unit is done)
+        int f[kXRows];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-              float gv[VEC];
-              load_t<T, VEC>(gv, static_cast<const T*>(a.gout_t) + ((size_t)seg * K + k) * a.C + c0);
+        for (int u = 0; u < kXRows; ++u) f[u] = j < cnt[u] ? a.mem[beg[u] + j] : -1;
+        int seg[kXRows];
+        float wk[kXRows][K];
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) acc[i] = fmaf(gv[i], wk[k], acc[i]);
-            }
+        for (int u = 0; u < kXRows; ++u) {
+          seg[u] = 0;
+#pragma unroll
+          for (int k = 0; k < K; ++k) wk[u][k] = 0.f;
+          if (f[u] >= 0) {
+            seg[u] = a.mem_seg[f[u]];
+            const int g = f[u] % a.G;
+#pragma unroll
+            for (int k = 0; k < K; ++k) wk[u][k] = a.w[(size_t)g * K + k];
           }
         }
-      }
-      for (int off = lpr; off < kWave; off <<= 1)
+        float gv[kXRows][K][VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
-      if (sub == 0 && cact) store_t<T, VEC>(static_cast<T*>(a.out) + (size_t)r * a.C + c0, acc);
+        for (int u = 0; u < kXRows; ++u)
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) gv[u][k][i] = 0.f;
+            if (f[u] >= 0 && cact)
+              load_t<T, VEC>(gv[u][k], static_cast<const T*>(a.gout_t) + proj_out_row<K>(a, seg[u], k) * a.C + c0);
+          }
+#pragma unroll
+        for (int u = 0; u < kXRows; ++u)
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[u][i] = fmaf(gv[u][k][i], wk[u][k], acc[u][i]);
+      }
+#pragma unroll
+      for (int u = 0; u < kXRows; ++u)
+        if (row[u] < a.rows && cact) store_t<T, VEC>(static_cast<T*>(a.out) + (size_t)row[u] * a.C + c0, acc[u]);
     }
   }
 }
@@ -166,34 +203,43 @@ __global__ __launch_bounds__(kBlock) void segment_project_bwd_w_kernel(const Pro
     for (int k = 0; k < K; ++k) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) gk[k][i] = 0.f;
-      if (cact && end > beg) load_t<T, VEC>(gk[k], static_cast<const T*>(a.gout_t) + ((size_t)r * K + k) * a.C + c0);
+      if (cact && end > beg) load_t<T, VEC>(gk[k], static_cast<const T*>(a.gout_t) + proj_out_row<K>(a, r, k) * a.C + c0);
     }
     for (int base = beg; base < end; base += kWave) {
       const int cnt = min(kWave, end - base);
       int my_row = -1, my_f = 0;
       if (lane < cnt) { my_f = a.mem[base + lane]; my_row = a.mem_row[my_f]; }
-      for (int kk = 0; kk < cnt; kk += groups) {
-        const int idx = kk + sub;
-        const int src = idx & (kWave - 1);
-        const int row = __shfl(my_row, src);
-        const int f = __shfl(my_f, src);
-        float xv[VEC];
+      // kPUnroll member rows per lane group in flight (one at a time left the gather latency-bound: 209 us for 0.65 GB)
+      for (int kk = 0; kk < cnt; kk += groups * kPUnroll) {
+        float xv[kPUnroll][VEC];
+        int fs[kPUnroll];
+        bool oks[kPUnroll];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) xv[i] = 0.f;
-        const bool ok = idx < cnt;
-        if (ok && cact && row >= 0) load_t<T, VEC>(xv, static_cast<const T*>(a.x) + (size_t)row * a.C + c0);
-        float dot[K];
+        for (int u = 0; u < kPUnroll; ++u) {
+          const int idx = kk + u * groups + sub;
+          const int src = idx & (kWave - 1);
+          const int row = __shfl(my_row, src);
+          fs[u] = __shfl(my_f, src);
+          oks[u] = idx < cnt;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          float s = 0.f;
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) s = fmaf(xv[i], gk[k][i], s);
-          for (int off = 1; off < lpr; off <<= 1) s += __shfl_xor(s, off);   // within the lane group
-          dot[k] = s;
+          for (int i = 0; i < VEC; ++i) xv[u][i] = 0.f;
+          if (oks[u] && cact && row >= 0) load_t<T, VEC>(xv[u], static_cast<const T*>(a.x) + (size_t)row * a.C + c0);
         }
-        if (ok && cl == 0) {
 #pragma unroll
-          for (int k = 0; k < K; ++k) a.gw_partial[(size_t)f * K + k] = dot[k];
+        for (int u = 0; u < kPUnroll; ++u) {
+          float dot[K];
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s = fmaf(xv[u][i], gk[k][i], s);
+            for (int off = 1; off < lpr; off <<= 1) s += __shfl_xor(s, off);   // within the lane group
+            dot[k] = s;
+          }
+          if (oks[u] && cl == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) a.gw_partial[(size_t)fs[u] * K + k] = dot[k];
+          }
         }
       }
     }
@@ -221,21 +267,29 @@ __global__ __launch_bounds__(kBlock) void segment_project_bwd_w_kernel(const Pro
 
 static bool p16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// n_groups = 0: the plain layout (segs_per_sample unused); otherwise whole samples of S segments, S a multiple of n_groups
+static bool proj_layout_ok(int64_t n_segments, int64_t S, int64_t n_groups) {
+  if (n_groups == 0) return true;
+  return n_groups > 0 && S > 0 && S <= INT32_MAX && S % n_groups == 0 && n_segments % S == 0;
+}
+
 }  // namespace mlgnn
 
 using namespace mlgnn;
 
 extern "C" int mlgnn_segment_project_fwd(const void* x, const float* w, const int32_t* seg_ptr,
                                          const int32_t* seg_mem, const int32_t* mem_row, void* out_t,
-                                         int64_t n_segments, int64_t C, int64_t G, int64_t K, int dtype,
-                                         void* stream) {
+                                         int64_t n_segments, int64_t C, int64_t G, int64_t K,
+                                         int64_t segs_per_sample, int64_t n_groups, int dtype, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (n_segments < 0 || C <= 0 || G <= 0 || K < 1 || K > 4 || n_segments > INT32_MAX) return MLGNN_E_SHAPE;
+  if (!proj_layout_ok(n_segments, segs_per_sample, n_groups)) return MLGNN_E_SHAPE;
   if (n_segments == 0) return 0;
   if (!x || !w || !seg_ptr || !mem_row || !out_t) return MLGNN_E_NULL;
   ProjArgs a{};
   a.x = x; a.w = w; a.ptr = seg_ptr; a.mem = seg_mem; a.mem_row = mem_row;
   a.out = out_t; a.rows = (int)n_segments; a.C = (int)C; a.G = (int)G;
+  a.S = (int)segs_per_sample; a.n_groups = (int)n_groups;
   const dim3 grid(grid_for_rows(n_segments)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   const bool bf16 = dtype == MLGNN_DTYPE_BF16;
@@ -252,10 +306,11 @@ extern "C" int mlgnn_segment_project_bwd(const void* gout_t, const void* x, cons
                                          const int32_t* node_ptr, const int32_t* node_mem,
                                          void* grad_x, float* gw_partial,
                                          int64_t n_segments, int64_t n_rows, int64_t C, int64_t G, int64_t K,
-                                         int dtype, void* stream) {
+                                         int64_t segs_per_sample, int64_t n_groups, int dtype, void* stream) {
   if (dtype != MLGNN_DTYPE_F32 && dtype != MLGNN_DTYPE_BF16) return MLGNN_E_DTYPE;
   if (n_segments < 0 || n_rows < 0 || C <= 0 || G <= 0 || K < 1 || K > 4 || n_rows > INT32_MAX ||
       n_segments > INT32_MAX) return MLGNN_E_SHAPE;
+  if (!proj_layout_ok(n_segments, segs_per_sample, n_groups)) return MLGNN_E_SHAPE;
   if (!gout_t || !w) return MLGNN_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   const dim3 block(kBlock);
@@ -267,6 +322,7 @@ extern "C" int mlgnn_segment_project_bwd(const void* gout_t, const void* x, cons
     ProjArgs a{};
     a.gout_t = gout_t; a.w = w; a.ptr = node_ptr; a.mem = node_mem; a.mem_seg = mem_seg;
     a.out = grad_x; a.rows = (int)n_rows; a.C = (int)C; a.G = (int)G;
+    a.S = (int)segs_per_sample; a.n_groups = (int)n_groups;
     const dim3 grid(grid_for_rows(n_rows));
     a.lpr_log2 = lanes_per_row_log2(C, wide ? vec : 1);
     MLGNN_PROJ_DISPATCH(segment_project_bwd_x_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
@@ -279,6 +335,7 @@ extern "C" int mlgnn_segment_project_bwd(const void* gout_t, const void* x, cons
     ProjArgs a{};
     a.gout_t = gout_t; a.x = x; a.ptr = seg_ptr; a.mem = seg_mem;
     a.mem_row = mem_row; a.gw_partial = gw_partial; a.rows = (int)n_segments; a.C = (int)C; a.G = (int)G;
+    a.S = (int)segs_per_sample; a.n_groups = (int)n_groups;
     const dim3 grid(grid_for_rows(n_segments));
     a.lpr_log2 = lanes_per_row_log2(C, wide ? vec : 1);
     MLGNN_PROJ_DISPATCH(segment_project_bwd_w_kernel, bf16, wide, (int)K, grid, block, 0, s, a);

@@ -109,21 +109,104 @@ __global__ __launch_bounds__(256) void node_embed_bwd_kernel(const float* __rest
 
 // Streaming ceiling of the box (bench.py `roofline.stream_copy_GBps`): 16 bytes per lane, non-temporal both ways, eight
 // independent loads in flight per thread -- the shape MI355X_MICROARCH.md quotes its float4-copy figure for.
+template <bool NT>
 __global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i + 7 * stride < n; i += 8 * stride) {
     float4 v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = stream_load4(src + i + q * stride);
+    for (int q = 0; q < 8; ++q) v[q] = NT ? stream_load4(src + i + q * stride) : src[i + q * stride];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const f4 t = {v[q].x, v[q].y, v[q].z, v[q].w};
-      __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst + i + q * stride));
+      if constexpr (NT) {
+        const f4 t = {v[q].x, v[q].y, v[q].z, v[q].w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst + i + q * stride));
+      } else {
+        dst[i + q * stride] = v[q];
+      }
     }
   }
   for (; i < n; i += stride) dst[i] = src[i];
 }
+
+// ---- Linear with a handful of input columns (the node encoder Linear(3, hidden) of deepergcn.py:199-210: x [N, 3]) ----
+// forward: one 16-byte store per thread, the R <= 8 inputs of the row broadcast to its lanes, W[4 columns][R] in registers.
+// A write-bound stream (328 MB at BASELINE configs[1]) that the library ran as a K = 3 GEMM (100 us).
+template <int LPR, int R>
+__global__ __launch_bounds__(256) void narrow_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float4* __restrict__ out,
+                                                                int64_t n_units) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int q = threadIdx.x & (LPR - 1);                 // (blockDim and the grid stride are multiples of LPR)
+  float wr[4][R], b4[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    b4[c] = bias ? bias[4 * q + c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < R; ++k) wr[c][k] = w[(4 * q + c) * R + k];
+  }
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += stride) {
+    const int64_t row = u / LPR;
+    float xv[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) xv[k] = x[row * R + k];
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      o[c] = b4[c];
+#pragma unroll
+      for (int k = 0; k < R; ++k) o[c] = fmaf(xv[k], wr[c][k], o[c]);
+    }
+    const f4 t = {o[0], o[1], o[2], o[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4*>(out + u));
+  }
+}
+
+// weight + bias gradient: a thread keeps its 4 columns x (R + 1) sums over the rows it walks; the row groups of a
+// workgroup are folded through LDS in order, one [J (R + 1)] partial per workgroup, reduced in a fixed order afterwards
+template <int LPR, int R>
+__global__ __launch_bounds__(256) void narrow_linear_bwd_kernel(const float4* __restrict__ go, const float* __restrict__ x,
+                                                                float* __restrict__ partial, int64_t n_units) {
+  __shared__ float red[256 * 4 * (R + 1)];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int q = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
+  constexpr int kGroups = 256 / LPR, J = 4 * LPR;
+  float acc[4][R + 1];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k <= R; ++k) acc[c][k] = 0.f;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += stride) {
+    const int64_t row = u / LPR;
+    const float4 g = stream_load4(go + u);
+    const float gv[4] = {g.x, g.y, g.z, g.w};
+    float xv[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) xv[k] = x[row * R + k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) acc[c][k] = fmaf(gv[c], xv[k], acc[c][k]);
+      acc[c][R] += gv[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k <= R; ++k) red[(grp * J + 4 * q + c) * (R + 1) + k] = acc[c][k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < J * (R + 1); i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < kGroups; ++g2) t += red[g2 * J * (R + 1) + i];
+    const int j = i / (R + 1), k = i - j * (R + 1);
+    // layout of the result: grad_w [J, R] then grad_b [J]
+    partial[(size_t)blockIdx.x * (J * (R + 1)) + (k < R ? j * R + k : J * R + j)] = t;
+  }
+}
+
+constexpr int kNarrowBlocks = 1024;
 
 static bool width_ok(int64_t J) {
   const int64_t l = J / 4;
@@ -195,12 +278,78 @@ extern "C" int mlgnn_node_embed_bwd(const float* x, const float* grad_h, float* 
   return (int)hipGetLastError();
 }
 
-extern "C" int mlgnn_stream_copy(const void* src, void* dst, int64_t bytes, void* stream) {
+extern "C" int mlgnn_stream_copy(const void* src, void* dst, int64_t bytes, int non_temporal, void* stream) {
   if (bytes < 0 || bytes % 16 != 0) return MLGNN_E_SHAPE;
   if (bytes == 0) return 0;
   if (!src || !dst) return MLGNN_E_NULL;
   if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) return MLGNN_E_ALIGN;
-  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), bytes / 16);
+  if (non_temporal)
+    hipLaunchKernelGGL(stream_copy_kernel<true>, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), bytes / 16);
+  else
+    hipLaunchKernelGGL(stream_copy_kernel<false>, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), bytes / 16);
+  return (int)hipGetLastError();
+}
+
+#define MLGNN_R_SWITCH(R_, BODY)                    \
+  switch (R_) {                                     \
+    case 1: { constexpr int RR = 1; BODY } break;   \
+    case 2: { constexpr int RR = 2; BODY } break;   \
+    case 3: { constexpr int RR = 3; BODY } break;   \
+    case 4: { constexpr int RR = 4; BODY } break;   \
+    case 5: { constexpr int RR = 5; BODY } break;   \
+    case 6: { constexpr int RR = 6; BODY } break;   \
+    case 7: { constexpr int RR = 7; BODY } break;   \
+    default: { constexpr int RR = 8; BODY } break;  \
+  }
+
+static bool narrow_ok(int64_t N, int64_t R, int64_t J) {
+  // J = 4 * lanes with 8, 16, 32 or 64 lanes per row (32 .. 256 columns); 1 .. 8 input columns
+  return N >= 0 && N <= INT32_MAX && R >= 1 && R <= 8 && (J == 32 || J == 64 || J == 128 || J == 256);
+}
+
+extern "C" int mlgnn_narrow_linear_supported(int64_t N, int64_t R, int64_t J) { return narrow_ok(N, R, J) ? 1 : 0; }
+
+extern "C" int64_t mlgnn_narrow_linear_bwd_workspace_floats(int64_t R, int64_t J) {
+  if (!narrow_ok(1, R, J)) return MLGNN_E_SHAPE;
+  return (int64_t)kNarrowBlocks * J * (R + 1);
+}
+
+#define MLGNN_NARROW_LPR(J_, BODY)                      \
+  switch ((int)(J_ / 4)) {                              \
+    case 8: { constexpr int L = 8; BODY } break;        \
+    case 16: { constexpr int L = 16; BODY } break;      \
+    case 32: { constexpr int L = 32; BODY } break;      \
+    default: { constexpr int L = 64; BODY } break;      \
+  }
+
+extern "C" int mlgnn_narrow_linear_fwd(const float* x, const float* w, const float* bias, float* out, int64_t N, int64_t R,
+                                       int64_t J, void* stream) {
+  if (!narrow_ok(N, R, J)) return MLGNN_E_SHAPE;
+  if (N == 0) return 0;
+  if (!x || !w || !out) return MLGNN_E_NULL;
+  if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return MLGNN_E_ALIGN;
+  const int64_t units = N * (J / 4);
+  hipStream_t s = (hipStream_t)stream;
+  MLGNN_NARROW_LPR(J, MLGNN_R_SWITCH((int)R, hipLaunchKernelGGL((narrow_linear_fwd_kernel<L, RR>), dim3(stream_grid(units)),
+                   dim3(256), 0, s, x, w, bias, reinterpret_cast<float4*>(out), units);))
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_narrow_linear_bwd(const float* grad_out, const float* x, float* grad_w_b, float* workspace,
+                                       int64_t workspace_floats, int64_t N, int64_t R, int64_t J, void* stream) {
+  if (!narrow_ok(N, R, J)) return MLGNN_E_SHAPE;
+  if (!grad_w_b || !workspace) return MLGNN_E_NULL;
+  if (N > 0 && (!grad_out || !x)) return MLGNN_E_NULL;
+  if (workspace_floats < mlgnn_narrow_linear_bwd_workspace_floats(R, J)) return MLGNN_E_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(grad_out) & 15) != 0) return MLGNN_E_ALIGN;
+  const int64_t units = N * (J / 4);
+  hipStream_t s = (hipStream_t)stream;
+  MLGNN_NARROW_LPR(J, MLGNN_R_SWITCH((int)R, hipLaunchKernelGGL((narrow_linear_bwd_kernel<L, RR>), dim3(kNarrowBlocks), dim3(256),
+                   0, s, reinterpret_cast<const float4*>(grad_out), x, workspace, units);))
+  const int err = (int)hipGetLastError();
+  if (err) return err;
+  launch_reduce_partials(workspace, grad_w_b, kNarrowBlocks, (int)(J * (R + 1)), s);
   return (int)hipGetLastError();
 }

@@ -32,9 +32,9 @@ SIGNATURES = {
     "mlgnn_table_grad_bytes": (_I64, [_I64, _I64]),
     "mlgnn_table_grad_begin": (_INT, [_P, _I64, _I64, _P, _P]),
     "mlgnn_table_grad_finish": (_INT, [_P, _P, _I64, _I64, _INT, _P]),
-    "mlgnn_segment_project_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P]),
+    "mlgnn_segment_project_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_segment_project_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                         _I64, _I64, _I64, _I64, _I64, _INT, _P]),
+                                         _I64, _I64, _I64, _I64, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_layernorm_bwd_workspace_floats": (_I64, [_I64, _I64, _INT]),
     "mlgnn_layernorm_act_fwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I64, _I64, _F, _INT, _INT, _P]),
     "mlgnn_layernorm_act_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _F, _I64, _I64, _INT, _INT, _P]),
@@ -79,7 +79,11 @@ SIGNATURES = {
     "mlgnn_leaky_relu_bwd": (_INT, [_P, _P, _P, _F, _P, _P, _I64, _I64, _P]),
     "mlgnn_node_embed_fwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "mlgnn_node_embed_bwd": (_INT, [_P, _P, _P, _I64, _I64, _I64, _P]),
-    "mlgnn_stream_copy": (_INT, [_P, _P, _I64, _P]),
+    "mlgnn_narrow_linear_supported": (_INT, [_I64, _I64, _I64]),
+    "mlgnn_narrow_linear_bwd_workspace_floats": (_I64, [_I64, _I64]),
+    "mlgnn_narrow_linear_fwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "mlgnn_narrow_linear_bwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_stream_copy": (_INT, [_P, _P, _I64, _INT, _P]),
     "mlgnn_gemm_bf16_nt_workgroups": (_INT, [_I64, _I64, _INT]),
     "mlgnn_gemm_bf16_nt": (_INT, [_c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64),
                                   _INT, _I64, _I64, _INT, _P, _P, _I64, _INT, _P, _I64, _P, _I64, _INT, _F,

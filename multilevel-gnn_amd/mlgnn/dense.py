@@ -498,10 +498,54 @@ class _WideLinearF32(torch.autograd.Function):
 WIDE_F32 = os.environ.get("MLGNN_WIDE_F32", "1") != "0"
 
 
+class _NarrowLinear(torch.autograd.Function):
+    """``y = x W^T + b`` for tall fp32 rows with 1..8 input columns (the node encoder ``Linear(3, hidden)``,
+    deepergcn.py:199-210): forward and weight / bias gradient as single streams over the ``[N, J]`` tensor
+    (``mlgnn_narrow_linear_fwd`` / ``_bwd``, csrc/sage.hip).  The input gradient (the raw node features are data; asked
+    for only by attribution tools) is a plain product."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, w = x.contiguous(), weight.contiguous()
+        N, R = x.shape
+        J = w.shape[0]
+        y = torch.empty((N, J), dtype=torch.float32, device=x.device)
+        b = bias.contiguous() if bias is not None else None
+        rc = _lib.lib.mlgnn_narrow_linear_fwd(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), N, R, J,
+                                              torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_narrow_linear_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w = ctx.saved_tensors
+        N, R = x.shape
+        J = w.shape[0]
+        go = _aligned(go)
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            n = int(_lib.lib.mlgnn_narrow_linear_bwd_workspace_floats(R, J))
+            ws = torch.empty(n, dtype=torch.float32, device=x.device)
+            out = torch.empty(J * R + J, dtype=torch.float32, device=x.device)
+            rc = _lib.lib.mlgnn_narrow_linear_bwd(go.data_ptr(), x.data_ptr(), out.data_ptr(), ws.data_ptr(), n, N, R, J,
+                                                  torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "mlgnn_narrow_linear_bwd")
+            gw, gb = out[:J * R].view(J, R), (out[J * R:] if ctx.has_bias else None)
+        gx = go.matmul(w) if ctx.needs_input_grad[0] else None
+        return gx, gw, gb
+
+
 def linear(x, weight, bias=None, residual=None):
     """``nn.Linear`` forward (+ ``residual``: the identity branch of a residual block, added in the GEMM
     epilogue) with the tall-matrix kernels behind it when they apply (2-D fp32 CUDA input, >= 8192 rows,
     <= 32 output tiles of 32x32); ``F.linear`` otherwise."""
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+            and x.shape[0] >= WGRAD_MIN_ROWS and x.shape[1] <= 8
+            and _lib.lib.mlgnn_narrow_linear_supported(x.shape[0], x.shape[1], weight.shape[0])):
+        out = _NarrowLinear.apply(x, weight, bias)
+        return out if residual is None else out + residual
     if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS
             and x.is_contiguous() and torch.is_grad_enabled()
             and _lib.lib.mlgnn_linear_wgrad_workspace_floats(x.shape[0], weight.shape[0], weight.shape[1], 0) > 0):

@@ -68,7 +68,7 @@ def membership_tables(gene_pca_match, raw_indice, nodes_per_graph, n_segments, n
 
 class _SegmentProject(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, tables):
+    def forward(ctx, x, w, tables, n_groups=0):
         # rows in the model's storage type (fp32 or bf16: the kernels accumulate in fp32 either way and round once at
         # the store); the projection weights and their gradient partials stay fp32
         if x.dtype == torch.bfloat16:
@@ -87,9 +87,11 @@ class _SegmentProject(torch.autograd.Function):
         out_t = torch.empty((tables.B * tables.S, K, C), dtype=x.dtype, device=x.device)
         rc = _lib.lib.mlgnn_segment_project_fwd(
             x.data_ptr(), w.data_ptr(), tables.seg_ptr.data_ptr(), _lib.ptr(tables.seg_mem),
-            tables.mem_row.data_ptr(), out_t.data_ptr(), tables.B * tables.S, C, G, K, dt, _stream())
+            tables.mem_row.data_ptr(), out_t.data_ptr(), tables.B * tables.S, C, G, K, tables.S, int(n_groups), dt,
+            _stream())
         _lib.check(rc, "mlgnn_segment_project_fwd")
         ctx.tables = tables
+        ctx.n_groups = int(n_groups)
         ctx.dt = dt
         ctx.save_for_backward(x, w)
         return out_t
@@ -106,25 +108,30 @@ class _SegmentProject(torch.autograd.Function):
         rc = _lib.lib.mlgnn_segment_project_bwd(
             gout_t.data_ptr(), x.data_ptr(), w.data_ptr(), t.seg_ptr.data_ptr(), _lib.ptr(t.seg_mem),
             t.mem_row.data_ptr(), t.mem_seg.data_ptr(), t.node_ptr.data_ptr(), _lib.ptr(t.node_mem),
-            _lib.ptr(gx), _lib.ptr(gwp), t.B * t.S, R, C, G, K, ctx.dt, _stream())
+            _lib.ptr(gx), _lib.ptr(gwp), t.B * t.S, R, C, G, K, t.S, ctx.n_groups, ctx.dt, _stream())
         _lib.check(rc, "mlgnn_segment_project_bwd")
         gw = gwp.reshape(t.B, G, K).sum(0).to(ctx.w_dtype) if gwp is not None else None
-        return gx, gw, None
+        return gx, gw, None, None
 
 
 def segment_project(x_nodes, gene_pca_match, raw_indice, weights, nodes_per_graph, n_segments,
-                    match_mask=True):
+                    match_mask=True, pooled_groups=0):
     """``x_nodes [B*NN, C]`` -> ``[B, C, n_segments, k]``; ``weights [G, k]`` already carries the
     info mask.  ``match_mask=False`` wraps a negative ``match`` exactly as the reference's advanced
-    indexing does."""
+    indexing does.  ``pooled_groups = NG > 0``: the same numbers as the contiguous batch of pathway graphs
+    ``[B * NG * k, n_segments / NG, C]`` -- what ``out.reshape(B, C, n_segments / NG, NG * k).permute(0, 3, 2, 1)
+    .reshape(-1, n_segments / NG, C)`` (vae.py:238-243) yields, written by the kernel in that order (no transposing
+    copy of the result or of its gradient)."""
     B = gene_pca_match.shape[0]
     tables = membership_tables(gene_pca_match, raw_indice, nodes_per_graph, n_segments, x_nodes.shape[0],
                                match_mask)
     C_in = x_nodes.shape[1]
     if x_nodes.dtype == torch.bfloat16 and C_in % 8 != 0 and C_in > 64:
         # (a bf16 width the 16-byte path does not take and the scalar weight-gradient kernel does not cover: fp32 rows)
-        out_t = _SegmentProject.apply(x_nodes.float(), weights.float(), tables).to(torch.bfloat16)
+        out_t = _SegmentProject.apply(x_nodes.float(), weights.float(), tables, int(pooled_groups)).to(torch.bfloat16)
     else:
-        out_t = _SegmentProject.apply(x_nodes, weights, tables)      # [B*S, k, C], in the storage type of x_nodes
+        out_t = _SegmentProject.apply(x_nodes, weights, tables, int(pooled_groups))   # [B*S, k, C], storage type of x_nodes
     k, C = out_t.shape[1], out_t.shape[2]
+    if pooled_groups:
+        return out_t.reshape(B * pooled_groups * k, n_segments // pooled_groups, C)
     return out_t.reshape(B, n_segments, k, C).permute(0, 3, 1, 2)    # [B, C, S, k]

@@ -129,11 +129,11 @@ class ThreeLevelGNN(nn.Module):
         h = y
         # level 1: gene -> pathway projection pooling (multilevel_gnn.py:212-242)
         B = batch.gene_pca_match.shape[0]
-        p = segment_project(h, batch.gene_pca_match, batch.raw_indice, self.learnable_pca_params,
-                            batch.nodes_per_graph, N_PATHWAYS * N_GROUPS, match_mask=True)
-        p = p.reshape(B, self.hidden, N_PATHWAYS, N_GROUPS * self.pca_dim)
-        # levels 2-3: DiffPool over the pathway graph (vae.py:238-243)
-        z = p.permute(0, 3, 2, 1).reshape(-1, N_PATHWAYS, self.hidden)
+        # levels 2-3: DiffPool over the pathway graph (vae.py:238-243): the projection writes the batch of pathway graphs
+        # [B * groups * k, 146, hidden] -- p.reshape(B, hidden, 146, groups * k).permute(0, 3, 2, 1).reshape(-1, 146,
+        # hidden) of the reference's [B, C, 438, k] result -- directly
+        z = segment_project(h, batch.gene_pca_match, batch.raw_indice, self.learnable_pca_params,
+                            batch.nodes_per_graph, N_PATHWAYS * N_GROUPS, match_mask=True, pooled_groups=N_GROUPS)
         z, link, ent = self.diff_pooling(z, self.pathway_adj)
         return F.softmax(self.head(z.reshape(B, -1)), dim=-1), link, ent
 

@@ -337,6 +337,7 @@ def test_bf16_parameter_copies_are_never_stale():
     ``p.data.copy_`` as the reference's utils/optim.py (RAdam, AdamW) does -- and after a storage change."""
     from mlgnn.norm import layer_norm_act
     from mlgnn import ops
+    DEV = "cuda:0"
     g = torch.Generator(device=DEV).manual_seed(4)
     x = torch.randn(9000, 256, device=DEV, generator=g).to(torch.bfloat16)
     ln = torch.nn.LayerNorm(256).to(DEV).to(torch.bfloat16)

@@ -82,3 +82,57 @@ def test_bf16_storage_is_the_fp32_kernel_rounded_once(C, K):
         assert float((got != ref.bfloat16()).float().mean()) < 1e-3
     assert gw16.dtype == torch.float32
     assert float((gw16 - gw32).abs().max()) <= 2e-6 * float(gw32.abs().max())
+
+
+@pytest.mark.parametrize("C,K,NG", [(128, 2, 3), (32, 3, 3), (64, 1, 2)])
+def test_pooled_layout_is_the_permuted_result(C, K, NG):
+    """``pooled_groups = NG``: the kernels write (and read, backwards) the batch of pathway graphs ``[B * NG * K, S / NG,
+    C]`` directly -- bit for bit the plain ``[B, C, S, K]`` result taken through the reference's ``reshape(B, C, S / NG,
+    NG * K).permute(0, 3, 2, 1).reshape(-1, S / NG, C)`` (models/vae.py:238-243), and the same gradients."""
+    from mlgnn.project import segment_project
+    gen = torch.Generator().manual_seed(C + K + NG)
+    dev = "cuda:0"
+    B, NN, G, S = 4, 300, 2500, 146 * NG
+    x = torch.randn(B * NN, C, generator=gen).to(dev)
+    w = (torch.randn(G, K, generator=gen) * 0.3).to(dev)
+    match = torch.randint(0, NN, (B, G), generator=gen)
+    match[:, ::11] = -1
+    seg = torch.sort(torch.randint(0, S, (B, G), generator=gen), dim=1)[0]
+    match, seg = match.to(dev), seg.to(dev)
+    cot = torch.randn(B * NG * K, S // NG, C, generator=gen).to(dev)
+
+    def run(pooled):
+        xd, wd = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        out = segment_project(xd, match, seg, wd, NN, S, True, pooled_groups=NG if pooled else 0)
+        if not pooled:
+            out = out.reshape(B, C, S // NG, NG * K).permute(0, 3, 2, 1).reshape(-1, S // NG, C)
+        gx, gw = torch.autograd.grad((out * cot).sum(), [xd, wd])
+        return out.detach(), gx, gw
+
+    o1, gx1, gw1 = run(True)
+    o0, gx0, gw0 = run(False)
+    assert o1.is_contiguous() and tuple(o1.shape) == (B * NG * K, S // NG, C)
+    assert torch.equal(o1, o0) and torch.equal(gx1, gx0) and torch.equal(gw1, gw0)
+
+
+def test_input_gradient_rows_with_many_and_no_members():
+    """The multi-row input-gradient walk (4 rows per lane group in flight): nodes without a membership, nodes with one,
+    and one node that 300 memberships point at, next to each other; the last rows of the table do not fill a unit."""
+    from mlgnn.project import segment_project
+    gen = torch.Generator().manual_seed(9)
+    dev = "cuda:0"
+    B, NN, G, S, C, K = 2, 1003, 3000, 438, 128, 2
+    match = torch.randint(0, NN, (B, G), generator=gen)
+    match[:, :300] = 17
+    match[:, 300:900] = torch.arange(600) % 40 + 500          # rows 500..539 with 15 members each; most others 0..3
+    seg = torch.sort(torch.randint(0, S, (B, G), generator=gen), dim=1)[0]
+    x = torch.randn(B * NN, C, generator=gen, requires_grad=True)
+    w = (torch.randn(G, K, generator=gen) * 0.3).requires_grad_(True)
+    cot = torch.randn(B, C, S, K, generator=gen)
+    ref = M.projection_pool(x, match, seg, w, None, NN, S, True)
+    gx_ref, gw_ref = torch.autograd.grad((ref * cot).sum(), [x, w])
+    xd, wd = x.detach().to(dev).requires_grad_(True), w.detach().to(dev).requires_grad_(True)
+    out = segment_project(xd, match.to(dev), seg.to(dev), wd, NN, S, True)
+    gx, gw = torch.autograd.grad((out * cot.to(dev)).sum(), [xd, wd])
+    assert_close(gx, gx_ref, 1e-4, "grad x", elementwise=True)
+    assert_close(gw, gw_ref, 1e-4, "grad w")

@@ -724,6 +724,17 @@ int mlgnn_sage_rewrite(const int64_t* edge_index, const float* edge_attr, int64_
                        int64_t* out_edge_index, float* out_weight, void* stream);
 
 /*
+ * CSR (both orderings) of `copies` block-diagonal copies of ONE graph with N nodes and E edges, from that graph's CSR:
+ * node ids shifted by b N, edge positions by b E (copy b's edges are COO positions [b E, (b + 1) E) of the batch, as a
+ * PyG collate concatenates them).  Bit for bit what mlgnn_coo_to_csr builds from the batched edge list, in one stream.
+ * For the fold-constant topology every sample of a TCGA batch shares (dataloader/multiloader.py:687-691).
+ */
+int mlgnn_csr_replicate(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const int32_t* rowptr_t,
+                        const int32_t* col_t, const int32_t* pos_t, const int32_t* eid_t, int32_t* out_rowptr,
+                        int32_t* out_col, int32_t* out_eid, int32_t* out_rowptr_t, int32_t* out_col_t, int32_t* out_pos_t,
+                        int32_t* out_eid_t, int64_t N, int64_t E, int64_t copies, void* stream);
+
+/*
  * SAGE update of one graph layer in ONE product (fp32):
  *     c [N,J] = leaky_relu([a | a2] * Bt^T + bias, act_slope) * row_scale[row]
  * a [N,R1], a2 [N,R2]: two column blocks of the left operand in tensors of their own (the node features and their

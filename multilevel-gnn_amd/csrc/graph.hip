@@ -466,6 +466,58 @@ extern "C" int mlgnn_sage_rewrite(const int64_t* edge_index, const float* edge_a
   return (int)hipGetLastError();
 }
 
+// B block-diagonal copies of one graph (the fold-constant gene network every sample of a TCGA batch carries,
+// dataloader/multiloader.py:687-691): the CSR of the batch IS the CSR of the single graph with node ids shifted by b n and
+// edge positions by b e -- the stable orderings are preserved copy by copy -- so it is written in one stream instead of
+// being sorted out of the B-fold edge list again.
+namespace mlgnn {
+__global__ __launch_bounds__(256) void csr_replicate_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                           const int* __restrict__ eid, const int* __restrict__ rowptr_t,
+                                                           const int* __restrict__ col_t, const int* __restrict__ pos_t,
+                                                           const int* __restrict__ eid_t, int* __restrict__ o_rowptr,
+                                                           int* __restrict__ o_col, int* __restrict__ o_eid,
+                                                           int* __restrict__ o_rowptr_t, int* __restrict__ o_col_t,
+                                                           int* __restrict__ o_pos_t, int* __restrict__ o_eid_t, int n, int e,
+                                                           int copies) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t total_e = (int64_t)copies * e, total_n = (int64_t)copies * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_e + total_n + 1; i += stride) {
+    if (i < total_e) {
+      const int b = (int)(i / e), k = (int)(i - (int64_t)b * e);
+      o_col[i] = col[k] + b * n;
+      o_eid[i] = eid[k] + b * e;
+      o_col_t[i] = col_t[k] + b * n;
+      o_pos_t[i] = pos_t[k] + b * e;
+      o_eid_t[i] = eid_t[k] + b * e;
+    } else {
+      const int64_t r = i - total_e;                      // 0 .. copies * n
+      const int b = (int)(r / n), k = (int)(r - (int64_t)b * n);
+      // (r = copies * n: b = copies, k = 0 -> rowptr[0] + copies * e = the total)
+      o_rowptr[r] = rowptr[k] + b * e;
+      o_rowptr_t[r] = rowptr_t[k] + b * e;
+    }
+  }
+}
+}  // namespace mlgnn
+
+extern "C" int mlgnn_csr_replicate(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const int32_t* rowptr_t,
+                                   const int32_t* col_t, const int32_t* pos_t, const int32_t* eid_t, int32_t* out_rowptr,
+                                   int32_t* out_col, int32_t* out_eid, int32_t* out_rowptr_t, int32_t* out_col_t,
+                                   int32_t* out_pos_t, int32_t* out_eid_t, int64_t N, int64_t E, int64_t copies,
+                                   void* stream) {
+  if (N <= 0 || E < 0 || copies < 1 || N * copies > INT32_MAX - 1 || E * copies > INT32_MAX) return MLGNN_E_SHAPE;
+  if (!rowptr || !rowptr_t || !out_rowptr || !out_rowptr_t) return MLGNN_E_NULL;
+  if (E > 0 && (!col || !eid || !col_t || !pos_t || !eid_t || !out_col || !out_eid || !out_col_t || !out_pos_t || !out_eid_t))
+    return MLGNN_E_NULL;
+  const int64_t n = (E + N) * copies + 1;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(csr_replicate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, eid,
+                     rowptr_t, col_t, pos_t, eid_t, out_rowptr, out_col, out_eid, out_rowptr_t, out_col_t, out_pos_t,
+                     out_eid_t, (int)N, (int)E, (int)copies);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mlgnn_edge_table_to_csr(const float* attr, int64_t row_stride, int64_t r, int64_t width,
                                        const int32_t* eid, const int32_t* eid_t, float* by_dst, float* by_src,
                                        int64_t E, void* stream) {

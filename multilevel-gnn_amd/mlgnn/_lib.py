@@ -73,6 +73,7 @@ SIGNATURES = {
     "mlgnn_tallgemm_lnbwd_supported": (_INT, [_I64, _I64, _I64]),
     "mlgnn_tallgemm_lnbwd_workspace_bytes": (_I64, [_I64, _I64]),
     "mlgnn_tallgemm_lnbwd": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_csr_replicate": (_INT, [_P] * 14 + [_I64, _I64, _I64, _P]),
     "mlgnn_sage_rewrite": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "mlgnn_tallgemm_dual_supported": (_INT, [_I64, _I64, _I64, _I64]),
     "mlgnn_tallgemm_dual": (_INT, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),

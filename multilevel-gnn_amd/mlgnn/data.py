@@ -41,6 +41,8 @@ class Data:
                 setattr(self, k, v.to(device, non_blocking=non_blocking))
             elif hasattr(v, "to") and k == "csr":
                 setattr(self, k, v.to(device))
+            elif hasattr(v, "to") and k == "shared_topology":
+                setattr(self, k, v.to(device, non_blocking=non_blocking))
         return self
 
 
@@ -79,10 +81,50 @@ class Batch(Data):
         out.batch = torch.repeat_interleave(torch.arange(len(data_list)), torch.tensor(sizes))
         out.ptr = torch.tensor(offsets)
         out.num_graphs = len(data_list)
+        shared = cls._shared_topology(data_list, sizes)
+        if shared is not None:
+            out.shared_topology = shared
         if with_csr:
             from .graph import CSRGraph
             out.csr = CSRGraph(out.edge_index, offsets[-1])
         return out
+
+
+    # ONE topology for every sample (dataloader/multiloader.py:687-691 assigns the same edge list to every patient of a
+    # fold): noticed here, on the loader side, so that the model can take the per-fold CSR instead of sorting the B-fold
+    # edge list of every batch.  Same tensor object in all samples: free; equal contents in different tensors (the
+    # reference builds one tensor per patient): compared once per pair of tensor identities.
+    _EQUAL = {}
+
+    @classmethod
+    def _same(cls, a, b):
+        if a is b:
+            return True
+        if a is None or b is None or a.shape != b.shape or a.dtype != b.dtype:
+            return False
+        key = (id(a), a._version, id(b), b._version)
+        hit = cls._EQUAL.get(key)
+        if hit is None or hit[1]() is not a or hit[2]() is not b:            # (ids can be recycled: weak references pin them)
+            import weakref
+            if len(cls._EQUAL) > 4096:
+                cls._EQUAL.clear()
+            hit = cls._EQUAL[key] = (bool(torch.equal(a, b)), weakref.ref(a), weakref.ref(b))
+        return hit[0]
+
+    @classmethod
+    def _shared_topology(cls, data_list, sizes):
+        d0 = data_list[0]
+        ei0, ea0 = getattr(d0, "edge_index", None), getattr(d0, "edge_attr", None)
+        if not torch.is_tensor(ei0) or ei0.dim() != 2 or len(set(sizes)) != 1 or ei0.shape[1] == 0:
+            return None
+        for d in data_list[1:]:
+            if not cls._same(ei0, getattr(d, "edge_index", None)):
+                return None
+            ea = getattr(d, "edge_attr", None)
+            if (ea0 is None) != (ea is None) or (ea0 is not None and not cls._same(ea0, ea)):
+                return None
+        from .graph import SharedTopology
+        return SharedTopology(ei0, ea0 if torch.is_tensor(ea0) else None, sizes[0], len(data_list))
 
 
 class DataLoader(_TorchLoader):

@@ -12,6 +12,7 @@ import torch
 # rows (in-edges of a node for the forward, out-edges for the backward) longer than this are cut into chunks that
 # run as rows of their own and are combined in order (csrc/hub.hip); 0 disables
 HUB_CAP = int(os.environ.get("MLGNN_HUB_CAP", "256"))
+_SHARED_TOPOLOGY = os.environ.get("MLGNN_SHARED_TOPOLOGY", "1") == "1"      # (0: sort every batch's edge list, for A/B runs)
 
 
 class CSRGraph:
@@ -92,6 +93,34 @@ class CSRGraph:
     @classmethod
     def clear_cache(cls):
         del cls._CACHE[:]
+
+    @classmethod
+    def replicated(cls, single, copies):
+        """``copies`` block-diagonal copies of the device graph ``single`` (``mlgnn_csr_replicate``): bit for bit the CSR
+        of the batched edge list a PyG collate makes of ``copies`` samples that share one topology."""
+        from . import _lib
+        n, e, B = single.num_nodes, single.num_edges, int(copies)
+        if not single.rowptr.is_cuda:
+            raise RuntimeError("replicated() works on device graphs")
+        if single.rowptr.numel() != n + 1:
+            raise ValueError("a graph with a spare row (the device SAGE rewrite) cannot be replicated")
+        g = cls.__new__(cls)
+        g.num_nodes, g.num_edges, g.device = n * B, e * B, single.device
+        i32 = dict(dtype=torch.int32, device=single.device)
+        g.rowptr, g.rowptr_t = torch.empty(n * B + 1, **i32), torch.empty(n * B + 1, **i32)
+        g.col, g.eid = torch.empty(e * B, **i32), torch.empty(e * B, **i32)
+        g.col_t, g.pos_t, g.eid_t = torch.empty(e * B, **i32), torch.empty(e * B, **i32), torch.empty(e * B, **i32)
+        rc = _lib.lib.mlgnn_csr_replicate(single.rowptr.data_ptr(), _lib.ptr(single.col), _lib.ptr(single.eid),
+                                          single.rowptr_t.data_ptr(), _lib.ptr(single.col_t), _lib.ptr(single.pos_t),
+                                          _lib.ptr(single.eid_t), g.rowptr.data_ptr(), _lib.ptr(g.col), _lib.ptr(g.eid),
+                                          g.rowptr_t.data_ptr(), _lib.ptr(g.col_t), _lib.ptr(g.pos_t), _lib.ptr(g.eid_t),
+                                          n, e, B, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_csr_replicate")
+        g._deg, g._scalar_cache, g._table_cache, g._hub = None, None, None, {}
+        ev = torch.cuda.Event()
+        ev.record()
+        g._built = (ev, torch.cuda.current_stream(single.device))
+        return g
 
     def _ordered_after_build(self):
         """A cached graph handed to a stream other than the one its build was enqueued on: that stream waits for the
@@ -321,13 +350,69 @@ def _sage_graph_device(edge_index, edge_attr, num_nodes):
     return graph, weight
 
 
-def sage_graph(edge_index, edge_attr, num_nodes):
+class SharedTopology:
+    """ONE topology carried by every sample of a batch (the reference's loader gives all patients of a fold the same gene
+    network, dataloader/multiloader.py:687-691; ``mlgnn.data.Batch.from_data_list`` notices and attaches this object as
+    ``batch.shared_topology``): ``edge_index [2, e]`` / ``edge_attr`` of ONE sample (not offset), ``nodes`` per sample,
+    ``copies`` samples.  ``key``: the loader-side tensors the device copies were made from -- the identity the per-fold
+    caches go by, since the device copies are new tensors in every batch."""
+
+    def __init__(self, edge_index, edge_attr, nodes, copies, key=None):
+        self.edge_index, self.edge_attr, self.nodes, self.copies = edge_index, edge_attr, int(nodes), int(copies)
+        self.key = key if key is not None else (edge_index, edge_attr)
+
+    def to(self, device, non_blocking=False):
+        ea = self.edge_attr.to(device, non_blocking=non_blocking) if self.edge_attr is not None else None
+        return SharedTopology(self.edge_index.to(device, non_blocking=non_blocking), ea, self.nodes, self.copies, self.key)
+
+
+_SHARED_SAGE_CACHE = []      # [(key tensors, versions, nodes, copies, device, with_attr, graph, weight)], most recent first
+
+
+def shared_sage_graph(shared, device, use_attr=True):
+    """SAGEConv's (self-loop rewritten) topology + weights for a batch of ``shared.copies`` samples of ONE graph: the
+    single graph is rewritten and sorted once per fold (exact compaction, host-style: one synchronisation, once), the batch
+    CSR is its replication (one kernel) -- and both are kept, so a training loop pays NO topology work per step
+    (the 10 launches / 0.5 ms of sorting the 64-fold edge list at config/kirc.yaml shape)."""
+    k_ei, k_ea = shared.key
+    if not use_attr:
+        k_ea = None
+    vers = (k_ei._version, k_ea._version if k_ea is not None else -1)
+    dev = torch.device(device)
+    for i, ent in enumerate(_SHARED_SAGE_CACHE):
+        if ent[0][0] is k_ei and ent[0][1] is k_ea and ent[1] == vers and ent[2:6] == (shared.nodes, shared.copies, dev,
+                                                                                        bool(use_attr)):
+            _SHARED_SAGE_CACHE.insert(0, _SHARED_SAGE_CACHE.pop(i))
+            return ent[6]._ordered_after_build(), ent[7]
+    n, B = shared.nodes, shared.copies
+    ei = shared.edge_index.to(dev)
+    keep = ei[0] != ei[1]
+    loops = torch.arange(n, dtype=ei.dtype, device=dev)
+    ei1 = torch.cat([ei[:, keep], loops.unsqueeze(0).expand(2, -1)], dim=1)
+    single = CSRGraph(ei1, n)
+    graph = CSRGraph.replicated(single, B)
+    weight = None
+    if use_attr and shared.edge_attr is not None:
+        ea = shared.edge_attr.to(dev).reshape(shared.edge_attr.shape[0], -1)
+        if ea.shape[1] != 1:
+            raise ValueError("SAGE edge weights must be scalar per edge")
+        w1 = torch.cat([ea[keep, 0].to(torch.float32), torch.ones(n, device=dev)])
+        weight = w1.repeat(B)
+    _SHARED_SAGE_CACHE.insert(0, ((k_ei, k_ea), vers, n, B, dev, bool(use_attr), graph, weight))
+    del _SHARED_SAGE_CACHE[4:]
+    return graph, weight
+
+
+def sage_graph(edge_index, edge_attr, num_nodes, shared=None):
     """Topology + weights SAGEConv propagates over (torch_vertex.py:272-273): existing self loops
     dropped, one self loop of weight 1.0 appended per node.  The layers of one forward pass hand in
     the very same tensors, so the last result is kept (identity + version checked; the cache holds
     the tensors, so their storage cannot be recycled under it)."""
     if isinstance(edge_index, CSRGraph):
         raise TypeError("SAGEConv rewrites self loops: pass the COO edge_index")
+    if (shared is not None and _SHARED_TOPOLOGY and edge_index.is_cuda and shared.nodes * shared.copies == num_nodes
+            and shared.edge_index.shape[1] * shared.copies == edge_index.shape[1]):
+        return shared_sage_graph(shared, edge_index.device, use_attr=edge_attr is not None)
     ea_v = None if edge_attr is None else edge_attr._version
     for ent in _SAGE_CACHE:
         if ent[0] is edge_index and ent[1] is edge_attr and ent[2] == num_nodes and \

@@ -131,13 +131,14 @@ class SAGEConv(nn.Module):
             return (0.0,)
         return None
 
-    def forward(self, x, edge_index, size=None, edge_attr=None, row_scale=None):
+    def forward(self, x, edge_index, size=None, edge_attr=None, row_scale=None, shared=None):
         """``row_scale`` [N] or None: the caller's next step is ``out * row_scale[:, None]`` (MultilevelGNN's value mask,
-        multilevel_gnn.py:205-207) -- applied here, in the update's epilogue when the fused layer runs."""
+        multilevel_gnn.py:205-207) -- applied here, in the update's epilogue when the fused layer runs.
+        ``shared``: the batch's :class:`mlgnn.graph.SharedTopology` (every sample carries the same graph) or None."""
         if size is not None:
             raise NotImplementedError("bipartite propagation is outside the accelerated path")
         x = x.unsqueeze(-1) if x.dim() == 1 else x
-        graph, weight = sage_graph(edge_index, edge_attr, x.shape[0])
+        graph, weight = sage_graph(edge_index, edge_attr, x.shape[0], shared)
         fused = self._fused_update() if _SAGE_FUSED else None
         if fused is not None and (row_scale is None or not row_scale.requires_grad):
             from mlgnn.sage import sage_layer, sage_layer_supported
@@ -184,5 +185,5 @@ class GraphConv(nn.Module):
         else:
             raise NotImplementedError('conv {} is not implemented'.format(conv))
 
-    def forward(self, x, edge_index, edge_attr=None, row_scale=None):
-        return self.gconv(x, edge_index, edge_attr=edge_attr, row_scale=row_scale)
+    def forward(self, x, edge_index, edge_attr=None, row_scale=None, shared=None):
+        return self.gconv(x, edge_index, edge_attr=edge_attr, row_scale=row_scale, shared=shared)

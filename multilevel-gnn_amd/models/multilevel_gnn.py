@@ -192,6 +192,8 @@ class MultilevelGNN(nn.Module):
             # NOTE: the reference slices edge_attr on dim 1 (:164), a no-op for [E,1] attributes at
             # device_num=1; the row slice above is the evident intent and identical there.
 
+            # every sample carries the same gene network (multiloader.py:687-691): the loader's collate says so
+            shared = getattr(input_batch, "shared_topology", None) if args.device_num == 1 else None
             feats = []
             last = len(self.gnn_model) - 1
             # the value mask behind the last layer (:205-207) rides that layer's epilogue
@@ -199,14 +201,14 @@ class MultilevelGNN(nn.Module):
                              and last >= 0 and not mask_x.requires_grad)
             for i, layer in enumerate(self.gnn_model):
                 if args.dense_gnn:
-                    x = layer(x, edge_index, edge_attr)
+                    x = layer(x, edge_index, edge_attr, shared=shared)
                     feats.append(x)
                 elif args.resgnn:
-                    x = layer(x, edge_index, edge_attr) + x
+                    x = layer(x, edge_index, edge_attr, shared=shared) + x
                 elif mask_in_layer and i == last:
-                    x = layer(x, edge_index, edge_attr, row_scale=mask_x.reshape(-1))
+                    x = layer(x, edge_index, edge_attr, row_scale=mask_x.reshape(-1), shared=shared)
                 else:
-                    x = layer(x, edge_index, edge_attr)
+                    x = layer(x, edge_index, edge_attr, shared=shared)
                 if i != last and args.repeat_mask and (i + 1) % args.repeat_cyclic == 0:
                     if args.repeat_norm:
                         x = x / (x ** 2).sum(1).sqrt()[:, None]

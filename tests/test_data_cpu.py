@@ -58,3 +58,25 @@ def test_harness_options_follow_the_reference_yaml():
     a = th.parse_opts(["--config", cfg, "--epochs", "2"])
     assert a.epochs == 2                               # explicit CLI flag kept
     assert a.batch_size == 32 and a.gnn_name == "sage" and a.hidden_channels == 64 and a.weight_balance is True
+
+
+def test_collate_notices_a_topology_shared_by_all_samples():
+    """The reference's loader gives every patient of a fold the same edge list (dataloader/multiloader.py:687-691): the
+    collate attaches ``shared_topology`` (one sample's edge list, nodes per sample, copies) -- whether the samples hold the
+    same tensor object or equal tensors of their own -- and does not when any sample differs."""
+    from mlgnn.data import Batch, SyntheticTCGA
+    ds = SyntheticTCGA(6, node_num=40, n_edges=300, n_members=200)
+    items = [ds[i] for i in range(4)]
+    b = Batch.from_data_list(items)
+    st = b.shared_topology
+    assert st.copies == 4 and st.nodes == 120 and st.edge_index is ds.edge_index and st.edge_attr is ds.edge_attr
+    assert torch.equal(b.edge_index, torch.cat([ds.edge_index + 120 * k for k in range(4)], dim=1))
+    for it in items:                                        # equal contents in tensors of their own (the reference's way)
+        it.edge_index, it.edge_attr = it.edge_index.clone(), it.edge_attr.clone()
+    assert Batch.from_data_list(items).shared_topology.copies == 4
+    items[2].edge_index = items[2].edge_index.clone()
+    items[2].edge_index[0, 5] += 1
+    assert not hasattr(Batch.from_data_list(items), "shared_topology")
+    items[2] = ds[2]
+    items[1].edge_attr = items[1].edge_attr + 1.0
+    assert not hasattr(Batch.from_data_list(items), "shared_topology")

@@ -111,3 +111,58 @@ def test_edge_table_one_column_tail():
     by_dst, by_src = g.edge_table(attr.cuda(), 1)
     assert torch.equal(by_dst.cpu(), attr[g.eid.cpu().long()])
     assert torch.equal(by_src.cpu(), attr[g.eid_t.cpu().long()])
+
+
+def test_replicated_graph_is_the_graph_of_the_batched_edge_list():
+    """``CSRGraph.replicated(single, B)`` (mlgnn_csr_replicate) against the CSR built from the B-fold block-diagonal edge
+    list: every array bit for bit (both orderings are stable, copy by copy)."""
+    import torch
+    from mlgnn import CSRGraph
+    gen = torch.Generator().manual_seed(12)
+    n, e, B = 1234, 9000, 7
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)])
+    ei[1, :400] = 5                                           # a long row
+    dev = "cuda:0"
+    single = CSRGraph(ei.to(dev), n)
+    rep = CSRGraph.replicated(single, B)
+    full = CSRGraph(torch.cat([ei + k * n for k in range(B)], dim=1).to(dev), n * B)
+    for name in ("rowptr", "col", "eid", "rowptr_t", "col_t", "pos_t", "eid_t"):
+        assert torch.equal(getattr(rep, name), getattr(full, name)), name
+    assert rep.num_nodes == full.num_nodes and rep.num_edges == full.num_edges
+
+
+def test_shared_topology_gives_the_same_sage_layer():
+    """SAGEConv over a batch whose samples share one graph: through the per-fold CSR (``shared=``) and through the sort of
+    the batched edge list -- same outputs and gradients bit for bit; the second call with the same fold tensors does no
+    topology work at all (cache hit)."""
+    import torch
+    from mlgnn import graph as G
+    from models.gcn_lib.sparse.torch_vertex import GraphConv
+    gen = torch.Generator().manual_seed(13)
+    n, e, B, cin, cout = 3000, 20000, 5, 32, 64
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)])
+    ei[1, :30] = ei[0, :30]                                   # self loops: dropped either way
+    w = torch.rand(e, 1, generator=gen) * 2 - 1
+    dev = "cuda:0"
+    torch.manual_seed(2)
+    conv = GraphConv(cin, cout, conv="sage", act="leakyrelu", mlp_norm="none").to(dev)
+    x = torch.randn(B * n, cin, generator=gen).to(dev)
+    ei_b = torch.cat([ei + k * n for k in range(B)], dim=1).to(dev)
+    w_b = w.repeat(B, 1).to(dev)
+    cot = torch.randn(B * n, cout, generator=gen).to(dev)
+    shared = G.SharedTopology(ei.to(dev), w.to(dev), n, B)
+
+    def run(sh):
+        for p in conv.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        out = conv(xg, ei_b, w_b, shared=sh)
+        (out * cot).sum().backward()
+        return out.detach(), xg.grad, [p.grad.clone() for p in conv.parameters() if p.grad is not None]
+
+    o0, gx0, gp0 = run(None)
+    o1, gx1, gp1 = run(shared)
+    assert torch.equal(o0, o1) and torch.equal(gx0, gx1) and all(torch.equal(a, b) for a, b in zip(gp0, gp1))
+    g_first = G.shared_sage_graph(shared, dev)[0]
+    assert G.shared_sage_graph(shared, dev)[0] is g_first      # per-fold cache: no work the second time
+    assert g_first.num_nodes == B * n

@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of FlatAdam")
+    ap.add_argument("--no-shared-topology", action="store_true",
+                    help="withhold the collate's note that every sample carries the same gene network (the per-fold CSR "
+                         "is then not used: every step sorts the batch's edge list)")
     ap.add_argument("--json")
     a = ap.parse_args()
     from mlgnn.optim import FlatAdam
@@ -66,6 +69,11 @@ def main():
     batch = SimpleNamespace(x=torch.rand(B * NN, 1, device=dev), edge_index=ei, edge_attr=w.repeat(B, 1).to(dev),
                             gene_pca_match=match[None].repeat(B, 1).to(dev), raw_indice=seg[None].repeat(B, 1).to(dev),
                             age=torch.rand(B, device=dev))
+    if not a.no_shared_topology:
+        # what mlgnn.data.Batch.from_data_list attaches when all samples of the batch carry one topology (the reference's
+        # loader gives every patient of a fold the same gene network, dataloader/multiloader.py:687-691)
+        from mlgnn.graph import SharedTopology
+        batch.shared_topology = SharedTopology(torch.stack([src, dst]).to(dev), w.to(dev), NN, B)
     y = torch.nn.functional.one_hot(torch.randint(0, 2, (B,), device=dev), 2).float()
     if a.torch_adam:
         opt = torch.optim.Adam(model.parameters(), lr=5e-5)
@@ -103,7 +111,7 @@ def main():
                        "G=25015 memberships, embedding %d -> 64 -> 32, pca_dim=%d, head_dim=%d; synthetic data; step = fwd + "
                        "loss + bwd + clip(20) + Adam (%s)" % (a.shape, B, args.node_embedding_dim, args.pca_dim,
                                                                args.head_dim, "torch.optim" if a.torch_adam else "FlatAdam"),
-           "shape": a.shape, "batch": B, "steps": a.steps, "ms_per_step": dt * 1e3, "graphs_per_s": B / dt,
+           "shape": a.shape, "batch": B, "steps": a.steps, "shared_topology": not a.no_shared_topology, "ms_per_step": dt * 1e3, "graphs_per_s": B / dt,
            "final_loss": float(loss.detach()), "params": sum(p.numel() for p in model.parameters())}
     print(json.dumps(out), flush=True)
     if a.json:

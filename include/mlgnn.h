@@ -790,6 +790,20 @@ int mlgnn_narrow_linear_bwd(const float* grad_out, const float* x, float* grad_w
                             int64_t workspace_floats, int64_t N, int64_t R, int64_t J, void* stream);
 
 /*
+ * Linear over a handful of rows with a very long input (fp32): y [M,J] = x [M,K] w[J,K]^T + bias, M <= 64, K % 4 == 0 --
+ * the first layer of MultilevelGNN's head (models/multilevel_gnn.py:121-127; config/kirc.yaml: Linear(84 096, 512) on
+ * 64 samples).  Every product of the layer is one stream over the weight (172 MB there): forward with fixed-order
+ * partial sums over K ranges (workspace: mlgnn_skinny_linear_fwd_workspace_floats), backward = grad_x [M,K] (NULL:
+ * skipped), grad_w [J,K] (NULL: skipped) and grad_b [J] (NULL: skipped), each written once.  Plain fp32 FMA arithmetic.
+ */
+int mlgnn_skinny_linear_supported(int64_t M, int64_t J, int64_t K);
+int64_t mlgnn_skinny_linear_fwd_workspace_floats(int64_t M, int64_t J, int64_t K);
+int mlgnn_skinny_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* workspace,
+                            int64_t workspace_floats, int64_t M, int64_t J, int64_t K, void* stream);
+int mlgnn_skinny_linear_bwd(const float* grad_out, const float* x, const float* w, float* grad_x, float* grad_w,
+                            float* grad_b, int64_t M, int64_t J, int64_t K, void* stream);
+
+/*
  * Measurement aid (bench.py: the box's streaming ceiling next to the 8 TB/s spec peak): dst = src, 16 bytes per lane,
  * non_temporal != 0: non-temporal loads and stores.  bytes a multiple of 16, 16-byte aligned pointers.
  */

@@ -254,6 +254,25 @@ __global__ __launch_bounds__((tg_block<JT, LN>())) void tallgemm_kernel(const Tg
     float m = 0.f;
     if (p.rowmax) {                                             // the producer of A already knows max |row|
       m = XT ? m_ahead : p.rowmax[arow];
+    } else if constexpr (DUAL) {
+      // (nobody hands the SAGE update its operands' row maxima: up to 8 k-steps -- 16 independent 16-byte loads per
+      // lane -- are requested before the first is looked at; two at a time left this pass latency-bound: a 32-row tile
+      // then cost four memory round trips before its first MFMA, 250 us for 0.63 GB at config/kirc.yaml shape)
+      constexpr int CH = KS < 8 ? KS : 8;
+#pragma unroll
+      for (int s0 = 0; s0 < KS; s0 += CH) {
+        float4 q0[CH], q1[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          q0[i] = *reinterpret_cast<const float4*>(kstep(s0 + i));
+          q1[i] = *reinterpret_cast<const float4*>(kstep(s0 + i) + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(q0[i].x), fabsf(q0[i].y)), fmaxf(fabsf(q0[i].z), fabsf(q0[i].w))),
+                             fmaxf(fmaxf(fabsf(q1[i].x), fabsf(q1[i].y)), fmaxf(fabsf(q1[i].z), fabsf(q1[i].w)))));
+      }
+      m = fmaxf(m, __shfl_xor(m, 32));
     } else {
 #pragma unroll 2
       for (int s = 0; s < KS; ++s) {

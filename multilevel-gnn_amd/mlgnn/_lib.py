@@ -84,6 +84,10 @@ SIGNATURES = {
     "mlgnn_narrow_linear_bwd_workspace_floats": (_I64, [_I64, _I64]),
     "mlgnn_narrow_linear_fwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "mlgnn_narrow_linear_bwd": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_skinny_linear_supported": (_INT, [_I64, _I64, _I64]),
+    "mlgnn_skinny_linear_fwd_workspace_floats": (_I64, [_I64, _I64, _I64]),
+    "mlgnn_skinny_linear_fwd": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_skinny_linear_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "mlgnn_stream_copy": (_INT, [_P, _P, _I64, _INT, _P]),
     "mlgnn_gemm_bf16_nt_workgroups": (_INT, [_I64, _I64, _INT]),
     "mlgnn_gemm_bf16_nt": (_INT, [_c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64),

@@ -496,6 +496,55 @@ class _WideLinearF32(torch.autograd.Function):
 
 
 WIDE_F32 = os.environ.get("MLGNN_WIDE_F32", "1") != "0"
+SKINNY_MIN_K = 8192            # below this the weight is a few MB and the library's GEMM is not a stream problem
+
+
+class _SkinnyLinear(torch.autograd.Function):
+    """``y = x W^T + b`` for at most 64 rows with a very long input (the first Linear of MultilevelGNN's head,
+    multilevel_gnn.py:121-127: ``[B, 84 096] -> 512`` at config/kirc.yaml): forward, input gradient and weight gradient as
+    streams over the weight (``mlgnn_skinny_linear_fwd`` / ``_bwd``, csrc/skinny.hip).  The weight gradient is written
+    straight into the parameter's slot of the flat gradient bucket when there is one (``mlgnn.dist.FlatGradBucket``): the
+    172 MB tensor is then not copied again by ``collect()``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, w = _aligned(x), _aligned(weight)
+        M, K = x.shape
+        J = w.shape[0]
+        y = torch.empty((M, J), dtype=torch.float32, device=x.device)
+        n = int(_lib.lib.mlgnn_skinny_linear_fwd_workspace_floats(M, J, K))
+        ws = torch.empty(n, dtype=torch.float32, device=x.device)
+        b = bias.contiguous() if bias is not None else None
+        rc = _lib.lib.mlgnn_skinny_linear_fwd(x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), ws.data_ptr(), n, M, J, K,
+                                              torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_skinny_linear_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.slot, ctx.param = getattr(weight, "_mlgnn_grad_slot", None), weight
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w = ctx.saved_tensors
+        M, K = x.shape
+        J = w.shape[0]
+        go = go.contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            slot = ctx.slot
+            # (only when this backward DEFINES the gradient -- .grad released before the step; a gradient that is being
+            # accumulated into must arrive in memory of its own)
+            if (slot is not None and ctx.param.grad is None and slot.numel() == J * K and slot.dtype == torch.float32
+                    and slot.device == x.device and slot.data_ptr() % 16 == 0):
+                gw = slot.view(J, K)                      # (a fresh alias: autograd adopts it as .grad without a copy)
+            else:
+                gw = torch.empty((J, K), dtype=torch.float32, device=x.device)
+        gb = torch.empty(J, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        rc = _lib.lib.mlgnn_skinny_linear_bwd(go.data_ptr(), x.data_ptr(), w.data_ptr(), _lib.ptr(gx), _lib.ptr(gw),
+                                              _lib.ptr(gb), M, J, K, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mlgnn_skinny_linear_bwd")
+        return gx, gw, gb
 
 
 class _NarrowLinear(torch.autograd.Function):
@@ -541,6 +590,11 @@ def linear(x, weight, bias=None, residual=None):
     """``nn.Linear`` forward (+ ``residual``: the identity branch of a residual block, added in the GEMM
     epilogue) with the tall-matrix kernels behind it when they apply (2-D fp32 CUDA input, >= 8192 rows,
     <= 32 output tiles of 32x32); ``F.linear`` otherwise."""
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+            and x.shape[1] >= SKINNY_MIN_K and torch.is_grad_enabled()
+            and _lib.lib.mlgnn_skinny_linear_supported(x.shape[0], weight.shape[0], x.shape[1])):
+        out = _SkinnyLinear.apply(x, weight, bias)
+        return out if residual is None else out + residual
     if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
             and x.shape[0] >= WGRAD_MIN_ROWS and x.shape[1] <= 8
             and _lib.lib.mlgnn_narrow_linear_supported(x.shape[0], x.shape[1], weight.shape[0])):

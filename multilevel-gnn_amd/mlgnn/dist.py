@@ -54,6 +54,10 @@ class FlatGradBucket:
         for p, off in zip(self.params, self.offsets):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             self.views.append(p.grad)
+            # a backward that produces this parameter's whole gradient in one kernel may write it here directly and hand
+            # autograd an alias (mlgnn.dense._SkinnyLinear: the 172 MB head weight at config/kirc.yaml) -- collect() then
+            # finds the gradient already in place
+            p._mlgnn_grad_slot = self.flat[off:off + p.numel()]
 
     # Two ways to fill the bucket.  (a) zero() before backward: autograd accumulates into the views in place -- one
     # small add kernel per parameter.  (b) release() before backward, collect() after it: autograd hands over fresh

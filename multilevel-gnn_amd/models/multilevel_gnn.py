@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from mlgnn.dense import linear as dense_linear
 from mlgnn.project import segment_project
 from mlgnn.sage import linear_act, linear_act_supported, node_embed, node_embed_supported
 from .gcn_lib.sparse.torch_vertex import GraphConv
@@ -160,7 +161,10 @@ class MultilevelGNN(nn.Module):
         x = torch.flatten(x, start_dim=1)
         if self.args.use_age:
             x = torch.cat([x, age[:, None]], dim=-1)
-        return self.head(x)
+        # (the first Linear reads a [B, 64 * 146 * 3k] row per sample: a stream over its weight, mlgnn.dense.linear)
+        for i, layer in enumerate(self.head):
+            x = dense_linear(x, layer.weight, layer.bias) if (i == 0 and type(layer) is nn.Linear) else layer(x)
+        return x
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_batch, x=None, gene_pca_match=None, raw_indice=None, age=None, require_grad=True):

@@ -78,7 +78,7 @@ def test_bench_two_gpus_as_the_driver_launches_it(line_n1):
     out = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                  "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + SMALL, env)
     single_only = {"cpu_baseline", "also_aggr", "no_overlap_ms_per_step", "roofline.stream_copy_GBps",
-                   "roofline.frac_of_stream_copy"}
+                   "roofline.frac_of_stream_copy", "roofline.stream_copy_variants_GBps"}
     want = {k for k in _keys(line_n1) if not any(k == s or k.startswith(s + ".") for s in single_only)}
     assert _keys(out) == want
     assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["collective_backend"] == "nccl"
@@ -108,7 +108,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(line_n1, tmp_path):
     out = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                  "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + small, env)
     single_only = {"cpu_baseline", "also_aggr", "no_overlap_ms_per_step", "roofline.stream_copy_GBps",
-                   "roofline.frac_of_stream_copy"}
+                   "roofline.frac_of_stream_copy", "roofline.stream_copy_variants_GBps"}
     want = {k for k in _keys(line_n1) if not any(k == s or k.startswith(s + ".") for s in single_only)}
     assert _keys(out) == want
     assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["collective_backend"] == "gloo"

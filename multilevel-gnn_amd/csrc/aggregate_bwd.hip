@@ -2,6 +2,7 @@
 // one wavefront per SOURCE node on the transposed CSR, atomic-free; plus the fixed-order partial
 // reduction shared by every kernel that sums per-workgroup partials.
 #include "aggregate_common.h"
+#include "aggregate_short.h"
 
 namespace mlgnn {
 
@@ -856,7 +857,16 @@ static int csr_aggregate_bwd_impl(const void* grad_out, const void* x, const voi
       else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
     });
   };
-  run(a, 0, BC<false>{});
+  // narrow fp32 rows, weighted sum / mean: one lane group per source row (aggregate_short.h)
+  static const bool short_on = [] { const char* e = getenv("MLGNN_SHORT_ROWS"); return !(e && e[0] == '0'); }();
+  if (short_on && !bf16 && vec == 4 && (mode == M_IDENTITY || mode == M_WEIGHTED) && ag == A_SUM && short_width_ok(d) &&
+      rk == 0 && !ln && !add_root && !wide && !grad_efull && (!a.mean || rowptr)) {
+    MLGNN_SHORT_DISPATCH(csr_short_bwd_kernel, d, mode == M_WEIGHTED, static_cast<const float*>(grad_out), rowptr_t, col_t,
+                         ew_t, rowptr, static_cast<float*>(grad_x), (int)N, a.mean, a.cap);
+    launched_blocks = 0;
+  } else {
+    run(a, 0, BC<false>{});
+  }
   int total_blocks = launched_blocks;
   if (split) {
     int err1 = (int)hipGetLastError();

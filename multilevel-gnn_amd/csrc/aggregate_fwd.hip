@@ -15,6 +15,7 @@
 // Built with -fno-honor-nans -fno-honor-infinities (plain v_max/v_min, no canonicalisation):
 // "minus infinity" sentinels are the finite kNegBig.
 #include "aggregate_common.h"
+#include "aggregate_short.h"
 
 namespace mlgnn {
 
@@ -437,7 +438,16 @@ extern "C" int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, con
       else { if (vec == 4) launch(TypeTag<float>{}, IC<4>{}); else launch(TypeTag<float>{}, IC<1>{}); }
     });
   };
-  run(a, grid, BC<false>{});
+  // narrow fp32 rows, weighted sum / mean (the SAGE layers of the shipped configs): one lane group per row
+  // (aggregate_short.h); same clamp-to-cap contract, so the long-row launches below follow either kernel
+  static const bool short_on = [] { const char* e = getenv("MLGNN_SHORT_ROWS"); return !(e && e[0] == '0'); }();
+  if (short_on && !bf16 && vec == 4 && (mode == M_IDENTITY || mode == M_WEIGHTED) && ag == A_SUM && short_width_ok(d) &&
+      !aux && !aux2 && !argmax && !row_max && !add_root && !wide) {
+    MLGNN_SHORT_DISPATCH(csr_short_fwd_kernel, d, mode == M_WEIGHTED, static_cast<const float*>(x), rowptr, col, ew,
+                         static_cast<float*>(out), (int)N, a.mean, a.cap);
+  } else {
+    run(a, grid, BC<false>{});
+  }
   int err = (int)hipGetLastError();
   if (err || !split) return err;
 

@@ -259,6 +259,30 @@ class CSRGraph:
         self._scalar_cache = (a, a._version, hit)
         return hit
 
+    def mean_edge_scalar(self, a=None):
+        """Per-edge weights of a MEAN aggregation folded with the 1 / in-degree of the edge's destination:
+        ``(w_e / deg(dst_e)`` in by-destination order, the same in by-source order``)`` -- a weighted SUM with these is the
+        weighted mean, and its backward is a plain weighted sum without the two row-pointer loads per edge the mean form
+        needs for ``deg(dst)`` (a dependent-load chain in a latency-bound kernel).  ``a``: ``[E]`` weights in COO order or
+        None (all ones).  Computed once per (graph, weights) and kept: worth it for a graph that outlives the step (the
+        fold-constant topology, :func:`shared_sage_graph`)."""
+        ent = getattr(self, "_mean_cache", None)
+        if ent is not None and ((a is None and ent[0] is None) or (a is not None and ent[0] is not None
+                                                                   and _same_view(ent[0], a) and ent[1] == a._version)):
+            return ent[2]
+        n = self.num_nodes
+        deg = (self.rowptr[1:n + 1] - self.rowptr[:n]).to(torch.float32).clamp(min=1.0)
+        inv_dst = torch.repeat_interleave(1.0 / deg, (self.rowptr[1:n + 1] - self.rowptr[:n]).long())      # by-destination order
+        inv_src = (1.0 / deg)[self.col_t[:inv_dst.numel()].long()]                                          # by-source order
+        if a is not None:
+            by_dst, by_src = self.edge_table(a, 1)
+            hit = ((by_dst.reshape(-1)[:inv_dst.numel()] * inv_dst).contiguous(),
+                   (by_src.reshape(-1)[:inv_src.numel()] * inv_src).contiguous())
+        else:
+            hit = (inv_dst.contiguous(), inv_src.contiguous())
+        self._mean_cache = (a, a._version if a is not None else -1, hit)
+        return hit
+
     def edge_table(self, a, width):
         """Per-edge attribute rows [E, r] (COO order) zero padded to ``width`` columns ->
         (by-destination order, by-source order), both [E, width] fp32; cached per tensor."""
@@ -398,6 +422,7 @@ def shared_sage_graph(shared, device, use_attr=True):
             raise ValueError("SAGE edge weights must be scalar per edge")
         w1 = torch.cat([ea[keep, 0].to(torch.float32), torch.ones(n, device=dev)])
         weight = w1.repeat(B)
+    graph.persistent = True                   # outlives the step: per-graph tables (mean weights) are worth keeping on it
     _SHARED_SAGE_CACHE.insert(0, ((k_ei, k_ea), vers, n, B, dev, bool(use_attr), graph, weight))
     del _SHARED_SAGE_CACHE[4:]
     return graph, weight

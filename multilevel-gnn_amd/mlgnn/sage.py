@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .dense import WGRAD_MIN_ROWS, _aligned, _wgrad, tall_matmul_nt, tall_matmul_supported
-from .ops import AGGR_MEAN, EDGE_NONE, MSG_IDENTITY, MSG_WEIGHTED, _DTYPE_IDS, _stream, tag_row_max
+from .ops import AGGR_MEAN, AGGR_SUM, EDGE_NONE, MSG_IDENTITY, MSG_WEIGHTED, _DTYPE_IDS, _stream, tag_row_max
 
 STATS = {"fused": 0, "fallback": 0}
 
@@ -40,19 +40,21 @@ def sage_layer_supported(x, w_nn, w_r, has_conv_bias):
 
 class _SageLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_nn, b_nn, w_r, row_scale, graph, ew_pair, slope, relative):
+    def forward(ctx, x, w_nn, b_nn, w_r, row_scale, graph, ew_pair, slope, relative, folded_mean):
         x = _aligned(x)
         N, cin = x.shape
         cout = w_nn.shape[0]
         dev = x.device
-        # neighbourhood mean (weighted; count = number of edges incl. the self loop)
+        # neighbourhood mean (weighted; count = number of edges incl. the self loop).  folded_mean: the weights already
+        # carry 1 / in-degree (CSRGraph.mean_edge_scalar) -- a weighted SUM
         agg = torch.empty_like(x)
         msg = MSG_WEIGHTED if ew_pair is not None else MSG_IDENTITY
+        aggr = AGGR_SUM if folded_mean else AGGR_MEAN
         ew = ew_pair[0] if ew_pair is not None else None
         hub, hub_keep = graph.hub_arg("dst", cin)
         rc = _lib.lib.mlgnn_csr_aggregate_fwd(
             x.data_ptr(), graph.rowptr.data_ptr(), graph.col.data_ptr(), _lib.ptr(ew), None, None, None, None,
-            agg.data_ptr(), None, None, None, None, N, cin, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, 0, AGGR_MEAN, 1.0, 1.0,
+            agg.data_ptr(), None, None, None, None, N, cin, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, 0, aggr, 1.0, 1.0,
             None, None, 0.0, 0, hub, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
         # lin_r folded into the update's weight
@@ -72,14 +74,14 @@ class _SageLayer(torch.autograd.Function):
         _lib.check(rc, "mlgnn_tallgemm_dual")
         ctx.save_for_backward(x, agg, y, w_nn, w_r, w_cat, rs, a_max)
         ctx.graph, ctx.ew_pair = graph, ew_pair
-        ctx.cfg = (float(slope), bool(relative), b_nn is not None, msg)
+        ctx.cfg = (float(slope), bool(relative), b_nn is not None, msg, aggr)
         ctx.mark_non_differentiable(y_max)
         return y, y_max
 
     @staticmethod
     def backward(ctx, gy, _g_max):
         x, agg, y, w_nn, w_r, w_cat, rs, a_max = ctx.saved_tensors
-        slope, relative, has_bias, msg = ctx.cfg
+        slope, relative, has_bias, msg, aggr = ctx.cfg
         g = ctx.graph
         N, cin = x.shape
         cout = y.shape[1]
@@ -100,7 +102,7 @@ class _SageLayer(torch.autograd.Function):
             rc = _lib.lib.mlgnn_csr_aggregate_bwd(
                 dagg.data_ptr(), None, None, None, None, g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.pos_t.data_ptr(),
                 g.rowptr.data_ptr(), _lib.ptr(ew_t), None, None, None, None, None, gagg.data_ptr(), None, None, None, 0,
-                N, cin, _DTYPE_IDS[dagg.dtype], msg, EDGE_NONE, 0, AGGR_MEAN, 0, 1.0, 1.0, None, None, 0.0, 0, 0, hub,
+                N, cin, _DTYPE_IDS[dagg.dtype], msg, EDGE_NONE, 0, aggr, 0, 1.0, 1.0, None, None, 0.0, 0, 0, hub,
                 None, None, _stream())
             _lib.check(rc, "mlgnn_csr_aggregate_bwd")
             gx = tall_matmul_nt(dz, w_x1.contiguous(), residual=gagg, row_max=dz_max, bt_transposed=True)
@@ -113,16 +115,21 @@ class _SageLayer(torch.autograd.Function):
         w_a = w_nn[:, cin:]
         g_nn = torch.cat([gw_x1, gw_c @ w_r.t()], dim=1)
         g_r = w_a.t() @ gw_c
-        return gx, g_nn, (gb if has_bias else None), g_r, None, None, None, None, None
+        return gx, g_nn, (gb if has_bias else None), g_r, None, None, None, None, None, None
 
 
 def sage_layer(x, graph, edge_weight, w_nn, b_nn, w_r, slope=0.2, relative=False, row_scale=None):
     """``leaky_relu(cat(x, mean_j(x_j w_ij [- x_i]) W_r^T) W_nn^T + b_nn, slope) [* row_scale]`` -- see the module
     docstring; the caller checks :func:`sage_layer_supported`.  ``edge_weight``: [E] in COO order of ``graph`` or None.
     The result carries its row maxima for the next layer's kernels."""
-    # (by-destination / by-source copies of the weights: one launch, mlgnn_edge_table_to_csr)
-    ew_pair = graph.edge_table(edge_weight, 1) if edge_weight is not None else None
-    y, y_max = _SageLayer.apply(x, w_nn, b_nn, w_r, row_scale, graph, ew_pair, float(slope), bool(relative))
+    folded = bool(getattr(graph, "persistent", False))
+    if folded:
+        # a graph that outlives the step (the fold's topology): 1 / in-degree folded into the per-edge weights, once
+        ew_pair = graph.mean_edge_scalar(edge_weight)
+    else:
+        # (by-destination / by-source copies of the weights: one launch, mlgnn_edge_table_to_csr)
+        ew_pair = graph.edge_table(edge_weight, 1) if edge_weight is not None else None
+    y, y_max = _SageLayer.apply(x, w_nn, b_nn, w_r, row_scale, graph, ew_pair, float(slope), bool(relative), folded)
     tag_row_max(y, y_max)
     STATS["fused"] += 1
     return y

@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--pmc-fetch")
     ap.add_argument("--pmc-write")
     ap.add_argument("--top", type=int, default=30)
+    ap.add_argument("--no-traffic-json", action="store_true",
+                    help="write only profiles/<tag>_pmc_traffic.json (bench.py's profiles/traffic.json belongs to the headline run)")
     a = ap.parse_args()
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     rows = list(csv.DictReader(open(find(a.stats))))
@@ -116,9 +118,11 @@ def main():
                             "counters": "2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes "
                                         "(MI355X_MICROARCH.md, HBM: FETCH_SIZE reports half of a 16 B/lane stream on gfx950)"}}
         blob.update(traffic)
-        json.dump(blob, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+        if not a.no_traffic_json:
+            json.dump(blob, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+        detail["_source"] = blob["_source"]
         json.dump(detail, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % a.tag), "w"), indent=1)
-        print("wrote profiles/traffic.json", traffic)
+        print("wrote traffic", traffic)
 
 
 if __name__ == "__main__":

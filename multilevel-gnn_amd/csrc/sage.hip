@@ -111,23 +111,24 @@ __global__ __launch_bounds__(256) void node_embed_bwd_kernel(const float* __rest
 // independent loads in flight per thread -- the shape MI355X_MICROARCH.md quotes its float4-copy figure for.
 template <bool NT>
 __global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 7 * stride < n; i += 8 * stride) {
+  // a workgroup moves contiguous 32 KB pieces (8 x 4 KB, one 16-byte access per lane each), pieces dealt round robin
+  const int64_t pieces = n / 2048;
+  for (int64_t p = blockIdx.x; p < pieces; p += gridDim.x) {
+    const int64_t base = p * 2048 + threadIdx.x;
     float4 v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = NT ? stream_load4(src + i + q * stride) : src[i + q * stride];
+    for (int q = 0; q < 8; ++q) v[q] = NT ? stream_load4(src + base + q * 256) : src[base + q * 256];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       if constexpr (NT) {
         const f4 t = {v[q].x, v[q].y, v[q].z, v[q].w};
-        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst + i + q * stride));
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst + base + q * 256));
       } else {
-        dst[i + q * stride] = v[q];
+        dst[base + q * 256] = v[q];
       }
     }
   }
-  for (; i < n; i += stride) dst[i] = src[i];
+  for (int64_t i = pieces * 2048 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 // ---- Linear with a handful of input columns (the node encoder Linear(3, hidden) of deepergcn.py:199-210: x [N, 3]) ----

@@ -29,8 +29,11 @@ prof() {   # prof <output dir name> <rocprofv3 options...> -- <program...>
 }
 STATS="--stats --output-format csv"
 want() { [ "$STAGE" = "all" ] || [ "$STAGE" = "$1" ]; }
-jsonline() {   # jsonline <log> <destination>
+jsonline() {   # jsonline <log> <destination>: the last line that is a JSON object
   if grep -q '^{' $1; then grep '^{' $1 | tail -1 > $2; else echo "WARNING: no JSON line in $1"; tail -3 $1; fi
+}
+jsonblob() {   # jsonblob <log> <destination>: everything from the first '{' (a pretty-printed object)
+  python3 -c "import sys; t = open(sys.argv[1]).read(); i = t.find('{'); open(sys.argv[2], 'w').write(t[i:]) if i >= 0 else print('WARNING: no JSON in', sys.argv[1])" $1 $2
 }
 
 if want headline; then
@@ -65,9 +68,9 @@ if want stress; then
   prof prof_dp32_stats_$TAG $STATS -d $R/gpurun_out/prof_dp32_stats_$TAG -- $DP --dtype fp32
   echo "stress / diffpool passes done"
   python3 tools/stress.py --steps 3 --dtype bf16 > gpurun_out/stress_$TAG.log 2>&1
-  jsonline gpurun_out/stress_$TAG.log profiles/${TAG}_stress_configs4_bf16.json
+  jsonblob gpurun_out/stress_$TAG.log profiles/${TAG}_stress_configs4_bf16.json
   python3 tools/stress.py --steps 3 --dtype fp32 > gpurun_out/stress32_$TAG.log 2>&1
-  jsonline gpurun_out/stress32_$TAG.log profiles/${TAG}_stress_configs4_fp32.json
+  jsonblob gpurun_out/stress32_$TAG.log profiles/${TAG}_stress_configs4_fp32.json
   python3 tools/bench_diffpool.py --json profiles/${TAG}_diffpool_configs4.json > gpurun_out/dp_$TAG.log 2>&1
   python3 tools/bench_diffpool.py --dtype fp32 --iters 10 --json profiles/${TAG}_diffpool_configs4_fp32.json > gpurun_out/dp32_$TAG.log 2>&1
   python3 tools/bench_skew.py > gpurun_out/skew_$TAG.log 2>&1

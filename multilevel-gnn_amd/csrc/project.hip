@@ -104,7 +104,66 @@ __global__ __launch_bounds__(kBlock) void segment_project_fwd_kernel(const ProjA
   }
 }
 
-// ---- input gradient: gx[row, :] = sum_{m -> row} sum_k gout_t[seg(m), k, :] * W[g(m), k]
+// ---- input gradient, WIDE rows (>= 128 channels: one or two lane groups per wave): one wave per node row, its lane groups
+// take the row's members round robin (the form of rounds 1-3; the multi-row walk below measured slower here: 326 vs 184 us
+// at BASELINE configs[1], where a unit of 4 rows per group runs to the longest of its rows) ----
+// one wave per node row; gx[row, :] = sum_{m -> row} sum_k gout_t[seg(m), k, :] * W[g(m), k]
+template <typename T, int VEC, int K>
+__global__ __launch_bounds__(kBlock) void segment_project_bwd_x_wave_kernel(const ProjArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << a.lpr_log2;
+  const int groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2;
+  const int cl = lane & (lpr - 1);
+  const RowWalk walk = make_row_walk(a.rows);
+  for (int cbase = 0; cbase < a.C; cbase += lpr * VEC) {
+    const int c0 = cbase + cl * VEC;
+    const bool cact = c0 < a.C;
+    for (int r = walk.first; r < walk.r_end; r += walk.stride) {
+      const int beg = a.ptr[r], end = a.ptr[r + 1];
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      for (int base = beg; base < end; base += kWave) {
+        const int cnt = min(kWave, end - base);
+        int my_seg = 0;
+        float my_w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) my_w[k] = 0.f;
+        if (lane < cnt) {
+          const int f = a.mem[base + lane];
+          my_seg = a.mem_seg[f];
+          const int g = f % a.G;
+#pragma unroll
+          for (int k = 0; k < K; ++k) my_w[k] = a.w[(size_t)g * K + k];
+        }
+        for (int kk = 0; kk < cnt; kk += groups) {
+          const int idx = kk + sub;
+          const int src = idx & (kWave - 1);
+          const int seg = __shfl(my_seg, src);
+          float wk[K];
+#pragma unroll
+          for (int k = 0; k < K; ++k) wk[k] = __shfl(my_w[k], src);
+          if (idx < cnt && cact) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              float gv[VEC];
+              load_t<T, VEC>(gv, static_cast<const T*>(a.gout_t) + proj_out_row<K>(a, seg, k) * a.C + c0);
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[i] = fmaf(gv[i], wk[k], acc[i]);
+            }
+          }
+        }
+      }
+      for (int off = lpr; off < kWave; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+      if (sub == 0 && cact) store_t<T, VEC>(static_cast<T*>(a.out) + (size_t)r * a.C + c0, acc);
+    }
+  }
+}
+
+// ---- input gradient, NARROW rows: gx[row, :] = sum_{m -> row} sum_k gout_t[seg(m), k, :] * W[g(m), k]
 // A node has 2.5 memberships on average (G = 25 000 over 10 000 genes), so the work per row is one short chain of
 // dependent loads (row pointer -> member -> segment / weights -> K cotangent rows) and one 512-byte store: a wave that
 // walks ONE row at a time (rounds 1-3: 184 us for a 328 MB write) waits out four memory latencies per row.  Here every
@@ -325,7 +384,9 @@ extern "C" int mlgnn_segment_project_bwd(const void* gout_t, const void* x, cons
     a.S = (int)segs_per_sample; a.n_groups = (int)n_groups;
     const dim3 grid(grid_for_rows(n_rows));
     a.lpr_log2 = lanes_per_row_log2(C, wide ? vec : 1);
-    MLGNN_PROJ_DISPATCH(segment_project_bwd_x_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
+    // four or more lane groups per wave (<= 64 fp32 channels): every group walks rows of its own; wider rows: a wave per row
+    if ((kWave >> a.lpr_log2) >= 4) MLGNN_PROJ_DISPATCH(segment_project_bwd_x_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
+    else MLGNN_PROJ_DISPATCH(segment_project_bwd_x_wave_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
     const int err = (int)hipGetLastError();
     if (err) return err;
   }

@@ -3,8 +3,10 @@
 // nn.Linear(64 * 146 * 9 = 84 096, 512) over a batch of 64 samples).  The weight (172 MB) is the only large operand of all
 // three products of the layer and is used once per sample: the layer is a STREAM over W (forward, input gradient) or over
 // dW (weight gradient), 22 us each at 8 TB/s, and nothing like the square GEMMs a library tunes for (measured: 189 + 108 +
-// 89 us).  Three kernels, fp32 FMA arithmetic on the vector ALUs (2 M J K = 5.5 GFLOP per product: below the stream time
-// on 256 CUs), tiles staged through LDS, every global access a 16-byte one along K:
+// 89 us).  Three kernels, plain fp32 arithmetic on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains; 2 M J K =
+// 5.5 GFLOP per product = 35 us of the 157 TFLOP/s pipe, next to the 22 us stream), tiles staged through LDS, every global
+// access a 16-byte one along K.  (The first version used packed VALU FMAs on 4x4 register tiles and was bound by LDS
+// bandwidth -- 8 x 16-byte LDS reads per 32 packed FMAs: 166 / 103 / 103 us; an MFMA takes its operands from LDS once per wave.)
 //
 //   forward   workgroup = (64 columns of J) x (a range of K); partial [M, 64] sums per K range, reduced in a fixed order
 //   dX        workgroup = 128 columns of K, the whole J range inside: dX[M, 128] written once
@@ -21,6 +23,10 @@ constexpr int kSkJ = 64;            // J tile
 constexpr int kSkK = 128;           // K tile
 constexpr int kSkLd = kSkK + 4;     // LDS row stride (floats): 16-byte aligned rows, neighbouring rows 4 banks apart
 constexpr int kSkThreads = 256;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
+// C/D: register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
+__device__ __forceinline__ int sk_crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // global [rows, ld] tile (rows x 128 floats from column k0, zero past `rows_valid` rows / `k_valid` columns) -> LDS [64][132]
 __device__ __forceinline__ void sk_load_tile(float* __restrict__ lds, const float* __restrict__ src, int64_t ld, int row0,
@@ -38,113 +44,100 @@ __device__ __forceinline__ void sk_load_tile(float* __restrict__ lds, const floa
 
 // ---- forward: partial[split][m][j] = sum_{k in range(split)} x[m, k] W[j, k] -----------------------------------------------
 __global__ __launch_bounds__(kSkThreads) void skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               float* __restrict__ partial, int M, int J, int K,
-                                                               int k_per_split) {
+                                                               const float* __restrict__ bias, float* __restrict__ partial,
+                                                               int M, int J, int K, int k_per_split) {
   extern __shared__ __attribute__((aligned(16))) float sk_smem[];          // 2 x 33 KB: past the 64 KB of static LDS
   float* xs = sk_smem;
   float* ws = sk_smem + kSkM * kSkLd;
   const int jt = blockIdx.x, split = blockIdx.y;
   const int k_begin = split * k_per_split, k_end = min(K, k_begin + k_per_split);
-  const int mi = threadIdx.x >> 4, ji = threadIdx.x & 15;            // 4 rows x 4 columns per thread
-  float acc[4][4];
+  // 4 waves: wave (wm, wj) owns the 32 x 32 block (rows 32 wm.., columns 32 wj..) of the [64 m, 64 j] tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wj = wave & 1, i31 = lane & 31, h = lane >> 5;
+  f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int k0 = k_begin; k0 < k_end; k0 += kSkK) {
     __syncthreads();
     sk_load_tile(xs, x, K, 0, M, k0, k_end);
     sk_load_tile(ws, w, K, jt * kSkJ, min(kSkJ, J - jt * kSkJ), k0, k_end);
     __syncthreads();
+    const float* ap = xs + (32 * wm + i31) * kSkLd + 4 * h;
+    const float* bp = ws + (32 * wj + i31) * kSkLd + 4 * h;
+    // 8 columns of K per 16-byte read pair: step s contracts k = k8 + s (half 0) with k8 + 4 + s (half 1) -- any pairing
+    // works as long as both operands use the same one
 #pragma unroll 4
-    for (int k4 = 0; k4 < kSkK / 4; ++k4) {
-      float4 a[4], b[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(xs + (4 * mi + r) * kSkLd + 4 * k4);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(ws + (4 * ji + c) * kSkLd + 4 * k4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          acc[r][c] = fmaf(a[r].x, b[c].x, fmaf(a[r].y, b[c].y, fmaf(a[r].z, b[c].z, fmaf(a[r].w, b[c].w, acc[r][c]))));
+    for (int k8 = 0; k8 < kSkK; k8 += 8) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + k8);
+      const float4 b = *reinterpret_cast<const float4*>(bp + k8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     }
   }
   float* out = partial + (size_t)split * M * J;
+  const int j = jt * kSkJ + 32 * wj + i31;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = 4 * mi + r;
-    if (m >= M) continue;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int j = jt * kSkJ + 4 * ji + c;
-      if (j < J) out[(size_t)m * J + j] = acc[r][c];
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int m = 32 * wm + sk_crow(r, h);
+    if (m < M && j < J) out[(size_t)m * J + j] = acc[r] + ((split == 0 && bias) ? bias[j] : 0.f);   // (the bias enters once)
   }
-}
-
-// y[m, j] = bias[j] + sum_split partial[split][m][j]  (splits in order)
-__global__ __launch_bounds__(256) void skinny_fwd_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
-                                                               float* __restrict__ y, int MJ, int J, int splits) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= MJ) return;
-  float s = 0.f;
-  for (int p = 0; p < splits; ++p) s += partial[(size_t)p * MJ + i];
-  y[i] = s + (bias ? bias[i % J] : 0.f);
 }
 
 // ---- input gradient: dx[m, k] = sum_j dy[m, j] W[j, k]; workgroup = 128 columns of K ------------------------------------------
 __global__ __launch_bounds__(kSkThreads) void skinny_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                               float* __restrict__ dx, int M, int J, int K) {
   __shared__ __attribute__((aligned(16))) float ws[kSkJ * kSkLd];          // W[j tile][k tile]
-  __shared__ __attribute__((aligned(16))) float ds[kSkJ * (kSkM + 4)];     // dy^T: [j][m]
+  __shared__ __attribute__((aligned(16))) float ds[kSkM * (kSkJ + 4)];     // dy[m][j tile]
   const int k0 = blockIdx.x * kSkK;
-  const int mi = threadIdx.x >> 4, ki = threadIdx.x & 15;            // 4 rows x 8 columns per thread: k = 4 ki + {0..3}, 64 + 4 ki + {0..3}
-  float acc[4][8];
+  // 4 waves: wave (wm, wk) owns rows 32 wm.. and columns 64 wk.. of the [64 m, 128 k] tile = two 32 x 32 blocks
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wk = wave & 1, i31 = lane & 31, h = lane >> 5;
+  f32x16 acc[2];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   for (int j0 = 0; j0 < J; j0 += kSkJ) {
     __syncthreads();
     sk_load_tile(ws, w, K, j0, min(kSkJ, J - j0), k0, K);
-    // dy tile [M, 64 j] -> LDS transposed [j][m] (16 KB: 16 elements per thread)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int u = threadIdx.x + i * kSkThreads;
       const int m = u >> 6, j = u & 63;
-      ds[j * (kSkM + 4) + m] = (m < M && j0 + j < J) ? dy[(size_t)m * J + j0 + j] : 0.f;
+      ds[m * (kSkJ + 4) + j] = (m < M && j0 + j < J) ? dy[(size_t)m * J + j0 + j] : 0.f;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < kSkJ; ++j) {
-      const float4 d = *reinterpret_cast<const float4*>(ds + j * (kSkM + 4) + 4 * mi);
-      const float4 w0 = *reinterpret_cast<const float4*>(ws + j * kSkLd + 4 * ki);
-      const float4 w1 = *reinterpret_cast<const float4*>(ws + j * kSkLd + 64 + 4 * ki);
-      const float dv[4] = {d.x, d.y, d.z, d.w};
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const float* ap = ds + (32 * wm + i31) * (kSkJ + 4) + 4 * h;          // A[m][j]: 4 consecutive j per read
+    const float* bp = ws + (4 * h) * kSkLd + 64 * wk + i31;                // B[j][k column]
+#pragma unroll 2
+    for (int j8 = 0; j8 < kSkJ; j8 += 8) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + j8);
+      const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[r][c] = fmaf(dv[r], wv[c], acc[r][c]);
+      for (int s2 = 0; s2 < 4; ++s2) {                                     // contracts j = j8 + s2 (half 0), j8 + 4 + s2 (half 1)
+        const float b0 = bp[(j8 + s2) * kSkLd], b1 = bp[(j8 + s2) * kSkLd + 32];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], b1, acc[1], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = 4 * mi + r;
-    if (m >= M) continue;
+  for (int t = 0; t < 2; ++t) {
+    const int k = k0 + 64 * wk + 32 * t + i31;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int k = k0 + 64 * half + 4 * ki;
-      if (k < K) *reinterpret_cast<float4*>(dx + (size_t)m * K + k) =
-          make_float4(acc[r][4 * half], acc[r][4 * half + 1], acc[r][4 * half + 2], acc[r][4 * half + 3]);
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * wm + sk_crow(r, h);
+      if (m < M && k < K) dx[(size_t)m * K + k] = acc[t][r];
     }
   }
 }
 
 // ---- weight gradient: dw[j, k] = sum_m dy[m, j] x[m, k]; workgroup = 64 rows of J x 128 columns of K ---------------------------
 __global__ __launch_bounds__(kSkThreads) void skinny_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                              float* __restrict__ dw, int M, int J, int K) {
+                                                              float* __restrict__ dw, float* __restrict__ db, int M, int J,
+                                                              int K) {
   __shared__ __attribute__((aligned(16))) float xs[kSkM * kSkLd];          // x[m][k tile]
   __shared__ __attribute__((aligned(16))) float ds[kSkM * (kSkJ + 4)];     // dy[m][j tile]
   const int k0 = blockIdx.x * kSkK, j0 = blockIdx.y * kSkJ;
@@ -156,6 +149,14 @@ __global__ __launch_bounds__(kSkThreads) void skinny_dw_kernel(const float* __re
     ds[m * (kSkJ + 4) + j] = (m < M && j0 + j < J) ? dy[(size_t)m * J + j0 + j] : 0.f;
   }
   __syncthreads();
+  // (packed VALU FMAs on 4 x 8 register tiles with 16-byte stores: 103 us; the fp32-MFMA form of this product -- 64 MFMAs per
+  // wave between a 48 KB tile load and a 32 KB store of 4-byte accumulator registers -- measured 126 us)
+  // the bias gradient rides along: the workgroups of the first K tile hold every dy tile once
+  if (db && blockIdx.x == 0 && threadIdx.x < kSkJ && j0 + (int)threadIdx.x < J) {
+    float t = 0.f;
+    for (int m = 0; m < kSkM; ++m) t += ds[m * (kSkJ + 4) + threadIdx.x];
+    db[j0 + threadIdx.x] = t;
+  }
   const int ji = threadIdx.x >> 4, ki = threadIdx.x & 15;            // 4 rows of J x 8 columns of K per thread
   float acc[4][8];
 #pragma unroll
@@ -245,9 +246,8 @@ extern "C" int mlgnn_skinny_linear_fwd(const float* x, const float* w, const flo
   constexpr int lds_bytes = (kSkM + kSkJ) * kSkLd * 4;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   hipLaunchKernelGGL(skinny_fwd_kernel, dim3((unsigned)((J + kSkJ - 1) / kSkJ), (unsigned)splits), dim3(kSkThreads), lds_bytes, s,
-                     x, w, workspace, (int)M, (int)J, (int)K, kps);
-  hipLaunchKernelGGL(skinny_fwd_reduce_kernel, dim3((unsigned)((M * J + 255) / 256)), dim3(256), 0, s, workspace, bias, y,
-                     (int)(M * J), (int)J, splits);
+                     x, w, bias, workspace, (int)M, (int)J, (int)K, kps);
+  launch_reduce_partials(workspace, y, splits, (int)(M * J), s);          // K ranges in order: bitwise reproducible
   return (int)hipGetLastError();
 }
 
@@ -263,7 +263,8 @@ extern "C" int mlgnn_skinny_linear_bwd(const float* grad_out, const float* x, co
   if (grad_x) hipLaunchKernelGGL(skinny_dx_kernel, dim3(kt), dim3(kSkThreads), 0, s, grad_out, w, grad_x, (int)M, (int)J, (int)K);
   if (grad_w)
     hipLaunchKernelGGL(skinny_dw_kernel, dim3(kt, (unsigned)((J + kSkJ - 1) / kSkJ)), dim3(kSkThreads), 0, s, grad_out, x, grad_w,
-                       (int)M, (int)J, (int)K);
-  if (grad_b) hipLaunchKernelGGL(skinny_db_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, s, grad_out, grad_b, (int)M, (int)J);
+                       grad_b, (int)M, (int)J, (int)K);
+  else if (grad_b)
+    hipLaunchKernelGGL(skinny_db_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, s, grad_out, grad_b, (int)M, (int)J);
   return (int)hipGetLastError();
 }

@@ -12,6 +12,10 @@ import torch
 # rows (in-edges of a node for the forward, out-edges for the backward) longer than this are cut into chunks that
 # run as rows of their own and are combined in order (csrc/hub.hip); 0 disables
 HUB_CAP = int(os.environ.get("MLGNN_HUB_CAP", "256"))
+# SAGE graphs (narrow rows walked by ONE lane group per row, csrc/aggregate_short.h): rows past this many edges -- a
+# transcription factor's targets -- are cut into chunks that the wave-per-row kernel takes (csrc/hub.hip), so a lane
+# group never walks more than this many edges on its own
+SAGE_HUB_CAP = int(os.environ.get("MLGNN_SAGE_HUB_CAP", "64")) if HUB_CAP > 0 else 0
 _SHARED_TOPOLOGY = os.environ.get("MLGNN_SHARED_TOPOLOGY", "1") == "1"      # (0: sort every batch's edge list, for A/B runs)
 
 
@@ -134,7 +138,8 @@ class CSRGraph:
         """Chunk tables of the long rows of one direction (``"dst"``: by-destination CSR, forward; ``"src"``:
         transposed CSR, backward), built on the device on first use: ``(vrows, hubs, counts, capacity)`` or ``None``
         (``HUB_CAP = 0``, a host graph, or no edge)."""
-        if HUB_CAP <= 0 or not self.rowptr.is_cuda or self.num_edges == 0:
+        cap = getattr(self, "hub_cap", HUB_CAP)
+        if cap <= 0 or not self.rowptr.is_cuda or self.num_edges == 0:
             return None
         hit = self._hub.get(direction)
         if hit is None and not self._hub:
@@ -146,11 +151,11 @@ class CSRGraph:
             del self._hub[direction]
         if hit is None:
             from . import _lib
-            cap_rows = int(_lib.lib.mlgnn_hub_capacity(self.num_edges, HUB_CAP))
+            cap_rows = int(_lib.lib.mlgnn_hub_capacity(self.num_edges, cap))
             i32 = dict(dtype=torch.int32, device=self.device)
             vrows, hubs, counts = torch.empty((cap_rows, 3), **i32), torch.empty((cap_rows, 3), **i32), torch.empty(2, **i32)
             rowptr = self.rowptr if direction == "dst" else self.rowptr_t
-            rc = _lib.lib.mlgnn_hub_rows(rowptr.data_ptr(), self.num_nodes, HUB_CAP, cap_rows, vrows.data_ptr(),
+            rc = _lib.lib.mlgnn_hub_rows(rowptr.data_ptr(), self.num_nodes, cap, cap_rows, vrows.data_ptr(),
                                          hubs.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "mlgnn_hub_rows")
             # the counts also travel to pinned host memory, asynchronously: once that copy is known to have finished
@@ -176,7 +181,7 @@ class CSRGraph:
         vrows, hubs, counts, cap_rows = tabs[:4]
         nbytes = int(_lib.lib.mlgnn_hub_scratch_bytes(cap_rows, d))
         tmp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        st = _lib.HubStruct(HUB_CAP, cap_rows, vrows.data_ptr(), hubs.data_ptr(), counts.data_ptr(), tmp.data_ptr(), nbytes)
+        st = _lib.HubStruct(getattr(self, "hub_cap", HUB_CAP), cap_rows, vrows.data_ptr(), hubs.data_ptr(), counts.data_ptr(), tmp.data_ptr(), nbytes)
         return ctypes.byref(st), (st, tmp)
 
     def _build_device(self, edge_index):
@@ -370,6 +375,7 @@ def _sage_graph_device(edge_index, edge_attr, num_nodes):
                                      torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "mlgnn_sage_rewrite")
     graph = CSRGraph(out, N + 1)
+    graph.hub_cap = SAGE_HUB_CAP
     graph.num_nodes = N                      # rowptr / rowptr_t carry one more (unused) row: the parked self loops
     return graph, weight
 
@@ -422,6 +428,7 @@ def shared_sage_graph(shared, device, use_attr=True):
             raise ValueError("SAGE edge weights must be scalar per edge")
         w1 = torch.cat([ea[keep, 0].to(torch.float32), torch.ones(n, device=dev)])
         weight = w1.repeat(B)
+    graph.hub_cap = SAGE_HUB_CAP
     graph.persistent = True                   # outlives the step: per-graph tables (mean weights) are worth keeping on it
     _SHARED_SAGE_CACHE.insert(0, ((k_ei, k_ea), vers, n, B, dev, bool(use_attr), graph, weight))
     del _SHARED_SAGE_CACHE[4:]

@@ -16,7 +16,9 @@ def _graph(n, e, gen):
     src = torch.randint(0, n, (e,), generator=gen)
     dst = torch.randint(0, n, (e,), generator=gen)
     dst[:50] = src[:50]                                   # self loops that the conv must drop
-    dst[50:400] = 3                                       # a hub row
+    dst[50:400] = 3                                       # a hub row (350 in-edges: past the 64-edge cap of the short-row kernels)
+    src[400:700] = 7                                      # ... and a node with 300 out-edges (the backward's long row)
+    dst[700:770] = 11                                     # 70 in-edges: just past the cap
     w = torch.rand(e, 1, generator=gen) * 2 - 1           # weights in [-1, 1] incl. negative ones (multiloader.py:671)
     return torch.stack([src, dst]), w
 

@@ -1,6 +1,8 @@
 #!/bin/bash
-R=$(pwd); mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_sage_layer_gpu.py tests/test_hub_gpu.py tests/test_graph_gpu.py tests/test_tcga_shape_gpu.py tests/test_models_gpu.py -x -q > gpurun_out/d_tests.log 2>&1 || { tail -30 gpurun_out/d_tests.log; exit 1; }
-tail -2 gpurun_out/d_tests.log
-python tools/bench_tcga.py --shape kirc | tail -1 | cut -c300-420
-python tools/bench_tcga.py --shape gbm | tail -1 | cut -c300-420
+mkdir -p gpurun_out
+for i in 1 2; do
+python bench.py --gpus 1 --global-batch 512 --steps 4 --warmup 2 --pool-batches 2 --no-cpu-baseline --no-extras > gpurun_out/d_strong_$i.log 2>&1
+python3 -c "
+import json
+d=json.loads([l for l in open('gpurun_out/d_strong_$i.log') if l.startswith('{')][-1]); print('strong', d['value'], d['ms_per_step'], {k:round(v['avg_ms'],3) for k,v in d['kernels'].items()})"
+done

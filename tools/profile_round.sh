@@ -52,7 +52,7 @@ if want headline; then
   python3 tools/summarize_prof.py --stats "gpurun_out/prof_csr_$TAG/**/*kernel_stats.csv" --tag ${TAG}_csr --commit "$MLGNN_COMMIT" \
     --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/bench_csr.py   (topology build of a configs[1] batch on its own: 64 graphs x 10k nodes / 160k edges, both CSR orderings + the rank-1 edge table)"
   python3 tools/bench_dense.py --iters 30 --json profiles/${TAG}_dense_kernels.json > gpurun_out/dense_$TAG.log 2>&1
-  python3 bench.py --gpus 1 --global-batch 512 --steps 3 --warmup 1 --pool-batches 2 --no-cpu-baseline --no-extras > gpurun_out/strong_n1_$TAG.log 2>&1
+  python3 bench.py --gpus 1 --global-batch 512 --steps 4 --warmup 2 --pool-batches 2 --no-cpu-baseline --no-extras > gpurun_out/strong_n1_$TAG.log 2>&1
   jsonline gpurun_out/strong_n1_$TAG.log profiles/${TAG}_strong_n1.json
   # the un-profiled bench line LAST: it picks up the traffic.json written above (same kernel sources -> not stale)
   python3 bench.py > gpurun_out/bench_$TAG.log 2>&1

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 15
+#define MLGNN_ABI_VERSION 16
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -754,6 +754,18 @@ int mlgnn_tallgemm_dual_supported(int64_t N, int64_t R1, int64_t R2, int64_t J);
 int mlgnn_tallgemm_dual(const float* a, const float* a2, const float* bt, const float* bias, float act_slope,
                         const float* row_scale, float* c, float* row_max_out, float* a_row_max_out, void* workspace,
                         int64_t workspace_bytes, int64_t N, int64_t R1, int64_t R2, int64_t J, void* stream);
+
+/*
+ * The fold of `lin_r` into the update's weight and its chain rule (one small launch each instead of mm / sub / cat chains):
+ *   fwd: W_c = W_a W_r with w_nn = [W_x | W_a] ([out, in + out]), w_r [out, in];  w_cat [out, 2 in] = [W_x - rel W_c | W_c],
+ *        and the two halves w_x1, w_c [out, in] on their own (operands of the backward's input-gradient products)
+ *   bwd: G_c = grad_w_c - rel grad_w_x1;  grad_w_nn [out, in + out] = [grad_w_x1 | G_c W_r^T];  grad_w_r [out, in] = W_a^T G_c
+ * Replaces: nothing of the reference (its per-edge `lin_r`, torch_vertex.py:282-286, is what the fold removes).
+ */
+int mlgnn_sage_fold_fwd(const float* w_nn, const float* w_r, float* w_cat, float* w_x1, float* w_c, int64_t cin, int64_t cout,
+                        int relative, void* stream);
+int mlgnn_sage_fold_bwd(const float* grad_w_x1, const float* grad_w_c, const float* w_nn, const float* w_r, float* grad_w_nn,
+                        float* grad_w_r, int64_t cin, int64_t cout, int relative, void* stream);
 
 /*
  * Backward of that epilogue (csrc/sage.hip):  grad_z = grad_out * row_scale[row] * (z > 0 ? 1 : slope), the sign of z

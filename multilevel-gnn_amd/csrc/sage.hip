@@ -209,6 +209,56 @@ __global__ __launch_bounds__(256) void narrow_linear_bwd_kernel(const float4* __
 
 constexpr int kNarrowBlocks = 1024;
 
+// ---- the fold of lin_r into the SAGE update's weight (mlgnn/sage.py) and its chain rule, on [out, in]-sized matrices ----
+// forward:  W_c = W_a W_r  (W_nn = [W_x | W_a], W_a [out, out], W_r [out, in]);  w_cat = [W_x - rel W_c | W_c]  [out, 2 in],
+//           plus the two halves as matrices of their own (the operands of the backward's input-gradient GEMMs)
+__global__ __launch_bounds__(256) void sage_fold_fwd_kernel(const float* __restrict__ w_nn, const float* __restrict__ w_r,
+                                                           float* __restrict__ w_cat, float* __restrict__ w_x1,
+                                                           float* __restrict__ w_c, int cin, int cout, int relative) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= cout * cin) return;
+  const int o = idx / cin, i = idx - o * cin;
+  const float* wa = w_nn + (size_t)o * (cin + cout) + cin;
+  float c = 0.f;
+  for (int k = 0; k < cout; ++k) c = fmaf(wa[k], w_r[(size_t)k * cin + i], c);
+  const float x1 = w_nn[(size_t)o * (cin + cout) + i] - (relative ? c : 0.f);
+  w_cat[(size_t)o * 2 * cin + i] = x1;
+  w_cat[(size_t)o * 2 * cin + cin + i] = c;
+  w_x1[idx] = x1;
+  w_c[idx] = c;
+}
+
+// backward:  G_c = gw_c - rel gw_x1;  g_nn = [gw_x1 | G_c W_r^T]  [out, in + out];  g_r = W_a^T G_c  [out, in]
+__global__ __launch_bounds__(256) void sage_fold_bwd_kernel(const float* __restrict__ gw_x1, const float* __restrict__ gw_c,
+                                                           const float* __restrict__ w_nn, const float* __restrict__ w_r,
+                                                           float* __restrict__ g_nn, float* __restrict__ g_r, int cin, int cout,
+                                                           int relative) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int n_nn = cout * (cin + cout), n_r = cout * cin;
+  if (idx < n_nn) {
+    const int o = idx / (cin + cout), j = idx - o * (cin + cout);
+    if (j < cin) {
+      g_nn[idx] = gw_x1[(size_t)o * cin + j];
+    } else {
+      const int k = j - cin;
+      float t = 0.f;
+      for (int i = 0; i < cin; ++i) {
+        const float g = gw_c[(size_t)o * cin + i] - (relative ? gw_x1[(size_t)o * cin + i] : 0.f);
+        t = fmaf(g, w_r[(size_t)k * cin + i], t);
+      }
+      g_nn[idx] = t;
+    }
+  } else if (idx < n_nn + n_r) {
+    const int e = idx - n_nn, k = e / cin, i = e - k * cin;
+    float t = 0.f;
+    for (int o = 0; o < cout; ++o) {
+      const float g = gw_c[(size_t)o * cin + i] - (relative ? gw_x1[(size_t)o * cin + i] : 0.f);
+      t = fmaf(w_nn[(size_t)o * (cin + cout) + cin + k], g, t);
+    }
+    g_r[e] = t;
+  }
+}
+
 static bool width_ok(int64_t J) {
   const int64_t l = J / 4;
   return J >= 4 && J % 4 == 0 && l <= 64 && (l & (l - 1)) == 0;
@@ -352,5 +402,24 @@ extern "C" int mlgnn_narrow_linear_bwd(const float* grad_out, const float* x, fl
   const int err = (int)hipGetLastError();
   if (err) return err;
   launch_reduce_partials(workspace, grad_w_b, kNarrowBlocks, (int)(J * (R + 1)), s);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_sage_fold_fwd(const float* w_nn, const float* w_r, float* w_cat, float* w_x1, float* w_c, int64_t cin,
+                                   int64_t cout, int relative, void* stream) {
+  if (cin < 1 || cout < 1 || cin > 4096 || cout > 4096) return MLGNN_E_SHAPE;
+  if (!w_nn || !w_r || !w_cat || !w_x1 || !w_c) return MLGNN_E_NULL;
+  hipLaunchKernelGGL(sage_fold_fwd_kernel, dim3((unsigned)((cin * cout + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_nn,
+                     w_r, w_cat, w_x1, w_c, (int)cin, (int)cout, relative);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_sage_fold_bwd(const float* grad_w_x1, const float* grad_w_c, const float* w_nn, const float* w_r,
+                                   float* grad_w_nn, float* grad_w_r, int64_t cin, int64_t cout, int relative, void* stream) {
+  if (cin < 1 || cout < 1 || cin > 4096 || cout > 4096) return MLGNN_E_SHAPE;
+  if (!grad_w_x1 || !grad_w_c || !w_nn || !w_r || !grad_w_nn || !grad_w_r) return MLGNN_E_NULL;
+  const int64_t n = cout * (cin + cout) + cout * cin;
+  hipLaunchKernelGGL(sage_fold_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_w_x1,
+                     grad_w_c, w_nn, w_r, grad_w_nn, grad_w_r, (int)cin, (int)cout, relative);
   return (int)hipGetLastError();
 }

@@ -57,10 +57,13 @@ class _SageLayer(torch.autograd.Function):
             agg.data_ptr(), None, None, None, None, N, cin, _DTYPE_IDS[x.dtype], msg, EDGE_NONE, 0, aggr, 1.0, 1.0,
             None, None, 0.0, 0, hub, _stream())
         _lib.check(rc, "mlgnn_csr_aggregate_fwd")
-        # lin_r folded into the update's weight
-        w_x, w_a = w_nn[:, :cin], w_nn[:, cin:]
-        w_c = w_a @ w_r                                            # [out, in]
-        w_cat = torch.cat([w_x - w_c if relative else w_x, w_c], dim=1).contiguous()
+        # lin_r folded into the update's weight: [W_x (- W_c) | W_c], W_c = W_a W_r  (one small launch)
+        w_nn_c, w_r_c = w_nn.contiguous(), w_r.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        w_cat, w_x1, w_c = torch.empty((cout, 2 * cin), **f32), torch.empty((cout, cin), **f32), torch.empty((cout, cin), **f32)
+        rc = _lib.lib.mlgnn_sage_fold_fwd(w_nn_c.data_ptr(), w_r_c.data_ptr(), w_cat.data_ptr(), w_x1.data_ptr(), w_c.data_ptr(),
+                                          cin, cout, int(bool(relative)), _stream())
+        _lib.check(rc, "mlgnn_sage_fold_fwd")
         y = torch.empty((N, cout), dtype=torch.float32, device=dev)
         y_max = torch.empty(N, dtype=torch.float32, device=dev)
         a_max = torch.empty(N, dtype=torch.float32, device=dev)
@@ -72,7 +75,7 @@ class _SageLayer(torch.autograd.Function):
                                           _lib.ptr(rs), y.data_ptr(), y_max.data_ptr(), a_max.data_ptr(), ws.data_ptr(),
                                           nbytes, N, cin, cin, cout, _stream())
         _lib.check(rc, "mlgnn_tallgemm_dual")
-        ctx.save_for_backward(x, agg, y, w_nn, w_r, w_cat, rs, a_max)
+        ctx.save_for_backward(x, agg, y, w_nn_c, w_r_c, w_x1, w_c, rs, a_max)
         ctx.graph, ctx.ew_pair = graph, ew_pair
         ctx.cfg = (float(slope), bool(relative), b_nn is not None, msg, aggr)
         ctx.mark_non_differentiable(y_max)
@@ -80,7 +83,7 @@ class _SageLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _g_max):
-        x, agg, y, w_nn, w_r, w_cat, rs, a_max = ctx.saved_tensors
+        x, agg, y, w_nn, w_r, w_x1, w_c, rs, a_max = ctx.saved_tensors
         slope, relative, has_bias, msg, aggr = ctx.cfg
         g = ctx.graph
         N, cin = x.shape
@@ -91,11 +94,10 @@ class _SageLayer(torch.autograd.Function):
         rc = _lib.lib.mlgnn_leaky_relu_bwd(gy.data_ptr(), y.data_ptr(), _lib.ptr(rs), slope, dz.data_ptr(), dz_max.data_ptr(),
                                            N, cout, _stream())
         _lib.check(rc, "mlgnn_leaky_relu_bwd")
-        w_x1, w_c = w_cat[:, :cin], w_cat[:, cin:]
         gx = None
         if ctx.needs_input_grad[0]:
             # d agg = dz W_c, through the transposed aggregation, then dx = dz W_x' + that (the sum in the GEMM's epilogue)
-            dagg = tall_matmul_nt(dz, w_c.contiguous(), row_max=dz_max, bt_transposed=True)
+            dagg = tall_matmul_nt(dz, w_c, row_max=dz_max, bt_transposed=True)
             gagg = torch.empty_like(dagg)
             ew_t = ctx.ew_pair[1] if ctx.ew_pair is not None else None
             hub, hub_keep = g.hub_arg("src", cin)
@@ -105,16 +107,17 @@ class _SageLayer(torch.autograd.Function):
                 N, cin, _DTYPE_IDS[dagg.dtype], msg, EDGE_NONE, 0, aggr, 0, 1.0, 1.0, None, None, 0.0, 0, 0, hub,
                 None, None, _stream())
             _lib.check(rc, "mlgnn_csr_aggregate_bwd")
-            gx = tall_matmul_nt(dz, w_x1.contiguous(), residual=gagg, row_max=dz_max, bt_transposed=True)
+            gx = tall_matmul_nt(dz, w_x1, residual=gagg, row_max=dz_max, bt_transposed=True)
         # dW of the folded weight: dz^T x and dz^T agg (split-row kernels; a_max bounds both operands' rows)
         gw_x1, gb = _wgrad(dz, x, go_max=dz_max, x_max=a_max)
         gw_c, _ = _wgrad(dz, agg, go_max=dz_max, x_max=a_max)
-        if relative:
-            gw_c = gw_c - gw_x1                                    # W_x' = W_x - W_c
-        # chain rule of the fold W_c = W_a W_r
-        w_a = w_nn[:, cin:]
-        g_nn = torch.cat([gw_x1, gw_c @ w_r.t()], dim=1)
-        g_r = w_a.t() @ gw_c
+        # chain rule of the fold (W_x' = W_x - rel W_c, W_c = W_a W_r): one small launch
+        g_nn = torch.empty_like(w_nn)
+        g_r = torch.empty_like(w_r)
+        gw_x1, gw_c = gw_x1.contiguous(), gw_c.contiguous()
+        rc = _lib.lib.mlgnn_sage_fold_bwd(gw_x1.data_ptr(), gw_c.data_ptr(), w_nn.data_ptr(), w_r.data_ptr(), g_nn.data_ptr(),
+                                          g_r.data_ptr(), cin, cout, int(relative), _stream())
+        _lib.check(rc, "mlgnn_sage_fold_bwd")
         return gx, g_nn, (gb if has_bias else None), g_r, None, None, None, None, None, None
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 16
+#define MLGNN_ABI_VERSION 17
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -110,7 +110,8 @@ int64_t mlgnn_csr_aggregate_bwd_workspace_floats(int64_t N, int64_t d, int dtype
  *                   before the outer clamp; may be NULL when no backward is wanted
  *   aux2    [N,d]   optional second moment for the learnable temperature / exponent:
  *                   SOFTMAX: sum_e w_e m_e^2 ; POWER: mean(clamp(m)^p * ln clamp(m)); NULL to skip
- *   argmax  [N,d]   MAX: by-destination edge position of the winner, -1 for an empty row
+ *   argmax  [N,d]   MAX: by-destination edge position of the winner; -1 where no gradient flows: an empty row, or a
+ *                   winner on relu's flat side (z <= 0: its message is the constant eps)
  *   row_max [N]     optional (NULL to skip): max_c |out[i][c]| per row, for the per-row scaling of the Linear that
  *                   consumes `out` (mlgnn_tallgemm_nt); only for d = 4 * 2^k <= 256 (fp32), 8 * 2^k <= 512 (bf16)
  *   t, p            softmax temperature / power exponent; when t_dev / p_dev is non-NULL the value is
@@ -147,6 +148,8 @@ int mlgnn_csr_aggregate_fwd(const void* x, const int32_t* rowptr, const int32_t*
  *   accumulate_efull  non-zero: grad_efull += instead of = (the same [E0,d] embedding feeds several layers --
  *                   deepergcn.py:232-281 passes one edge_emb to every GENConv -- and their edge gradients are
  *                   summed in place instead of by separate [E0,d] additions)
+ *                   3 (MAX over fp32 rows with a TABLE read through eid): nothing per edge is produced, grad_efull is
+ *                   NULL -- the table's gradient comes from the destination side (mlgnn_max_table_grad)
  *                   2 (MAX over fp32 rows with a TABLE read through eid): grad_efull is the fixed-point accumulator of
  *                   the TABLE's gradient prepared by mlgnn_table_grad_begin and geid_t names every edge's table row
  *                   (= eid_t): with max only the winning edge of (i, c) has a gradient, 1 / degree of the [E,d]
@@ -565,6 +568,32 @@ int mlgnn_embedding_bwd(const float* grad_e, const int32_t* perm, const int32_t*
  *     gradient (the per-edge path would confine it to the rows it touches).
  */
 int64_t mlgnn_table_grad_bytes(int64_t T, int64_t d);
+
+/*
+ * The same gradient from the DESTINATION side, without atomics and without a per-edge buffer (the default for the
+ * reference's default flags).  The forward's argmax [N,d] names the winning edge of (i, c) by its by-destination position,
+ * or -1 where no gradient flows (no incoming edge, or the winner's relu is on its flat side), so
+ *   grad_table[t][c] (+)= sum over { i : rows_by_dst[argmax[i][c]] = t } of grad_out[i][c]
+ * is one streaming pass over grad_out and argmax (N d 8 bytes); rows_by_dst [E] int32: table row of every edge in
+ * by-destination order.  The aggregation backward then runs with accumulate_efull = 3 and writes nothing per edge.
+ * fp32, d % 4 == 0, d <= 1024, T <= 36 (mlgnn_max_table_grad_supported); workspace:
+ * mlgnn_max_table_grad_workspace_floats(N, d, T) floats (per-workgroup partial tables, added in workgroup order:
+ * bitwise reproducible).  accumulate: grad_table += (the layers of one backward that share the table).
+ *
+ * mlgnn_max_table_grad_by_type: the same sum for a table of ANY size (nn.Embedding(pathway_edge_num, hidden) has one row
+ * per KEGG membership: tens of thousands) -- one wavefront per table row walks that row's edges and gathers the
+ * cotangent and argmax rows of their destinations.  pos_sorted [E] int32: the by-destination edge positions sorted
+ * (stably) by table row, dst_sorted [E]: the destination node of each, rowptr [T+1]: row t owns
+ * [rowptr[t], rowptr[t+1]).  fp32, d % 4 == 0; no workspace; fixed order (bitwise reproducible).
+ */
+int mlgnn_max_table_grad_supported(int64_t N, int64_t d, int64_t T);
+int64_t mlgnn_max_table_grad_workspace_floats(int64_t N, int64_t d, int64_t T);
+int mlgnn_max_table_grad(const float* grad_out, const int32_t* argmax, const int32_t* rows_by_dst, float* grad_table,
+                         float* workspace, int64_t workspace_floats, int64_t N, int64_t d, int64_t T, int accumulate,
+                         void* stream);
+int mlgnn_max_table_grad_by_type(const float* grad_out, const int32_t* argmax, const int32_t* dst_sorted,
+                                 const int32_t* pos_sorted, const int32_t* rowptr, float* grad_table, int64_t N, int64_t d,
+                                 int64_t T, int accumulate, void* stream);
 int mlgnn_table_grad_begin(const float* grad_out, int64_t rows, int64_t d, void* accumulator, void* stream);
 int mlgnn_table_grad_finish(void* accumulator, float* grad_table, int64_t T, int64_t d, int accumulate, void* stream);
 

@@ -79,6 +79,9 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
   // atomics: order-independent) instead of being written per edge and reduced later (csrc/embedding.hip)
   constexpr bool kCanFix = MODE == M_GEN_FULL && AGGR == A_MAX && sizeof(T) == 4;
   const bool fix = kCanFix && a.ge_accumulate == 2;
+  // ge_accumulate == 3: the table's gradient is taken from the destination side (mlgnn_max_table_grad, csrc/embedding.hip);
+  // nothing per edge leaves this kernel
+  const bool skip_ge = kCanFix && a.ge_accumulate == 3;
   const float fix_scale = fix ? fix_scale_of(static_cast<const uint32_t*>(a.ge)) : 0.f;
   unsigned long long* fix_tab = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(a.ge) + kFixHeaderBytes);
 
@@ -202,7 +205,8 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
       float xj[VEC], gx[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { xj[i] = 0.f; gx[i] = 0.f; }
-      if (is_gen<MODE>() && end > beg) load_t<T, VEC>(xj, X + (size_t)xr * a.d + c0);
+      // max: the forward names a winner only where its z > 0 (argmax = -1 otherwise): z is not needed again
+      if (is_gen<MODE>() && AGGR != A_MAX && end > beg) load_t<T, VEC>(xj, X + (size_t)xr * a.d + c0);
       float xjv[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) xjv[i] = xj[i] + ev[i];
@@ -223,7 +227,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
           if constexpr (ES > 0) {
             load_edge_scalars<ES>(my_ew, a.ew_t, (size_t)(base + lane));
           }
-          if (MODE == M_GEN_FULL) {
+          if (MODE == M_GEN_FULL && !skip_ge) {
             my_eid = a.eid_t[base + lane];
             my_gid = a.geid_t ? a.geid_t[base + lane] : my_eid;
           }
@@ -258,7 +262,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
               if (AGGR == A_SOFTMAX && LEARN_T) load_row<T, VEC>(gc[u], OUTS, off);
               if (AGGR == A_MAX && !SHIFT) load_row<VEC>(ai[u], a.argmax, off * kWide);
               if (AGGR == A_MAX && SHIFT) load_slots<VEC>(ai[u], a.slot8 + off / (uint32_t)sizeof(T));
-              if (MODE == M_GEN_FULL) load_t<T, VEC>(ef[u], EF + (size_t)e0[u] * a.d + c0);
+              if (MODE == M_GEN_FULL && AGGR != A_MAX) load_t<T, VEC>(ef[u], EF + (size_t)e0[u] * a.d + c0);
             }
           }
           // lane-group chunks of a partial batch past the row's last edge contribute nothing: skipped as a whole
@@ -270,7 +274,8 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
               float coef, z = 0.f, m = 0.f;
-              if constexpr (RK > 0) {               // x_j + v is constant along the row: the fma chain starts from it
+              if constexpr (AGGR == A_MAX) {        // (the winner's z > 0 by construction of argmax)
+              } else if constexpr (RK > 0) {        // x_j + v is constant along the row: the fma chain starts from it
                 z = xjv[i];
 #pragma unroll
                 for (int q = 0; q < RK; ++q) z = fmaf(wa[u][q], eu[i][q], z);
@@ -295,7 +300,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
                 coef = inr ? ga[u][i] * fast_exp2((sc.p - 1.0f) * fast_log2(mc)) : 0.f;
               }
               if constexpr (MODE == M_WEIGHTED) coef *= wa[u][0];
-              if constexpr (is_gen<MODE>()) coef = (z > 0.f) ? coef : 0.f;
+              if constexpr (is_gen<MODE>() && AGGR != A_MAX) coef = (z > 0.f) ? coef : 0.f;
               dz[i] = (FULL || valid[u]) ? coef : 0.f;
               gx[i] += dz[i];
               if constexpr (RK > 0) {               // (d loss / d v = sum of all dz: taken from gx once per row, below)
@@ -313,6 +318,7 @@ __device__ __forceinline__ void csr_aggregate_bwd_body(const BwdArgs& a, float (
                 }
                 continue;
               }
+              if (skip_ge) continue;
             }
             if (MODE == M_GEN_FULL && valid[u] && cact) {
               T* gep = GE + (size_t)g0[u] * a.d + c0;
@@ -707,7 +713,7 @@ static int csr_aggregate_bwd_impl(const void* grad_out, const void* x, const voi
   const int rk = rank_of_mode(mode);
   if ((mode == M_WEIGHTED || rk > 0) && !ew_t && col_t) return MLGNN_E_NULL;
   if (rk > 0 && (!eu || !ev || !grad_uv)) return MLGNN_E_NULL;
-  if (mode == M_GEN_FULL && col_t && (!efull || !eid_t || !grad_efull)) return MLGNN_E_NULL;
+  if (mode == M_GEN_FULL && col_t && (!efull || !eid_t || (!grad_efull && accumulate_efull != 3))) return MLGNN_E_NULL;
   const int nblk = grid_for_rows(N);
   const bool bf16 = dtype == MLGNN_DTYPE_BF16;
   const bool split = hub && hub->cap > 0 && col_t;
@@ -735,6 +741,7 @@ static int csr_aggregate_bwd_impl(const void* grad_out, const void* x, const voi
   a.ge_accumulate = accumulate_efull;
   // 2: grad_efull is the fixed-point accumulator of a TABLE gradient (mlgnn_table_grad_begin), geid_t names every
   // edge's table row -- the max aggregator over fp32 rows only
+  if (accumulate_efull == 3 && (ag != A_MAX || mode != M_GEN_FULL || bf16 || grad_efull)) return MLGNN_E_MODE;
   if (accumulate_efull == 2 && (ag != A_MAX || mode != M_GEN_FULL || bf16 || !grad_efull || !geid_t)) return MLGNN_E_MODE;
   a.cap = split ? hub->cap : kNoCap; a.vrows = nullptr; a.vcount = nullptr;
   if (add_root && learn_t) return MLGNN_E_MODE;       // `out` must be the bare aggregate for d/dt

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_fwd_kernel(const FwdArgs
             o[i] = a.mean ? tot * inv : tot;
           } else if constexpr (AGGR == A_MAX) {
             o[i] = (bpos[i] >= 0) ? acc[i] + (kLateEps ? a.eps : 0.f) : 0.f;
-            am[i] = bpos[i];
+            am[i] = acc[i] > 0.f ? bpos[i] : -1;     // a winner on relu's flat side carries no gradient: not named
           } else if constexpr (AGGR == A_SOFTMAX) {
             if (deg > 0) {
               const float rs = __builtin_amdgcn_rcpf(acc[i]);

@@ -101,6 +101,141 @@ __global__ __launch_bounds__(256) void fix_to_table_kernel(long long* __restrict
   }
 }
 
+
+// ---- table gradient of the max aggregator from the DESTINATION side -------------------------------------------------
+// Under max only the winning edge of (i, c) carries gradient, and the forward names it: argmax[i][c] = its position in
+// the by-destination edge order, or -1 where no gradient flows (no incoming edge, or the winner sits on relu's flat
+// side).  So  grad_table[t][c] = sum over { i : rows_by_dst[argmax[i][c]] = t } of grad_out[i][c]  -- a STREAMING pass
+// over two [N, d] arrays (the winners of one destination row are edges of that row: their table rows sit in one or two
+// cache lines) instead of an [E, d] per-edge gradient written, re-read per layer and reduced (5.2 GB per layer for a
+// BASELINE configs[1] batch).  A thread owns one column quad and walks rows; its sums live in LDS slots of its own
+// ([T][4][256] floats: no atomics, no conflicts), the threads of a workgroup that share a column quad are added in thread
+// order, workgroups leave partial tables that reduce_partials adds in workgroup order: bitwise reproducible.
+using emb_f4 = __attribute__((ext_vector_type(4))) float;
+
+struct MaxTableArgs {
+  const float* go; const int* argmax; const int* rows_dst; float* partials;
+  int N; int d; int T; int rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void max_table_grad_kernel(const MaxTableArgs a) {
+  extern __shared__ float tab_acc[];                       // [T][4][256]
+  const int tid = threadIdx.x;
+  const int Q = a.d >> 2;                                  // column quads per row (<= 256)
+  const int rpp = 256 / Q;                                 // rows per pass of the workgroup
+  for (int k = tid; k < a.T * 1024; k += 256) tab_acc[k] = 0.f;
+  __syncthreads();
+  const int rr = tid / Q, cq = tid - rr * Q;
+  const int r_beg = blockIdx.x * a.rows_per_block, r_end = min(a.N, r_beg + a.rows_per_block);
+  if (rr < rpp) {
+    constexpr int kU = 4;
+    for (int r = r_beg + rr; r < r_end; r += rpp * kU) {
+      int4 am[kU];
+      float4 g[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int ru = r + u * rpp;
+        am[u] = make_int4(-1, -1, -1, -1);
+        g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ru < r_end) {
+          const size_t q = (size_t)ru * Q + cq;
+          am[u] = reinterpret_cast<const int4*>(a.argmax)[q];
+          const emb_f4 gv = __builtin_nontemporal_load(reinterpret_cast<const emb_f4*>(a.go) + q);   // read once
+          g[u] = make_float4(gv.x, gv.y, gv.z, gv.w);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int e[4] = {am[u].x, am[u].y, am[u].z, am[u].w};
+        const float v[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+        int t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = e[i] >= 0 ? a.rows_dst[e[i]] : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (t[i] >= 0) tab_acc[(t[i] * 4 + i) * 256 + tid] += v[i];
+      }
+    }
+  }
+  __syncthreads();
+  // partial table of this workgroup: the rpp threads of a column quad in thread order
+  float* part = a.partials + (size_t)blockIdx.x * a.T * a.d;
+  for (int k = tid; k < a.T * a.d; k += 256) {
+    const int t = k / a.d, c = k - t * a.d;
+    const float* slot = tab_acc + (t * 4 + (c & 3)) * 256 + (c >> 2);
+    float sum = 0.f;
+    for (int j = 0; j < rpp; ++j) sum += slot[j * Q];
+    part[k] = sum;
+  }
+}
+
+constexpr int kMaxTableBlocks = 1024;
+
+// ---- the same gradient for a LARGE table: one wavefront per table row --------------------------------------------------
+// nn.Embedding(pathway_edge_num, hidden) has one row per (gene, pathway) membership of KEGG (multiloader.py:105-106,
+// 991-1005: tens of thousands of rows, a handful of edges per row and graph), so per-workgroup partial tables do not fit
+// anywhere.  The edges -- by-destination positions -- are sorted by table row once per batch (stable: destination order
+// inside a row, so the wavefronts sweep the graphs of the batch together and the cotangent rows they gather stay in L2 /
+// Infinity Cache); a wavefront walks the edges of its row, gathers the cotangent and argmax rows of each edge's
+// destination and keeps the channels that edge won:  acc[c] += (argmax[i][c] == pos) ? grad_out[i][c] : 0.
+// Nothing per edge is ever written (the [E, d] gradient this replaces: 5.2 GB written, re-read and reduced per layer at
+// BASELINE configs[1] size).  Fixed order: bitwise reproducible.
+struct MaxTypeArgs {
+  const float* go; const int* argmax; const int* dst_s; const int* pos_s; const int* rowptr; float* out;
+  int T; int d; int lpr_log2; int accumulate;
+};
+
+__global__ __launch_bounds__(kBlock) void max_table_grad_by_type_kernel(const MaxTypeArgs a) {
+  constexpr int kUnroll = 4;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << a.lpr_log2, groups = kWave >> a.lpr_log2;
+  const int sub = lane >> a.lpr_log2, cl = lane & (lpr - 1);
+  const int wave_global = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int n_waves = gridDim.x * kWavesPerBlock;
+  for (int cbase = 0; cbase < a.d; cbase += lpr * 4) {
+    const int c0 = min(cbase + cl * 4, a.d - 4);
+    const bool cact = cbase + cl * 4 < a.d;
+    for (int t = wave_global; t < a.T; t += n_waves) {
+      const int beg = a.rowptr[t], end = a.rowptr[t + 1];
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k = beg + sub; k < end; k += groups * kUnroll) {
+        float v[kUnroll][4];
+        int am[kUnroll][4], pos[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int kk = k + u * groups;
+          pos[u] = -2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { v[u][i] = 0.f; am[u][i] = -1; }
+          if (kk < end) {
+            const size_t row = (size_t)a.dst_s[kk] * a.d + c0;
+            pos[u] = a.pos_s[kk];
+            load_vec<4>(v[u], a.go + row);
+            load_vec<4>(am[u], a.argmax + row);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] += (am[u][i] == pos[u]) ? v[u][i] : 0.f;
+      }
+      for (int off = lpr; off < kWave; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], off);
+      if (sub == 0 && cact) {
+        float* o = a.out + (size_t)t * a.d + c0;
+        if (a.accumulate) {
+          float prev[4];
+          load_vec<4>(prev, o);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] += prev[i];
+        }
+        store_vec<4>(o, acc);
+      }
+    }
+  }
+}
+
 }  // namespace mlgnn
 
 using namespace mlgnn;
@@ -156,5 +291,71 @@ extern "C" int mlgnn_embedding_bwd(const float* grad_e, const int32_t* perm, con
   int64_t blocks = (T + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
   hipLaunchKernelGGL(embedding_grad_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+static int max_table_blocks(int64_t N, int64_t d, int* rows_per_block) {
+  const int rpp = 256 / (int)(d / 4);
+  int64_t rpb = (N + kMaxTableBlocks - 1) / kMaxTableBlocks;
+  rpb = (rpb + rpp - 1) / rpp * rpp;
+  if (rpb < 4 * rpp) rpb = 4 * rpp;
+  *rows_per_block = (int)rpb;
+  return (int)((N + rpb - 1) / rpb);
+}
+
+extern "C" int mlgnn_max_table_grad_supported(int64_t N, int64_t d, int64_t T) {
+  return N > 0 && N <= INT32_MAX && d >= 4 && d % 4 == 0 && d <= 1024 && N * d < ((int64_t)1 << 40) && T >= 1 && T <= 36;
+}
+
+extern "C" int64_t mlgnn_max_table_grad_workspace_floats(int64_t N, int64_t d, int64_t T) {
+  if (!mlgnn_max_table_grad_supported(N, d, T)) return MLGNN_E_SHAPE;
+  int rpb = 0;
+  return (int64_t)max_table_blocks(N, d, &rpb) * T * d;
+}
+
+extern "C" int mlgnn_max_table_grad(const float* grad_out, const int32_t* argmax, const int32_t* rows_by_dst,
+                                    float* grad_table, float* workspace, int64_t workspace_floats, int64_t N, int64_t d,
+                                    int64_t T, int accumulate, void* stream) {
+  if (!mlgnn_max_table_grad_supported(N, d, T)) return MLGNN_E_SHAPE;
+  if (!grad_out || !argmax || !rows_by_dst || !grad_table || !workspace) return MLGNN_E_NULL;
+  if (((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(argmax) | reinterpret_cast<uintptr_t>(workspace) |
+        reinterpret_cast<uintptr_t>(grad_table)) & 15) != 0)
+    return MLGNN_E_ALIGN;
+  MaxTableArgs a;
+  a.go = grad_out; a.argmax = argmax; a.rows_dst = rows_by_dst; a.partials = workspace;
+  a.N = (int)N; a.d = (int)d; a.T = (int)T;
+  const int blocks = max_table_blocks(N, d, &a.rows_per_block);
+  if (workspace_floats < (int64_t)blocks * T * d) return MLGNN_E_WORKSPACE;
+  const size_t lds = (size_t)T * 1024 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(max_table_grad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024 * (int)sizeof(float));
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(max_table_grad_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
+  int err = (int)hipGetLastError();
+  if (err) return err;
+  launch_reduce_partials(workspace, grad_table, blocks, (int)(T * d), s, accumulate != 0);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_max_table_grad_by_type(const float* grad_out, const int32_t* argmax, const int32_t* dst_sorted,
+                                            const int32_t* pos_sorted, const int32_t* rowptr, float* grad_table, int64_t N,
+                                            int64_t d, int64_t T, int accumulate, void* stream) {
+  if (N <= 0 || N > INT32_MAX || T < 0 || T > INT32_MAX || d <= 0 || d % 4 != 0 || d > 4096) return MLGNN_E_SHAPE;
+  if (T == 0) return 0;
+  if (!grad_out || !argmax || !dst_sorted || !pos_sorted || !rowptr || !grad_table) return MLGNN_E_NULL;
+  if (((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(argmax) | reinterpret_cast<uintptr_t>(grad_table)) &
+       15) != 0)
+    return MLGNN_E_ALIGN;
+  MaxTypeArgs a;
+  a.go = grad_out; a.argmax = argmax; a.dst_s = dst_sorted; a.pos_s = pos_sorted; a.rowptr = rowptr; a.out = grad_table;
+  a.T = (int)T; a.d = (int)d; a.lpr_log2 = lanes_per_row_log2(d, 4); a.accumulate = accumulate;
+  int64_t blocks = (T + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  hipLaunchKernelGGL(max_table_grad_by_type_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

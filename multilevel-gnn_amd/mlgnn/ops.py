@@ -342,6 +342,11 @@ def edge_type_embedding(table, idx):
 # the reference's default DeeperGCN flags (22.6 vs 21.9 ms, same box): 82 M sparse 8-byte atomics per layer execute at
 # the memory side, one 64-byte request each.  Off by default.
 TABLE_DIRECT = os.environ.get("MLGNN_TABLE_DIRECT", "0") == "1"
+# max + TableEdge, the default since round 4: the table gradient from the DESTINATION side -- the forward's argmax names
+# the winner of every (node, channel), so the gradient is one streaming pass over grad_out and argmax
+# (mlgnn_max_table_grad) and the aggregation backward writes nothing per edge.  MLGNN_TABLE_DEST=0: the per-edge buffer.
+TABLE_DEST = os.environ.get("MLGNN_TABLE_DEST", "1") == "1"
+TABLE_DEST_STATS = {"calls": 0, "streamed": 0, "by_type": 0}
 
 
 class _GradSink:
@@ -487,6 +492,23 @@ class TableEdge:
         return self._sorted[1], self._sorted[2]
 
 
+    def winners_by_type(self, graph):
+        """``(by-destination edge positions sorted (stably) by table row, the destination node of each, row pointer)``
+        (int32) -- what mlgnn_max_table_grad_by_type walks: destination order inside a table row, so the rows gathered for
+        it run through the batch graph by graph.  Derived once per (graph, source), like the other index arrays."""
+        shared = self._graph_cache(graph)
+        store = shared if shared is not None else self.__dict__.setdefault("_winners", {})
+        key = "winners" if shared is not None else id(graph)
+        if key not in store:
+            by_dst = self.rows_for(graph)[0].long()
+            order = torch.sort(by_dst, stable=True)[1]
+            rowptr = torch.zeros(self.table_rows + 1, dtype=torch.int64, device=self.idx.device)
+            torch.cumsum(torch.bincount(by_dst, minlength=self.table_rows), 0, out=rowptr[1:])
+            dst = torch.searchsorted(graph.rowptr.long(), order, right=True) - 1
+            store[key] = (order.to(torch.int32), dst.to(torch.int32), rowptr.to(torch.int32))
+        return store[key]
+
+
 def share_edge_gradient(e):
     """Mark a dense edge embedding as shared by several :func:`gen_aggregate` calls (see :class:`_EdgeFanout`)."""
     if not (torch.is_tensor(e) and e.dim() == 2 and e.requires_grad and torch.is_grad_enabled()):
@@ -613,7 +635,35 @@ class _GenAggregate(torch.autograd.Function):
         # fixed-point accumulator inside the kernel (no [E, d] gradient written, re-read and reduced)
         fix_table = (TABLE_DIRECT and te is not None and sink is not None and aggr_id == AGGR_MAX and edge_mode == EDGE_FULL
                      and x.dtype == torch.float32 and d % 4 == 0 and ctx.post_ln is None)
-        if fix_table:
+        dest_table = (not fix_table and TABLE_DEST and te is not None and sink is not None and aggr_id == AGGR_MAX
+                      and edge_mode == EDGE_FULL and x.dtype == torch.float32 and argmax is not None and d % 4 == 0
+                      and go_k.data_ptr() % 16 == 0 and argmax.data_ptr() % 16 == 0)
+        if dest_table:
+            T = te.table_rows
+            first = sink.total is None
+            if first:
+                sink.total = torch.empty((T, d), dtype=torch.float32, device=x.device)
+            if bool(_lib.lib.mlgnn_max_table_grad_supported(N, d, T)):
+                # a few table rows: one streaming pass, per-workgroup partial tables in LDS
+                rows_dst = te.rows_for(g)[0]
+                mt_n = int(_lib.lib.mlgnn_max_table_grad_workspace_floats(N, d, T))
+                mt_ws = torch.empty(mt_n, dtype=torch.float32, device=x.device)
+                rc = _lib.lib.mlgnn_max_table_grad(go_k.data_ptr(), argmax.data_ptr(), rows_dst.data_ptr(),
+                                                   sink.total.data_ptr(), mt_ws.data_ptr(), mt_n, N, d, T, 0 if first else 1,
+                                                   _stream())
+                _lib.check(rc, "mlgnn_max_table_grad")
+                TABLE_DEST_STATS["streamed"] += 1
+            else:
+                # one row per KEGG membership (tens of thousands): a wavefront per table row gathers its edges' winners
+                pos_s, dst_s, rp_s = te.winners_by_type(g)
+                rc = _lib.lib.mlgnn_max_table_grad_by_type(go_k.data_ptr(), argmax.data_ptr(), dst_s.data_ptr(),
+                                                           pos_s.data_ptr(), rp_s.data_ptr(), sink.total.data_ptr(), N, d, T,
+                                                           0 if first else 1, _stream())
+                _lib.check(rc, "mlgnn_max_table_grad_by_type")
+                TABLE_DEST_STATS["by_type"] += 1
+            TABLE_DEST_STATS["calls"] += 1
+            ge, ge_accumulate, geid_t = None, 3, None
+        elif fix_table:
             T = te.table_rows
             if sink.fix is None or sink.fix.numel() != int(_lib.lib.mlgnn_table_grad_bytes(T, d)):
                 sink.fix = torch.zeros(int(_lib.lib.mlgnn_table_grad_bytes(T, d)), dtype=torch.uint8, device=x.device)

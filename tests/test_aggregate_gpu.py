@@ -426,6 +426,7 @@ def test_max_table_gradient_summed_in_the_kernel(layers, monkeypatch):
 
     def run(direct, cotangent):
         monkeypatch.setattr(ops, "TABLE_DIRECT", direct)
+        monkeypatch.setattr(ops, "TABLE_DEST", False)
         xd, td = x0.clone().requires_grad_(True), table0.clone().requires_grad_(True)
         te = TableEdge(td, idx)
         h = xd
@@ -444,6 +445,55 @@ def test_max_table_gradient_summed_in_the_kernel(layers, monkeypatch):
     bad[5, 7] = float("nan")
     _, gtn = run(True, bad)
     assert bool(torch.isnan(gtn).all())
+
+
+@pytest.mark.parametrize("layers,d,T", [(1, 128, 8), (3, 128, 8), (2, 100, 36), (1, 64, 1), (2, 256, 5), (1, 4, 3),
+                                        (1, 128, 37), (3, 128, 2000), (2, 100, 700), (1, 320, 60000), (2, 8, 90)])
+def test_max_table_gradient_from_the_destination_side(layers, d, T, monkeypatch):
+    """max + ``TableEdge``, the default: the forward's argmax names the winner of every (node, channel) -- and names none
+    (-1) where the winner's relu is flat -- so the table gradient is a streaming pass over grad_out and argmax
+    (mlgnn_max_table_grad: few table rows; mlgnn_max_table_grad_by_type: a wavefront per table row gathers the winners of
+    its edges) and the aggregation backward writes nothing per edge (``accumulate_efull = 3``).  Against the
+    per-edge path on the same inputs: grad x bitwise equal, the table gradient equal up to fp32 summation order; bitwise
+    repeatable; rows no edge reads stay zero; against the fp64 oracle of the reference's formulation."""
+    from mlgnn import CSRGraph, TableEdge, gen_aggregate, ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(190 + layers + d)
+    N, E = 3001, 50000
+    ei = _graph(gen, N, E, hub=True)
+    x0 = torch.randn(N, d, generator=gen)
+    table0 = torch.randn(T, d, generator=gen) * 0.5
+    idx = torch.randint(0, max(T - 1, 1), (E,), generator=gen)           # the last row is read by no edge (T > 1)
+    cot = torch.randn(N, d, generator=gen)
+    graph = CSRGraph(ei.to(dev), N)
+
+    def run(dest):
+        monkeypatch.setattr(ops, "TABLE_DEST", dest)
+        xd, td = x0.to(dev).requires_grad_(True), table0.to(dev).requires_grad_(True)
+        te = TableEdge(td, idx.to(dev))
+        h = xd
+        for _ in range(layers):
+            h = gen_aggregate(h, graph, te, aggr="max") * 0.5
+        return torch.autograd.grad((h * cot.to(dev)).sum(), [xd, td])
+
+    gx0, gt0 = run(False)
+    before = ops.TABLE_DEST_STATS["calls"]
+    gx1, gt1 = run(True)
+    assert ops.TABLE_DEST_STATS["calls"] == before + layers              # the destination-side pass ran, once per layer
+    assert ops.TABLE_DEST_STATS["streamed" if T <= 36 else "by_type"] >= layers
+    gx2, gt2 = run(True)
+    assert torch.equal(gx0, gx1) and torch.equal(gx1, gx2) and torch.equal(gt1, gt2)
+    assert_close(gt1, gt0, 2e-6, "table gradient vs the per-edge path")
+    if T > 1:
+        assert not bool(gt1[T - 1].any())
+    # the reference's formulation in fp64: messages relu(x_j + table[idx]) + eps, max per destination
+    xr, tr = x0.double().requires_grad_(True), table0.double().requires_grad_(True)
+    h = xr
+    for _ in range(layers):
+        h = G.gen_aggregate(torch.relu(h[ei[0]] + tr[idx]) + 1e-7, ei[1], N, "max") * 0.5
+    gxr, gtr = torch.autograd.grad((h * cot.double()).sum(), [xr, tr])
+    assert_close(gx1, gxr, 1e-5, "grad x vs oracle")
+    assert_close(gt1, gtr, 1e-5, "grad table vs oracle")
 
 
 def test_table_edge_index_arrays_are_kept_on_the_graph_for_a_repeated_source():

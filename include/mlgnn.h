@@ -585,6 +585,11 @@ int64_t mlgnn_table_grad_bytes(int64_t T, int64_t d);
  * cotangent and argmax rows of their destinations.  pos_sorted [E] int32: the by-destination edge positions sorted
  * (stably) by table row, dst_sorted [E]: the destination node of each, rowptr [T+1]: row t owns
  * [rowptr[t], rowptr[t+1]).  fp32, d % 4 == 0; no workspace; fixed order (bitwise reproducible).
+ * slots (or NULL) + rel_sorted [E] (position of each edge INSIDE its destination row): the one-byte winner slots the
+ * MAX backward of the same layer left in its workspace -- workspace + mlgnn_csr_aggregate_bwd_slots_offset_floats(N, d,
+ * edge_rank) floats: {int32 flag (non-zero: some row is longer than 254 edges, slots unusable), 12 bytes, slots [N,d]};
+ * call after that backward on the same stream.  The kernel then gathers 1 instead of 4 bytes of winner information per
+ * channel (flag set: it reads argmax as without slots).  Same results.
  */
 int mlgnn_max_table_grad_supported(int64_t N, int64_t d, int64_t T);
 int64_t mlgnn_max_table_grad_workspace_floats(int64_t N, int64_t d, int64_t T);
@@ -592,8 +597,10 @@ int mlgnn_max_table_grad(const float* grad_out, const int32_t* argmax, const int
                          float* workspace, int64_t workspace_floats, int64_t N, int64_t d, int64_t T, int accumulate,
                          void* stream);
 int mlgnn_max_table_grad_by_type(const float* grad_out, const int32_t* argmax, const int32_t* dst_sorted,
-                                 const int32_t* pos_sorted, const int32_t* rowptr, float* grad_table, int64_t N, int64_t d,
-                                 int64_t T, int accumulate, void* stream);
+                                 const int32_t* pos_sorted, const int32_t* rel_sorted, const int32_t* rowptr,
+                                 const void* slots, float* grad_table, int64_t N, int64_t d, int64_t T, int accumulate,
+                                 void* stream);
+int64_t mlgnn_csr_aggregate_bwd_slots_offset_floats(int64_t N, int64_t d, int edge_rank);
 int mlgnn_table_grad_begin(const float* grad_out, int64_t rows, int64_t d, void* accumulator, void* stream);
 int mlgnn_table_grad_finish(void* accumulator, float* grad_table, int64_t T, int64_t d, int accumulate, void* stream);
 

@@ -685,6 +685,13 @@ static int num_cus() {
   return n;
 }
 
+extern "C" int64_t mlgnn_csr_aggregate_bwd_slots_offset_floats(int64_t N, int64_t d, int edge_rank) {
+  if (N <= 0 || d <= 0 || d % 4 != 0) return MLGNN_E_SHAPE;
+  if (edge_rank != 0 && edge_rank != 1 && edge_rank != 2 && edge_rank != 4 && edge_rank != 8) return MLGNN_E_MODE;
+  const int rk = edge_rank;
+  return rk > 0 ? (int64_t)(grid_for_rows(N) + kHubBlocks) * (rk + 1) * d : 0;
+}
+
 static int csr_aggregate_bwd_impl(const void* grad_out, const void* x, const void* out, const float* aux,
                                        const int32_t* argmax,
                                        const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,

@@ -180,12 +180,17 @@ constexpr int kMaxTableBlocks = 1024;
 // destination and keeps the channels that edge won:  acc[c] += (argmax[i][c] == pos) ? grad_out[i][c] : 0.
 // Nothing per edge is ever written (the [E, d] gradient this replaces: 5.2 GB written, re-read and reduced per layer at
 // BASELINE configs[1] size).  Fixed order: bitwise reproducible.
+// The winner of (i, c) is read as the ONE-BYTE slot the aggregation backward derived from argmax for its own gathers
+// (max_slot_kernel, csrc/aggregate_bwd.hip: the winner's position inside row i) when that call left them valid
+// (*spread == 0: no row longer than 254 edges): 640 instead of 1024 gathered bytes per edge.
 struct MaxTypeArgs {
-  const float* go; const int* argmax; const int* dst_s; const int* pos_s; const int* rowptr; float* out;
+  const float* go; const int* argmax; const int* dst_s; const int* pos_s; const int* rel_s; const int* rowptr; float* out;
+  const uint8_t* slot8; const int* spread;
   int T; int d; int lpr_log2; int accumulate;
 };
 
-__global__ __launch_bounds__(kBlock) void max_table_grad_by_type_kernel(const MaxTypeArgs a) {
+template <bool SLOTS>
+__device__ __forceinline__ void max_table_grad_by_type_body(const MaxTypeArgs& a) {
   constexpr int kUnroll = 4;
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << a.lpr_log2, groups = kWave >> a.lpr_log2;
@@ -209,9 +214,15 @@ __global__ __launch_bounds__(kBlock) void max_table_grad_by_type_kernel(const Ma
           for (int i = 0; i < 4; ++i) { v[u][i] = 0.f; am[u][i] = -1; }
           if (kk < end) {
             const size_t row = (size_t)a.dst_s[kk] * a.d + c0;
-            pos[u] = a.pos_s[kk];
+            pos[u] = SLOTS ? a.rel_s[kk] : a.pos_s[kk];
             load_vec<4>(v[u], a.go + row);
-            load_vec<4>(am[u], a.argmax + row);
+            if constexpr (SLOTS) {
+              const uint32_t w = *reinterpret_cast<const uint32_t*>(a.slot8 + row);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) am[u][i] = (int)((w >> (8 * i)) & 0xffu);
+            } else {
+              load_vec<4>(am[u], a.argmax + row);
+            }
           }
         }
 #pragma unroll
@@ -234,6 +245,11 @@ __global__ __launch_bounds__(kBlock) void max_table_grad_by_type_kernel(const Ma
       }
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void max_table_grad_by_type_kernel(const MaxTypeArgs a) {
+  if (a.slot8 != nullptr && *a.spread == 0) max_table_grad_by_type_body<true>(a);     // (uniform over the launch)
+  else max_table_grad_by_type_body<false>(a);
 }
 
 }  // namespace mlgnn
@@ -343,8 +359,9 @@ extern "C" int mlgnn_max_table_grad(const float* grad_out, const int32_t* argmax
 }
 
 extern "C" int mlgnn_max_table_grad_by_type(const float* grad_out, const int32_t* argmax, const int32_t* dst_sorted,
-                                            const int32_t* pos_sorted, const int32_t* rowptr, float* grad_table, int64_t N,
-                                            int64_t d, int64_t T, int accumulate, void* stream) {
+                                            const int32_t* pos_sorted, const int32_t* rel_sorted, const int32_t* rowptr,
+                                            const void* slots, float* grad_table, int64_t N, int64_t d, int64_t T,
+                                            int accumulate, void* stream) {
   if (N <= 0 || N > INT32_MAX || T < 0 || T > INT32_MAX || d <= 0 || d % 4 != 0 || d > 4096) return MLGNN_E_SHAPE;
   if (T == 0) return 0;
   if (!grad_out || !argmax || !dst_sorted || !pos_sorted || !rowptr || !grad_table) return MLGNN_E_NULL;
@@ -353,6 +370,11 @@ extern "C" int mlgnn_max_table_grad_by_type(const float* grad_out, const int32_t
     return MLGNN_E_ALIGN;
   MaxTypeArgs a;
   a.go = grad_out; a.argmax = argmax; a.dst_s = dst_sorted; a.pos_s = pos_sorted; a.rowptr = rowptr; a.out = grad_table;
+  a.rel_s = rel_sorted; a.slot8 = nullptr; a.spread = nullptr;
+  if (slots && rel_sorted && (reinterpret_cast<uintptr_t>(slots) & 15) == 0) {     // {int32 spread flag, 12 bytes, slots [N, d]}
+    a.spread = static_cast<const int*>(slots);
+    a.slot8 = static_cast<const uint8_t*>(slots) + 16;
+  }
   a.T = (int)T; a.d = (int)d; a.lpr_log2 = lanes_per_row_log2(d, 4); a.accumulate = accumulate;
   int64_t blocks = (T + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;

@@ -346,6 +346,7 @@ TABLE_DIRECT = os.environ.get("MLGNN_TABLE_DIRECT", "0") == "1"
 # the winner of every (node, channel), so the gradient is one streaming pass over grad_out and argmax
 # (mlgnn_max_table_grad) and the aggregation backward writes nothing per edge.  MLGNN_TABLE_DEST=0: the per-edge buffer.
 TABLE_DEST = os.environ.get("MLGNN_TABLE_DEST", "1") == "1"
+TABLE_SLOTS = os.environ.get("MLGNN_TABLE_SLOTS", "1") == "1"      # A/B: the by-type pass reads one-byte winner slots
 TABLE_DEST_STATS = {"calls": 0, "streamed": 0, "by_type": 0}
 
 
@@ -493,8 +494,8 @@ class TableEdge:
 
 
     def winners_by_type(self, graph):
-        """``(by-destination edge positions sorted (stably) by table row, the destination node of each, row pointer)``
-        (int32) -- what mlgnn_max_table_grad_by_type walks: destination order inside a table row, so the rows gathered for
+        """``(by-destination edge positions sorted (stably) by table row, the destination node of each, row pointer,
+        position of each edge inside its destination row)`` (int32) -- what mlgnn_max_table_grad_by_type walks: destination order inside a table row, so the rows gathered for
         it run through the batch graph by graph.  Derived once per (graph, source), like the other index arrays."""
         shared = self._graph_cache(graph)
         store = shared if shared is not None else self.__dict__.setdefault("_winners", {})
@@ -504,8 +505,9 @@ class TableEdge:
             order = torch.sort(by_dst, stable=True)[1]
             rowptr = torch.zeros(self.table_rows + 1, dtype=torch.int64, device=self.idx.device)
             torch.cumsum(torch.bincount(by_dst, minlength=self.table_rows), 0, out=rowptr[1:])
-            dst = torch.searchsorted(graph.rowptr.long(), order, right=True) - 1
-            store[key] = (order.to(torch.int32), dst.to(torch.int32), rowptr.to(torch.int32))
+            rp = graph.rowptr.long()
+            dst = torch.searchsorted(rp, order, right=True) - 1
+            store[key] = (order.to(torch.int32), dst.to(torch.int32), rowptr.to(torch.int32), (order - rp[dst]).to(torch.int32))
         return store[key]
 
 
@@ -635,6 +637,7 @@ class _GenAggregate(torch.autograd.Function):
         # fixed-point accumulator inside the kernel (no [E, d] gradient written, re-read and reduced)
         fix_table = (TABLE_DIRECT and te is not None and sink is not None and aggr_id == AGGR_MAX and edge_mode == EDGE_FULL
                      and x.dtype == torch.float32 and d % 4 == 0 and ctx.post_ln is None)
+        by_type_after = False
         dest_table = (not fix_table and TABLE_DEST and te is not None and sink is not None and aggr_id == AGGR_MAX
                       and edge_mode == EDGE_FULL and x.dtype == torch.float32 and argmax is not None and d % 4 == 0
                       and go_k.data_ptr() % 16 == 0 and argmax.data_ptr() % 16 == 0)
@@ -654,13 +657,7 @@ class _GenAggregate(torch.autograd.Function):
                 _lib.check(rc, "mlgnn_max_table_grad")
                 TABLE_DEST_STATS["streamed"] += 1
             else:
-                # one row per KEGG membership (tens of thousands): a wavefront per table row gathers its edges' winners
-                pos_s, dst_s, rp_s = te.winners_by_type(g)
-                rc = _lib.lib.mlgnn_max_table_grad_by_type(go_k.data_ptr(), argmax.data_ptr(), dst_s.data_ptr(),
-                                                           pos_s.data_ptr(), rp_s.data_ptr(), sink.total.data_ptr(), N, d, T,
-                                                           0 if first else 1, _stream())
-                _lib.check(rc, "mlgnn_max_table_grad_by_type")
-                TABLE_DEST_STATS["by_type"] += 1
+                by_type_after = True                         # (below, behind the backward: it reads that call's winner slots)
             TABLE_DEST_STATS["calls"] += 1
             ge, ge_accumulate, geid_t = None, 3, None
         elif fix_table:
@@ -733,6 +730,16 @@ class _GenAggregate(torch.autograd.Function):
                 _lib.ptr(shifted[0]) if shifted else None, _lib.ptr(shifted[1]) if shifted else None, _stream())
             _lib.check(rc, "mlgnn_csr_aggregate_bwd")
         del hub_keep
+        if by_type_after:
+            # one row per KEGG membership (tens of thousands): a wavefront per table row gathers its edges' winners
+            pos_s, dst_s, rp_s, rel_s = te.winners_by_type(g)
+            off = int(_lib.lib.mlgnn_csr_aggregate_bwd_slots_offset_floats(N, d, rank))
+            slots = ws.data_ptr() + 4 * off if (ws is not None and off >= 0 and TABLE_SLOTS) else None
+            rc = _lib.lib.mlgnn_max_table_grad_by_type(go_k.data_ptr(), argmax.data_ptr(), dst_s.data_ptr(), pos_s.data_ptr(),
+                                                       rel_s.data_ptr(), rp_s.data_ptr(), slots, sink.total.data_ptr(), N, d,
+                                                       te.table_rows, 0 if first else 1, _stream())
+            _lib.check(rc, "mlgnn_max_table_grad_by_type")
+            TABLE_DEST_STATS["by_type"] += 1
         if fix_table:
             first = sink.total is None
             if first:

@@ -167,6 +167,22 @@ class CSRGraph:
             hit = self._hub[direction] = [vrows, hubs, counts, cap_rows, host, done, None]
         return hit
 
+    def known_short_rows(self):
+        """True once BOTH directions are known on the host -- without ever having waited for it -- to hold no row longer
+        than the cap (at most 256 edges): what the compact max backward (csrc/max_sparse.hip) requires."""
+        cap = getattr(self, "hub_cap", HUB_CAP)
+        if cap <= 0 or cap > 256:
+            return False
+        for direction in ("dst", "src"):
+            tabs = self.hub_tables(direction)
+            if tabs is None:
+                return False
+            if tabs[6] is None and tabs[5].query():
+                tabs[6] = int(tabs[4][0]) > 0
+            if tabs[6] is not False:
+                return False
+        return True
+
     def hub_arg(self, direction, d):
         """``(pointer to a mlgnn_hub_t or None, objects to keep alive until the launch is enqueued)`` for one kernel
         call on ``[N, d]`` features: the tables above plus fresh scratch for the chunks' partial results."""

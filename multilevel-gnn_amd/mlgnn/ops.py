@@ -346,6 +346,9 @@ TABLE_DIRECT = os.environ.get("MLGNN_TABLE_DIRECT", "0") == "1"
 # the winner of every (node, channel), so the gradient is one streaming pass over grad_out and argmax
 # (mlgnn_max_table_grad) and the aggregation backward writes nothing per edge.  MLGNN_TABLE_DEST=0: the per-edge buffer.
 TABLE_DEST = os.environ.get("MLGNN_TABLE_DEST", "1") == "1"
+# max aggregator, the backward from compact winner lists (csrc/max_sparse.hip): on by default where it applies
+SPARSE_MAX = os.environ.get("MLGNN_SPARSE_MAX", "1") == "1"
+SPARSE_MAX_STATS = {"calls": 0, "table": 0}
 TABLE_SLOTS = os.environ.get("MLGNN_TABLE_SLOTS", "1") == "1"      # A/B: the by-type pass reads one-byte winner slots
 TABLE_DEST_STATS = {"calls": 0, "streamed": 0, "by_type": 0}
 
@@ -637,6 +640,48 @@ class _GenAggregate(torch.autograd.Function):
         # fixed-point accumulator inside the kernel (no [E, d] gradient written, re-read and reduced)
         fix_table = (TABLE_DIRECT and te is not None and sink is not None and aggr_id == AGGR_MAX and edge_mode == EDGE_FULL
                      and x.dtype == torch.float32 and d % 4 == 0 and ctx.post_ln is None)
+        sparse = (SPARSE_MAX and not fix_table and aggr_id == AGGR_MAX and x.dtype == torch.float32 and argmax is not None
+                  and ctx.post_ln is None and g.num_edges > 0 and go_k.data_ptr() % 16 == 0 and argmax.data_ptr() % 16 == 0
+                  and (edge_mode == EDGE_NONE or (edge_mode == EDGE_FULL and te is not None and TABLE_DEST))
+                  and bool(_lib.lib.mlgnn_max_sparse_supported(N, d)) and g.known_short_rows())
+        if sparse:
+            # every (node, channel) has ONE winning edge: its cotangent goes to that edge's source -- and to the table row
+            # the edge reads -- through compact per-edge runs of (value, channel) pairs instead of whole gathered rows
+            dev = x.device
+            wval = torch.empty((N, d), dtype=torch.float32, device=dev)
+            wch = torch.empty((N, d), dtype=torch.uint8, device=dev)
+            meta = torch.empty(g.num_edges, dtype=torch.int32, device=dev)
+            rc = _lib.lib.mlgnn_max_winners(go_k.data_ptr(), argmax.data_ptr(), g.rowptr.data_ptr(), wval.data_ptr(),
+                                            wch.data_ptr(), meta.data_ptr(), N, d, _stream())
+            _lib.check(rc, "mlgnn_max_winners")
+            rc = _lib.lib.mlgnn_max_sparse_bwd(wval.data_ptr(), wch.data_ptr(), meta.data_ptr(), g.rowptr_t.data_ptr(),
+                                               g.col_t.data_ptr(), g.pos_t.data_ptr(), go_k.data_ptr() if add_root else None,
+                                               gx.data_ptr(), N, d, _stream())
+            _lib.check(rc, "mlgnn_max_sparse_bwd")
+            SPARSE_MAX_STATS["calls"] += 1
+            if te is not None and sink is not None:
+                T = te.table_rows
+                first = sink.total is None
+                if first:
+                    sink.total = torch.empty((T, d), dtype=torch.float32, device=dev)
+                if bool(_lib.lib.mlgnn_max_table_grad_supported(N, d, T)):
+                    rows_dst = te.rows_for(g)[0]              # a few table rows: the streaming pass with LDS partial tables
+                    mt_n = int(_lib.lib.mlgnn_max_table_grad_workspace_floats(N, d, T))
+                    mt_ws = torch.empty(mt_n, dtype=torch.float32, device=dev)
+                    rc = _lib.lib.mlgnn_max_table_grad(go_k.data_ptr(), argmax.data_ptr(), rows_dst.data_ptr(),
+                                                       sink.total.data_ptr(), mt_ws.data_ptr(), mt_n, N, d, T,
+                                                       0 if first else 1, _stream())
+                    _lib.check(rc, "mlgnn_max_table_grad")
+                    TABLE_DEST_STATS["streamed"] += 1
+                else:
+                    pos_s, dst_s, rp_s, _ = te.winners_by_type(g)
+                    rc = _lib.lib.mlgnn_max_sparse_table_grad(wval.data_ptr(), wch.data_ptr(), meta.data_ptr(), dst_s.data_ptr(),
+                                                              pos_s.data_ptr(), rp_s.data_ptr(), sink.total.data_ptr(), N, d, T,
+                                                              0 if first else 1, _stream())
+                    _lib.check(rc, "mlgnn_max_sparse_table_grad")
+                    SPARSE_MAX_STATS["table"] += 1
+                TABLE_DEST_STATS["calls"] += 1
+            return gx, None, None, None, grad_t, grad_p, None, None, None, None, None, None, None, None, None, None
         by_type_after = False
         dest_table = (not fix_table and TABLE_DEST and te is not None and sink is not None and aggr_id == AGGR_MAX
                       and edge_mode == EDGE_FULL and x.dtype == torch.float32 and argmax is not None and d % 4 == 0

@@ -39,6 +39,11 @@ def pmc_per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
+def _own(name):
+    """a kernel of libmlgnn.so (rocprofv3 leaves some names mangled: _ZN5mlgnn...)"""
+    return "mlgnn::" in name or "_ZN5mlgnn" in name
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stats", required=True)
@@ -61,8 +66,8 @@ def main():
         if a.cmd:
             f.write("Command: `%s`\n\n" % a.cmd)
         f.write("Total kernel time: %.2f ms over %d distinct kernels.\n\n" % (total / 1e6, len(rows)))
-        own = sum(float(r["TotalDurationNs"]) for r in rows if "mlgnn::" in r["Name"])
-        own_calls = sum(int(r["Calls"]) for r in rows if "mlgnn::" in r["Name"])
+        own = sum(float(r["TotalDurationNs"]) for r in rows if _own(r["Name"]))
+        own_calls = sum(int(r["Calls"]) for r in rows if _own(r["Name"]))
         calls = sum(int(r["Calls"]) for r in rows)
         f.write("Hand-written (`mlgnn::`) kernels: %.1f %% of kernel time, %d of %d launches.\n\n"
                 % (100.0 * own / max(total, 1.0), own_calls, calls))
@@ -73,7 +78,7 @@ def main():
                 float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["Percentage"])))
         f.write("\n## hand-written kernels (libmlgnn.so)\n\n| kernel | calls | avg us |\n|---|---|---|\n")
         for r in rows:
-            if "mlgnn::" in r["Name"]:
+            if _own(r["Name"]):
                 f.write("| `%s` | %s | %.1f |\n" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e3))
     print("wrote", out)
     if a.pmc_fetch and a.pmc_write:

@@ -19,6 +19,11 @@ NN, E1, G, S = 5135 * 3, 60000, 25015, 438
 SHAPES = {"kirc": dict(B=64, dims=(32, 64, 32), k=3), "gbm": dict(B=32, dims=(64, 64, 32), k=2)}
 
 
+def _own(name):
+    """a kernel of libmlgnn.so (rocprofv3 leaves some names mangled: _ZN5mlgnn...)"""
+    return "mlgnn::" in name or "_ZN5mlgnn" in name
+
+
 def main():
     tag = sys.argv[1]
     commit = sys.argv[2] if len(sys.argv) > 2 else "unknown"
@@ -44,13 +49,13 @@ def main():
         rows = list(csv.DictReader(open(hits[-1])))
         steps = 13                                        # 3 warm-up + 10 timed
         total = sum(float(r["TotalDurationNs"]) for r in rows)
-        own = sum(float(r["TotalDurationNs"]) for r in rows if "mlgnn::" in r["Name"])
+        own = sum(float(r["TotalDurationNs"]) for r in rows if _own(r["Name"]))
         ent["kernel_ms_per_step"] = total / steps / 1e6
         ent["mlgnn_share_of_kernel_time"] = own / total
         ent["launches_per_step"] = sum(int(r["Calls"]) for r in rows) / steps
-        ent["mlgnn_launches_per_step"] = sum(int(r["Calls"]) for r in rows if "mlgnn::" in r["Name"]) / steps
+        ent["mlgnn_launches_per_step"] = sum(int(r["Calls"]) for r in rows if _own(r["Name"])) / steps
         ent["top_non_mlgnn"] = [{"kernel": r["Name"][:90], "us_per_step": float(r["TotalDurationNs"]) / steps / 1e3}
-                                for r in rows if "mlgnn::" not in r["Name"]][:6]
+                                for r in rows if not _own(r["Name"])][:6]
         tr_path = os.path.join(ROOT, "profiles", "%s_tcga_%s_pmc_traffic.json" % (tag, shape))
         traffic = json.load(open(tr_path)) if os.path.exists(tr_path) else {}
         B, k = cfg["B"], cfg["k"]

@@ -607,24 +607,25 @@ int mlgnn_table_grad_begin(const float* grad_out, int64_t rows, int64_t d, void*
  * Backward of the MAX aggregator (the reference's default, opt.py:144; torch_message.py:46-47) from compact winner lists
  * (csrc/max_sparse.hip) -- for graphs whose rows hold at most 256 edges in BOTH directions (the caller knows: longer
  * rows take mlgnn_csr_aggregate_bwd), fp32, 32 <= d <= 256, d % 4 == 0 (mlgnn_max_sparse_supported):
- *   mlgnn_max_winners       by destination row: wval [N,d] fp32 / wch [N,d] uint8 = the cotangent values / channels of
- *                           row i sorted by winning edge, meta [E] uint32 = offset | count << 16 of every edge's run
- *                           inside its row (by-destination position).  argmax as written by the forward (-1: no gradient).
+ *   mlgnn_max_winners       by destination row: records [mlgnn_max_sparse_records(N, d, E)] x 8 bytes = {cotangent value,
+ *                           channel} of row i sorted by winning edge (row i starts at even(i (d + 2) + rowptr[i]), every
+ *                           run on an even record), meta [E] x 8 bytes = {first record, count} of every edge's run
+ *                           (by-destination position).  argmax as written by the forward (-1: no gradient).
  *   mlgnn_max_sparse_bwd    grad_x[j][ch] = sum of the runs of j's outgoing edges (+ root[j] when given: the identity
- *                           branch of h = x + m; pass grad_out) -- rowptr_t / col_t / pos_t: the by-source CSR.
+ *                           branch of h = x + m; pass grad_out) -- rowptr_t / pos_t: the by-source CSR.
  *   mlgnn_max_sparse_table_grad   grad_table[t] (+)= the same sum over the edges that read table row t: pos_sorted /
- *                           dst_sorted / rowptr as for mlgnn_max_table_grad_by_type.
+ *                           rowptr as for mlgnn_max_table_grad_by_type.
  * About d / in-degree (value, channel) pairs are read per edge instead of the destination's whole cotangent and winner
- * rows.  No atomics between workgroups; bitwise reproducible.
+ * rows.  No atomics between workgroups; bitwise reproducible.  records and meta: 16-byte aligned.
  */
 int mlgnn_max_sparse_supported(int64_t N, int64_t d);
-int mlgnn_max_winners(const float* grad_out, const int32_t* argmax, const int32_t* rowptr, float* wval, void* wch, void* meta,
+int64_t mlgnn_max_sparse_records(int64_t N, int64_t d, int64_t E);
+int mlgnn_max_winners(const float* grad_out, const int32_t* argmax, const int32_t* rowptr, void* records, void* meta,
                       int64_t N, int64_t d, void* stream);
-int mlgnn_max_sparse_bwd(const float* wval, const void* wch, const void* meta, const int32_t* rowptr_t, const int32_t* col_t,
-                         const int32_t* pos_t, const float* root, float* grad_x, int64_t N, int64_t d, void* stream);
-int mlgnn_max_sparse_table_grad(const float* wval, const void* wch, const void* meta, const int32_t* dst_sorted,
-                                const int32_t* pos_sorted, const int32_t* rowptr, float* grad_table, int64_t N, int64_t d,
-                                int64_t T, int accumulate, void* stream);
+int mlgnn_max_sparse_bwd(const void* records, const void* meta, const int32_t* rowptr_t, const int32_t* pos_t,
+                         const float* root, float* grad_x, int64_t N, int64_t d, void* stream);
+int mlgnn_max_sparse_table_grad(const void* records, const void* meta, const int32_t* pos_sorted, const int32_t* rowptr,
+                                float* grad_table, int64_t N, int64_t d, int64_t T, int accumulate, void* stream);
 int mlgnn_table_grad_finish(void* accumulator, float* grad_table, int64_t T, int64_t d, int accumulate, void* stream);
 
 /*

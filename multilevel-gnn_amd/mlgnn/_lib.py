@@ -35,9 +35,10 @@ SIGNATURES = {
     "mlgnn_max_table_grad_by_type": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_csr_aggregate_bwd_slots_offset_floats": (_I64, [_I64, _I64, _INT]),
     "mlgnn_max_sparse_supported": (_INT, [_I64, _I64]),
-    "mlgnn_max_winners": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
-    "mlgnn_max_sparse_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
-    "mlgnn_max_sparse_table_grad": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P]),
+    "mlgnn_max_sparse_records": (_I64, [_I64, _I64, _I64]),
+    "mlgnn_max_winners": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mlgnn_max_sparse_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mlgnn_max_sparse_table_grad": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P]),
     "mlgnn_table_grad_bytes": (_I64, [_I64, _I64]),
     "mlgnn_table_grad_begin": (_INT, [_P, _I64, _I64, _P, _P]),
     "mlgnn_table_grad_finish": (_INT, [_P, _P, _I64, _I64, _INT, _P]),

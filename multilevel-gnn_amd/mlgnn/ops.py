@@ -643,20 +643,18 @@ class _GenAggregate(torch.autograd.Function):
         sparse = (SPARSE_MAX and not fix_table and aggr_id == AGGR_MAX and x.dtype == torch.float32 and argmax is not None
                   and ctx.post_ln is None and g.num_edges > 0 and go_k.data_ptr() % 16 == 0 and argmax.data_ptr() % 16 == 0
                   and (edge_mode == EDGE_NONE or (edge_mode == EDGE_FULL and te is not None and TABLE_DEST))
-                  and bool(_lib.lib.mlgnn_max_sparse_supported(N, d)) and g.known_short_rows())
+                  and int(_lib.lib.mlgnn_max_sparse_records(N, d, g.num_edges)) > 0 and g.known_short_rows())
         if sparse:
             # every (node, channel) has ONE winning edge: its cotangent goes to that edge's source -- and to the table row
             # the edge reads -- through compact per-edge runs of (value, channel) pairs instead of whole gathered rows
             dev = x.device
-            wval = torch.empty((N, d), dtype=torch.float32, device=dev)
-            wch = torch.empty((N, d), dtype=torch.uint8, device=dev)
-            meta = torch.empty(g.num_edges, dtype=torch.int32, device=dev)
-            rc = _lib.lib.mlgnn_max_winners(go_k.data_ptr(), argmax.data_ptr(), g.rowptr.data_ptr(), wval.data_ptr(),
-                                            wch.data_ptr(), meta.data_ptr(), N, d, _stream())
+            recs = torch.empty((int(_lib.lib.mlgnn_max_sparse_records(N, d, g.num_edges)), 2), dtype=torch.int32, device=dev)
+            meta = torch.empty((g.num_edges, 2), dtype=torch.int32, device=dev)
+            rc = _lib.lib.mlgnn_max_winners(go_k.data_ptr(), argmax.data_ptr(), g.rowptr.data_ptr(), recs.data_ptr(),
+                                            meta.data_ptr(), N, d, _stream())
             _lib.check(rc, "mlgnn_max_winners")
-            rc = _lib.lib.mlgnn_max_sparse_bwd(wval.data_ptr(), wch.data_ptr(), meta.data_ptr(), g.rowptr_t.data_ptr(),
-                                               g.col_t.data_ptr(), g.pos_t.data_ptr(), go_k.data_ptr() if add_root else None,
-                                               gx.data_ptr(), N, d, _stream())
+            rc = _lib.lib.mlgnn_max_sparse_bwd(recs.data_ptr(), meta.data_ptr(), g.rowptr_t.data_ptr(), g.pos_t.data_ptr(),
+                                               go_k.data_ptr() if add_root else None, gx.data_ptr(), N, d, _stream())
             _lib.check(rc, "mlgnn_max_sparse_bwd")
             SPARSE_MAX_STATS["calls"] += 1
             if te is not None and sink is not None:
@@ -674,10 +672,9 @@ class _GenAggregate(torch.autograd.Function):
                     _lib.check(rc, "mlgnn_max_table_grad")
                     TABLE_DEST_STATS["streamed"] += 1
                 else:
-                    pos_s, dst_s, rp_s, _ = te.winners_by_type(g)
-                    rc = _lib.lib.mlgnn_max_sparse_table_grad(wval.data_ptr(), wch.data_ptr(), meta.data_ptr(), dst_s.data_ptr(),
-                                                              pos_s.data_ptr(), rp_s.data_ptr(), sink.total.data_ptr(), N, d, T,
-                                                              0 if first else 1, _stream())
+                    pos_s, _, rp_s, _ = te.winners_by_type(g)
+                    rc = _lib.lib.mlgnn_max_sparse_table_grad(recs.data_ptr(), meta.data_ptr(), pos_s.data_ptr(), rp_s.data_ptr(),
+                                                              sink.total.data_ptr(), N, d, T, 0 if first else 1, _stream())
                     _lib.check(rc, "mlgnn_max_sparse_table_grad")
                     SPARSE_MAX_STATS["table"] += 1
                 TABLE_DEST_STATS["calls"] += 1

@@ -105,8 +105,9 @@ def test_sparse_max_backward_is_not_taken_with_long_rows(monkeypatch):
 
 
 def test_winner_runs_partition_the_channels():
-    """mlgnn_max_winners through the C ABI: the runs of a row's edges tile its packed list, every (value, channel) pair is a
-    winner of that edge with the cotangent of its channel, and channels without a winner appear in no run."""
+    """mlgnn_max_winners through the C ABI: the runs of a row's edges tile its records (each run on an even record), every
+    (value, channel) pair is a winner of that edge with the cotangent of its channel, and channels without a winner appear
+    in no run."""
     from mlgnn import CSRGraph, _lib
     gen = torch.Generator().manual_seed(11)
     N, E, d = 500, 6000, 128
@@ -121,22 +122,25 @@ def test_winner_runs_partition_the_channels():
             a = torch.randint(0, int(deg[i]), (d,), generator=gen) + int(rowptr[i])
             a[torch.rand(d, generator=gen) < 0.1] = -1
             argmax[i] = a.int()
-    wval = torch.zeros(N, d, device=DEV)
-    wch = torch.zeros(N, d, dtype=torch.uint8, device=DEV)
-    meta = torch.zeros(E, dtype=torch.int32, device=DEV)
-    rc = _lib.lib.mlgnn_max_winners(go.data_ptr(), argmax.to(DEV).data_ptr(), graph.rowptr.data_ptr(), wval.data_ptr(),
-                                    wch.data_ptr(), meta.data_ptr(), N, d, torch.cuda.current_stream().cuda_stream)
+    n_rec = int(_lib.lib.mlgnn_max_sparse_records(N, d, E))
+    recs = torch.zeros((n_rec, 2), dtype=torch.int32, device=DEV)
+    meta = torch.zeros((E, 2), dtype=torch.int32, device=DEV)
+    rc = _lib.lib.mlgnn_max_winners(go.data_ptr(), argmax.to(DEV).data_ptr(), graph.rowptr.data_ptr(), recs.data_ptr(),
+                                    meta.data_ptr(), N, d, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
-    wval, wch, meta, go = wval.cpu(), wch.cpu().long(), meta.cpu().long(), go.cpu()
+    recs, meta, go = recs.cpu(), meta.cpu().long(), go.cpu()
+    wval, wch = recs[:, 0].contiguous().view(torch.float32), recs[:, 1].long()
     for i in range(0, N, 7):
-        at, seen = 0, torch.zeros(d, dtype=torch.bool)
+        at = (i * (d + 2) + int(rowptr[i]) + 1) // 2 * 2                 # the row's first record (even)
+        seen, total = torch.zeros(d, dtype=torch.bool), 0
         for p in range(int(rowptr[i]), int(rowptr[i + 1])):
-            off, cnt = int(meta[p]) & 0xffff, int(meta[p]) >> 16
-            assert off == at
-            ch = wch[i, off:off + cnt]
+            off, cnt = int(meta[p, 0]), int(meta[p, 1])
+            assert off == at and off % 2 == 0
+            ch = wch[off:off + cnt]
             assert bool((argmax[i, ch] == p).all()) and not bool(seen[ch].any())
-            assert torch.equal(wval[i, off:off + cnt], go[i, ch])
+            assert torch.equal(wval[off:off + cnt], go[i, ch])
             assert cnt == int((argmax[i] == p).sum())
             seen[ch] = True
-            at += cnt
-        assert at == int((argmax[i] >= 0).sum())
+            at += (cnt + 1) // 2 * 2
+            total += cnt
+        assert total == int((argmax[i] >= 0).sum())

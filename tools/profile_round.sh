@@ -14,7 +14,8 @@
 #           stats + FETCH / WRITE passes -> <tag>_tcga_{kirc,gbm}_kernel_stats.md, <tag>_tcga_*_pmc_traffic.json, <tag>_tcga.json;
 #           DeeperGCN with the reference's default flags -> <tag>_deepergcn_default*
 # pmc       SQ / TCC counters of the aggregation kernels at configs[1] (fp32) and configs[4] (bf16) shape
-#           -> <tag>_aggregate_pmc.json, <tag>_aggregate_pmc_configs4.json; of the one-pass Linear backward -> <tag>_linear_bwd_pmc.json
+#           -> <tag>_aggregate_pmc.json, <tag>_aggregate_pmc_configs4.json; of the one-pass Linear backward -> <tag>_linear_bwd_pmc.json;
+#           of the max backward's kernels in the default-flag DeeperGCN step -> <tag>_max_sparse_pmc.json
 # The program always follows `rocprofv3 ... --` directly (no wrapper process).  Raw outputs: gpurun_out/prof_*_<tag>/; a copy
 # of what a stage wrote under profiles/ travels back in gpurun_out/profiles_<tag>/.
 TAG=${1:-r04}
@@ -122,6 +123,8 @@ if want pmc; then
   bash tools/pmc_aggregate.sh $TAG "$MLGNN_COMMIT" configs4 > gpurun_out/pmc_agg4_$TAG.log 2>&1 || echo "aggregate PMC (configs[4]) failed"
   tail -1 gpurun_out/pmc_agg4_$TAG.log
   bash tools/pmc_linear_bwd.sh $TAG "$MLGNN_COMMIT" > gpurun_out/pmc_lb_$TAG.log 2>&1 || echo "linear_bwd PMC failed"
+  bash tools/pmc_max_sparse.sh 16 $TAG "$MLGNN_COMMIT" > gpurun_out/pmc_ms_$TAG.log 2>&1 || echo "max_sparse PMC failed"
+  tail -1 gpurun_out/pmc_ms_$TAG.log
   echo "pmc passes done"
 fi
 

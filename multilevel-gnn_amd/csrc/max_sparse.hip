@@ -58,9 +58,24 @@ __device__ __forceinline__ void ms_units_of_block(int n_units, int& u, int& u_en
   stride = gridDim.x / kXcds;
 }
 
-inline int ms_grid(int64_t n_units) {
+// persistent grid: every workgroup resident at once (a second, partly filled round of workgroups would add its whole
+// length to the launch), a multiple of 8; `slot` caches the occupancy of one kernel at one LDS size
+struct MsOcc { size_t lds = ~(size_t)0; int per_cu = 0; int cus = 0; };
+template <typename K>
+static int ms_grid(K kernel, size_t lds, int64_t n_units, MsOcc& slot) {
+  if (slot.lds != lds) {
+    int n = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kMsBlock, lds) != hipSuccess || n < 1) n = 1;
+    slot.cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    slot.per_cu = n;
+    slot.lds = lds;
+  }
   int64_t b = (n_units + kXcds - 1) / kXcds * kXcds;
+  const int64_t cap = (int64_t)slot.cus * slot.per_cu / kXcds * kXcds;
+  if (b > cap) b = cap;
   if (b > kMsMaxBlocks) b = kMsMaxBlocks;
+  if (b < kXcds) b = kXcds;
   return (int)b;
 }
 
@@ -304,8 +319,10 @@ extern "C" int mlgnn_max_winners(const float* grad_out, const int32_t* argmax, c
     return MLGNN_E_ALIGN;
   const int lpr_log2 = lanes_per_row_log2(d, 4);
   const int rows_per_unit = kMsWaves * (kWave >> lpr_log2);
-  hipLaunchKernelGGL(max_winners_kernel, dim3((unsigned)ms_grid((N + rows_per_unit - 1) / rows_per_unit)), dim3(kMsBlock),
-                     (size_t)rows_per_unit * kMsBins * sizeof(uint32_t), (hipStream_t)stream, grad_out, argmax, rowptr, static_cast<uint2*>(records), static_cast<uint2*>(meta), (int)N,
+  const size_t lds = (size_t)rows_per_unit * kMsBins * sizeof(uint32_t);
+  static MsOcc occ;
+  hipLaunchKernelGGL(max_winners_kernel, dim3((unsigned)ms_grid(max_winners_kernel, lds, (N + rows_per_unit - 1) / rows_per_unit, occ)),
+                     dim3(kMsBlock), lds, (hipStream_t)stream, grad_out, argmax, rowptr, static_cast<uint2*>(records), static_cast<uint2*>(meta), (int)N,
                      (int)d, lpr_log2);
   return (int)hipGetLastError();
 }
@@ -317,7 +334,9 @@ extern "C" int mlgnn_max_sparse_bwd(const void* records, const void* meta, const
   if (((reinterpret_cast<uintptr_t>(grad_x) | reinterpret_cast<uintptr_t>(root) | reinterpret_cast<uintptr_t>(records)) & 15) != 0)
     return MLGNN_E_ALIGN;
   const size_t lds = (size_t)kMsWaves * 8 * d * sizeof(float);
-  hipLaunchKernelGGL(max_sparse_bwd_kernel, dim3((unsigned)ms_grid((N + kMsWaves * 8 - 1) / (kMsWaves * 8))), dim3(kMsBlock), lds,
+  static MsOcc occ;
+  hipLaunchKernelGGL(max_sparse_bwd_kernel,
+                     dim3((unsigned)ms_grid(max_sparse_bwd_kernel, lds, (N + kMsWaves * 8 - 1) / (kMsWaves * 8), occ)), dim3(kMsBlock), lds,
                      (hipStream_t)stream, static_cast<const uint2*>(records), static_cast<const uint2*>(meta), rowptr_t, pos_t, root,
                      grad_x, (int)N, (int)d);
   return (int)hipGetLastError();
@@ -330,8 +349,8 @@ extern "C" int mlgnn_max_sparse_table_grad(const void* records, const void* meta
   if (!records || !meta || !pos_sorted || !rowptr || !grad_table) return MLGNN_E_NULL;
   if ((reinterpret_cast<uintptr_t>(records) & 15) != 0) return MLGNN_E_ALIGN;
   const size_t lds = (size_t)kMsWaves * 8 * d * sizeof(float);
-  int64_t blocks = (T + kMsWaves - 1) / kMsWaves;
-  if (blocks > kMsMaxBlocks) blocks = kMsMaxBlocks;
+  static MsOcc occ;
+  const int blocks = ms_grid(max_sparse_table_grad_kernel, lds, (T + kMsWaves - 1) / kMsWaves, occ);
   hipLaunchKernelGGL(max_sparse_table_grad_kernel, dim3((unsigned)blocks), dim3(kMsBlock), lds, (hipStream_t)stream,
                      static_cast<const uint2*>(records), static_cast<const uint2*>(meta), pos_sorted, rowptr, grad_table, (int)T,
                      (int)d, accumulate);

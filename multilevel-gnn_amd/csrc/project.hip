@@ -163,6 +163,96 @@ __global__ __launch_bounds__(kBlock) void segment_project_bwd_x_wave_kernel(cons
   }
 }
 
+// ---- input gradient, WIDE rows, units of eight node rows (round 4) ----
+// The wave-per-row form above waits out four dependent memory latencies per ROW (row pointer -> member -> segment /
+// weights -> cotangent rows; 277 us at BASELINE configs[1] for a 328 MB write).  Here a wave takes a unit of eight
+// consecutive rows and fetches the membership data of the whole unit in one shot -- lane = (row slot, member slot): eight
+// rows x eight members per round, 2.5 members per row on average -- then walks the member slots with the gathers of all
+// its rows in flight: three metadata round trips and about six gather rounds per EIGHT rows.
+template <typename T, int VEC, int K, int GROUPS>
+__device__ __forceinline__ void segment_project_bwd_x_unit_body(const ProjArgs& a) {
+  constexpr int kU = 8;                                        // rows per unit = member slots per round
+  constexpr int kMine = kU / GROUPS;                           // rows of the unit this lane group accumulates
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = kWave / GROUPS;
+  const int sub = lane / lpr, cl = lane - sub * lpr;
+  const int us = lane >> 3, ms = lane & 7;                     // metadata phase: row slot, member slot
+  const RowWalk walk = make_row_walk((a.rows + kU - 1) / kU);
+  const uint32_t kstride = a.n_groups > 0 ? (uint32_t)(a.S / a.n_groups) : 1u;      // cotangent rows of one segment: k apart
+  const T* GO = static_cast<const T*>(a.gout_t);
+  for (int cbase = 0; cbase < a.C; cbase += lpr * VEC) {
+    const int c0 = cbase + cl * VEC;
+    const bool cact = c0 < a.C;
+    for (int unit = walk.first; unit < walk.r_end; unit += walk.stride) {
+      const int mrow = unit * kU + us;
+      int beg = 0, cnt = 0;
+      if (mrow < a.rows) {
+        beg = a.ptr[mrow];
+        cnt = a.ptr[mrow + 1] - beg;
+      }
+      int longest = cnt;
+#pragma unroll
+      for (int off = 8; off < kWave; off <<= 1) longest = max(longest, __shfl_xor(longest, off));
+      float acc[kMine][VEC];
+#pragma unroll
+      for (int p = 0; p < kMine; ++p)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[p][i] = 0.f;
+      for (int mb = 0; mb < longest; mb += kU) {               // (one round unless a row has more than eight members)
+        uint32_t obase = 0;
+        float w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[k] = 0.f;
+        if (mb + ms < cnt) {
+          const int f = a.mem[beg + mb + ms];
+          obase = (uint32_t)proj_out_row<K>(a, a.mem_seg[f], 0);
+          const int g = f % a.G;
+#pragma unroll
+          for (int k = 0; k < K; ++k) w[k] = a.w[(size_t)g * K + k];
+        }
+        const int slots = min(kU, longest - mb);
+        for (int m = 0; m < slots; ++m) {                      // (uniform over the wave)
+          float gv[kMine][K][VEC], wk[kMine][K];
+#pragma unroll
+          for (int p = 0; p < kMine; ++p) {
+            const int src = (p * GROUPS + sub) * kU + m;       // the lane that holds member m of this group's p-th row
+            const uint32_t ob = (uint32_t)__shfl((int)obase, src);
+            const bool on = mb + m < __shfl(cnt, src) && cact;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              wk[p][k] = __shfl(w[k], src);
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) gv[p][k][i] = 0.f;
+              if (on) load_t<T, VEC>(gv[p][k], GO + (size_t)(ob + (uint32_t)k * kstride) * a.C + c0);
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < kMine; ++p)
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[p][i] = fmaf(gv[p][k][i], wk[p][k], acc[p][i]);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < kMine; ++p) {
+        const int r = unit * kU + p * GROUPS + sub;
+        if (r < a.rows && cact) store_t<T, VEC>(static_cast<T*>(a.out) + (size_t)r * a.C + c0, acc[p]);
+      }
+    }
+  }
+}
+
+// (GROUPS = lane groups per wave: 2 at 128 fp32 channels, 1 at 256)
+template <typename T, int VEC, int K>
+__global__ __launch_bounds__(kBlock) void segment_project_bwd_x_unit2_kernel(const ProjArgs a) {
+  segment_project_bwd_x_unit_body<T, VEC, K, 2>(a);
+}
+template <typename T, int VEC, int K>
+__global__ __launch_bounds__(kBlock) void segment_project_bwd_x_unit1_kernel(const ProjArgs a) {
+  segment_project_bwd_x_unit_body<T, VEC, K, 1>(a);
+}
+
 // ---- input gradient, NARROW rows: gx[row, :] = sum_{m -> row} sum_k gout_t[seg(m), k, :] * W[g(m), k]
 // A node has 2.5 memberships on average (G = 25 000 over 10 000 genes), so the work per row is one short chain of
 // dependent loads (row pointer -> member -> segment / weights -> K cotangent rows) and one 512-byte store: a wave that
@@ -385,7 +475,13 @@ extern "C" int mlgnn_segment_project_bwd(const void* gout_t, const void* x, cons
     const dim3 grid(grid_for_rows(n_rows));
     a.lpr_log2 = lanes_per_row_log2(C, wide ? vec : 1);
     // four or more lane groups per wave (<= 64 fp32 channels): every group walks rows of its own; wider rows: a wave per row
-    if ((kWave >> a.lpr_log2) >= 4) MLGNN_PROJ_DISPATCH(segment_project_bwd_x_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
+    // (wider: units of eight rows with their membership data fetched in one shot; MLGNN_PROJ_UNIT=0: the wave-per-row form)
+    static const bool unit_on = [] { const char* e = getenv("MLGNN_PROJ_UNIT"); return !(e && e[0] == '0'); }();
+    const int lane_groups = kWave >> a.lpr_log2;
+    const dim3 ugrid(grid_for_rows((n_rows + 7) / 8));
+    if (lane_groups >= 4) MLGNN_PROJ_DISPATCH(segment_project_bwd_x_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
+    else if (unit_on && lane_groups == 2) MLGNN_PROJ_DISPATCH(segment_project_bwd_x_unit2_kernel, bf16, wide, (int)K, ugrid, block, 0, s, a);
+    else if (unit_on && lane_groups == 1 && K <= 2) MLGNN_PROJ_DISPATCH(segment_project_bwd_x_unit1_kernel, bf16, wide, (int)K, ugrid, block, 0, s, a);
     else MLGNN_PROJ_DISPATCH(segment_project_bwd_x_wave_kernel, bf16, wide, (int)K, grid, block, 0, s, a);
     const int err = (int)hipGetLastError();
     if (err) return err;

@@ -115,13 +115,16 @@ def test_pooled_layout_is_the_permuted_result(C, K, NG):
     assert torch.equal(o1, o0) and torch.equal(gx1, gx0) and torch.equal(gw1, gw0)
 
 
-def test_input_gradient_rows_with_many_and_no_members():
-    """The multi-row input-gradient walk (4 rows per lane group in flight): nodes without a membership, nodes with one,
-    and one node that 300 memberships point at, next to each other; the last rows of the table do not fill a unit."""
+@pytest.mark.parametrize("C,K", [(128, 2), (256, 2), (64, 3), (128, 4), (256, 3)])
+def test_input_gradient_rows_with_many_and_no_members(C, K):
+    """The multi-row input-gradient walks (narrow rows: 4 rows per lane group in flight; wide rows: units of eight rows whose
+    membership data is fetched in one shot, eight member slots per round; 256 channels x 3: the wave-per-row form): nodes
+    without a membership, nodes with one, and one node that 300 memberships point at, next to each other; the last rows of
+    the table do not fill a unit."""
     from mlgnn.project import segment_project
     gen = torch.Generator().manual_seed(9)
     dev = "cuda:0"
-    B, NN, G, S, C, K = 2, 1003, 3000, 438, 128, 2
+    B, NN, G, S = 2, 1003, 3000, 438
     match = torch.randint(0, NN, (B, G), generator=gen)
     match[:, :300] = 17
     match[:, 300:900] = torch.arange(600) % 40 + 500          # rows 500..539 with 15 members each; most others 0..3

@@ -102,9 +102,13 @@ def cpu_baseline(args, model_sd):
                       "step)" % (nb, len(fwd))}
 
 
-def load_traffic():
+PROFILED_WORKLOAD = "64x10000x160000x128"     # graphs per GPU x nodes x edges x hidden of the PMC passes (bench.py defaults)
+
+
+def load_traffic(workload):
     """profiles/traffic.json (HBM bytes per launch from the PMC passes of tools/profile_round.sh) -- only if it was
-    measured on THESE kernel sources; a stale file is reported loudly and not used."""
+    measured on THESE kernel sources AND at this run's workload size (bytes per launch scale with the batch); a stale
+    file is reported loudly and not used."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None, {"file": "profiles/traffic.json", "stale": True, "reason": "missing"}
@@ -123,6 +127,10 @@ def load_traffic():
               file=sys.stderr, flush=True)
         return None, src
     src["stale"] = False
+    if src.get("workload", PROFILED_WORKLOAD) != workload:
+        src.update(applicable=False, reason="counters were collected at workload %s, this run is %s: compulsory bytes stand in"
+                                            % (src.get("workload", PROFILED_WORKLOAD), workload))
+        return None, src
     return blob, src
 
 
@@ -325,7 +333,7 @@ def main():
                        "allreduce_bytes": bucket.flat_all.numel() * 4,      # gradients + one reached flag per parameter
                        "final_loss": final_loss},
         }
-        blob, tsrc = load_traffic()
+        blob, tsrc = load_traffic("%dx%dx%dx%d" % (B, args.nodes, args.edges, args.hidden))
         N_all, E_all = B * args.nodes, B * args.edges
 
         def kernel_table(summary):

@@ -55,6 +55,9 @@ def test_bench_line_n1_schema(line_n1):
     assert out["config"]["world_size"] == 1 and out["config"]["allreduce_ms"] is None
     assert out["roofline"]["kernel"].startswith("csr_aggregate_") and 0 < out["roofline"]["frac"] <= 1.0
     assert out["roofline"]["frac_basis"] in ("hbm_counter", "compulsory") and "arith" in out
+    # the committed PMC bytes per launch belong to the default workload (64 x 10000 x 160000 x 128): at any other size the
+    # compulsory bytes stand in (a counter figure of another batch size once gave frac = 12.6 here)
+    assert out["roofline"]["frac_basis"] == "compulsory" and out["roofline"]["traffic"] is None
     assert 0 < out["roofline"]["frac_of_stream_copy"] <= 1.5 and out["roofline"]["stream_copy_GBps"] > 1000
     assert all(0 < k["frac"] <= 1.0 for k in out["roofline"].get("also", []))
     assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])

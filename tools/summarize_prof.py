@@ -120,6 +120,7 @@ def main():
         import build_native
         blob = {"_source": {"tag": a.tag, "commit": a.commit or os.environ.get("MLGNN_COMMIT", "unknown"),
                             "command": a.pmc_cmd or a.cmd, "kernel_sources_sha256": build_native.sources_digest(),
+                            "workload": "64x10000x160000x128",       # graphs per GPU x nodes x edges x hidden (bench.py defaults)
                             "counters": "2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes "
                                         "(MI355X_MICROARCH.md, HBM: FETCH_SIZE reports half of a 16 B/lane stream on gfx950)"}}
         blob.update(traffic)

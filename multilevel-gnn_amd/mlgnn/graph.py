@@ -481,3 +481,24 @@ def sage_graph(edge_index, edge_attr, num_nodes, shared=None):
         graph = CSRGraph(ei, num_nodes)
     _SAGE_CACHE[:] = [(edge_index, edge_attr, num_nodes, edge_index._version, ea_v, graph, weight)]
     return graph, weight
+
+
+def _release_at_exit():
+    """Topologies, pinned count buffers and events cached at module level are released while torch and the HIP runtime are
+    still whole (atexit runs before module teardown): otherwise they are destroyed in arbitrary order during interpreter
+    finalisation, next to the runtime's own teardown (one ``terminate called without an active exception`` was seen after
+    the last case of tools/fuzz_aggregate.py in round 4, with two cached graphs alive)."""
+    try:
+        CSRGraph._CACHE[:] = []
+        _SAGE_CACHE[:] = []
+        _SHARED_SAGE_CACHE[:] = []
+        from . import project
+        project._MEMBERSHIP_CACHE[:] = []
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:                                  # noqa: BLE001 -- never turn a clean exit into an error
+        pass
+
+
+import atexit  # noqa: E402
+atexit.register(_release_at_exit)

@@ -421,6 +421,11 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # leave nothing for interpreter finalisation to destroy next to the runtime's own teardown
+    for batch in pool:
+        batch.csr = None
+    pool.clear()
+    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MLGNN_ABI_VERSION 18
+#define MLGNN_ABI_VERSION 19
 
 /* argument errors */
 #define MLGNN_E_NULL      (-1)  /* a required pointer is NULL                  */
@@ -826,6 +826,12 @@ int mlgnn_sage_fold_fwd(const float* w_nn, const float* w_r, float* w_cat, float
                         int relative, void* stream);
 int mlgnn_sage_fold_bwd(const float* grad_w_x1, const float* grad_w_c, const float* w_nn, const float* w_r, float* grad_w_nn,
                         float* grad_w_r, int64_t cin, int64_t cout, int relative, void* stream);
+
+/*
+ * dst [B, C, R] = src [B, R, C]^T per sample (fp32).  Replaces: the copy inside `torch.flatten(x, start_dim=1)` in front of
+ * MultilevelGNN's first head Linear (models/multilevel_gnn.py:277) when x lives channel-last, and its autograd.
+ */
+int mlgnn_transpose_batched(const float* src, float* dst, int64_t B, int64_t R, int64_t C, void* stream);
 
 /*
  * Backward of that epilogue (csrc/sage.hip):  grad_z = grad_out * row_scale[row] * (z > 0 ? 1 : slope), the sign of z

@@ -259,6 +259,25 @@ __global__ __launch_bounds__(256) void sage_fold_bwd_kernel(const float* __restr
   }
 }
 
+
+// ---- batched transpose [B, R, C] -> [B, C, R] (fp32) -------------------------------------------------------------------
+// The flatten in front of MultilevelGNN's first head Linear (multilevel_gnn.py:277: torch.flatten of the [B, C, 146, 3k]
+// convolution result) when the result lives channel-last (the layout the 1x1 convolutions compute in): a 64 x 64 tile through
+// LDS, both sides in 256-byte pieces.  The backward is the same kernel the other way round.
+constexpr int kTrTile = 64;
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+  __shared__ float tile[kTrTile][kTrTile + 1];
+  const int b = blockIdx.z, r0 = blockIdx.x * kTrTile, c0 = blockIdx.y * kTrTile;
+  const float* s = src + (size_t)b * R * C;
+  float* d = dst + (size_t)b * R * C;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;             // 64 x 4
+  for (int i = ty; i < kTrTile; i += 4)
+    if (r0 + i < R && c0 + tx < C) tile[i][tx] = s[(size_t)(r0 + i) * C + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < kTrTile; i += 4)
+    if (c0 + i < C && r0 + tx < R) d[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
 static bool width_ok(int64_t J) {
   const int64_t l = J / 4;
   return J >= 4 && J % 4 == 0 && l <= 64 && (l & (l - 1)) == 0;
@@ -421,5 +440,15 @@ extern "C" int mlgnn_sage_fold_bwd(const float* grad_w_x1, const float* grad_w_c
   const int64_t n = cout * (cin + cout) + cout * cin;
   hipLaunchKernelGGL(sage_fold_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_w_x1,
                      grad_w_c, w_nn, w_r, grad_w_nn, grad_w_r, (int)cin, (int)cout, relative);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mlgnn_transpose_batched(const float* src, float* dst, int64_t B, int64_t R, int64_t C, void* stream) {
+  if (B < 0 || R < 0 || C < 0 || B > 65535 || R > INT32_MAX || C > INT32_MAX || (C + kTrTile - 1) / kTrTile > 65535)
+    return MLGNN_E_SHAPE;
+  if (B == 0 || R == 0 || C == 0) return 0;
+  if (!src || !dst) return MLGNN_E_NULL;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)((R + kTrTile - 1) / kTrTile), (unsigned)((C + kTrTile - 1) / kTrTile), (unsigned)B),
+                     dim3(256), 0, (hipStream_t)stream, src, dst, (int)R, (int)C);
   return (int)hipGetLastError();
 }

@@ -87,6 +87,7 @@ SIGNATURES = {
     "mlgnn_sage_rewrite": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "mlgnn_tallgemm_dual_supported": (_INT, [_I64, _I64, _I64, _I64]),
     "mlgnn_tallgemm_dual": (_INT, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
+    "mlgnn_transpose_batched": (_INT, [_P, _P, _I64, _I64, _I64, _P]),
     "mlgnn_sage_fold_fwd": (_INT, [_P, _P, _P, _P, _P, _I64, _I64, _INT, _P]),
     "mlgnn_sage_fold_bwd": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _INT, _P]),
     "mlgnn_leaky_relu_bwd": (_INT, [_P, _P, _P, _F, _P, _P, _I64, _I64, _P]),

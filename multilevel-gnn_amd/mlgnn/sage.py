@@ -238,3 +238,34 @@ def linear_act(x, w, b, slope):
     """-> ``leaky_relu(x @ w.T + b, slope)`` tagged with its row maxima; the caller checks :func:`linear_act_supported`."""
     y, y_max = _LinearAct.apply(x, w, b, float(slope))
     return tag_row_max(y, y_max)
+
+
+class _TransposeBatched(torch.autograd.Function):
+    """``[B, R, C] -> [B, C, R]`` (fp32, contiguous both sides), its backward the same kernel the other way round."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, R, C = x.shape
+        y = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib.mlgnn_transpose_batched(x.data_ptr(), y.data_ptr(), B, R, C, _stream()), "mlgnn_transpose_batched")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        B, C, R = gy.shape
+        gx = torch.empty((B, R, C), dtype=torch.float32, device=gy.device)
+        _lib.check(_lib.lib.mlgnn_transpose_batched(gy.data_ptr(), gx.data_ptr(), B, C, R, _stream()), "mlgnn_transpose_batched")
+        return gx
+
+
+def flatten_channel_last(x):
+    """``torch.flatten(x, start_dim=1)`` of a ``[B, C, H, W]`` tensor that lives channel-last in memory (the layout the head's
+    1x1 convolutions compute in, models.multilevel_gnn.HeadConv2d): one tiled transpose instead of ATen's generic strided
+    copy -- and, in the backward, the gradient arrives channel-last again.  Any other layout / dtype: plain flatten."""
+    if (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= 65535
+            and x.permute(0, 2, 3, 1).is_contiguous() and not x.is_contiguous()):
+        B, C, H, W = x.shape
+        rows = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        return _TransposeBatched.apply(rows).reshape(B, C * H * W)
+    return torch.flatten(x, start_dim=1)

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from mlgnn.dense import linear as dense_linear
 from mlgnn.project import segment_project
-from mlgnn.sage import linear_act, linear_act_supported, node_embed, node_embed_supported
+from mlgnn.sage import flatten_channel_last, linear_act, linear_act_supported, node_embed, node_embed_supported
 from .gcn_lib.sparse.torch_vertex import GraphConv
 
 
@@ -158,7 +158,7 @@ class MultilevelGNN(nn.Module):
         if (self.pathway_pool_dim, self.pca_pool_dim) != (1, 1):     # (a 1 x 1 window is the identity: kirc.yaml)
             x = self.pooling(x)
         x = self.drop1(x)
-        x = torch.flatten(x, start_dim=1)
+        x = flatten_channel_last(x)                      # (:277 torch.flatten; a tiled transpose when x is channel-last)
         if self.args.use_age:
             x = torch.cat([x, age[:, None]], dim=-1)
         # (the first Linear reads a [B, 64 * 146 * 3k] row per sample: a stream over its weight, mlgnn.dense.linear)

@@ -25,7 +25,7 @@ def test_header_and_binding_agree():
 def test_version_and_error_codes():
     from mlgnn import _lib
     lib = _lib.lib
-    assert lib.mlgnn_version() == 18
+    assert lib.mlgnn_version() == 19
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 1, 0, 0) == (8 + 256) * 2 * 128      # 8 workgroups minimum + the long-row launch
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 8, 0, 0) == (8 + 256) * 9 * 128
     assert lib.mlgnn_csr_aggregate_bwd_workspace_floats(10, 128, 0, 9, 0, 0) == -2

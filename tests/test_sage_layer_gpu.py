@@ -113,3 +113,22 @@ def test_node_embedding_rows():
     assert_close(got, emb.grad, 1e-6, "grad embedding", elementwise=True)
     from mlgnn.ops import row_max_of
     assert torch.equal(row_max_of(h), ref.detach().abs().amax(1))
+
+
+@pytest.mark.parametrize("B,C,H,W", [(64, 64, 146, 9), (3, 32, 36, 3), (2, 7, 5, 1), (1, 65, 130, 2)])
+def test_flatten_of_a_channel_last_tensor(B, C, H, W):
+    """torch.flatten(x, start_dim=1) of a [B, C, H, W] tensor that lives channel-last (the head of MultilevelGNN,
+    multilevel_gnn.py:277): the tiled transpose gives the same bytes and routes the gradient back channel-last."""
+    from mlgnn import sage as S
+    gen = torch.Generator().manual_seed(B + C)
+    rows = torch.randn(B, H, W, C, generator=gen).to(DEV).requires_grad_(True)
+    x = rows.permute(0, 3, 1, 2)                            # logical [B, C, H, W], channel-last in memory
+    got = S.flatten_channel_last(x)
+    assert got.grad_fn is not None and "TransposeBatched" in type(got.grad_fn).__name__ + str(got.grad_fn.next_functions)
+    assert torch.equal(got, torch.flatten(x, start_dim=1))
+    cot = torch.randn(B, C * H * W, generator=gen).to(DEV)
+    g1, = torch.autograd.grad((got * cot).sum(), rows)
+    g2, = torch.autograd.grad((torch.flatten(x, start_dim=1) * cot).sum(), rows)
+    assert torch.equal(g1, g2)
+    y = torch.randn(B, C, H, W, generator=gen).to(DEV)       # a contiguous tensor takes the plain flatten
+    assert torch.equal(S.flatten_channel_last(y), y.reshape(B, -1))
